@@ -1,0 +1,110 @@
+"""ctypes binding of libcrnerf_hip.so (the C ABI declared in include/crnerf.h).
+
+The library is the product: if it is missing or fails to load, every call raises -- there is no
+eager/CPU fallback behind these functions.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrnerf_hip.so")
+
+EXPORTS = [
+    "crnerf_abi_version", "crnerf_last_error", "crnerf_packed_mlp_bytes", "crnerf_pack_mlp_weights",
+    "crnerf_posenc_f32", "crnerf_mlp_forward_f32", "crnerf_composite_f32", "crnerf_sample_pdf_merge_f32",
+    "crnerf_render_rays_f32", "crnerf_crossray_workspace_bytes", "crnerf_crossray_chansum_f32",
+    "crnerf_crossray_gram_f32", "crnerf_crossray_matrix_f32", "crnerf_crossray_fold_f32",
+    "crnerf_crossray_apply_f32",
+]
+
+_c_fp = ctypes.c_void_p  # device float*
+
+
+class RenderArgs(ctypes.Structure):
+    """struct crnerf_render_args (include/crnerf.h)."""
+    _fields_ = [
+        ("packed_coarse", ctypes.c_void_p), ("packed_fine", ctypes.c_void_p),
+        ("rays", _c_fp), ("view_dir", _c_fp), ("z_coarse", _c_fp), ("u", _c_fp),
+        ("noise_coarse", _c_fp), ("noise_fine", _c_fp),
+        ("noise_std", ctypes.c_float), ("use_disp", ctypes.c_int32),
+        ("n_rays", ctypes.c_int64), ("n_samples", ctypes.c_int32), ("n_importance", ctypes.c_int32),
+        ("weights_coarse", _c_fp), ("feature_coarse", _c_fp), ("depth_coarse", _c_fp),
+        ("weights_fine", _c_fp), ("feature_fine", _c_fp), ("depth_fine", _c_fp), ("z_fine", _c_fp),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "crnerf_amd: %s not found -- build it with `python cr-nerf-pytorch_amd/build.py` "
+                "(or __graft_entry__.build()); there is no fallback path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        i64, i32, vp, f32, f64 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_double
+        pp = ctypes.POINTER(ctypes.c_void_p)
+        sig = {
+            "crnerf_abi_version": (ctypes.c_int, []),
+            "crnerf_last_error": (ctypes.c_char_p, []),
+            "crnerf_packed_mlp_bytes": (ctypes.c_size_t, []),
+            "crnerf_crossray_workspace_bytes": (ctypes.c_size_t, []),
+            "crnerf_pack_mlp_weights": (ctypes.c_int, [pp, vp, vp]),
+            "crnerf_posenc_f32": (ctypes.c_int, [vp, vp, i64, i32, vp]),
+            "crnerf_mlp_forward_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, vp]),
+            "crnerf_composite_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, i64, i32, vp]),
+            "crnerf_sample_pdf_merge_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+            "crnerf_render_rays_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
+            "crnerf_crossray_chansum_f32": (ctypes.c_int, [vp, i64, vp, vp, vp]),
+            "crnerf_crossray_gram_f32": (ctypes.c_int, [vp, i64, vp, pp, vp, vp, vp]),
+            "crnerf_crossray_matrix_f32": (ctypes.c_int, [vp, f64, vp, vp, vp, vp]),
+            "crnerf_crossray_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, pp, vp, vp]),
+            "crnerf_crossray_apply_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().crnerf_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t, name="tensor", dtype=torch.float32):
+    """Pointer of a contiguous device tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("crnerf_amd: %s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("crnerf_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("crnerf_amd: %s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors, name):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = dev_ptr(t, "%s[%d]" % (name, i)).value
+    return arr

@@ -1,0 +1,141 @@
+// extern "C" surface of libcrnerf_hip.so -- see include/crnerf.h for the contract of every symbol.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/crnerf.h"
+#include "crossray.h"
+#include "kernels.h"
+#include "layout.h"
+
+namespace crnerf {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return CRNERF_ERR_HIP;
+}
+
+}  // namespace crnerf
+
+using namespace crnerf;
+
+#define REQUIRE(p, name) \
+  if (!(p)) return set_error(CRNERF_ERR_NULL, name " is NULL")
+
+extern "C" {
+
+int crnerf_abi_version(void) { return CRNERF_ABI_VERSION; }
+const char* crnerf_last_error(void) { return g_err; }
+size_t crnerf_packed_mlp_bytes(void) { return PACKED_BYTES; }
+size_t crnerf_crossray_workspace_bytes(void) { return CROSSRAY_WORKSPACE_BYTES; }
+
+int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors");
+  REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights: a tensor pointer is NULL");
+  MlpTensors t;
+  for (int i = 0; i < 8; ++i) { t.w[i] = tensors[2 * i]; t.b[i] = tensors[2 * i + 1]; }
+  t.w_final = tensors[16]; t.b_final = tensors[17];
+  t.w_sigma = tensors[18]; t.b_sigma = tensors[19];
+  t.w_dir = tensors[20]; t.b_dir = tensors[21];
+  t.w_rgb = tensors[22]; t.b_rgb = tensors[23];
+  return launch_pack_mlp(t, packed, (hipStream_t)stream);
+}
+
+int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(x, "x");
+  REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "posenc: negative n");
+  return launch_posenc(x, out, (long)n, n_freqs, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed");
+  REQUIRE(x, "x");
+  REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward: negative n");
+  return launch_mlp_forward(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+}
+
+int crnerf_composite_f32(const float* raw, const float* z, const float* noise, float noise_std, float* weights, float* feature,
+                         float* depth, int64_t R, int N, void* stream) {
+  if (R == 0) return 0;
+  REQUIRE(raw, "raw"); REQUIRE(z, "z"); REQUIRE(weights, "weights"); REQUIRE(feature, "feature"); REQUIRE(depth, "depth");
+  if (R < 0) return set_error(CRNERF_ERR_SHAPE, "composite: negative R");
+  return launch_composite(raw, z, noise, noise_std, weights, feature, depth, (long)R, N, (hipStream_t)stream);
+}
+
+int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, float* z_sorted,
+                                float* z_samples, int64_t R, int Nc, int Ni, void* stream) {
+  if (R == 0) return 0;
+  REQUIRE(z_coarse, "z_coarse"); REQUIRE(weights_coarse, "weights_coarse"); REQUIRE(z_sorted, "z_sorted");
+  if (R < 0) return set_error(CRNERF_ERR_SHAPE, "sample_pdf_merge: negative R");
+  return launch_sample_pdf_merge(z_coarse, weights_coarse, u, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
+}
+
+int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays: negative n_rays");
+  REQUIRE(a->packed_coarse, "packed_coarse"); REQUIRE(a->rays, "rays");
+  REQUIRE(a->weights_coarse, "weights_coarse"); REQUIRE(a->feature_coarse, "feature_coarse"); REQUIRE(a->depth_coarse, "depth_coarse");
+  if (a->n_importance > 0) {
+    REQUIRE(a->packed_fine, "packed_fine");
+    REQUIRE(a->weights_fine, "weights_fine"); REQUIRE(a->feature_fine, "feature_fine"); REQUIRE(a->depth_fine, "depth_fine");
+  }
+  RenderArgs r;
+  r.packed_coarse = a->packed_coarse; r.packed_fine = a->packed_fine; r.rays = a->rays; r.view_dir = a->view_dir;
+  r.z_coarse = a->z_coarse; r.u = a->u; r.noise_coarse = a->noise_coarse; r.noise_fine = a->noise_fine;
+  r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
+  r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
+  r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
+  return launch_render_rays(r, (hipStream_t)stream);
+}
+
+int crnerf_crossray_chansum_f32(const float* x, int64_t HW, float* sum64, void* workspace, void* stream) {
+  REQUIRE(x, "x"); REQUIRE(sum64, "sum64"); REQUIRE(workspace, "workspace");
+  return launch_crossray_chansum(x, (long)HW, sum64, (float*)workspace, (hipStream_t)stream);
+}
+
+int crnerf_crossray_gram_f32(const float* x, int64_t HW, const float* mean64, const float* const* cnn, float* gram_sum,
+                             void* workspace, void* stream) {
+  REQUIRE(x, "x"); REQUIRE(mean64, "mean64"); REQUIRE(cnn, "cnn"); REQUIRE(gram_sum, "gram_sum"); REQUIRE(workspace, "workspace");
+  for (int i = 0; i < 6; ++i)
+    if (!cnn[i]) return set_error(CRNERF_ERR_NULL, "crossray_gram: a cnn tensor pointer is NULL");
+  CnnTensors w{cnn[0], cnn[1], cnn[2], cnn[3], cnn[4], cnn[5]};
+  return launch_crossray_gram(x, (long)HW, mean64, w, gram_sum, (float*)workspace, (hipStream_t)stream);
+}
+
+int crnerf_crossray_matrix_f32(const float* gram_sum, double count, const float* fc_w, const float* fc_b, float* out, void* stream) {
+  REQUIRE(gram_sum, "gram_sum"); REQUIRE(fc_w, "fc_w"); REQUIRE(fc_b, "fc_b"); REQUIRE(out, "out");
+  return launch_crossray_matrix(gram_sum, count, fc_w, fc_b, out, (hipStream_t)stream);
+}
+
+int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const float* c_mean64, const float* s_mean64,
+                             const float* const* lin, float* affine, void* stream) {
+  REQUIRE(lin, "lin"); REQUIRE(affine, "affine");
+  for (int i = 0; i < 6; ++i)
+    if (!lin[i]) return set_error(CRNERF_ERR_NULL, "crossray_fold: a tensor pointer is NULL");
+  if (s_matrix) { REQUIRE(c_matrix, "c_matrix"); REQUIRE(c_mean64, "c_mean64"); REQUIRE(s_mean64, "s_mean64"); }
+  FoldTensors w{lin[0], lin[1], lin[2], lin[3], lin[4], lin[5]};
+  return launch_crossray_fold(s_matrix, c_matrix, c_mean64, s_mean64, w, affine, (hipStream_t)stream);
+}
+
+int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride, void* stream) {
+  if (HW == 0) return 0;
+  REQUIRE(x, "x"); REQUIRE(affine, "affine"); REQUIRE(rgb, "rgb");
+  return launch_crossray_apply(x, (long)HW, affine, rgb, (long)plane_stride, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// Launchers of the cross-ray decoder kernels (crossray.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace crnerf {
+
+constexpr int CROSSRAY_MAX_BLOCKS = 1024;
+// workspace floats: max(chansum partials 1024*64, gram partials 256*1024)
+constexpr size_t CROSSRAY_WORKSPACE_BYTES = (size_t)256 * 1024 * 4;
+
+struct CnnTensors {  // CNN.convs, models/linearStyleTransfer.py:11-15 (1x1 convs = [out,in] matrices)
+  const float* w1; const float* b1;  // 64 -> 128
+  const float* w2; const float* b2;  // 128 -> 64
+  const float* w3; const float* b3;  // 64 -> 32
+};
+struct FoldTensors {  // MulLayer.compress/unzip :54-55, NeuralRenderer.feat_2_rgb_list[0]
+  const float* comp_w; const float* comp_b;    // [32,64], [32]
+  const float* unzip_w; const float* unzip_b;  // [64,32], [64]
+  const float* rgb_w; const float* rgb_b;      // [3,64], [3]
+};
+
+int launch_crossray_chansum(const float* x, long HW, float* sum_out, float* workspace, hipStream_t stream);
+int launch_crossray_gram(const float* x, long HW, const float* mean, const CnnTensors& w, float* gram_sum, float* workspace,
+                         hipStream_t stream);
+int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_w, const float* fc_b, float* out, hipStream_t stream);
+int launch_crossray_fold(const float* sM, const float* cM, const float* c_mean, const float* s_mean, const FoldTensors& w,
+                         float* affine, hipStream_t stream);
+int launch_crossray_apply(const float* x, long HW, const float* affine, float* rgb, long plane_stride, hipStream_t stream);
+
+}  // namespace crnerf

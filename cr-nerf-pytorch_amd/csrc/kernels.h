@@ -1,0 +1,52 @@
+// Internal launcher declarations shared by the .hip translation units and the C-ABI (abi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crnerf {
+
+// thread-local last-error slot behind crnerf_last_error(); returns code
+int set_error(int code, const char* msg);
+int check_launch(const char* what);
+
+struct MlpTensors {  // device pointers to the 24 tensors of one NeRF_sigma (models/nerf.py:137-154)
+  const float* w[8];   // xyz_encoding_{1..8}.0.weight
+  const float* b[8];   // xyz_encoding_{1..8}.0.bias
+  const float* w_final; const float* b_final;  // xyz_encoding_final
+  const float* w_sigma; const float* b_sigma;  // static_sigma.0
+  const float* w_dir;   const float* b_dir;    // dir_encoding.0
+  const float* w_rgb;   const float* b_rgb;    // static_rgb.0
+};
+
+int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
+int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
+int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
+                     float* feature, float* depth, long R, int N, hipStream_t stream);
+int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, float* z_fine_sorted,
+                            float* z_samples, long R, int Nc, int Ni, hipStream_t stream);
+
+struct RenderArgs {
+  const void* packed_coarse;
+  const void* packed_fine;     // may be null when n_importance == 0
+  const float* rays;           // [R,8]
+  const float* view_dir;       // [R,3] or null -> rays[:,3:6]
+  const float* z_coarse;       // [R,Nc] or null -> computed from near/far (perturb == 0)
+  const float* u;              // [R,Ni] or null -> linspace(0,1,Ni) (det)
+  const float* noise_coarse;   // [R,Nc] or null
+  const float* noise_fine;     // [R,Nc+Ni] or null
+  float noise_std;
+  int use_disp;
+  long R;
+  int Nc, Ni;
+  float* weights_coarse;       // [R,Nc]
+  float* feature_coarse;       // [R,64]
+  float* depth_coarse;         // [R]
+  float* weights_fine;         // [R,Nc+Ni]
+  float* feature_fine;         // [R,64]
+  float* depth_fine;           // [R]
+  float* z_fine;               // [R,Nc+Ni] optional (null to skip)
+};
+int launch_render_rays(const RenderArgs& a, hipStream_t stream);
+
+}  // namespace crnerf

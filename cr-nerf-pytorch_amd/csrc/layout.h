@@ -1,0 +1,97 @@
+// Packed-weight layout shared by the pack kernel, the MLP core and the host shim.
+//
+// Reference weight layout being re-packed: NeRF_sigma.__init__, models/nerf.py:116-154
+// (24 nn.Linear tensors, weight [out,in] row-major, bias [out]).
+//
+// One packed model = [ consts | weight stream ].
+//
+//   consts  : biases + the sigma head, compact fp32 (CONST_FLOATS floats, padded to CONST_BYTES)
+//   stream  : a flat sequence of 1 KiB "fragments".  One fragment is exactly what one wavefront
+//             reads with a single ds_read_b128 (64 lanes x 4 floats) and feeds to four
+//             v_mfma_f32_32x32x2_f32 as the A operand:
+//                 frag(layer, group v, tile t)[lane = 32*kk + i][j] = W[32*t + i][col(8*v + 4*kk + j)]
+//             i.e. output-feature row 32t+i, and the four k-values this lane supplies for the
+//             four MFMAs of k-group v.  Fragments are ordered group-major, tile-minor inside a
+//             layer, layers in execution order, and cut into 16-fragment (16 KiB) "stages" that
+//             the kernels stream through an LDS ring with global_load_lds.
+//
+// "col(k)" maps the kernel's k order onto the reference's input-column order; it is the identity
+// for hidden activations and the pair-interleaved order of posenc_slots.h for the two positional
+// embeddings (so that one lane computes sin AND cos of the same argument with one sincosf).
+#pragma once
+#include <stdint.h>
+
+namespace crnerf {
+
+constexpr int W_HIDDEN = 256;
+constexpr int XYZ_FREQS = 15;             // N_emb_xyz, opt.py:46
+constexpr int DIR_FREQS = 4;              // N_emb_dir, opt.py:48
+constexpr int XYZ_DIM = 6 * XYZ_FREQS + 3;  // 93
+constexpr int DIR_DIM = 6 * DIR_FREQS + 3;  // 27
+constexpr int XYZ_PAD = 96;
+constexpr int DIR_PAD = 32;
+constexpr int IN_DIM = XYZ_DIM + DIR_DIM;   // 120
+constexpr int FEAT_DIM = 64;                // nerf_out_dim, opt.py:93
+constexpr int OUT_DIM = FEAT_DIM + 1;       // 65
+
+constexpr int FRAG_FLOATS = 256;
+constexpr int FRAG_BYTES = 1024;
+constexpr int STAGE_FRAGS = 16;
+constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;  // 16 KiB
+
+// k-groups (8 k-values each) and output tiles (32 rows each) per layer
+constexpr int G_XYZ = XYZ_PAD / 8;   // 12
+constexpr int G_HID = W_HIDDEN / 8;  // 32
+constexpr int G_DIR = DIR_PAD / 8;   // 4
+constexpr int G_HALF = 128 / 8;      // 16
+
+// fragments per layer, in execution order
+constexpr int FR_L1 = G_XYZ * 8;            //  96  xyz_encoding_1      93(96)->256
+constexpr int FR_HID = G_HID * 8;           // 256  xyz_encoding_{2,3,4,6,7,8}, xyz_encoding_final
+constexpr int FR_L5 = (G_XYZ + G_HID) * 8;  // 352  xyz_encoding_5      [xyz(96), h(256)]->256
+constexpr int FR_DIR = (G_HID + G_DIR) * 4; // 144  dir_encoding        [final(256), dir(32)]->128
+constexpr int FR_RGB = G_HALF * 2;          //  32  static_rgb          128->64
+
+constexpr int OFF_L1 = 0;
+constexpr int OFF_L2 = OFF_L1 + FR_L1;      // L2,L3,L4 contiguous
+constexpr int OFF_L5 = OFF_L2 + 3 * FR_HID;
+constexpr int OFF_L6 = OFF_L5 + FR_L5;      // L6,L7,L8 contiguous
+constexpr int OFF_FIN = OFF_L6 + 3 * FR_HID;
+constexpr int OFF_DIR = OFF_FIN + FR_HID;
+constexpr int OFF_RGB = OFF_DIR + FR_DIR;
+constexpr int STREAM_FRAGS = OFF_RGB + FR_RGB;               // 2416
+constexpr int STAGES_PER_PASS = STREAM_FRAGS / STAGE_FRAGS;  // 151
+static_assert(STREAM_FRAGS % STAGE_FRAGS == 0, "stream must be whole stages");
+static_assert(FR_L1 % STAGE_FRAGS == 0 && FR_L5 % STAGE_FRAGS == 0 && FR_DIR % STAGE_FRAGS == 0 &&
+              FR_RGB % STAGE_FRAGS == 0, "layers must be whole stages");
+
+// consts block (float offsets)
+constexpr int C_BIAS = 0;                    // 8 x 256: xyz_encoding_{1..8} biases
+constexpr int C_BFIN = 8 * W_HIDDEN;         // 256: xyz_encoding_final bias
+constexpr int C_WSIG = C_BFIN + W_HIDDEN;    // 256: static_sigma weight row
+constexpr int C_BSIG = C_WSIG + W_HIDDEN;    // 1 (+3 pad): static_sigma bias
+constexpr int C_BDIR = C_BSIG + 4;           // 128: dir_encoding bias
+constexpr int C_BRGB = C_BDIR + 128;         // 64: static_rgb bias
+constexpr int CONST_FLOATS = C_BRGB + 64;    // 2756
+constexpr int CONST_BYTES = 11264;           // padded to 11 KiB (multiple of 1 KiB)
+static_assert(CONST_FLOATS * 4 <= CONST_BYTES, "consts overflow");
+
+constexpr size_t PACKED_BYTES = (size_t)CONST_BYTES + (size_t)STREAM_FRAGS * FRAG_BYTES;  // 2,485,248
+
+// Positional-embedding slot order.  An embedding with F frequencies occupies 8*ceil((3F+2)/4)
+// padded k-slots.  Slot k = 8q + 4h + 2p + sc belongs to "argument" a = 4q + 2h + p:
+//   a <  3F     : (sin, cos)[sc] of 2^(a/3) * x[a%3]   -> reference column 3 + 6(a/3) + 3sc + a%3
+//   a == 3F     : (x, y)[sc]                           -> reference column sc
+//   a == 3F + 1 : (z, 0)[sc]                           -> reference column 2 / pad
+//   otherwise   : zero pad
+// Reference column order: PosEmbedding.forward, models/nerf.py:17-30.
+__host__ __device__ inline int posenc_slot_to_col(int k, int F) {
+  const int q = k >> 3, h = (k >> 2) & 1, p = (k >> 1) & 1, sc = k & 1;
+  const int a = 4 * q + 2 * h + p;
+  if (a < 3 * F) return 3 + 6 * (a / 3) + 3 * sc + (a % 3);
+  if (a == 3 * F) return sc;
+  if (a == 3 * F + 1) return sc == 0 ? 2 : -1;
+  return -1;
+}
+
+}  // namespace crnerf

@@ -1,0 +1,92 @@
+// Weight pre-pack (24 nn.Linear tensors of one NeRF_sigma -> consts + MFMA fragment stream) and the
+// stand-alone positional-embedding kernel.
+// Reference layouts: NeRF_sigma.__init__ models/nerf.py:137-154; PosEmbedding.forward models/nerf.py:17-30.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "layout.h"
+
+namespace crnerf {
+
+__global__ void pack_stream_kernel(MlpTensors t, float* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAM_FRAGS * FRAG_FLOATS) return;
+  const int frag = (int)(idx / FRAG_FLOATS);
+  const int lane = (int)(idx % FRAG_FLOATS) / 4, j = (int)(idx % 4);
+  const int i = lane & 31, kk = lane >> 5;
+
+  const float* W;
+  int in_dim, nt, phi, kind;  // kind: 0 hidden, 1 L1, 2 L5 (skip), 3 dir, 4 rgb
+  if (frag < OFF_L2) { W = t.w[0]; in_dim = XYZ_DIM; nt = 8; phi = frag - OFF_L1; kind = 1; }
+  else if (frag < OFF_L5) { const int l = (frag - OFF_L2) / FR_HID; W = t.w[1 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFF_L2) % FR_HID; kind = 0; }
+  else if (frag < OFF_L6) { W = t.w[4]; in_dim = XYZ_DIM + W_HIDDEN; nt = 8; phi = frag - OFF_L5; kind = 2; }
+  else if (frag < OFF_FIN) { const int l = (frag - OFF_L6) / FR_HID; W = t.w[5 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFF_L6) % FR_HID; kind = 0; }
+  else if (frag < OFF_DIR) { W = t.w_final; in_dim = W_HIDDEN; nt = 8; phi = frag - OFF_FIN; kind = 0; }
+  else if (frag < OFF_RGB) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; nt = 4; phi = frag - OFF_DIR; kind = 3; }
+  else { W = t.w_rgb; in_dim = 128; nt = 2; phi = frag - OFF_RGB; kind = 4; }
+
+  const int v = phi / nt, tile = phi % nt;
+  const int k = 8 * v + 4 * kk + j;
+  const int row = 32 * tile + i;
+  int col;
+  switch (kind) {
+    case 1: col = posenc_slot_to_col(k, XYZ_FREQS); break;
+    case 2: col = k < XYZ_PAD ? posenc_slot_to_col(k, XYZ_FREQS) : XYZ_DIM + (k - XYZ_PAD); break;  // nerf.py:169 cat([xyz, h])
+    case 3: col = k < W_HIDDEN ? k : (posenc_slot_to_col(k - W_HIDDEN, DIR_FREQS) < 0 ? -1 : W_HIDDEN + posenc_slot_to_col(k - W_HIDDEN, DIR_FREQS)); break;
+    default: col = k; break;
+  }
+  stream[idx] = col >= 0 ? W[(long)row * in_dim + col] : 0.0f;
+}
+
+__global__ void pack_consts_kernel(MlpTensors t, float* __restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CONST_BYTES / 4) return;
+  float v = 0.0f;
+  if (i < C_BFIN) v = t.b[i / W_HIDDEN][i % W_HIDDEN];
+  else if (i < C_WSIG) v = t.b_final[i - C_BFIN];
+  else if (i < C_BSIG) v = t.w_sigma[i - C_WSIG];
+  else if (i == C_BSIG) v = t.b_sigma[0];
+  else if (i < C_BDIR) v = 0.0f;
+  else if (i < C_BRGB) v = t.b_dir[i - C_BDIR];
+  else if (i < CONST_FLOATS) v = t.b_rgb[i - C_BRGB];
+  c[i] = v;
+}
+
+int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  float* wstream = (float*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAM_FRAGS * FRAG_FLOATS;
+  hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlp");
+}
+
+// x[n,3] -> out[n, 6F+3]; one thread per (row, argument) pair; accurate sincosf (see posenc.h).
+__global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ out, long n, int F) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = 3 * F + 1;
+  if (idx >= n * per_row) return;
+  const long row = idx / per_row;
+  const int a = (int)(idx % per_row);
+  const int D = 6 * F + 3;
+  const float* xr = x + row * 3;
+  float* o = out + row * D;
+  if (a == 3 * F) {
+    o[0] = xr[0]; o[1] = xr[1]; o[2] = xr[2];
+  } else {
+    const int f = a / 3, d = a % 3;
+    float s, c;
+    sincosf(ldexpf(1.0f, f) * xr[d], &s, &c);
+    o[3 + 6 * f + d] = s;
+    o[3 + 6 * f + 3 + d] = c;
+  }
+}
+
+int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n_freqs < 0 || n_freqs > 30) return set_error(-2, "posenc: n_freqs must be in [0, 30]");
+  const long total = n * (3 * n_freqs + 1);
+  hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, out, n, n_freqs);
+  return check_launch("posenc_kernel");
+}
+
+}  // namespace crnerf

@@ -1,0 +1,108 @@
+// Stand-alone (un-fused) per-ray kernels: alpha compositing over a materialised [R,N,65] tensor and
+// sample_pdf + merge.  They back the C-ABI test entry points and the general-N fallback path; the
+// production path is render_fused.hip.  Both are HBM-bandwidth kernels: one ray per wavefront,
+// coalesced 260-B sample rows, wave-prefix transmittance.
+// Reference: models/rendering.py:116-143 (compositing), :7-46 + :183-187 (sample_pdf, merge).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "ray_ops.h"
+
+namespace crnerf {
+
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                        const float* __restrict__ noise, float noise_std,
+                                                        float* __restrict__ weights, float* __restrict__ feature,
+                                                        float* __restrict__ depth, long R, int N) {
+  __shared__ float wbuf[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    const float* rr = raw + r * (long)N * OUT_DIM;
+    const float* zr = z + r * (long)N;
+    double carry = 1.0;
+    float facc = 0.0f, dacc = 0.0f;
+    for (int base = 0; base < N; base += 64) {
+      const int n = base + lane;
+      const bool valid = n < N;
+      const int nc = valid ? n : N - 1;
+      const float zn = zr[nc];
+      const float znext = zr[nc + 1 < N ? nc + 1 : N - 1];
+      const float sigma = rr[(long)nc * OUT_DIM + FEAT_DIM];
+      const float nz = (noise && valid) ? noise[r * (long)N + n] * noise_std : 0.0f;
+      const float delta = (n == N - 1) ? 1e2f : znext - zn;
+      const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sigma + nz, 0.0f)) : 0.0f;
+      double incl = (double)(1.0f - alpha);
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_f64(incl, d, 64);
+        if (lane >= d) incl *= o;
+      }
+      double excl = shfl_up_f64(incl, 1, 64);
+      if (lane == 0) excl = 1.0;
+      const float T = (float)(carry * excl);
+      carry *= shfl_f64(incl, 63, 64);
+      const float w = alpha * T;
+      if (valid) weights[r * (long)N + n] = w;
+      dacc += w * zn;
+      wbuf[wave][lane] = w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int cnt = N - base < 64 ? N - base : 64;
+      for (int i = 0; i < cnt; ++i) facc += wbuf[wave][i] * rr[(long)(base + i) * OUT_DIM + lane];  // lane = channel
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dacc += __shfl_xor(dacc, d);
+    feature[r * FEAT_DIM + lane] = facc;
+    if (lane == 0) depth[r] = dacc;
+  }
+}
+
+int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights, float* feature,
+                     float* depth, long R, int N, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (N < 1) return set_error(-2, "composite: N must be >= 1");
+  const long blocks = (R + 3) / 4;
+  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  hipLaunchKernelGGL(composite_kernel, dim3(grid), dim3(256), 0, stream, raw, z, noise, noise_std, weights, feature, depth, R, N);
+  return check_launch("composite_kernel");
+}
+
+__global__ __launch_bounds__(64) void sample_pdf_merge_kernel(const float* __restrict__ z_coarse, const float* __restrict__ w_coarse,
+                                                              const float* __restrict__ u, float* __restrict__ z_sorted,
+                                                              float* __restrict__ z_samples, long R, int Nc, int Ni) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  RayScratch s;
+  s.bind((lds_char*)smem, Nc, Ni);
+  for (long r = blockIdx.x; r < R; r += gridDim.x) {
+    for (int n = lane; n < Nc; n += 64) {
+      s.zc[n] = z_coarse[r * Nc + n];
+      s.wc[n] = w_coarse[r * Nc + n];
+    }
+    wave_lds_fence();
+    sample_pdf_wave(s, Nc, Ni, u ? u + r * Ni : nullptr, lane);
+    merge_sort_wave(s, Nc, Ni, lane);
+    for (int n = lane; n < Nc + Ni; n += 64) z_sorted[r * (long)(Nc + Ni) + n] = s.zs[n];
+    if (z_samples)
+      for (int n = lane; n < Ni; n += 64) z_samples[r * (long)Ni + n] = s.zf[n];
+    wave_lds_fence();
+  }
+}
+
+int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, float* z_fine_sorted,
+                            float* z_samples, long R, int Nc, int Ni, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (Nc < 3 || Ni < 1) return set_error(-2, "sample_pdf_merge: need N_samples >= 3 and N_importance >= 1");
+  const size_t shmem = (size_t)(3 * Nc + 2 * Ni) * 4;
+  if (shmem > 160 * 1024) return set_error(-2, "sample_pdf_merge: 3*N_samples + 2*N_importance exceeds LDS");
+  hipError_t e = hipFuncSetAttribute((const void*)sample_pdf_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(sample_pdf_merge_kernel) failed");
+  const int grid = (int)(R < 8192 ? R : 8192);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), shmem, stream, z_coarse, weights_coarse, u, z_fine_sorted,
+                     z_samples, R, Nc, Ni);
+  return check_launch("sample_pdf_merge_kernel");
+}
+
+}  // namespace crnerf

@@ -1,0 +1,206 @@
+// Per-ray (= per-wavefront) operations of the volumetric renderer: sample depths, alpha
+// compositing with a wave-prefix transmittance, inverse-CDF hierarchical sampling and the z merge.
+// One ray per wavefront; all per-ray arrays live in a wave-private LDS scratch.
+//
+// Reference: models/rendering.py
+//   :161-178  coarse depths (linear / disparity)           -> coarse_depth()
+//   :116-143  deltas, alpha, exclusive cumprod, weights    -> composite_tile() / wave reductions
+//   :7-46     sample_pdf                                   -> sample_pdf_wave()
+//   :187      sort(cat(z_coarse, z_fine))                  -> merge_sort_wave()
+//
+// Numerical notes (parity with the reference's CPU path): products that the reference evaluates
+// as separate mul/add are kept un-fused (this TU is built with -ffp-contract=off); the two scans
+// (cumsum of the pdf, cumprod of 1-alpha) run in fp64 like ATen's CPU cumsum/cumprod accumulators,
+// then round to fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mlp_core.h"
+
+namespace crnerf {
+
+constexpr int MAX_NC = 256;
+constexpr int MAX_NI = 256;
+constexpr int SCRATCH_FLOATS = MAX_NC + MAX_NC + MAX_NI + (MAX_NC + MAX_NI);  // zc, wc, zf, zs
+constexpr int SCRATCH_BYTES = SCRATCH_FLOATS * 4;                             // 5 KiB per wave
+
+struct RayScratch {
+  lds_float* zc;   // [Nc] coarse depths
+  lds_float* wc;   // [Nc] coarse weights, then reused as the cdf [Nc-1]
+  lds_float* zf;   // [Ni] importance samples
+  lds_float* zs;   // [Nc+Ni] merged, ascending
+  __device__ __forceinline__ void bind(lds_char* base, int nc_cap = MAX_NC, int ni_cap = MAX_NI) {
+    zc = (lds_float*)base;
+    wc = zc + nc_cap;
+    zf = wc + nc_cap;
+    zs = zf + ni_cap;
+  }
+};
+
+// wave-private LDS traffic only needs the LDS queue drained, not a workgroup barrier
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// torch.linspace(0, 1, n)[i] as ATen computes it (symmetric around the midpoint)
+__device__ __forceinline__ float linspace01(int i, int n) {
+  const float step = 1.0f / (float)(n - 1);
+  return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+// rendering.py:161-165
+__device__ __forceinline__ float coarse_depth(float near, float far, int i, int n, int use_disp) {
+  const float s = (n > 1) ? linspace01(i, n) : 0.0f;
+  const float t = 1.0f - s;
+  if (!use_disp) return near * t + far * s;
+  return 1.0f / ((1.0f / near) * t + (1.0f / far) * s);
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v, int delta, int width) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_up(lo, delta, width);
+  hi = __shfl_up(hi, delta, width);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_f64(double v, int src, int width) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src, width);
+  hi = __shfl(hi, src, width);
+  return __hiloint2double(hi, lo);
+}
+
+// State of one compositing pass over a ray, distributed as lane (p = lane&31, h = lane>>5).
+struct CompositeState {
+  double t_carry;     // transmittance entering the current tile
+  f32x16 facc[2];     // sum_n w_n * feat_n, this lane's point column, features 32t+8q+4h+j
+  float dacc;         // sum_n w_n * z_n (lanes h == 0 only)
+  __device__ __forceinline__ void reset() {
+    t_carry = 1.0;
+    dacc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) facc[t][r] = 0.0f;
+  }
+};
+
+// One 32-sample tile.  zn / znext: depth of this lane's sample and the following one; is_last:
+// n == N-1 (delta = 1e2, rendering.py:122); valid: n < N.  Returns the weight w_n.
+__device__ __forceinline__ float composite_tile(CompositeState& st, const f32x16 (&feat)[2], float sigma, float noise,
+                                                float zn, float znext, bool is_last, bool valid, int p) {
+  const float delta = is_last ? 1e2f : znext - zn;
+  const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sigma + noise, 0.0f)) : 0.0f;
+  double incl = (double)(1.0f - alpha);  // inclusive prefix product over the 32 lanes of this half
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const double o = shfl_up_f64(incl, d, 32);
+    if (p >= d) incl *= o;
+  }
+  double excl = shfl_up_f64(incl, 1, 32);
+  if (p == 0) excl = 1.0;
+  const float T = (float)(st.t_carry * excl);
+  st.t_carry *= shfl_f64(incl, 31, 32);
+  const float w = alpha * T;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st.facc[t][r] += w * feat[t][r];
+  st.dacc += w * zn;
+  return w;
+}
+
+// Cross-lane reduction of the accumulators over the 32 point-lanes of each half; afterwards every
+// lane holds the totals (features 32t+8q+4h+j of the ray in facc[t][4q+j]).
+__device__ __forceinline__ void composite_finish(CompositeState& st) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.facc[t][r] += __shfl_xor(st.facc[t][r], d);
+    st.dacc += __shfl_xor(st.dacc, d);
+  }
+}
+
+__device__ __forceinline__ void store_ray_feature(const CompositeState& st, float* feature_row, float* depth, int p, int h) {
+  if (p == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {st.facc[t][4 * q + 0], st.facc[t][4 * q + 1], st.facc[t][4 * q + 2], st.facc[t][4 * q + 3]};
+        *(f32x4*)(feature_row + 32 * t + 8 * q + 4 * h) = v;
+      }
+    if (h == 0) *depth = st.dacc;
+  }
+}
+
+// sample_pdf(bins = z_mid, weights = w[1:-1], Ni, det) -- rendering.py:7-46, called at :183-184.
+// In: s.zc[Nc], s.wc[Nc] (coarse weights).  Out: s.zf[Ni].  u_row: per-ray uniforms or null (det).
+__device__ __forceinline__ void sample_pdf_wave(RayScratch& s, int Nc, int Ni, const float* u_row, int lane) {
+  const int n_ = Nc - 2;       // number of pdf bins
+  const float eps = 1e-5f;
+  // sum of (w + eps) over the interior weights
+  float part = 0.0f;
+  for (int i = lane; i < n_; i += 64) part += s.wc[1 + i] + eps;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  const float wsum = part;
+  // cdf[0] = 0, cdf[k] = float(sum_{i<k} double(pdf_i)); computed chunk-wise with an fp64 wave scan
+  double carry = 0.0;
+  for (int base = 0; base < n_; base += 64) {
+    const int i = base + lane;
+    const float pdf = (i < n_) ? (s.wc[1 + i] + eps) / wsum : 0.0f;
+    double incl = (double)pdf;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = shfl_up_f64(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    incl += carry;
+    carry = shfl_f64(incl, 63, 64);
+    wave_lds_fence();  // all lanes have read wc[1+i] of this chunk before cdf overwrites wc[i+1]
+    if (i < n_) s.wc[i + 1] = (float)incl;
+  }
+  if (lane == 0) s.wc[0] = 0.0f;
+  wave_lds_fence();
+  const lds_float* cdf = s.wc;  // [n_ + 1]
+  for (int k = lane; k < Ni; k += 64) {
+    const float u = u_row ? u_row[k] : linspace01(k, Ni);
+    // searchsorted(cdf, u, right=True): number of entries <= u
+    int lo = 0, hi = n_ + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 < 0 ? 0 : lo - 1;
+    const int above = lo > n_ ? n_ : lo;
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = 0.5f * (s.zc[below] + s.zc[below + 1]);
+    const float b1 = 0.5f * (s.zc[above] + s.zc[above + 1]);
+    float denom = c1 - c0;
+    if (denom < eps) denom = 1.0f;
+    s.zf[k] = b0 + (u - c0) / denom * (b1 - b0);
+  }
+  wave_lds_fence();
+}
+
+// zs = sort(cat(zc, zf)) by rank counting (stable: coarse before fine, then by index); O(N^2/64)
+// compares per lane, negligible beside the MLP and valid for unsorted zf (perturb > 0).
+__device__ __forceinline__ void merge_sort_wave(RayScratch& s, int Nc, int Ni, int lane) {
+  const int N = Nc + Ni;
+  for (int e = lane; e < N; e += 64) {
+    const bool is_c = e < Nc;
+    const float v = is_c ? s.zc[e] : s.zf[e - Nc];
+    int rank = 0;
+    for (int j = 0; j < Nc; ++j) {
+      const float o = s.zc[j];
+      rank += (o < v) || (o == v && (!is_c || j < e));
+    }
+    for (int j = 0; j < Ni; ++j) {
+      const float o = s.zf[j];
+      rank += (o < v) || (o == v && !is_c && j < e - Nc);
+    }
+    s.zs[rank] = v;
+  }
+  wave_lds_fence();
+}
+
+}  // namespace crnerf

@@ -1,0 +1,95 @@
+"""Cross-ray appearance transfer + decoder with the reference's class names, constructor
+signatures and state_dict keys (reference models/linearStyleTransfer.py: CNN :6-37, MulLayer :43-94,
+style_net :278-291), computed by the HIP kernels of csrc/crossray.hip.
+
+The modules only own parameters; style_net.forward drives the kernel sequence
+chansum -> (mean) -> gram -> matrix -> fold -> apply.  When a torch.distributed process group is
+passed (rays sharded across GPUs), the two tiny reductions become RCCL all-reduces (parallel.py)."""
+import torch
+from torch import nn
+
+from .. import ops
+from .nerf_decoder_stylenerf import NeuralRenderer
+
+
+def _pixel_major(x):
+    """[1,C,H,W] -> ([HW,C] contiguous, (H,W)).  A grid built the reference way
+    (feature[R,64] -> transpose -> view, eval.py:291-292) is already pixel-major in memory, so this
+    is a zero-copy view; a plain NCHW tensor is transposed once."""
+    if x.dim() != 4 or x.shape[0] != 1:
+        raise ValueError("expected a [1,C,H,W] grid, got %s" % (tuple(x.shape),))
+    _, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(H * W, C).contiguous(), (H, W)
+
+
+class CNN(nn.Module):
+    def __init__(self, matrixSize=32, in_channel=64):
+        super().__init__()
+        if matrixSize != 32 or in_channel != 64:
+            raise NotImplementedError("crnerf_amd: CNN is implemented for matrixSize=32, in_channel=64")
+        self.convs = nn.Sequential(nn.Conv2d(in_channel, 128, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
+                                   nn.Conv2d(128, 64, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
+                                   nn.Conv2d(64, matrixSize, 1, 1, 0))
+        self.fc = nn.Linear(matrixSize * matrixSize, matrixSize * matrixSize)
+
+    def conv_tensors(self):
+        c0, c2, c4 = self.convs[0], self.convs[2], self.convs[4]
+        return [c0.weight.reshape(128, 64), c0.bias, c2.weight.reshape(64, 128), c2.bias, c4.weight.reshape(32, 64), c4.bias]
+
+    def gram_sum(self, x_pm, mean):
+        """Sum over pixels of f(x-mean) f(x-mean)^T (before the /(h*w), CNN.forward :31-34)."""
+        return ops.crossray_gram(x_pm, mean, self.conv_tensors())
+
+    def matrix(self, gram_sum, count):
+        return ops.crossray_matrix(gram_sum, count, self.fc.weight, self.fc.bias)
+
+    def forward(self, x):
+        """x: centred [1,64,h,w] -> [1,1024] (reference CNN.forward)."""
+        xp, (H, W) = _pixel_major(x)
+        zero = torch.zeros(64, device=x.device)
+        return self.matrix(self.gram_sum(xp, zero), H * W).view(1, -1)
+
+
+class MulLayer(nn.Module):
+    def __init__(self, matrixSize=32, in_channel=64):
+        super().__init__()
+        self.snet = CNN(matrixSize)
+        self.cnet = CNN(matrixSize)
+        self.matrixSize = matrixSize
+        self.compress = nn.Conv2d(in_channel, matrixSize, 1, 1, 0)
+        self.unzip = nn.Conv2d(matrixSize, in_channel, 1, 1, 0)
+        self.transmatrix = None
+
+    def lin_tensors(self):
+        return [self.compress.weight.reshape(32, 64), self.compress.bias, self.unzip.weight.reshape(64, 32), self.unzip.bias]
+
+
+class style_net(nn.Module):
+    def __init__(self, args, residual_blocks=2):
+        super().__init__()
+        nerf_channel = args.nerf_out_dim
+        self.multi_net = MulLayer(in_channel=nerf_channel)
+        self.decoder = NeuralRenderer(img_size=(args.img_wh[0], args.img_wh[1]), featmap_size=(args.img_wh[0], args.img_wh[1]),
+                                      feat_nc=args.nerf_out_dim, out_dim=3, args_here=args)
+
+    def affine_from_stats(self, c_sum, c_gram, c_count, style_feature):
+        """Everything downstream of the two global reductions: replicated, tiny.  c_sum[64] and
+        c_gram[1024] are GLOBAL sums over all content pixels, c_count the global pixel count."""
+        mn = self.multi_net
+        sp, _ = _pixel_major(style_feature)
+        s_mean = ops.crossray_chansum(sp) / sp.shape[0]
+        s_matrix = mn.snet.matrix(mn.snet.gram_sum(sp, s_mean), sp.shape[0])
+        c_mean = c_sum / c_count
+        c_matrix = mn.cnet.matrix(c_gram, c_count)
+        return ops.crossray_fold(s_matrix, c_matrix, c_mean, s_mean, mn.lin_tensors() + list(self.decoder.rgb_tensors()))
+
+    def forward(self, content_feature, style_feature, type=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad()")
+        if style_feature is None and type == "content":
+            return self.decoder(content_feature)
+        xp, (H, W) = _pixel_major(content_feature)
+        c_sum = ops.crossray_chansum(xp)
+        c_gram = self.multi_net.cnet.gram_sum(xp, c_sum / xp.shape[0])
+        affine = self.affine_from_stats(c_sum, c_gram, xp.shape[0], style_feature)
+        return ops.crossray_apply(xp, affine).view(1, 3, H, W)

@@ -1,0 +1,76 @@
+"""PosEmbedding and NeRF_sigma with the reference's constructor signatures and state_dict keys
+(reference: models/nerf.py:4-30 and :115-182), backed by the HIP kernels.
+
+Only the classes the reference instantiates are mirrored (NeRF and NeRF_sigma_tanh are never
+constructed -- SURVEY 2, row 2).
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+_XYZ_FREQS, _DIR_FREQS, _W, _OUT = 15, 4, 256, 64
+
+
+class PosEmbedding(nn.Module):
+    """(x, sin(2^k x), cos(2^k x), ...) -- reference models/nerf.py:4-30."""
+
+    def __init__(self, max_logscale, N_freqs, logscale=True):
+        super().__init__()
+        if not logscale:
+            raise NotImplementedError("crnerf_amd: only logscale=True frequencies are implemented in HIP "
+                                      "(the reference never constructs logscale=False)")
+        if max_logscale != N_freqs - 1:
+            raise NotImplementedError("crnerf_amd: frequencies must be 2^0..2^(N_freqs-1), i.e. max_logscale == N_freqs-1 "
+                                      "(how every reference call site builds it: eval.py:91-92)")
+        self.N_freqs = int(N_freqs)
+        self.max_logscale = max_logscale
+        self.freqs = 2 ** torch.linspace(0, max_logscale, N_freqs)
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        return ops.posenc(x.reshape(-1, 3), self.N_freqs).reshape(*lead, 6 * self.N_freqs + 3)
+
+
+class NeRF_sigma(nn.Module):
+    """8x256 density/feature MLP -- reference models/nerf.py:115-182 (same ctor, attributes, keys)."""
+
+    def __init__(self, typ, args, D=8, W=256, skips=[4], in_channels_xyz=63, in_channels_dir=27,
+                 encode_appearance=False, in_channels_a=48, encode_random=False):
+        super().__init__()
+        self.typ = typ
+        self.D, self.W, self.skips = D, W, skips
+        self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
+        self.encode_appearance = False if typ == 'coarse' else encode_appearance
+        self.in_channels_a = in_channels_a if encode_appearance else 0
+        self.encode_random = False if typ == 'coarse' else encode_random
+        out_dim = args.nerf_out_dim
+        if (D, W, list(skips), in_channels_xyz, in_channels_dir, out_dim) != (8, _W, [4], 6 * _XYZ_FREQS + 3, 6 * _DIR_FREQS + 3, _OUT):
+            raise NotImplementedError(
+                "crnerf_amd: the HIP kernels are specialised for the shipped network (D=8, W=256, skips=[4], "
+                "in_channels_xyz=93, in_channels_dir=27, nerf_out_dim=64); got D=%r W=%r skips=%r xyz=%r dir=%r out=%r"
+                % (D, W, skips, in_channels_xyz, in_channels_dir, out_dim))
+        for i in range(D):
+            fan_in = in_channels_xyz if i == 0 else (W + in_channels_xyz if i in skips else W)
+            setattr(self, "xyz_encoding_%d" % (i + 1), nn.Sequential(nn.Linear(fan_in, W), nn.ReLU(True)))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.static_sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.ReLU(True))
+        self.static_rgb = nn.Sequential(nn.Linear(W // 2, out_dim), nn.Sigmoid())
+        self._packed = None
+        self._packed_key = None
+
+    # ---- packed weights (kernel layout), rebuilt whenever a parameter changes
+    def packed_weights(self):
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if self._packed is None or key != self._packed_key:
+            self._packed = ops.pack_mlp_weights(params, out=None)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x, sigma_only=False, output_random=True):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad() "
+                                      "(as eval.py:29 and appearance_modification_video.py:71 do)")
+        return ops.mlp_forward(self.packed_weights(), x, sigma_only=sigma_only)

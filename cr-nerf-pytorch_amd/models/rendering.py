@@ -1,0 +1,82 @@
+"""render_rays_cross_ray with the reference's signature (models/rendering.py:50-63) on the fused HIP
+renderer.  Callers: train_mask_grid_sample.py:185-197, eval.py:39-52,
+appearance_modification_video.py:82-95 -- all pass the first 11 arguments positionally."""
+import torch
+
+from .. import ops
+from .nerf import NeRF_sigma, PosEmbedding
+
+__all__ = ['render_rays_cross_ray']
+
+_FUSED_MAX = 256
+
+
+def _coarse_depths(rays, N_samples, use_disp, perturb):
+    """Stratified coarse depths for perturb > 0 (models/rendering.py:161-176), drawn with torch's RNG."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    s = torch.linspace(0, 1, N_samples, device=rays.device)
+    z = near * (1 - s) + far * s if not use_disp else 1 / (1 / near * (1 - s) + 1 / far * s)
+    z = z.expand(rays.shape[0], N_samples)
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    upper = torch.cat([mid, z[:, -1:]], -1)
+    lower = torch.cat([z[:, :1], mid], -1)
+    return (lower + (upper - lower) * (perturb * torch.rand_like(z))).contiguous()
+
+
+def _check_embedding(emb, n_freqs, what):
+    if not isinstance(emb, PosEmbedding) or emb.N_freqs != n_freqs:
+        raise NotImplementedError("crnerf_amd: embeddings['%s'] must be crnerf_amd PosEmbedding(%d, %d); the fused kernel computes "
+                                  "the embedding in registers and cannot call an arbitrary Python callable" % (what, n_freqs - 1, n_freqs))
+
+
+def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=False, perturb=0, noise_std=1,
+                          N_importance=0, chunk=1024 * 32, white_back=False, test_time=False, **kwargs):
+    """Same contract as the reference: returns weights_/feature_/depth_ for 'coarse' and, when
+    N_importance > 0, 'fine' (+ 'feature_fine_random', the SAME tensor object as 'feature_fine',
+    models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
+    reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible)."""
+    args = kwargs['args']
+    if getattr(args, 'pertubeCord', False):
+        raise NotImplementedError("crnerf_amd: args.pertubeCord (models/rendering.py:102-104) is not implemented in the HIP path")
+    if getattr(args, 'nerf_out_dim', 64) != 64:
+        raise NotImplementedError("crnerf_amd: nerf_out_dim must be 64")
+    _check_embedding(embeddings['xyz'], 15, 'xyz')
+    _check_embedding(embeddings['dir'], 4, 'dir')
+    coarse = models['coarse']
+    fine = models.get('fine') if N_importance > 0 else None
+    for m in (coarse, fine):
+        if m is not None and not isinstance(m, NeRF_sigma):
+            raise NotImplementedError("crnerf_amd: models must be crnerf_amd NeRF_sigma instances")
+    if torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters()):
+        raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad()")
+    if N_samples > _FUSED_MAX or N_importance > _FUSED_MAX:
+        raise NotImplementedError("crnerf_amd: the fused renderer handles N_samples, N_importance <= 256")
+
+    rays = rays.to(torch.float32).contiguous()
+    R = rays.shape[0]
+    view_dir = kwargs.get('view_dir', None)
+    z_coarse = u = noise_c = noise_f = None
+    if perturb > 0:
+        z_coarse = _coarse_depths(rays, N_samples, use_disp, perturb)
+        if N_importance > 0:
+            u = torch.rand(R, N_importance, device=rays.device)
+    if noise_std != 0:
+        noise_c = torch.randn(R, N_samples, device=rays.device)
+        if N_importance > 0:
+            noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
+
+    out = ops.render_rays(coarse.packed_weights(), fine.packed_weights() if fine is not None else None, rays,
+                          N_samples, N_importance, use_disp=use_disp, view_dir=view_dir, z_coarse=z_coarse, u=u,
+                          noise_coarse=noise_c, noise_fine=noise_f, noise_std=float(noise_std))
+
+    typ_c = coarse.typ
+    results = {'weights_%s' % typ_c: out['weights_coarse'], 'feature_%s' % typ_c: out['feature_coarse'],
+               'depth_%s' % typ_c: out['depth_coarse']}
+    if N_importance > 0:
+        typ_f = fine.typ
+        results['weights_%s' % typ_f] = out['weights_fine']
+        results['feature_%s' % typ_f] = out['feature_fine']
+        if kwargs.get('output_random', True) and fine.encode_random:
+            results['feature_fine_random'] = out['feature_fine']
+        results['depth_%s' % typ_f] = out['depth_fine']
+    return results

@@ -1,0 +1,189 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, enqueue the HIP kernels on the
+current stream.  Every function here runs on the GPU or raises."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MLP_TENSOR_NAMES = (
+    [n for i in range(1, 9) for n in ("xyz_encoding_%d.0.weight" % i, "xyz_encoding_%d.0.bias" % i)]
+    + ["xyz_encoding_final.weight", "xyz_encoding_final.bias", "static_sigma.0.weight", "static_sigma.0.bias",
+       "dir_encoding.0.weight", "dir_encoding.0.bias", "static_rgb.0.weight", "static_rgb.0.bias"])
+MLP_TENSOR_SHAPES = (
+    [(256, 93), (256,)] + [(256, 256), (256,)] * 3 + [(256, 349), (256,)] + [(256, 256), (256,)] * 3
+    + [(256, 256), (256,), (1, 256), (1,), (128, 283), (128,), (64, 128), (64,)])
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    if not t.is_cuda:
+        raise RuntimeError("crnerf_amd: %s is on %s; the HIP path needs GPU tensors and has no CPU fallback" % (name, t.device))
+    return t
+
+
+def pack_mlp_weights(state, out=None):
+    """state: mapping name -> device tensor with the 24 NeRF_sigma tensors (models/nerf.py:137-154)."""
+    lib = _lib.load()
+    tensors = []
+    for name, shape in zip(MLP_TENSOR_NAMES, MLP_TENSOR_SHAPES):
+        t = state[name]
+        if tuple(t.shape) != shape:
+            raise ValueError("crnerf_amd: %s has shape %s, the HIP kernels are built for %s "
+                             "(D=8, W=256, N_emb_xyz=15, N_emb_dir=4, nerf_out_dim=64)" % (name, tuple(t.shape), shape))
+        tensors.append(_f32c(t.detach(), name))
+    nbytes = lib.crnerf_packed_mlp_bytes()
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
+    arr = _lib.ptr_array(tensors, "mlp tensor")
+    _lib.check(lib.crnerf_pack_mlp_weights(arr, ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()), "crnerf_pack_mlp_weights")
+    return out
+
+
+def posenc(x, n_freqs):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise ValueError("posenc expects [n,3], got %s" % (tuple(x.shape),))
+    out = torch.empty(x.shape[0], 6 * n_freqs + 3, dtype=torch.float32, device=x.device)
+    _lib.check(lib.crnerf_posenc_f32(_lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], n_freqs, _lib.stream_ptr()), "crnerf_posenc_f32")
+    return out
+
+
+def mlp_forward(packed, x, sigma_only=False):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    want = 93 if sigma_only else 120
+    if x.dim() != 2 or x.shape[1] != want:
+        raise ValueError("mlp_forward expects [n,%d], got %s" % (want, tuple(x.shape)))
+    out = torch.empty(x.shape[0], 1 if sigma_only else 65, dtype=torch.float32, device=x.device)
+    _lib.check(lib.crnerf_mlp_forward_f32(ctypes.c_void_p(packed.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0],
+                                          int(bool(sigma_only)), _lib.stream_ptr()), "crnerf_mlp_forward_f32")
+    return out
+
+
+def composite(raw, z, noise=None, noise_std=0.0):
+    lib = _lib.load()
+    raw, z = _f32c(raw, "raw"), _f32c(z, "z")
+    R, N = z.shape
+    if tuple(raw.shape) != (R, N, 65):
+        raise ValueError("composite expects raw [R,N,65], got %s" % (tuple(raw.shape),))
+    if noise is not None:
+        noise = _f32c(noise, "noise")
+    w = torch.empty(R, N, dtype=torch.float32, device=z.device)
+    feat = torch.empty(R, 64, dtype=torch.float32, device=z.device)
+    depth = torch.empty(R, dtype=torch.float32, device=z.device)
+    _lib.check(lib.crnerf_composite_f32(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(noise), float(noise_std), _lib.dev_ptr(w),
+                                        _lib.dev_ptr(feat), _lib.dev_ptr(depth), R, N, _lib.stream_ptr()), "crnerf_composite_f32")
+    return w, feat, depth
+
+
+def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samples=False):
+    lib = _lib.load()
+    z_coarse, weights_coarse = _f32c(z_coarse, "z_coarse"), _f32c(weights_coarse, "weights_coarse")
+    R, Nc = z_coarse.shape
+    if u is not None:
+        u = _f32c(u, "u")
+    zs = torch.empty(R, Nc + n_importance, dtype=torch.float32, device=z_coarse.device)
+    smp = torch.empty(R, n_importance, dtype=torch.float32, device=z_coarse.device) if return_samples else None
+    _lib.check(lib.crnerf_sample_pdf_merge_f32(_lib.dev_ptr(z_coarse), _lib.dev_ptr(weights_coarse), _lib.dev_ptr(u), _lib.dev_ptr(zs),
+                                               _lib.dev_ptr(smp), R, Nc, n_importance, _lib.stream_ptr()), "crnerf_sample_pdf_merge_f32")
+    return (zs, smp) if return_samples else zs
+
+
+def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, u=None,
+                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False):
+    """Fused renderer.  Returns a dict of freshly allocated tensors."""
+    lib = _lib.load()
+    rays = _f32c(rays, "rays")
+    if rays.dim() != 2 or rays.shape[1] != 8:
+        raise ValueError("rays must be [R,8], got %s" % (tuple(rays.shape),))
+    R, dev = rays.shape[0], rays.device
+    Nc, Ni = int(n_samples), int(n_importance)
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    out = {"weights_coarse": new(R, Nc), "feature_coarse": new(R, 64), "depth_coarse": new(R)}
+    if Ni > 0:
+        out.update({"weights_fine": new(R, Nc + Ni), "feature_fine": new(R, 64), "depth_fine": new(R)})
+        if want_z_fine:
+            out["z_fine"] = new(R, Nc + Ni)
+    if R == 0:
+        return out
+    keep = [t if t is None else _f32c(t, n) for t, n in ((view_dir, "view_dir"), (z_coarse, "z_coarse"), (u, "u"),
+                                                         (noise_coarse, "noise_coarse"), (noise_fine, "noise_fine"))]
+    a = _lib.RenderArgs()
+    a.packed_coarse = packed_coarse.data_ptr()
+    a.packed_fine = packed_fine.data_ptr() if packed_fine is not None else None
+    a.rays = rays.data_ptr()
+    for field, t in zip(("view_dir", "z_coarse", "u", "noise_coarse", "noise_fine"), keep):
+        setattr(a, field, t.data_ptr() if t is not None else None)
+    a.noise_std = float(noise_std)
+    a.use_disp = int(bool(use_disp))
+    a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
+    for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine"):
+        setattr(a, k, out[k].data_ptr() if k in out else None)
+    _lib.check(lib.crnerf_render_rays_f32(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32")
+    return out
+
+
+# ---------------------------------------------------------------- cross-ray decoder pieces
+_ws_cache = {}
+
+
+def crossray_workspace(device):
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(_lib.load().crnerf_crossray_workspace_bytes(), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def crossray_chansum(x):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    out = torch.empty(64, dtype=torch.float32, device=x.device)
+    ws = crossray_workspace(x.device)
+    _lib.check(lib.crnerf_crossray_chansum_f32(_lib.dev_ptr(x), x.shape[0], _lib.dev_ptr(out), ctypes.c_void_p(ws.data_ptr()),
+                                               _lib.stream_ptr()), "crnerf_crossray_chansum_f32")
+    return out
+
+
+def crossray_gram(x, mean, cnn):
+    lib = _lib.load()
+    x, mean = _f32c(x, "x"), _f32c(mean, "mean")
+    cnn = [_f32c(t.detach(), "cnn") for t in cnn]
+    out = torch.empty(1024, dtype=torch.float32, device=x.device)
+    ws = crossray_workspace(x.device)
+    _lib.check(lib.crnerf_crossray_gram_f32(_lib.dev_ptr(x), x.shape[0], _lib.dev_ptr(mean), _lib.ptr_array(cnn, "cnn"), _lib.dev_ptr(out),
+                                            ctypes.c_void_p(ws.data_ptr()), _lib.stream_ptr()), "crnerf_crossray_gram_f32")
+    return out
+
+
+def crossray_matrix(gram_sum, count, fc_w, fc_b):
+    lib = _lib.load()
+    fc_w, fc_b = _f32c(fc_w.detach(), "fc_w"), _f32c(fc_b.detach(), "fc_b")
+    out = torch.empty(1024, dtype=torch.float32, device=gram_sum.device)
+    _lib.check(lib.crnerf_crossray_matrix_f32(_lib.dev_ptr(gram_sum), float(count), _lib.dev_ptr(fc_w), _lib.dev_ptr(fc_b),
+                                              _lib.dev_ptr(out), _lib.stream_ptr()), "crnerf_crossray_matrix_f32")
+    return out
+
+
+def crossray_fold(s_matrix, c_matrix, c_mean, s_mean, lin):
+    lib = _lib.load()
+    lin = [_f32c(t.detach(), "lin") for t in lin]
+    out = torch.empty(195, dtype=torch.float32, device=lin[0].device)
+    _lib.check(lib.crnerf_crossray_fold_f32(_lib.dev_ptr(s_matrix), _lib.dev_ptr(c_matrix), _lib.dev_ptr(c_mean), _lib.dev_ptr(s_mean),
+                                            _lib.ptr_array(lin, "lin"), _lib.dev_ptr(out), _lib.stream_ptr()), "crnerf_crossray_fold_f32")
+    return out
+
+
+def crossray_apply(x, affine, out=None):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    HW = x.shape[0]
+    if out is None:
+        out = torch.empty(3, HW, dtype=torch.float32, device=x.device)
+    _lib.check(lib.crnerf_crossray_apply_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(affine), _lib.dev_ptr(out), out.stride(0), _lib.stream_ptr()),
+               "crnerf_crossray_apply_f32")
+    return out

@@ -1,0 +1,125 @@
+/*
+ * crnerf.h -- C ABI of the MI355X-native CR-NeRF rendering hot path (libcrnerf_hip.so).
+ *
+ * The reference (YifYang993/CR-NeRF-PyTorch) has no FFI layer: its boundary for this path is the
+ * Python call render_rays_cross_ray(...) plus the nn.Module protocol of NeRF_sigma / PosEmbedding /
+ * style_net.  Each entry point below replaces the eager-PyTorch op cluster cited next to it; the
+ * Python shim in cr-nerf-pytorch_amd/models/ presents the reference signatures on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a caller-owned, contiguous fp32 buffer unless stated;
+ *   - nothing is allocated inside; scratch comes from caller-provided workspaces whose size is
+ *     returned by the *_bytes() queries;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue work;
+ *   - return value: 0 on success, negative error code otherwise; crnerf_last_error() returns the
+ *     thread-local message of the last failing call; nothing throws;
+ *   - the network shape is the one the reference ships and hard-wires (models/nerf.py:117,
+ *     opt.py:46-48,93): D=8, W=256, skip at layer 5, N_emb_xyz=15, N_emb_dir=4, nerf_out_dim=64.
+ */
+#ifndef CRNERF_H
+#define CRNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRNERF_ABI_VERSION 1
+
+#define CRNERF_OK 0
+#define CRNERF_ERR_NULL (-1)     /* required pointer is NULL */
+#define CRNERF_ERR_SHAPE (-2)    /* unsupported size */
+#define CRNERF_ERR_CONFIG (-3)   /* inconsistent arguments */
+#define CRNERF_ERR_HIP (-10)     /* HIP runtime / launch failure */
+
+int crnerf_abi_version(void);
+const char* crnerf_last_error(void);
+
+/* Tensor order of one NeRF_sigma state_dict (models/nerf.py:137-154):
+ *   [2i], [2i+1]  xyz_encoding_{i+1}.0.weight / .bias   i = 0..7   ([256,93] [256,256]x3 [256,349] [256,256]x3)
+ *   [16],[17]     xyz_encoding_final.weight / .bias     [256,256]
+ *   [18],[19]     static_sigma.0.weight / .bias         [1,256]
+ *   [20],[21]     dir_encoding.0.weight / .bias         [128,283]
+ *   [22],[23]     static_rgb.0.weight / .bias           [64,128]                                        */
+#define CRNERF_MLP_TENSORS 24
+
+/* Bytes of one packed model (consts + MFMA fragment stream). */
+size_t crnerf_packed_mlp_bytes(void);
+
+/* Re-pack the 24 nn.Linear tensors into the kernels' layout (padded K = 96/352/288, A-operand
+ * fragment order).  Replaces nothing in the reference (it feeds at::addmm the raw tensors);
+ * called once per weight update.  `tensors` is a HOST array of 24 device pointers. */
+int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* stream);
+
+/* PosEmbedding.forward, models/nerf.py:17-30 (logscale freqs 2^0..2^(F-1)): x[n,3] -> out[n,6F+3]. */
+int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream);
+
+/* NeRF_sigma.forward, models/nerf.py:157-182: x[n,120] -> out[n,65] (64 features then sigma);
+ * sigma_only != 0: x[n,93] -> out[n,1] (models/nerf.py:159-160,173-174). */
+int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream);
+
+/* Compositing part of the nested inference(), models/rendering.py:116-143:
+ * raw[R,N,65], z[R,N], optional noise[R,N] (scaled by noise_std) -> weights[R,N], feature[R,64], depth[R]. */
+int crnerf_composite_f32(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
+                         float* feature, float* depth, int64_t R, int N, void* stream);
+
+/* sample_pdf + merge, models/rendering.py:7-46 and :183-187:
+ * z_coarse[R,Nc], weights_coarse[R,Nc] (the full coarse weights; [:,1:-1] is taken inside),
+ * u[R,Ni] or NULL (deterministic linspace) -> z_sorted[R,Nc+Ni]; z_samples[R,Ni] optional (NULL to skip). */
+int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, float* z_sorted,
+                                float* z_samples, int64_t R, int Nc, int Ni, void* stream);
+
+/* render_rays_cross_ray, models/rendering.py:50-196, fully fused (coarse -> sample_pdf -> fine). */
+typedef struct crnerf_render_args {
+  const void* packed_coarse;    /* crnerf_pack_mlp_weights output for models['coarse'] */
+  const void* packed_fine;      /* ... for models['fine']; may be NULL when n_importance == 0 */
+  const float* rays;            /* [R,8] = o(3) d(3) near far, rendering.py:152-153 */
+  const float* view_dir;        /* [R,3] or NULL -> rays[:,3:6], rendering.py:155 */
+  const float* z_coarse;        /* [R,Nc] or NULL -> rendering.py:161-165 computed in-kernel (perturb == 0) */
+  const float* u;               /* [R,Ni] or NULL -> linspace(0,1,Ni) (det = perturb == 0), rendering.py:26-31 */
+  const float* noise_coarse;    /* [R,Nc] standard-normal or NULL, rendering.py:125 */
+  const float* noise_fine;      /* [R,Nc+Ni] or NULL */
+  float noise_std;
+  int32_t use_disp;
+  int64_t n_rays;
+  int32_t n_samples;            /* Nc in [2,256] */
+  int32_t n_importance;         /* Ni in [0,256] */
+  float* weights_coarse;        /* [R,Nc] */
+  float* feature_coarse;        /* [R,64] */
+  float* depth_coarse;          /* [R] */
+  float* weights_fine;          /* [R,Nc+Ni]  (ignored when Ni == 0) */
+  float* feature_fine;          /* [R,64] */
+  float* depth_fine;            /* [R] */
+  float* z_fine;                /* [R,Nc+Ni] optional debug/test output, NULL to skip */
+} crnerf_render_args;
+int crnerf_render_rays_f32(const crnerf_render_args* args, void* stream);
+
+/* Cross-ray transformation + decoder: style_net.forward models/linearStyleTransfer.py:284-291,
+ * MulLayer.forward :58-94, CNN.forward :28-37, NeuralRenderer.forward nerf_decoder_stylenerf.py:279-291.
+ * Feature grids are pixel-major x[HW,64]; split at the two global reductions (see crossray.hip). */
+size_t crnerf_crossray_workspace_bytes(void);
+/* per-channel sums over pixels (divide by the GLOBAL pixel count to get MulLayer's mean, :59-65/:67-73) */
+int crnerf_crossray_chansum_f32(const float* x, int64_t HW, float* sum64, void* workspace, void* stream);
+/* cnn[6] = HOST array of device pointers: convs.0.weight[128,64], .bias, convs.2.weight[64,128], .bias,
+ * convs.4.weight[32,64], .bias.  gram_sum[32*32] = sum over pixels of f(x-mean) f(x-mean)^T  (CNN.forward :29-34
+ * before the division by h*w). */
+int crnerf_crossray_gram_f32(const float* x, int64_t HW, const float* mean64, const float* const* cnn, float* gram_sum,
+                             void* workspace, void* stream);
+/* out[1024] = fc(gram_sum / count)   (CNN.forward :34-37) */
+int crnerf_crossray_matrix_f32(const float* gram_sum, double count, const float* fc_w, const float* fc_b, float* out,
+                               void* stream);
+/* lin[6] = HOST array of device pointers: compress.weight[32,64], .bias, unzip.weight[64,32], .bias,
+ * feat_2_rgb_list.0.weight[3,64], .bias.  Folds MulLayer :76-89 + the 1x1 rgb conv into affine[195] =
+ * A[3][64] then v[3].  s_matrix == NULL selects the type=="content" path (:285-287: decoder only). */
+int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const float* c_mean64, const float* s_mean64,
+                             const float* const* lin, float* affine, void* stream);
+/* rgb[c*plane_stride + px] = sigmoid(A[c] . x[px] + v[c]) */
+int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRNERF_H */

@@ -1,0 +1,177 @@
+"""CPU oracle: a plain-PyTorch (fp32, CPU) restatement of the reference's rendering hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by the product package.
+
+The reference is pure Python/PyTorch (no native code), so the oracle is Python/PyTorch too; a C
+restatement would have to re-implement ATen's sin/cos/exp/sgemm and would pin nothing extra.
+PARITY PIN: tests/golden/*.npz were produced by importing the reference itself in the build
+container (tests/golden/make_golden.py); tests/test_oracle.py checks every function below against
+them, so the oracle is pinned to the reference's own outputs.
+
+Each function cites the reference lines (under /root/reference) that it restates.  Weights are plain
+dicts name -> tensor using the reference's state_dict keys.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ models/nerf.py
+def posenc(x, n_freqs):
+    """PosEmbedding.forward, models/nerf.py:17-30, with freqs 2^0..2^(n_freqs-1) (ctor :12-13)."""
+    cols = [x]
+    for k in range(n_freqs):
+        scaled = float(2 ** k) * x
+        cols.append(scaled.sin())
+        cols.append(scaled.cos())
+    return torch.cat(cols, dim=-1)
+
+
+def mlp_forward(w, x, sigma_only=False):
+    """NeRF_sigma.forward, models/nerf.py:157-182.  x: [p,120] (or [p,93] when sigma_only)."""
+    xyz = x if sigma_only else x[:, :93]
+    h = xyz
+    for layer in range(1, 9):
+        if layer == 5:  # skip connection, input first (:168-169)
+            h = torch.cat((xyz, h), dim=1)
+        h = F.relu(F.linear(h, w["xyz_encoding_%d.0.weight" % layer], w["xyz_encoding_%d.0.bias" % layer]))
+    sigma = F.softplus(F.linear(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))  # :172, beta=1 thr=20
+    if sigma_only:
+        return sigma
+    final = F.linear(h, w["xyz_encoding_final.weight"], w["xyz_encoding_final.bias"])       # :176
+    g = F.relu(F.linear(torch.cat((final, x[:, 93:]), dim=1), w["dir_encoding.0.weight"], w["dir_encoding.0.bias"]))
+    feat = torch.sigmoid(F.linear(g, w["static_rgb.0.weight"], w["static_rgb.0.bias"]))      # :180
+    return torch.cat((feat, sigma), dim=-1)                                                  # :181
+
+
+# ------------------------------------------------------------------ models/rendering.py
+def composite(raw, z, noise=None, noise_std=0.0):
+    """Compositing half of inference(), models/rendering.py:116-143.
+    raw [R,N,65], z [R,N] -> weights [R,N], feature [R,64], depth [R]."""
+    feats, sigma = raw[..., :64], raw[..., 64]
+    delta = torch.cat((z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e2)), dim=-1)     # :121-123
+    if noise is not None:
+        sigma = sigma + noise * noise_std                                                  # :125-126
+    alpha = 1 - torch.exp(-delta * torch.relu(sigma))
+    trans = torch.cumprod(torch.cat((torch.ones_like(alpha[:, :1]), 1 - alpha), dim=-1)[:, :-1], dim=-1)  # :128-130
+    weights = alpha * trans                                                                # :132
+    feature = (weights.unsqueeze(-1) * feats).sum(dim=1)                                   # :136-138
+    depth = (weights * z).sum(dim=1)                                                       # :143
+    return weights, feature, depth
+
+
+def sample_pdf(bins, weights, n_importance, det=True, u=None, eps=1e-5):
+    """sample_pdf, models/rendering.py:7-46.  bins [R,M+1], weights [R,M]; u overrides the draw."""
+    R, M = weights.shape
+    wts = weights + eps
+    pdf = wts / wts.sum(dim=1, keepdim=True)
+    cdf = torch.cat((torch.zeros(R, 1, dtype=pdf.dtype), torch.cumsum(pdf, dim=-1)), dim=-1)  # :22-23
+    if u is None:
+        u = torch.linspace(0, 1, n_importance).expand(R, n_importance) if det else torch.rand(R, n_importance)
+    u = u.contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)                                           # :33
+    lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(M)
+    c_lo, c_hi = cdf.gather(1, lo), cdf.gather(1, hi)
+    b_lo, b_hi = bins.gather(1, lo), bins.gather(1, hi)
+    denom = c_hi - c_lo
+    denom = torch.where(denom < eps, torch.ones_like(denom), denom)                        # :41-42
+    return b_lo + (u - c_lo) / denom * (b_hi - b_lo)                                        # :45
+
+
+def coarse_depths(rays, n_samples, use_disp=False):
+    """models/rendering.py:160-167 (perturb == 0)."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    s = torch.linspace(0, 1, n_samples)
+    if use_disp:
+        z = 1 / (1 / near * (1 - s) + 1 / far * s)
+    else:
+        z = near * (1 - s) + far * s
+    return z.expand(rays.shape[0], n_samples)
+
+
+def fine_depths(z_coarse, weights_coarse, n_importance, det=True, u=None):
+    """models/rendering.py:183-187: z_mid, sample_pdf on weights[:,1:-1], sort(cat)."""
+    mid = 0.5 * (z_coarse[:, :-1] + z_coarse[:, 1:])
+    extra = sample_pdf(mid, weights_coarse[:, 1:-1], n_importance, det=det, u=u)
+    return torch.sort(torch.cat((z_coarse, extra), dim=-1), dim=-1)[0], extra
+
+
+def _run_model(w, rays, z, dir_emb, chunk):
+    """Point-chunk loop of inference(), models/rendering.py:100-116."""
+    R, N = z.shape
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)          # :178 / :188
+    dirs = dir_emb[:, None, :].expand(R, N, dir_emb.shape[-1]).reshape(R * N, -1)           # :108
+    outs = []
+    for i in range(0, R * N, chunk):
+        outs.append(mlp_forward(w, torch.cat((posenc(pts[i:i + chunk], 15), dirs[i:i + chunk]), dim=1)))
+    return torch.cat(outs, dim=0).view(R, N, 65)
+
+
+def render_rays(w_coarse, w_fine, rays, n_samples, n_importance, use_disp=False, chunk=32768, view_dir=None,
+                z_coarse=None, u=None, noise_coarse=None, noise_fine=None, noise_std=0.0, return_raw=False):
+    """render_rays_cross_ray, models/rendering.py:50-196, with perturb == 0 unless z_coarse/u are supplied."""
+    dir_emb = posenc(rays[:, 3:6] if view_dir is None else view_dir, 4)                     # :155
+    z = coarse_depths(rays, n_samples, use_disp) if z_coarse is None else z_coarse
+    out = {}
+    raw_c = _run_model(w_coarse, rays, z, dir_emb, chunk)
+    out["weights_coarse"], out["feature_coarse"], out["depth_coarse"] = composite(raw_c, z, noise_coarse, noise_std)
+    if return_raw:
+        out["raw_coarse"], out["z_coarse"] = raw_c, z
+    if n_importance > 0:
+        z_f, _ = fine_depths(z, out["weights_coarse"], n_importance, det=(u is None), u=u)
+        raw_f = _run_model(w_fine, rays, z_f, dir_emb, chunk)
+        out["weights_fine"], out["feature_fine"], out["depth_fine"] = composite(raw_f, z_f, noise_fine, noise_std)
+        out["z_fine"] = z_f
+        if return_raw:
+            out["raw_fine"] = raw_f
+    return out
+
+
+# ------------------------------------------------------------------ models/linearStyleTransfer.py, nerf_decoder_stylenerf.py
+def _conv1x1(x, w, b):
+    """1x1 Conv2d on a [C,P] matrix of P pixels."""
+    return w.reshape(w.shape[0], -1) @ x + b[:, None]
+
+
+def cnn_matrix(d, net, x):
+    """CNN.forward, models/linearStyleTransfer.py:28-37 on a centred [64,P] matrix -> [32,32]."""
+    p = "multi_net.%s." % net
+    h = F.leaky_relu(_conv1x1(x, d[p + "convs.0.weight"], d[p + "convs.0.bias"]), 0.2)
+    h = F.leaky_relu(_conv1x1(h, d[p + "convs.2.weight"], d[p + "convs.2.bias"]), 0.2)
+    h = _conv1x1(h, d[p + "convs.4.weight"], d[p + "convs.4.bias"])
+    gram = (h @ h.t()) / x.shape[1]
+    return F.linear(gram.reshape(1, -1), d[p + "fc.weight"], d[p + "fc.bias"]).view(32, 32)
+
+
+def crossray_decode(d, content, style, mode=None):
+    """style_net.forward :284-291 -> MulLayer.forward :58-94 -> NeuralRenderer.forward (n_blocks=0)
+    nerf_decoder_stylenerf.py:279-291.  content [1,64,H,W], style [1,64,h,w] or None -> [1,3,H,W]."""
+    _, C, H, W = content.shape
+    x = content.reshape(C, H * W)
+    if style is None and mode == "content":
+        fused = x
+    else:
+        s = style.reshape(C, -1)
+        c_mean, s_mean = x.mean(dim=1, keepdim=True), s.mean(dim=1, keepdim=True)
+        xc, sc = x - c_mean, s - s_mean
+        comp = _conv1x1(xc, d["multi_net.compress.weight"], d["multi_net.compress.bias"])    # :76-78
+        trans = cnn_matrix(d, "snet", sc) @ cnn_matrix(d, "cnet", xc)                         # :81-86
+        fused = _conv1x1(trans @ comp, d["multi_net.unzip.weight"], d["multi_net.unzip.bias"]) + s_mean  # :87-89
+    rgb = torch.sigmoid(_conv1x1(fused, d["decoder.feat_2_rgb_list.0.weight"], d["decoder.feat_2_rgb_list.0.bias"]))
+    return rgb.view(1, 3, H, W)
+
+
+def feature_to_grid(feature, H, W):
+    """Caller-side glue, eval.py:291-292 / train_mask_grid_sample.py:132-133: [HW,64] -> [1,64,H,W]."""
+    return feature.t().reshape(1, feature.shape[1], H, W)
+
+
+def psnr(a, b):
+    """metrics.py:12-13."""
+    return -10.0 * math.log10(float(((a - b) ** 2).mean()))
+
+
+def to_torch(state):
+    return {k: torch.from_numpy(v) if not torch.is_tensor(v) else v for k, v in state.items()}

@@ -1,0 +1,208 @@
+"""Generates tests/golden/*.npz by IMPORTING THE REFERENCE (/root/reference) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The fixtures hold data only: seeded synthetic inputs and the reference's outputs on them.  Network
+weights are NOT stored -- both sides regenerate them from the seed with crnerf_amd.synth (numpy
+default_rng); a float64 checksum per weight set is stored to catch RNG drift.  The reference never
+travels to the GPU box; these files do.  
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+# models/nerf_decoder_stylenerf.py:104 imports kornia.filters.filter2d at module import; it is only used
+# by Blur.forward, unreachable at n_blocks == 0.  Stub the import in THIS process only.
+_k, _kf = types.ModuleType("kornia"), types.ModuleType("kornia.filters")
+_kf.filter2d = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("filter2d is not reachable at n_blocks=0"))
+_k.filters = _kf
+sys.modules.setdefault("kornia", _k)
+sys.modules.setdefault("kornia.filters", _kf)
+
+from models.linearStyleTransfer import style_net  # noqa: E402  (reference)
+from models.nerf import NeRF_sigma, PosEmbedding  # noqa: E402  (reference)
+from models.rendering import render_rays_cross_ray, sample_pdf  # noqa: E402  (reference)
+
+import crnerf_amd.synth as synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+class Args:
+    nerf_out_dim = 64
+    pertubeCord = False
+    img_wh = [40, 24]
+
+
+def ref_mlp(typ, state):
+    m = NeRF_sigma(typ, Args(), in_channels_xyz=93, in_channels_dir=27, encode_appearance=True, in_channels_a=48,
+                   encode_random=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    return m.eval()
+
+
+def checksum(state):
+    return float(sum(float(np.asarray(v, dtype=np.float64).sum()) for v in state.values()))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+@torch.no_grad()
+def main():
+    rng = np.random.default_rng(20240928)
+    emb_xyz, emb_dir = PosEmbedding(14, 15), PosEmbedding(3, 4)
+
+    # ---- G1 positional embedding
+    x = rng.uniform(-5, 5, size=(257, 3)).astype(np.float32)
+    special = [0.0, 5.0, -5.0, 1e-3, 4.999999] + [math_pi / 2 ** k for k in range(0, 15)] + [-math_pi / 2 ** k for k in range(0, 15)]
+    x[: len(special), 0] = np.array(special, dtype=np.float32)
+    xt = torch.from_numpy(x)
+    save("g1_posenc", x=x, xyz=emb_xyz(xt), dir=emb_dir(xt))
+
+    # ---- G2 MLP, default-like and peaky weights
+    pts = rng.uniform(-3, 3, size=(512, 3)).astype(np.float32)
+    dirs = rng.normal(size=(512, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    xin = torch.cat([emb_xyz(torch.from_numpy(pts)), emb_dir(torch.from_numpy(dirs))], 1)
+    g2 = {"x": xin}
+    for tag, seed, gain in (("default", 11, 1.0), ("peaky", 12, 3.0)):
+        st = synth.mlp_state(seed, gain)
+        m = ref_mlp("fine", st)
+        g2["out_" + tag] = m(xin)
+        g2["sigma_" + tag] = m(xin[:, :93], sigma_only=True)
+        g2["seed_" + tag], g2["gain_" + tag], g2["wsum_" + tag] = seed, gain, checksum(st)
+    save("g2_mlp", **g2)
+
+    # ---- G3 compositing, computed by the reference's own inference() (rendering.py:82-145): a canned
+    # "model" returns prescribed raw [P,65] rows, torch.sort / torch.randn_like are wrapped for the
+    # duration of the call to capture the depths and to inject known noise.
+    R3, NC3, NI3 = 12, 64, 128
+    raw_c = rng.uniform(0, 1, size=(R3, NC3, 65)).astype(np.float32)
+    raw_f = rng.uniform(0, 1, size=(R3, NC3 + NI3, 65)).astype(np.float32)
+    scale = rng.choice([0.1, 1, 10, 100], size=(R3, 1)).astype(np.float32)
+    raw_c[..., 64] = np.abs(rng.normal(size=(R3, NC3))).astype(np.float32) * scale
+    raw_f[..., 64] = np.abs(rng.normal(size=(R3, NC3 + NI3))).astype(np.float32) * scale
+    raw_c[0, :, 64] = 0.0; raw_f[0, :, 64] = 0.0          # empty ray
+    raw_c[1, :, 64] = 1e4; raw_f[1, :, 64] = 1e4          # transmittance underflows after sample 0
+    raw_f[2, :100, 64] = 0.0                              # mass only in the back
+    raw_f[3, :, 64] = -1.0                                # negative raw sigma -> relu clamps
+    rays3 = synth.rays(R3, seed=9)
+    rays3[:, 6] = rng.uniform(0.3, 1.0, size=R3); rays3[:, 7] = rng.uniform(3.0, 5.0, size=R3)
+    rays3[4, 7] = rays3[4, 6]                             # near == far: every delta is 0
+
+    class Canned(torch.nn.Module):
+        def __init__(self, typ, rows):
+            super().__init__()
+            self.typ, self.encode_random, self.rows = typ, False, torch.from_numpy(rows).reshape(-1, 65)
+
+        def forward(self, xx, output_random=True):
+            assert xx.shape[0] == self.rows.shape[0]
+            return self.rows
+
+    g3 = {"raw_coarse": raw_c, "raw_fine": raw_f, "rays": rays3}
+    noise_c = rng.normal(size=(R3, NC3)).astype(np.float32)
+    noise_f = rng.normal(size=(R3, NC3 + NI3)).astype(np.float32)
+    g3["noise_coarse"], g3["noise_fine"] = noise_c, noise_f
+    real_sort, real_randn_like = torch.sort, torch.randn_like
+    for tag, nstd in (("det", 0.0), ("noisy", 1.0)):
+        captured = {}
+
+        def sort_spy(t, *a, **k):
+            out = real_sort(t, *a, **k)
+            captured["cat"], captured["sorted"] = t.clone(), out[0].clone()
+            return out
+
+        def randn_like_canned(t, *a, **k):
+            return torch.from_numpy(noise_c if t.shape[1] == NC3 else noise_f)
+
+        torch.sort, torch.randn_like = sort_spy, randn_like_canned
+        try:
+            res = render_rays_cross_ray({"coarse": Canned("coarse", raw_c), "fine": Canned("fine", raw_f)},
+                                        {"xyz": emb_xyz, "dir": emb_dir}, torch.from_numpy(rays3), None, NC3, False, 0, nstd,
+                                        NI3, 1 << 30, False, args=Args())
+        finally:
+            torch.sort, torch.randn_like = real_sort, real_randn_like
+        g3["z_coarse"] = captured["cat"][:, :NC3]
+        g3["z_fine_" + tag] = captured["sorted"]
+        for k, v in res.items():
+            g3["%s__%s" % (tag, k)] = v
+    save("g3_composite", **g3)
+
+    # ---- G4 sample_pdf (reference function, det=True and explicit-u via monkeypatched torch.rand)
+    R4, M = 64, 62
+    zc = np.sort(rng.uniform(0.3, 5.0, size=(R4, M + 2)).astype(np.float32), axis=-1)
+    bins = 0.5 * (zc[:, :-1] + zc[:, 1:])
+    w4 = (rng.uniform(0, 1, size=(R4, M)) ** 4).astype(np.float32)
+    w4[0] = 0.0                                # all-zero -> uniform
+    w4[1] = 0.0; w4[1, 17] = 1.0               # one-hot
+    w4[2] = 0.0; w4[2, 0] = 1.0                # first bin only
+    w4[3] = 0.0; w4[3, -1] = 1.0               # last bin only
+    w4[4] = 1.0                                # exactly uniform
+    w4[5, ::2] = 0.0                           # alternating empty bins
+    g4 = {"z_coarse": zc, "bins": bins, "weights": w4}
+    for ni in (64, 128):
+        g4["det_%d" % ni] = sample_pdf(torch.from_numpy(bins), torch.from_numpy(w4), ni, det=True)
+    u = rng.uniform(0, 1, size=(R4, 128)).astype(np.float32)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(u)
+    try:
+        g4["rand_128"] = sample_pdf(torch.from_numpy(bins), torch.from_numpy(w4), 128, det=False)
+    finally:
+        torch.rand = real_rand
+    g4["u_128"] = u
+    save("g4_sample_pdf", **g4)
+
+    # ---- G5 end-to-end render_rays_cross_ray + G7 chunk invariance
+    st_c, st_f = synth.mlp_state(21, 3.0, sigma_bias=1.0), synth.mlp_state(22, 3.0, sigma_bias=1.0)
+    models = {"coarse": ref_mlp("coarse", st_c), "fine": ref_mlp("fine", st_f)}
+    embeddings = {"xyz": emb_xyz, "dir": emb_dir}
+    rays = torch.from_numpy(synth.rays(64, seed=5))
+    g5 = {"rays": rays, "seed_coarse": 21, "seed_fine": 22, "gain": 3.0, "sigma_bias": 1.0,
+          "wsum_coarse": checksum(st_c), "wsum_fine": checksum(st_f)}
+    ts = torch.zeros(64, dtype=torch.long)
+    for tag, ni, disp in (("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)):
+        res = render_rays_cross_ray(models, embeddings, rays, ts, 64, disp, 0, 0, ni, 32768, False, test_time=True, args=Args())
+        if ni > 0:
+            assert res["feature_fine_random"] is res["feature_fine"]
+        for k, v in res.items():
+            if k != "feature_fine_random":
+                g5["%s__%s" % (tag, k)] = v
+        res2 = render_rays_cross_ray(models, embeddings, rays, ts, 64, disp, 0, 0, ni, 2048, False, test_time=True, args=Args())
+        for k in res:   # G7: chunk must not matter (bit-identical on the reference CPU path)
+            assert torch.equal(res[k], res2[k]), (tag, k)
+    # view_dir override (rendering.py:155)
+    vd = torch.from_numpy(np.roll(synth.rays(64, seed=5)[:, 3:6], 7, axis=0).copy())
+    res = render_rays_cross_ray(models, embeddings, rays, ts, 64, False, 0, 0, 128, 32768, False, test_time=True, args=Args(), view_dir=vd)
+    g5["view_dir"] = vd
+    g5["viewdir__feature_fine"] = res["feature_fine"]
+    save("g5_render", **g5)
+
+    # ---- G6 cross-ray decoder
+    dst = synth.decoder_state(31, 1.0)
+    net = style_net(Args()).eval()
+    assert net.decoder.n_blocks == 0
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
+    content = torch.from_numpy(rng.uniform(0, 1, size=(1, 64, 24, 40)).astype(np.float32))
+    style = torch.from_numpy(rng.uniform(0, 1, size=(1, 64, 32, 32)).astype(np.float32))
+    save("g6_decoder", content=content, style=style, seed=31, wsum=checksum(dst),
+         rgb=net(content.clone(), style.clone()), rgb_content=net(content.clone(), None, type="content"))
+
+
+if __name__ == "__main__":
+    import math
+    math_pi = np.float32(math.pi)
+    main()

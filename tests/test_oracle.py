@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/cpu_ref.py) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle -- SURVEY 8c."""
+import numpy as np
+import torch
+
+import crnerf_amd.synth as synth
+from oracle import cpu_ref as O
+
+T = torch.from_numpy
+
+
+def _state_checksum(state):
+    return float(sum(float(np.asarray(v, dtype=np.float64).sum()) for v in state.values()))
+
+
+def test_g1_posenc(golden):
+    g = golden("g1_posenc")
+    assert torch.equal(O.posenc(T(g["x"]), 15), T(g["xyz"]))
+    assert torch.equal(O.posenc(T(g["x"]), 4), T(g["dir"]))
+
+
+def test_g2_mlp(golden):
+    g = golden("g2_mlp")
+    for tag in ("default", "peaky"):
+        st = synth.mlp_state(int(g["seed_" + tag]), float(g["gain_" + tag]))
+        assert _state_checksum(st) == float(g["wsum_" + tag]), "numpy RNG drift: weights no longer match the fixture"
+        w = O.to_torch(st)
+        torch.testing.assert_close(O.mlp_forward(w, T(g["x"])), T(g["out_" + tag]), rtol=0, atol=1e-6)
+        torch.testing.assert_close(O.mlp_forward(w, T(g["x"])[:, :93], sigma_only=True), T(g["sigma_" + tag]), rtol=1e-6, atol=1e-6)
+
+
+def test_g3_composite(golden):
+    g = golden("g3_composite")
+    for tag, nstd in (("det", 0.0), ("noisy", 1.0)):
+        w, f, d = O.composite(T(g["raw_coarse"]), T(g["z_coarse"]), T(g["noise_coarse"]), nstd)
+        assert torch.equal(w, T(g[tag + "__weights_coarse"]))
+        torch.testing.assert_close(f, T(g[tag + "__feature_coarse"]), rtol=0, atol=1e-6)
+        torch.testing.assert_close(d, T(g[tag + "__depth_coarse"]), rtol=0, atol=1e-6)
+        w, f, d = O.composite(T(g["raw_fine"]), T(g["z_fine_" + tag]), T(g["noise_fine"]), nstd)
+        assert torch.equal(w, T(g[tag + "__weights_fine"]))
+        torch.testing.assert_close(f, T(g[tag + "__feature_fine"]), rtol=0, atol=1e-6)
+        torch.testing.assert_close(d, T(g[tag + "__depth_fine"]), rtol=0, atol=2e-6)
+        # and the depth pipeline that produced z_fine: coarse depths -> sample_pdf -> merge
+        zc = O.coarse_depths(T(g["rays"]), 64)
+        assert torch.equal(zc, T(g["z_coarse"]))
+        zf, _ = O.fine_depths(zc, T(g[tag + "__weights_coarse"]), 128)
+        assert torch.equal(zf, T(g["z_fine_" + tag]))
+
+
+def test_g4_sample_pdf(golden):
+    g = golden("g4_sample_pdf")
+    bins, w = T(g["bins"]), T(g["weights"])
+    assert torch.equal(0.5 * (T(g["z_coarse"])[:, :-1] + T(g["z_coarse"])[:, 1:]), bins)
+    for ni in (64, 128):
+        assert torch.equal(O.sample_pdf(bins, w, ni, det=True), T(g["det_%d" % ni]))
+    assert torch.equal(O.sample_pdf(bins, w, 128, det=False, u=T(g["u_128"])), T(g["rand_128"]))
+
+
+def test_g5_render(golden):
+    g = golden("g5_render")
+    st_c = synth.mlp_state(int(g["seed_coarse"]), float(g["gain"]), float(g["sigma_bias"]))
+    st_f = synth.mlp_state(int(g["seed_fine"]), float(g["gain"]), float(g["sigma_bias"]))
+    assert _state_checksum(st_c) == float(g["wsum_coarse"]) and _state_checksum(st_f) == float(g["wsum_fine"])
+    wc, wf, rays = O.to_torch(st_c), O.to_torch(st_f), T(g["rays"])
+    for tag, ni, disp in (("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)):
+        out = O.render_rays(wc, wf, rays, 64, ni, use_disp=disp)
+        keys = [k[len(tag) + 2:] for k in g if k.startswith(tag + "__")]
+        assert keys
+        for k in keys:
+            torch.testing.assert_close(out[k], T(g["%s__%s" % (tag, k)]), rtol=0, atol=0, msg=lambda m: "%s %s: %s" % (tag, k, m))
+    out = O.render_rays(wc, wf, rays, 64, 128, view_dir=T(g["view_dir"]))
+    assert torch.equal(out["feature_fine"], T(g["viewdir__feature_fine"]))
+
+
+def test_g6_decoder(golden):
+    g = golden("g6_decoder")
+    st = synth.decoder_state(int(g["seed"]))
+    assert _state_checksum(st) == float(g["wsum"])
+    d = O.to_torch(st)
+    torch.testing.assert_close(O.crossray_decode(d, T(g["content"]), T(g["style"])), T(g["rgb"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(O.crossray_decode(d, T(g["content"]), None, mode="content"), T(g["rgb_content"]), rtol=0, atol=1e-6)
+    # the glue the callers apply around the decoder (eval.py:291-294)
+    feat = T(g["content"])[0].reshape(64, -1).t().contiguous()
+    assert torch.equal(O.feature_to_grid(feat, 24, 40), T(g["content"]))
