@@ -27,7 +27,7 @@ class RenderArgs(ctypes.Structure):
     """struct crnerf_render_args (include/crnerf.h)."""
     _fields_ = [
         ("packed_coarse", ctypes.c_void_p), ("packed_fine", ctypes.c_void_p),
-        ("rays", _c_fp), ("view_dir", _c_fp), ("z_coarse", _c_fp), ("u", _c_fp),
+        ("rays", _c_fp), ("view_dir", _c_fp), ("z_coarse", _c_fp), ("z_steps", _c_fp), ("u", _c_fp), ("u_stride", ctypes.c_int64),
         ("noise_coarse", _c_fp), ("noise_fine", _c_fp),
         ("noise_std", ctypes.c_float), ("use_disp", ctypes.c_int32),
         ("n_rays", ctypes.c_int64), ("n_samples", ctypes.c_int32), ("n_importance", ctypes.c_int32),
@@ -64,7 +64,7 @@ def load():
             "crnerf_posenc_f32": (ctypes.c_int, [vp, vp, i64, i32, vp]),
             "crnerf_mlp_forward_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, vp]),
             "crnerf_composite_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, i64, i32, vp]),
-            "crnerf_sample_pdf_merge_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+            "crnerf_sample_pdf_merge_f32": (ctypes.c_int, [vp, vp, vp, i64, vp, vp, i64, i32, i32, vp]),
             "crnerf_render_rays_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
             "crnerf_crossray_chansum_f32": (ctypes.c_int, [vp, i64, vp, vp, vp]),
             "crnerf_crossray_gram_f32": (ctypes.c_int, [vp, i64, vp, pp, vp, vp, vp]),

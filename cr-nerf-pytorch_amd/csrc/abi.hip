@@ -76,12 +76,12 @@ int crnerf_composite_f32(const float* raw, const float* z, const float* noise, f
   return launch_composite(raw, z, noise, noise_std, weights, feature, depth, (long)R, N, (hipStream_t)stream);
 }
 
-int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, float* z_sorted,
+int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, int64_t u_stride, float* z_sorted,
                                 float* z_samples, int64_t R, int Nc, int Ni, void* stream) {
   if (R == 0) return 0;
   REQUIRE(z_coarse, "z_coarse"); REQUIRE(weights_coarse, "weights_coarse"); REQUIRE(z_sorted, "z_sorted");
   if (R < 0) return set_error(CRNERF_ERR_SHAPE, "sample_pdf_merge: negative R");
-  return launch_sample_pdf_merge(z_coarse, weights_coarse, u, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
+  return launch_sample_pdf_merge(z_coarse, weights_coarse, u, (long)u_stride, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
 }
 
 int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
@@ -96,7 +96,7 @@ int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
   }
   RenderArgs r;
   r.packed_coarse = a->packed_coarse; r.packed_fine = a->packed_fine; r.rays = a->rays; r.view_dir = a->view_dir;
-  r.z_coarse = a->z_coarse; r.u = a->u; r.noise_coarse = a->noise_coarse; r.noise_fine = a->noise_fine;
+  r.z_coarse = a->z_coarse; r.z_steps = a->z_steps; r.u = a->u; r.u_stride = (long)a->u_stride; r.noise_coarse = a->noise_coarse; r.noise_fine = a->noise_fine;
   r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;

@@ -23,7 +23,7 @@ int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t s
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
                      float* feature, float* depth, long R, int N, hipStream_t stream);
-int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, float* z_fine_sorted,
+int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, long u_stride, float* z_fine_sorted,
                             float* z_samples, long R, int Nc, int Ni, hipStream_t stream);
 
 struct RenderArgs {
@@ -32,7 +32,9 @@ struct RenderArgs {
   const float* rays;           // [R,8]
   const float* view_dir;       // [R,3] or null -> rays[:,3:6]
   const float* z_coarse;       // [R,Nc] or null -> computed from near/far (perturb == 0)
-  const float* u;              // [R,Ni] or null -> linspace(0,1,Ni) (det)
+  const float* z_steps;        // [Nc] linspace(0,1,Nc) table or null -> in-kernel formula
+  const float* u;              // [R,Ni] (u_stride = Ni) / shared [Ni] table (u_stride = 0) or null -> in-kernel linspace
+  long u_stride;
   const float* noise_coarse;   // [R,Nc] or null
   const float* noise_fine;     // [R,Nc+Ni] or null
   float noise_std;

@@ -70,7 +70,7 @@ int launch_composite(const float* raw, const float* z, const float* noise, float
 }
 
 __global__ __launch_bounds__(64) void sample_pdf_merge_kernel(const float* __restrict__ z_coarse, const float* __restrict__ w_coarse,
-                                                              const float* __restrict__ u, float* __restrict__ z_sorted,
+                                                              const float* __restrict__ u, long u_stride, float* __restrict__ z_sorted,
                                                               float* __restrict__ z_samples, long R, int Nc, int Ni) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void sample_pdf_merge_kernel(const float* __res
       s.wc[n] = w_coarse[r * Nc + n];
     }
     wave_lds_fence();
-    sample_pdf_wave(s, Nc, Ni, u ? u + r * Ni : nullptr, lane);
+    sample_pdf_wave(s, Nc, Ni, u ? u + r * u_stride : nullptr, lane);
     merge_sort_wave(s, Nc, Ni, lane);
     for (int n = lane; n < Nc + Ni; n += 64) z_sorted[r * (long)(Nc + Ni) + n] = s.zs[n];
     if (z_samples)
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void sample_pdf_merge_kernel(const float* __res
   }
 }
 
-int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, float* z_fine_sorted,
+int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, long u_stride, float* z_fine_sorted,
                             float* z_samples, long R, int Nc, int Ni, hipStream_t stream) {
   if (R <= 0) return 0;
   if (Nc < 3 || Ni < 1) return set_error(-2, "sample_pdf_merge: need N_samples >= 3 and N_importance >= 1");
@@ -100,7 +100,7 @@ int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, 
   hipError_t e = hipFuncSetAttribute((const void*)sample_pdf_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(sample_pdf_merge_kernel) failed");
   const int grid = (int)(R < 8192 ? R : 8192);
-  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), shmem, stream, z_coarse, weights_coarse, u, z_fine_sorted,
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), shmem, stream, z_coarse, weights_coarse, u, u_stride, z_fine_sorted,
                      z_samples, R, Nc, Ni);
   return check_launch("sample_pdf_merge_kernel");
 }

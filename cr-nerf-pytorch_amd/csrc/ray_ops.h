@@ -41,13 +41,13 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 
 // torch.linspace(0, 1, n)[i] as ATen computes it (symmetric around the midpoint)
 __device__ __forceinline__ float linspace01(int i, int n) {
+  if (n <= 1) return 0.0f;
   const float step = 1.0f / (float)(n - 1);
   return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
 // rendering.py:161-165
-__device__ __forceinline__ float coarse_depth(float near, float far, int i, int n, int use_disp) {
-  const float s = (n > 1) ? linspace01(i, n) : 0.0f;
+__device__ __forceinline__ float coarse_depth(float near, float far, float s, int use_disp) {
   const float t = 1.0f - s;
   if (!use_disp) return near * t + far * s;
   return 1.0f / ((1.0f / near) * t + (1.0f / far) * s);

@@ -21,7 +21,9 @@ struct RenderParams {
   const float* rays;
   const float* view_dir;
   const float* z_coarse;
+  const float* z_steps;
   const float* u;
+  long u_stride;
   const float* noise_c;
   const float* noise_f;
   float noise_std;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void render_rays_kernel(RenderParams a) {
       for (int i = 0; i < 16; ++i) dv[0][i] = tmp[i];
     }
     for (int n = lane; n < Nc; n += 64)
-      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, n, Nc, a.use_disp);
+      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
     wave_lds_fence();
 
     // pass 0 = coarse model on zc, pass 1 = fine model on the merged zs; ONE copy of the MLP code
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void render_rays_kernel(RenderParams a) {
         store_ray_feature(st, (pass ? a.feature_f : a.feature_c) + r * FEAT_DIM, (pass ? a.depth_f : a.depth_c) + r, p, h);
       if (pass == 0 && Ni > 0) {
         wave_lds_fence();
-        sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * Ni : nullptr, lane);
+        sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane);
         merge_sort_wave(scr, Nc, Ni, lane);
         if (a.z_fine && ray_ok)
           for (int n = lane; n < Nf; n += 64) a.z_fine[r * Nf + n] = scr.zs[n];
@@ -136,7 +138,7 @@ int launch_render_rays(const RenderArgs& a, hipStream_t stream) {
   RenderParams k;
   k.packed0 = (const char*)a.packed_coarse;
   k.packed1 = (const char*)(a.packed_fine ? a.packed_fine : a.packed_coarse);
-  k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.u = a.u;
+  k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.z_steps = a.z_steps; k.u = a.u; k.u_stride = a.u_stride;
   k.noise_c = a.noise_coarse; k.noise_f = a.noise_fine; k.noise_std = a.noise_std; k.use_disp = a.use_disp;
   k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;

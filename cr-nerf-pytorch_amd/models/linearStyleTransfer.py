@@ -72,16 +72,18 @@ class style_net(nn.Module):
         self.decoder = NeuralRenderer(img_size=(args.img_wh[0], args.img_wh[1]), featmap_size=(args.img_wh[0], args.img_wh[1]),
                                       feat_nc=args.nerf_out_dim, out_dim=3, args_here=args)
 
-    def affine_from_stats(self, c_sum, c_gram, c_count, style_feature):
+    def affine_from_stats(self, c_sum, c_gram, c_count, style_feature, kernels=None):
         """Everything downstream of the two global reductions: replicated, tiny.  c_sum[64] and
         c_gram[1024] are GLOBAL sums over all content pixels, c_count the global pixel count."""
+        k = kernels or ops
         mn = self.multi_net
         sp, _ = _pixel_major(style_feature)
-        s_mean = ops.crossray_chansum(sp) / sp.shape[0]
-        s_matrix = mn.snet.matrix(mn.snet.gram_sum(sp, s_mean), sp.shape[0])
-        c_mean = c_sum / c_count
-        c_matrix = mn.cnet.matrix(c_gram, c_count)
-        return ops.crossray_fold(s_matrix, c_matrix, c_mean, s_mean, mn.lin_tensors() + list(self.decoder.rgb_tensors()))
+        s_mean = (k.crossray_chansum(sp) / sp.shape[0]).contiguous()
+        s_gram = k.crossray_gram(sp, s_mean, mn.snet.conv_tensors())
+        s_matrix = k.crossray_matrix(s_gram, sp.shape[0], mn.snet.fc.weight, mn.snet.fc.bias)
+        c_mean = (c_sum / c_count).contiguous()
+        c_matrix = k.crossray_matrix(c_gram, c_count, mn.cnet.fc.weight, mn.cnet.fc.bias)
+        return k.crossray_fold(s_matrix, c_matrix, c_mean, s_mean, mn.lin_tensors() + list(self.decoder.rgb_tensors()))
 
     def forward(self, content_feature, style_feature, type=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -90,6 +92,6 @@ class style_net(nn.Module):
             return self.decoder(content_feature)
         xp, (H, W) = _pixel_major(content_feature)
         c_sum = ops.crossray_chansum(xp)
-        c_gram = self.multi_net.cnet.gram_sum(xp, c_sum / xp.shape[0])
+        c_gram = self.multi_net.cnet.gram_sum(xp, (c_sum / xp.shape[0]).contiguous())
         affine = self.affine_from_stats(c_sum, c_gram, xp.shape[0], style_feature)
         return ops.crossray_apply(xp, affine).view(1, 3, H, W)

@@ -83,16 +83,18 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
     lib = _lib.load()
     z_coarse, weights_coarse = _f32c(z_coarse, "z_coarse"), _f32c(weights_coarse, "weights_coarse")
     R, Nc = z_coarse.shape
+    u_stride = 0
     if u is not None:
         u = _f32c(u, "u")
+        u_stride = 0 if u.dim() == 1 else n_importance
     zs = torch.empty(R, Nc + n_importance, dtype=torch.float32, device=z_coarse.device)
     smp = torch.empty(R, n_importance, dtype=torch.float32, device=z_coarse.device) if return_samples else None
-    _lib.check(lib.crnerf_sample_pdf_merge_f32(_lib.dev_ptr(z_coarse), _lib.dev_ptr(weights_coarse), _lib.dev_ptr(u), _lib.dev_ptr(zs),
+    _lib.check(lib.crnerf_sample_pdf_merge_f32(_lib.dev_ptr(z_coarse), _lib.dev_ptr(weights_coarse), _lib.dev_ptr(u), u_stride, _lib.dev_ptr(zs),
                                                _lib.dev_ptr(smp), R, Nc, n_importance, _lib.stream_ptr()), "crnerf_sample_pdf_merge_f32")
     return (zs, smp) if return_samples else zs
 
 
-def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, u=None,
+def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
                 noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False):
     """Fused renderer.  Returns a dict of freshly allocated tensors."""
     lib = _lib.load()
@@ -109,13 +111,14 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
             out["z_fine"] = new(R, Nc + Ni)
     if R == 0:
         return out
-    keep = [t if t is None else _f32c(t, n) for t, n in ((view_dir, "view_dir"), (z_coarse, "z_coarse"), (u, "u"),
+    keep = [t if t is None else _f32c(t, n) for t, n in ((view_dir, "view_dir"), (z_coarse, "z_coarse"), (z_steps, "z_steps"), (u, "u"),
                                                          (noise_coarse, "noise_coarse"), (noise_fine, "noise_fine"))]
     a = _lib.RenderArgs()
     a.packed_coarse = packed_coarse.data_ptr()
     a.packed_fine = packed_fine.data_ptr() if packed_fine is not None else None
     a.rays = rays.data_ptr()
-    for field, t in zip(("view_dir", "z_coarse", "u", "noise_coarse", "noise_fine"), keep):
+    a.u_stride = 0 if (u is None or u.dim() == 1) else Ni
+    for field, t in zip(("view_dir", "z_coarse", "z_steps", "u", "noise_coarse", "noise_fine"), keep):
         setattr(a, field, t.data_ptr() if t is not None else None)
     a.noise_std = float(noise_std)
     a.use_disp = int(bool(use_disp))

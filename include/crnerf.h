@@ -67,8 +67,9 @@ int crnerf_composite_f32(const float* raw, const float* z, const float* noise, f
 
 /* sample_pdf + merge, models/rendering.py:7-46 and :183-187:
  * z_coarse[R,Nc], weights_coarse[R,Nc] (the full coarse weights; [:,1:-1] is taken inside),
- * u[R,Ni] or NULL (deterministic linspace) -> z_sorted[R,Nc+Ni]; z_samples[R,Ni] optional (NULL to skip). */
-int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, float* z_sorted,
+ * u: per-ray uniforms [R,Ni] (u_stride = Ni), one shared row [Ni] (u_stride = 0; e.g. torch.linspace(0,1,Ni)),
+ * or NULL (in-kernel linspace) -> z_sorted[R,Nc+Ni]; z_samples[R,Ni] optional (NULL to skip). */
+int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, int64_t u_stride, float* z_sorted,
                                 float* z_samples, int64_t R, int Nc, int Ni, void* stream);
 
 /* render_rays_cross_ray, models/rendering.py:50-196, fully fused (coarse -> sample_pdf -> fine). */
@@ -78,7 +79,10 @@ typedef struct crnerf_render_args {
   const float* rays;            /* [R,8] = o(3) d(3) near far, rendering.py:152-153 */
   const float* view_dir;        /* [R,3] or NULL -> rays[:,3:6], rendering.py:155 */
   const float* z_coarse;        /* [R,Nc] or NULL -> rendering.py:161-165 computed in-kernel (perturb == 0) */
-  const float* u;               /* [R,Ni] or NULL -> linspace(0,1,Ni) (det = perturb == 0), rendering.py:26-31 */
+  const float* z_steps;         /* [Nc] = torch.linspace(0,1,Nc) (rendering.py:160) or NULL -> same formula in-kernel */
+  const float* u;               /* rendering.py:26-31: [R,Ni] uniforms (u_stride = Ni), one shared row (u_stride = 0,
+                                   e.g. torch.linspace(0,1,Ni) when det) or NULL -> in-kernel linspace */
+  int64_t u_stride;
   const float* noise_coarse;    /* [R,Nc] standard-normal or NULL, rendering.py:125 */
   const float* noise_fine;      /* [R,Nc+Ni] or NULL */
   float noise_std;

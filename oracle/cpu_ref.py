@@ -80,10 +80,11 @@ def sample_pdf(bins, weights, n_importance, det=True, u=None, eps=1e-5):
     return b_lo + (u - c_lo) / denom * (b_hi - b_lo)                                        # :45
 
 
-def coarse_depths(rays, n_samples, use_disp=False):
-    """models/rendering.py:160-167 (perturb == 0)."""
+def coarse_depths(rays, n_samples, use_disp=False, z_steps=None):
+    """models/rendering.py:160-167 (perturb == 0).  z_steps: optional precomputed linspace(0,1,n) table
+    (ATen's CPU linspace differs in the last bit between SIMD widths; fixtures carry the table used)."""
     near, far = rays[:, 6:7], rays[:, 7:8]
-    s = torch.linspace(0, 1, n_samples)
+    s = torch.linspace(0, 1, n_samples) if z_steps is None else z_steps
     if use_disp:
         z = 1 / (1 / near * (1 - s) + 1 / far * s)
     else:
@@ -92,8 +93,11 @@ def coarse_depths(rays, n_samples, use_disp=False):
 
 
 def fine_depths(z_coarse, weights_coarse, n_importance, det=True, u=None):
-    """models/rendering.py:183-187: z_mid, sample_pdf on weights[:,1:-1], sort(cat)."""
+    """models/rendering.py:183-187: z_mid, sample_pdf on weights[:,1:-1], sort(cat).
+    u: [R,Ni] uniforms, or a shared [Ni] row (e.g. a precomputed linspace table)."""
     mid = 0.5 * (z_coarse[:, :-1] + z_coarse[:, 1:])
+    if u is not None and u.dim() == 1:
+        u = u.expand(z_coarse.shape[0], n_importance)
     extra = sample_pdf(mid, weights_coarse[:, 1:-1], n_importance, det=det, u=u)
     return torch.sort(torch.cat((z_coarse, extra), dim=-1), dim=-1)[0], extra
 
@@ -110,10 +114,10 @@ def _run_model(w, rays, z, dir_emb, chunk):
 
 
 def render_rays(w_coarse, w_fine, rays, n_samples, n_importance, use_disp=False, chunk=32768, view_dir=None,
-                z_coarse=None, u=None, noise_coarse=None, noise_fine=None, noise_std=0.0, return_raw=False):
+                z_coarse=None, u=None, noise_coarse=None, noise_fine=None, noise_std=0.0, return_raw=False, z_steps=None):
     """render_rays_cross_ray, models/rendering.py:50-196, with perturb == 0 unless z_coarse/u are supplied."""
     dir_emb = posenc(rays[:, 3:6] if view_dir is None else view_dir, 4)                     # :155
-    z = coarse_depths(rays, n_samples, use_disp) if z_coarse is None else z_coarse
+    z = coarse_depths(rays, n_samples, use_disp, z_steps) if z_coarse is None else z_coarse
     out = {}
     raw_c = _run_model(w_coarse, rays, z, dir_emb, chunk)
     out["weights_coarse"], out["feature_coarse"], out["depth_coarse"] = composite(raw_c, z, noise_coarse, noise_std)

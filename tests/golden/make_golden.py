@@ -174,10 +174,27 @@ def main():
     g5 = {"rays": rays, "seed_coarse": 21, "seed_fine": 22, "gain": 3.0, "sigma_bias": 1.0,
           "wsum_coarse": checksum(st_c), "wsum_fine": checksum(st_f)}
     ts = torch.zeros(64, dtype=torch.long)
+    # the linspace tables the reference builds on its device (rendering.py:160, :27); ATen's CPU linspace
+    # differs in the last bit between vector widths, so the fixture carries the exact tables used
+    g5["z_steps_64"] = torch.linspace(0, 1, 64)
+    g5["u_steps_64"], g5["u_steps_128"] = torch.linspace(0, 1, 64), torch.linspace(0, 1, 128)
+    real_sort = torch.sort
     for tag, ni, disp in (("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)):
-        res = render_rays_cross_ray(models, embeddings, rays, ts, 64, disp, 0, 0, ni, 32768, False, test_time=True, args=Args())
+        captured = {}
+
+        def sort_spy(t, *a, **k):
+            out = real_sort(t, *a, **k)
+            captured["z_fine"] = out[0].clone()
+            return out
+
+        torch.sort = sort_spy
+        try:
+            res = render_rays_cross_ray(models, embeddings, rays, ts, 64, disp, 0, 0, ni, 32768, False, test_time=True, args=Args())
+        finally:
+            torch.sort = real_sort
         if ni > 0:
             assert res["feature_fine_random"] is res["feature_fine"]
+            g5["%s__z_fine" % tag] = captured["z_fine"]
         for k, v in res.items():
             if k != "feature_fine_random":
                 g5["%s__%s" % (tag, k)] = v

@@ -1,0 +1,154 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/crnerf.h declares, the drop-in
+modules carry the reference's constructor signatures / attributes / state_dict keys, the product fails
+loudly without a GPU (no silent fallback), and the weight-pack layout helpers are self-consistent."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import crnerf_amd
+import crnerf_amd.synth as synth
+from crnerf_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Args:
+    nerf_out_dim, img_wh, pertubeCord = 64, [40, 24], False
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "crnerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crnerf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_expects():
+    assert header_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "libcrnerf_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    lib.crnerf_abi_version.restype = ctypes.c_int
+    assert lib.crnerf_abi_version() == 1
+    lib.crnerf_packed_mlp_bytes.restype = ctypes.c_size_t
+    assert lib.crnerf_packed_mlp_bytes() == 11264 + 2416 * 1024
+    # error path without touching a device: NULL arguments are rejected with a message
+    lib.crnerf_posenc_f32.restype = ctypes.c_int
+    lib.crnerf_posenc_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    assert lib.crnerf_posenc_f32(None, None, 4, 15, None) == -1
+    lib.crnerf_last_error.restype = ctypes.c_char_p
+    assert b"NULL" in lib.crnerf_last_error()
+    assert lib.crnerf_posenc_f32(None, None, 0, 15, None) == 0      # empty input is a no-op
+
+
+def test_render_args_struct_matches_header_field_order():
+    text = open(os.path.join(ROOT, "include", "crnerf.h")).read()
+    body = text[text.index("typedef struct crnerf_render_args {"):text.index("} crnerf_render_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b([a-z_0-9]+)\s*;", body)
+    assert fields == [f[0] for f in _lib.RenderArgs._fields_]
+
+
+def test_nerf_sigma_mirrors_reference_module():
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    m = NeRF_sigma('fine', Args(), in_channels_xyz=93, in_channels_dir=27, encode_appearance=True, in_channels_a=48, encode_random=True)
+    assert list(m.state_dict().keys()) == ops.MLP_TENSOR_NAMES
+    assert [tuple(v.shape) for v in m.state_dict().values()] == list(ops.MLP_TENSOR_SHAPES)
+    assert sum(p.numel() for p in m.parameters()) == 619073
+    assert (m.typ, m.encode_random, m.encode_appearance, m.in_channels_a) == ('fine', True, True, 48)
+    c = NeRF_sigma('coarse', Args(), in_channels_xyz=93, in_channels_dir=27, encode_appearance=True, encode_random=True)
+    assert (c.typ, c.encode_random, c.encode_appearance) == ('coarse', False, False)  # nerf.py:132-134
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1).items()})  # strict
+    with pytest.raises(NotImplementedError):
+        NeRF_sigma('coarse', Args())                                              # default in_channels_xyz=63 is not the shipped net
+    e = PosEmbedding(14, 15)
+    assert torch.equal(e.freqs, 2 ** torch.arange(15, dtype=torch.float32))
+    with pytest.raises(NotImplementedError):
+        PosEmbedding(14, 15, logscale=False)
+
+
+def test_style_net_mirrors_reference_module():
+    from crnerf_amd.models.linearStyleTransfer import style_net
+    net = style_net(Args())
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == synth.DECODER_SHAPES
+    assert list(net.state_dict().keys()) == list(synth.DECODER_SHAPES.keys())
+    assert sum(p.numel() for p in net.parameters()) == 2140899
+    assert net.decoder.n_blocks == 0
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+
+
+def test_no_silent_cpu_fallback():
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    from crnerf_amd.models.rendering import render_rays_cross_ray
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            PosEmbedding(3, 4)(torch.zeros(5, 3))
+        m = NeRF_sigma('coarse', Args(), in_channels_xyz=93, in_channels_dir=27)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(torch.zeros(4, 120))
+        emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            render_rays_cross_ray({"coarse": m}, emb, torch.from_numpy(synth.rays(4)), None, 64, False, 0, 0, 0, 1024, False, args=Args())
+
+
+def test_render_shim_validates_like_the_boundary_says():
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    from crnerf_amd.models.rendering import render_rays_cross_ray
+    m = NeRF_sigma('coarse', Args(), in_channels_xyz=93, in_channels_dir=27)
+    rays = torch.from_numpy(synth.rays(4))
+    emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
+    with pytest.raises(NotImplementedError, match="backward"):      # grad mode with trainable params
+        render_rays_cross_ray({"coarse": m}, emb, rays, None, 64, False, 0, 0, 0, 1024, False, args=Args())
+    with torch.no_grad():
+        class P(Args):
+            pertubeCord = True
+        with pytest.raises(NotImplementedError, match="pertubeCord"):
+            render_rays_cross_ray({"coarse": m}, emb, rays, None, 64, False, 0, 0, 0, 1024, False, args=P())
+        with pytest.raises(NotImplementedError, match="PosEmbedding"):
+            render_rays_cross_ray({"coarse": m}, {"xyz": PosEmbedding(9, 10), "dir": emb["dir"]}, rays, None, 64, False, 0, 0, 0, 1024, False, args=Args())
+        with pytest.raises(KeyError):                                # reference reads kwargs['args'] unconditionally
+            render_rays_cross_ray({"coarse": m}, emb, rays, None)
+
+
+def test_posenc_slot_order_is_a_permutation_of_the_reference_columns():
+    """layout.h posenc_slot_to_col restated: every reference column appears exactly once, pads elsewhere."""
+    def slot_to_col(k, F):
+        q, h, p, sc = k >> 3, (k >> 2) & 1, (k >> 1) & 1, k & 1
+        a = 4 * q + 2 * h + p
+        if a < 3 * F:
+            return 3 + 6 * (a // 3) + 3 * sc + a % 3
+        if a == 3 * F:
+            return sc
+        if a == 3 * F + 1:
+            return 2 if sc == 0 else -1
+        return -1
+    for F, pad in ((15, 96), (4, 32)):
+        cols = [slot_to_col(k, F) for k in range(pad)]
+        assert sorted(c for c in cols if c >= 0) == list(range(6 * F + 3))
+        assert cols.count(-1) == pad - (6 * F + 3)
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = synth.mlp_state(5, 3.0), synth.mlp_state(5, 3.0)
+    assert all(np.array_equal(a[k], b[k]) for k in a) and list(a) == ops.MLP_TENSOR_NAMES
+    r = synth.rays(1000, seed=1)
+    assert r.shape == (1000, 8) and r.dtype == np.float32
+    assert np.allclose(np.linalg.norm(r[:, 3:6], axis=1), 1, atol=1e-6) and (r[:, 6] < r[:, 7]).all()
+
+
+def test_shard_bounds_cover_without_overlap():
+    from crnerf_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 8, 1024, 65537):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_bounds(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -41,9 +41,10 @@ def test_g3_composite(golden):
         torch.testing.assert_close(f, T(g[tag + "__feature_fine"]), rtol=0, atol=1e-6)
         torch.testing.assert_close(d, T(g[tag + "__depth_fine"]), rtol=0, atol=2e-6)
         # and the depth pipeline that produced z_fine: coarse depths -> sample_pdf -> merge
-        zc = O.coarse_depths(T(g["rays"]), 64)
+        tab = golden("g5_render")
+        zc = O.coarse_depths(T(g["rays"]), 64, z_steps=T(tab["z_steps_64"]))
         assert torch.equal(zc, T(g["z_coarse"]))
-        zf, _ = O.fine_depths(zc, T(g[tag + "__weights_coarse"]), 128)
+        zf, _ = O.fine_depths(zc, T(g[tag + "__weights_coarse"]), 128, u=T(tab["u_steps_128"]))
         assert torch.equal(zf, T(g["z_fine_" + tag]))
 
 
@@ -51,8 +52,9 @@ def test_g4_sample_pdf(golden):
     g = golden("g4_sample_pdf")
     bins, w = T(g["bins"]), T(g["weights"])
     assert torch.equal(0.5 * (T(g["z_coarse"])[:, :-1] + T(g["z_coarse"])[:, 1:]), bins)
+    tab = golden("g5_render")
     for ni in (64, 128):
-        assert torch.equal(O.sample_pdf(bins, w, ni, det=True), T(g["det_%d" % ni]))
+        assert torch.equal(O.sample_pdf(bins, w, ni, u=T(tab["u_steps_%d" % ni]).expand(64, ni)), T(g["det_%d" % ni]))
     assert torch.equal(O.sample_pdf(bins, w, 128, det=False, u=T(g["u_128"])), T(g["rand_128"]))
 
 
@@ -63,12 +65,12 @@ def test_g5_render(golden):
     assert _state_checksum(st_c) == float(g["wsum_coarse"]) and _state_checksum(st_f) == float(g["wsum_fine"])
     wc, wf, rays = O.to_torch(st_c), O.to_torch(st_f), T(g["rays"])
     for tag, ni, disp in (("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)):
-        out = O.render_rays(wc, wf, rays, 64, ni, use_disp=disp)
+        out = O.render_rays(wc, wf, rays, 64, ni, use_disp=disp, z_steps=T(g["z_steps_64"]), u=T(g["u_steps_%d" % ni]) if ni else None)
         keys = [k[len(tag) + 2:] for k in g if k.startswith(tag + "__")]
         assert keys
         for k in keys:
             torch.testing.assert_close(out[k], T(g["%s__%s" % (tag, k)]), rtol=0, atol=0, msg=lambda m: "%s %s: %s" % (tag, k, m))
-    out = O.render_rays(wc, wf, rays, 64, 128, view_dir=T(g["view_dir"]))
+    out = O.render_rays(wc, wf, rays, 64, 128, view_dir=T(g["view_dir"]), z_steps=T(g["z_steps_64"]), u=T(g["u_steps_128"]))
     assert torch.equal(out["feature_fine"], T(g["viewdir__feature_fine"]))
 
 
