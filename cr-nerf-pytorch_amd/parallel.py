@@ -32,12 +32,14 @@ class _HipKernels:
         return getattr(ops, name)
 
 
-def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None):
+def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False):
     """Cross-ray decode of a ray-sharded feature grid.
 
     net: style_net; feature_local: this rank's [R_local,64] block of feature_fine (pixel-major, rank
     order = pixel order); style_feature: [1,64,h,w], replicated.  Returns RGB planar: [3, R_total] on
-    every rank when gather=True (ranks may hold different R_local), else this rank's [3, R_local]."""
+    every rank when gather=True (ranks may hold different R_local), else this rank's [3, R_local].
+    equal_shards=True promises every rank holds the same R_local: the pixel count is then known on the
+    host and the call enqueues without any device->host synchronisation."""
     k = kernels or _HipKernels()
     dev = feature_local.device
     n_local = feature_local.shape[0]
@@ -45,7 +47,8 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     stat = torch.cat([k.crossray_chansum(feature_local) if n_local else torch.zeros(64, device=dev),
                       torch.tensor([float(n_local)], device=dev)])
     dist.all_reduce(stat, group=group)
-    c_sum, count = stat[:64].contiguous(), float(stat[64].item())
+    ws = dist.get_world_size(group)
+    c_sum, count = stat[:64].contiguous(), (float(n_local * ws) if equal_shards else float(stat[64].item()))
     # reduction 2: Gram of the centred conv chain        (linearStyleTransfer.py:29-34)
     cnet = net.multi_net.cnet
     gram = k.crossray_gram(feature_local, (c_sum / count).contiguous(), cnet.conv_tensors()) if n_local else torch.zeros(1024, device=dev)
@@ -54,7 +57,10 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     rgb_local = k.crossray_apply(feature_local, affine) if n_local else torch.zeros(3, 0, device=dev)
     if not gather:
         return rgb_local
-    ws = dist.get_world_size(group)
+    if equal_shards:
+        full = torch.empty(ws * 3, n_local, device=dev)
+        dist.all_gather_into_tensor(full, rgb_local.contiguous(), group=group)
+        return full.view(ws, 3, n_local).permute(1, 0, 2).reshape(3, ws * n_local)
     sizes = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(ws)]
     dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.long, device=dev), group=group)
     sizes = [int(s.item()) for s in sizes]

@@ -76,12 +76,16 @@ def _worker(rank, world, port, n_pixels, out_q):
             rgb = decode_sharded(net, feat[lo:hi].contiguous(), style, kernels=CpuKernels())
             local = decode_sharded(net, feat[lo:hi].contiguous(), style, gather=False, kernels=CpuKernels())
         assert torch.equal(local, rgb[:, lo:hi])
+        if n_pixels % world == 0:
+            with torch.no_grad():
+                fast = decode_sharded(net, feat[lo:hi].contiguous(), style, kernels=CpuKernels(), equal_shards=True)
+            assert torch.equal(fast, rgb)
         out_q.put((rank, rgb.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pixels", [35 * 29, 3, 1])   # 1 pixel: one rank holds nothing
+@pytest.mark.parametrize("n_pixels", [35 * 29, 32 * 32, 3, 1])   # 1 pixel: one rank holds nothing
 def test_decode_sharded_matches_single_process(n_pixels):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
