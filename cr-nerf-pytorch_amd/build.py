@@ -16,7 +16,8 @@ SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "render_fused.hip", "ray_ke
 HEADERS = ["layout.h", "mlp_core.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
 # the kernels call fmaf() explicitly wherever a fused multiply-add is wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+         + os.environ.get("CRNERF_EXTRA_FLAGS", "").split())   # tuning builds only, e.g. -DCRNERF_TIMING
 
 
 def _hipcc():

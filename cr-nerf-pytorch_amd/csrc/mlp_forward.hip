@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char* __restr
   load_consts(lds, packed, packed);
   WeightPipe pipe;
   pipe.start(lds, (gbl_char*)(packed + CONST_BYTES), (gbl_char*)(packed + CONST_BYTES), 1, 1, lane, wave);
+  f32x4 cur[8];
+  pipe.prime(cur);
+  PhaseTimer tm;
+  tm.start(false);
 
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char* __restr
 #pragma unroll
       for (int i = 0; i < 16; ++i) dv[0][i] = tmpd[i];
     }
-    mlp_tile(pipe, 0, pe, dv, feat, sigma, h);
+    mlp_tile(pipe, 0, pe, dv, feat, sigma, h, cur, tm);
     if (valid) {
       if (sigma_only) {
         if (h == 0) out[n] = sigma;

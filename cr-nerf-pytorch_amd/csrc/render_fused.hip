@@ -15,6 +15,10 @@
 
 namespace crnerf {
 
+#ifdef CRNERF_TIMING
+__device__ unsigned long long crnerf_timing[T_COUNT];
+#endif
+
 struct RenderParams {
   const char* packed0;
   const char* packed1;
@@ -56,6 +60,10 @@ __global__ __launch_bounds__(256, 1) void render_rays_kernel(RenderParams a) {
   WeightPipe pipe;
   pipe.start(lds, (gbl_char*)(a.packed0 + CONST_BYTES), (gbl_char*)(a.packed1 + CONST_BYTES), tiles_c, tiles_c + tiles_f,
              lane, wave);
+  f32x4 cur[8];
+  pipe.prime(cur);
+  PhaseTimer tm;
+  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
 
 #pragma unroll 1
   for (int it = 0; it < a.iters; ++it) {
@@ -106,13 +114,14 @@ __global__ __launch_bounds__(256, 1) void render_rays_kernel(RenderParams a) {
           for (int i = 0; i < 48; ++i) pe[i / 16][i % 16] = tmp[i];
         }
         float sigma;
-        mlp_tile(pipe, pass, pe, dv, feat, sigma, h);
+        mlp_tile(pipe, pass, pe, dv, feat, sigma, h, cur, tm);
         const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
         const float w = composite_tile(st, feat, sigma, noise, zn, znext, n == N - 1, valid, p);
         if (valid && h == 0) {
           if (ray_ok) weights_row[n] = w;
           if (pass == 0) scr.wc[n] = w;
         }
+        tm.tick(T_COMPOSITE);
       }
       composite_finish(st);
       if (ray_ok)
@@ -124,8 +133,10 @@ __global__ __launch_bounds__(256, 1) void render_rays_kernel(RenderParams a) {
         if (a.z_fine && ray_ok)
           for (int n = lane; n < Nf; n += 64) a.z_fine[r * Nf + n] = scr.zs[n];
       }
+      tm.tick(T_RAYLEVEL);
     }
   }
+  tm.flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -152,5 +163,11 @@ int launch_render_rays(const RenderArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(render_rays_kernel, dim3(grid), dim3(256), shmem, stream, k);
   return check_launch("render_rays_kernel");
 }
+
+#ifdef CRNERF_TIMING
+extern "C" int crnerf_debug_read_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_timing), sizeof(unsigned long long) * T_COUNT);
+}
+#endif
 
 }  // namespace crnerf

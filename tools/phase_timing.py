@@ -1,0 +1,29 @@
+"""Tuning tool (GPU box): rebuilds with -DCRNERF_TIMING, runs the headline config and prints the
+per-phase cycle breakdown of wave 0 / block 0 (shader clock)."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+env = dict(os.environ, CRNERF_EXTRA_FLAGS="-DCRNERF_TIMING " + os.environ.get("CRNERF_EXTRA_FLAGS", ""))
+subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], env=env, stdout=subprocess.DEVNULL)
+print("flags:", env["CRNERF_EXTRA_FLAGS"])
+import torch
+import crnerf_amd.synth as synth
+from crnerf_amd import ops, _lib
+dev = torch.device("cuda:0")
+C = lambda s: {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+pc, pf = ops.pack_mlp_weights(C(synth.mlp_state(1, 3.0, 1.0))), ops.pack_mlp_weights(C(synth.mlp_state(2, 3.0, 1.0)))
+rays = torch.from_numpy(synth.rays(1024)).to(dev)
+for _ in range(3):
+    ops.render_rays(pc, pf, rays, 64, 128)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * 7)()
+lib.crnerf_debug_read_timing.argtypes = [ctypes.c_void_p]
+assert lib.crnerf_debug_read_timing(buf) == 0
+names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"]
+tot = buf[6]
+for n, v in zip(names, buf):
+    print("%-18s %12d cycles  %6.2f %%" % (n, v, 100.0 * v / tot))
+print("ideal mma cycles: %d (8 tiles x 9664 MFMA x 64)" % (8 * 9664 * 64))
+if not os.environ.get("CRNERF_KEEP_BUILD"):   # restore the production build
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
