@@ -17,7 +17,7 @@ EXPORTS = [
     "crnerf_posenc_f32", "crnerf_mlp_forward_f32", "crnerf_composite_f32", "crnerf_sample_pdf_merge_f32",
     "crnerf_render_rays_f32", "crnerf_crossray_workspace_bytes", "crnerf_crossray_chansum_f32",
     "crnerf_crossray_gram_f32", "crnerf_crossray_matrix_f32", "crnerf_crossray_fold_f32",
-    "crnerf_crossray_apply_f32",
+    "crnerf_crossray_apply_f32", "crnerf_crossray_decode_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -71,6 +71,7 @@ def load():
             "crnerf_crossray_matrix_f32": (ctypes.c_int, [vp, f64, vp, vp, vp, vp]),
             "crnerf_crossray_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, pp, vp, vp]),
             "crnerf_crossray_apply_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, vp]),
+            "crnerf_crossray_decode_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, vp, i64, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h

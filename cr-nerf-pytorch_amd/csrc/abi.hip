@@ -132,6 +132,22 @@ int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const
   return launch_crossray_fold(s_matrix, c_matrix, c_mean64, s_mean64, w, affine, (hipStream_t)stream);
 }
 
+int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* w,
+                               void* workspace, float* rgb, int64_t plane_stride, void* stream) {
+  if (HW == 0) return 0;
+  REQUIRE(content, "content"); REQUIRE(w, "weights"); REQUIRE(workspace, "workspace"); REQUIRE(rgb, "rgb");
+  if (HW < 0 || HWs < 0) return set_error(CRNERF_ERR_SHAPE, "crossray_decode: negative size");
+  for (int i = 0; i < CRNERF_DECODER_TENSORS; ++i)
+    if (!w[i]) return set_error(CRNERF_ERR_NULL, "crossray_decode: a weight pointer is NULL");
+  DecodeArgs d;
+  d.content = content; d.HW = (long)HW; d.style = style; d.HWs = (long)HWs;
+  d.snet = CnnTensors{w[0], w[1], w[2], w[3], w[4], w[5]}; d.snet_fc_w = w[6]; d.snet_fc_b = w[7];
+  d.cnet = CnnTensors{w[8], w[9], w[10], w[11], w[12], w[13]}; d.cnet_fc_w = w[14]; d.cnet_fc_b = w[15];
+  d.lin = FoldTensors{w[16], w[17], w[18], w[19], w[20], w[21]};
+  d.workspace = workspace; d.rgb = rgb; d.plane_stride = (long)plane_stride;
+  return launch_crossray_decode(d, (hipStream_t)stream);
+}
+
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride, void* stream) {
   if (HW == 0) return 0;
   REQUIRE(x, "x"); REQUIRE(affine, "affine"); REQUIRE(rgb, "rgb");

@@ -4,9 +4,10 @@
 
 namespace crnerf {
 
-constexpr int CROSSRAY_MAX_BLOCKS = 1024;
-// workspace floats: max(chansum partials 1024*64, gram partials 256*1024)
-constexpr size_t CROSSRAY_WORKSPACE_BYTES = (size_t)256 * 1024 * 4;
+constexpr int CROSSRAY_SUM_BLOCKS = 64;    // partial rows of the channel-sum reduction
+constexpr int CROSSRAY_GRAM_BLOCKS = 256;  // partial Grams (one workgroup per CU)
+// two jobs x (sum partials + Gram partials) + stats; see WS_* in crossray.hip
+constexpr size_t CROSSRAY_WORKSPACE_BYTES = (size_t)2560 * 1024;
 
 struct CnnTensors {  // CNN.convs, models/linearStyleTransfer.py:11-15 (1x1 convs = [out,in] matrices)
   const float* w1; const float* b1;  // 64 -> 128
@@ -18,6 +19,15 @@ struct FoldTensors {  // MulLayer.compress/unzip :54-55, NeuralRenderer.feat_2_r
   const float* unzip_w; const float* unzip_b;  // [64,32], [64]
   const float* rgb_w; const float* rgb_b;      // [3,64], [3]
 };
+struct DecodeArgs {
+  const float* content; long HW;
+  const float* style; long HWs;      // style == nullptr: type == "content" (decoder only)
+  CnnTensors snet; const float* snet_fc_w; const float* snet_fc_b;
+  CnnTensors cnet; const float* cnet_fc_w; const float* cnet_fc_b;
+  FoldTensors lin;
+  void* workspace;
+  float* rgb; long plane_stride;
+};
 
 int launch_crossray_chansum(const float* x, long HW, float* sum_out, float* workspace, hipStream_t stream);
 int launch_crossray_gram(const float* x, long HW, const float* mean, const CnnTensors& w, float* gram_sum, float* workspace,
@@ -26,5 +36,6 @@ int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_
 int launch_crossray_fold(const float* sM, const float* cM, const float* c_mean, const float* s_mean, const FoldTensors& w,
                          float* affine, hipStream_t stream);
 int launch_crossray_apply(const float* x, long HW, const float* affine, float* rgb, long plane_stride, hipStream_t stream);
+int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream);
 
 }  // namespace crnerf

@@ -17,6 +17,13 @@
 //   fold      : everything after the Gram is affine per pixel: rgb_pre = A x + v with
 //               A = Wrgb Wunzip T Wcomp (3x64), T = sMatrix cMatrix; folded once per image
 //   apply     : rgb = sigmoid(A x + v)                             (HBM-bound stream: 256 B in, 12 B out)
+// Every kernel takes up to two "jobs" (content grid, style grid) so the single-GPU entry
+// crnerf_crossray_decode_f32 is 6 launches from one host call.
+//
+// gram is the only piece with real arithmetic (18.4 k MAC/pixel): it runs on the fp32 MFMA with the
+// same swapped-operand trick as the NeRF MLP (mlp_core.h): 32 pixels per wavefront, the conv chain's
+// activations stay in registers, the 72 KiB of weights sit in LDS as A-operand fragments, and the
+// 32x32 Gram update itself is 16 more MFMAs per tile (H H^T through a 4 KiB LDS transpose).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "crossray.h"
@@ -24,174 +31,243 @@
 namespace crnerf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// ---------------------------------------------------------------- channel sums
-__global__ __launch_bounds__(256) void chansum_partial_kernel(const float* __restrict__ x, long HW, float* __restrict__ partial) {
+// ---------------------------------------------------------------- channel sums (two jobs)
+struct SumJob { const float* x; long HW; float* partial; int nblk; };
+
+__global__ __launch_bounds__(256) void chansum_partial_kernel(SumJob j0, SumJob j1) {
   // thread = (pixel slot, channel quad); 16 channel quads x 16 pixel slots per block
   __shared__ f32x4 red[256];
+  const bool second = (int)blockIdx.x >= j0.nblk;
+  const SumJob j = second ? j1 : j0;
+  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
   const int cq = threadIdx.x & 15, ps = threadIdx.x >> 4;
   f32x4 acc = {0, 0, 0, 0};
-  for (long px = (long)blockIdx.x * 16 + ps; px < HW; px += (long)gridDim.x * 16) acc += *(const f32x4*)(x + px * 64 + cq * 4);
+  for (long px = (long)blk * 16 + ps; px < j.HW; px += (long)j.nblk * 16) acc += *(const f32x4*)(j.x + px * 64 + cq * 4);
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 8; s >= 1; s >>= 1) {
     if (ps < s) red[threadIdx.x] += red[threadIdx.x + s * 16];
     __syncthreads();
   }
-  if (ps == 0) *(f32x4*)(partial + (long)blockIdx.x * 64 + cq * 4) = red[cq];
+  if (ps == 0) *(f32x4*)(j.partial + (long)blk * 64 + cq * 4) = red[cq];
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ partial, int rows, int cols, float* __restrict__ out) {
+struct RedJob { const float* partial; int rows; float* out; };
+// out[c] = sum_r partial[r][c], cols columns per job, fixed order (deterministic)
+__global__ void reduce_rows_kernel(RedJob j0, RedJob j1, int cols) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  const RedJob j = blockIdx.y ? j1 : j0;
+  if (c >= cols || !j.out) return;
   float s = 0.0f;
-  for (int r = 0; r < rows; ++r) s += partial[(long)r * cols + c];
-  out[c] = s;
+  for (int r = 0; r < j.rows; ++r) s += j.partial[(long)r * cols + c];
+  j.out[c] = s;
+}
+
+static int chansum_blocks(long HW) {
+  const long b = (HW + 15) / 16;
+  return (int)(b < CROSSRAY_SUM_BLOCKS ? (b < 1 ? 1 : b) : CROSSRAY_SUM_BLOCKS);
 }
 
 int launch_crossray_chansum(const float* x, long HW, float* sum_out, float* workspace, hipStream_t stream) {
   if (HW <= 0) return set_error(-2, "crossray_chansum: empty grid");
-  const int grid = (int)((HW + 15) / 16 < CROSSRAY_MAX_BLOCKS ? (HW + 15) / 16 : CROSSRAY_MAX_BLOCKS);
-  hipLaunchKernelGGL(chansum_partial_kernel, dim3(grid), dim3(256), 0, stream, x, HW, workspace);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, stream, workspace, grid, 64, sum_out);
+  SumJob j{x, HW, workspace, chansum_blocks(HW)}, none{nullptr, 0, nullptr, 0};
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(j.nblk), dim3(256), 0, stream, j, none);
+  RedJob r{workspace, j.nblk, sum_out}, rn{nullptr, 0, nullptr};
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(64), 0, stream, r, rn, 64);
   return check_launch("crossray_chansum");
 }
 
-// ---------------------------------------------------------------- Gram of the conv chain
-constexpr int GR_W1 = 0;                      // [128][64]
-constexpr int GR_W2 = GR_W1 + 128 * 64;       // [64][128]
-constexpr int GR_W3 = GR_W2 + 64 * 128;       // [32][64]
-constexpr int GR_B1 = GR_W3 + 32 * 64;        // 128
-constexpr int GR_B2 = GR_B1 + 128;            // 64
-constexpr int GR_B3 = GR_B2 + 64;             // 32
-constexpr int GR_MEAN = GR_B3 + 32;           // 64
-constexpr int GR_H3 = GR_MEAN + 64;           // [256][33]
-constexpr int GR_FLOATS = GR_H3 + 256 * 33;
+// ---------------------------------------------------------------- Gram of the conv chain on the fp32 MFMA
+// LDS (floats): A-operand fragments of the three 1x1 convs, biases, mean, per-wave transpose buffers
+constexpr int GF_L1 = 0;                    // 32 fragments: 8 k-groups x 4 tiles   (64 -> 128)
+constexpr int GF_L2 = GF_L1 + 32 * 256;     // 32 fragments: 16 k-groups x 2 tiles  (128 -> 64)
+constexpr int GF_L3 = GF_L2 + 32 * 256;     //  8 fragments: 8 k-groups x 1 tile    (64 -> 32)
+constexpr int GF_B1 = GF_L3 + 8 * 256;      // 128
+constexpr int GF_B2 = GF_B1 + 128;          // 64
+constexpr int GF_B3 = GF_B2 + 64;           // 32
+constexpr int GF_MEAN = GF_B3 + 32;         // 64
+constexpr int GF_HB = GF_MEAN + 64;         // 4 waves x [32 px][33]
+constexpr int GF_FLOATS = GF_HB + 4 * 32 * 33;
+
+struct GramJob {
+  const float* x; long HW;
+  const float* mean;          // [64] or null -> mean = (sum of chan_partial rows) * inv_count
+  const float* chan_partial; int chan_rows; float inv_count;
+  CnnTensors w;
+  float* gram_partial;        // [nblk][1024]
+  float* mean_out;            // [64] or null
+  int nblk;
+};
 
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
 
-__global__ __launch_bounds__(256, 1) void gram_partial_kernel(const float* __restrict__ x, long HW, const float* __restrict__ mean,
-                                                              CnnTensors w, float* __restrict__ partial) {
+template <int NT>
+__device__ __forceinline__ void bias_init(f32x16 (&acc)[NT], const float* bias, int h) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4*)(bias + 32 * t + 8 * q + 4 * h);
+      acc[t][4 * q + 0] = b[0]; acc[t][4 * q + 1] = b[1]; acc[t][4 * q + 2] = b[2]; acc[t][4 * q + 3] = b[3];
+    }
+}
+
+// acc[t] += W-fragments (LDS, fragment (v*NT + t)) x src, NG k-groups
+template <int NT, int NG, int NSRC>
+__device__ __forceinline__ void conv_mfma(const float* frags, int lane, const f32x16 (&src)[NSRC], f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int v = 0; v < NG; ++v)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 a = *(const f32x4*)(frags + (v * NT + t) * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = MFMA32(a[j], src[v >> 2][(v & 3) * 4 + j], acc[t]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j1) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 128 * 64; i += 256) { sm[GR_W1 + i] = w.w1[i]; sm[GR_W2 + i] = w.w2[i]; }
-  for (int i = tid; i < 32 * 64; i += 256) sm[GR_W3 + i] = w.w3[i];
-  if (tid < 128) sm[GR_B1 + tid] = w.b1[tid];
-  if (tid < 64) { sm[GR_B2 + tid] = w.b2[tid]; sm[GR_MEAN + tid] = mean[tid]; }
-  if (tid < 32) sm[GR_B3 + tid] = w.b3[tid];
+  const bool second = (int)blockIdx.x >= j0.nblk;
+  const GramJob J = second ? j1 : j0;
+  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+
+  // fragments: frag(v,t)[lane = 32kk + i][j] = W[32t + i][8v + 4kk + j]
+  for (int idx = tid; idx < GF_B1; idx += 256) {
+    const int frag = idx >> 8, l = (idx & 255) >> 2, j = idx & 3, i = l & 31, kk = l >> 5;
+    float val;
+    if (frag < 32) { const int v = frag >> 2, t = frag & 3; val = J.w.w1[(32 * t + i) * 64 + 8 * v + 4 * kk + j]; }
+    else if (frag < 64) { const int f = frag - 32, v = f >> 1, t = f & 1; val = J.w.w2[(32 * t + i) * 128 + 8 * v + 4 * kk + j]; }
+    else { const int v = frag - 64; val = J.w.w3[i * 64 + 8 * v + 4 * kk + j]; }
+    sm[idx] = val;
+  }
+  if (tid < 128) sm[GF_B1 + tid] = J.w.b1[tid];
+  if (tid < 64) {
+    sm[GF_B2 + tid] = J.w.b2[tid];
+    float m;
+    if (J.mean) m = J.mean[tid];
+    else {
+      float s = 0.0f;
+      for (int r = 0; r < J.chan_rows; ++r) s += J.chan_partial[r * 64 + tid];
+      m = s * J.inv_count;
+    }
+    sm[GF_MEAN + tid] = m;
+    if (blk == 0 && J.mean_out) J.mean_out[tid] = m;
+  }
+  if (tid < 32) sm[GF_B3 + tid] = J.w.b3[tid];
   __syncthreads();
 
-  // this thread's 4 Gram entries: row a, columns b0..b0+3
-  const int ga = tid >> 3, gb0 = (tid & 7) * 4;
-  float g[4] = {0, 0, 0, 0};
+  float* hb = sm + GF_HB + wave * 32 * 33;
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) G[r] = 0.0f;
 
-  const long nbatch = (HW + 255) / 256;
-  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-    const long px = batch * 256 + tid;
-    const bool valid = px < HW;
-    float xin[64];
-    {
-      const float* row = x + (valid ? px : 0) * 64;
+  const long tiles = (J.HW + 31) / 32;
+  for (long tile = (long)blk * 4 + wave; tile < tiles; tile += (long)J.nblk * 4) {
+    const long px = tile * 32 + p;
+    const bool valid = px < J.HW;
+    const float* row = J.x + (valid ? px : 0) * 64;
+    f32x16 xin[2];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const f32x4 v = *(const f32x4*)(row + 4 * c);
-        const f32x4 m = *(const f32x4*)(sm + GR_MEAN + 4 * c);
-        xin[4 * c + 0] = v[0] - m[0]; xin[4 * c + 1] = v[1] - m[1]; xin[4 * c + 2] = v[2] - m[2]; xin[4 * c + 3] = v[3] - m[3];
-      }
+    for (int v = 0; v < 8; ++v) {
+      const f32x4 xv = *(const f32x4*)(row + 8 * v + 4 * h);
+      const f32x4 mv = *(const f32x4*)(sm + GF_MEAN + 8 * v + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xin[v >> 2][(v & 3) * 4 + j] = xv[j] - mv[j];      // cF - cMean, :59-65
     }
-    float h2[64];
+    f32x16 a1[4], a2[2], a3[1];
+    bias_init<4>(a1, sm + GF_B1, h);
+    conv_mfma<4, 8>(sm + GF_L1, lane, xin, a1);
 #pragma unroll
-    for (int o = 0; o < 64; ++o) h2[o] = sm[GR_B2 + o];
-    // layer 1 (64->128, LeakyReLU 0.2) produced 8 outputs at a time and folded straight into layer 2
-#pragma unroll 1
-    for (int oc = 0; oc < 128; oc += 8) {
-      float h1[8];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        float a = sm[GR_B1 + oc + u];
-        const float* wr = sm + GR_W1 + (oc + u) * 64;
+      for (int r = 0; r < 16; ++r) a1[t][r] = lrelu02(a1[t][r]);
+    bias_init<2>(a2, sm + GF_B2, h);
+    conv_mfma<2, 16>(sm + GF_L2, lane, a1, a2);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const f32x4 wv = *(const f32x4*)(wr + 4 * c);
-          a = fmaf(wv[0], xin[4 * c + 0], a); a = fmaf(wv[1], xin[4 * c + 1], a);
-          a = fmaf(wv[2], xin[4 * c + 2], a); a = fmaf(wv[3], xin[4 * c + 3], a);
-        }
-        h1[u] = lrelu02(a);
-      }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int o = 0; o < 64; ++o) {
-        const f32x4 wa = *(const f32x4*)(sm + GR_W2 + o * 128 + oc);
-        const f32x4 wb = *(const f32x4*)(sm + GR_W2 + o * 128 + oc + 4);
-        float a = h2[o];
-        a = fmaf(wa[0], h1[0], a); a = fmaf(wa[1], h1[1], a); a = fmaf(wa[2], h1[2], a); a = fmaf(wa[3], h1[3], a);
-        a = fmaf(wb[0], h1[4], a); a = fmaf(wb[1], h1[5], a); a = fmaf(wb[2], h1[6], a); a = fmaf(wb[3], h1[7], a);
-        h2[o] = a;
-      }
+      for (int r = 0; r < 16; ++r) a2[t][r] = lrelu02(a2[t][r]);
+    bias_init<1>(a3, sm + GF_B3, h);
+    conv_mfma<1, 8>(sm + GF_L3, lane, a2, a3);
+    // transpose through LDS: hb[px][feat], feat = 8q + 4h + j; padded pixels contribute nothing
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hb[p * 33 + 8 * (r >> 2) + 4 * h + (r & 3)] = valid ? a3[0][r] : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // G += H H^T : A[i][k] = H[feat i][px k], B[k][j] = H[feat j][px k] -> the same register
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float a = hb[(2 * s + h) * 33 + p];
+      G = MFMA32(a, a, G);
     }
-#pragma unroll
-    for (int o = 0; o < 64; ++o) h2[o] = lrelu02(h2[o]);
-    __syncthreads();  // previous batch's Gram reads of the h3 buffer are done
-#pragma unroll 4
-    for (int o = 0; o < 32; ++o) {
-      float a = sm[GR_B3 + o];
-      const float* wr = sm + GR_W3 + o * 64;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const f32x4 wv = *(const f32x4*)(wr + 4 * c);
-        a = fmaf(wv[0], h2[4 * c + 0], a); a = fmaf(wv[1], h2[4 * c + 1], a);
-        a = fmaf(wv[2], h2[4 * c + 2], a); a = fmaf(wv[3], h2[4 * c + 3], a);
-      }
-      sm[GR_H3 + tid * 33 + o] = valid ? a : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < 256; ++p) {
-      const float ha = sm[GR_H3 + p * 33 + ga];
-      g[0] = fmaf(ha, sm[GR_H3 + p * 33 + gb0 + 0], g[0]);
-      g[1] = fmaf(ha, sm[GR_H3 + p * 33 + gb0 + 1], g[1]);
-      g[2] = fmaf(ha, sm[GR_H3 + p * 33 + gb0 + 2], g[2]);
-      g[3] = fmaf(ha, sm[GR_H3 + p * 33 + gb0 + 3], g[3]);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  float* out = partial + (long)blockIdx.x * 1024 + ga * 32 + gb0;
-  out[0] = g[0]; out[1] = g[1]; out[2] = g[2]; out[3] = g[3];
+  // cross-wave reduction (fragment area is dead now); D layout: col j = p, row i = (r&3) + 8(r>>2) + 4h
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sm[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + p] = G[r];
+  __syncthreads();
+  const f32x4 s = *(f32x4*)(sm + tid * 4) + *(f32x4*)(sm + 1024 + tid * 4) + *(f32x4*)(sm + 2048 + tid * 4) + *(f32x4*)(sm + 3072 + tid * 4);
+  *(f32x4*)(J.gram_partial + (long)blk * 1024 + tid * 4) = s;
+}
+
+static int gram_blocks(long HW) {
+  const long b = ((HW + 31) / 32 + 3) / 4;
+  return (int)(b < CROSSRAY_GRAM_BLOCKS ? (b < 1 ? 1 : b) : CROSSRAY_GRAM_BLOCKS);
+}
+
+static int launch_gram(const GramJob& a, const GramJob& b, hipStream_t stream) {
+  const size_t shmem = (size_t)GF_FLOATS * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(gram_mfma_kernel) failed");
+  hipLaunchKernelGGL(gram_mfma_kernel, dim3(a.nblk + b.nblk), dim3(256), shmem, stream, a, b);
+  return 0;
 }
 
 int launch_crossray_gram(const float* x, long HW, const float* mean, const CnnTensors& w, float* gram_sum, float* workspace,
                          hipStream_t stream) {
   if (HW <= 0) return set_error(-2, "crossray_gram: empty grid");
-  const long nbatch = (HW + 255) / 256;
-  const int grid = (int)(nbatch < 256 ? nbatch : 256);
-  const size_t shmem = (size_t)GR_FLOATS * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)gram_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(gram_partial_kernel) failed");
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(grid), dim3(256), shmem, stream, x, HW, mean, w, workspace);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(4), dim3(256), 0, stream, workspace, grid, 1024, gram_sum);
+  GramJob a{x, HW, mean, nullptr, 0, 0.0f, w, workspace, nullptr, gram_blocks(HW)};
+  GramJob none{};
+  none.nblk = 0;
+  if (int rc = launch_gram(a, none, stream)) return rc;
+  RedJob r{workspace, a.nblk, gram_sum}, rn{nullptr, 0, nullptr};
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 1), dim3(256), 0, stream, r, rn, 1024);
   return check_launch("crossray_gram");
 }
 
 // ---------------------------------------------------------------- M = fc(G_sum / count): one wave per output row
-__global__ __launch_bounds__(256) void gram_fc_kernel(const float* __restrict__ gram_sum, float inv_count, const float* __restrict__ fc_w,
-                                                      const float* __restrict__ fc_b, float* __restrict__ out) {
+struct FcJob { const float* gram_sum; float inv_count; const float* fc_w; const float* fc_b; float* out; };
+
+__global__ __launch_bounds__(256) void gram_fc_kernel(FcJob j0, FcJob j1) {
+  const FcJob j = blockIdx.y ? j1 : j0;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const float* wr = fc_w + (long)row * 1024;
+  const float* wr = j.fc_w + (long)row * 1024;
   float a = 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const f32x4 wv = *(const f32x4*)(wr + k * 256 + lane * 4);
-    const f32x4 gv = *(const f32x4*)(gram_sum + k * 256 + lane * 4);
-    a = fmaf(wv[0], gv[0] * inv_count, a); a = fmaf(wv[1], gv[1] * inv_count, a);
-    a = fmaf(wv[2], gv[2] * inv_count, a); a = fmaf(wv[3], gv[3] * inv_count, a);
+    const f32x4 gv = *(const f32x4*)(j.gram_sum + k * 256 + lane * 4);
+    a = fmaf(wv[0], gv[0] * j.inv_count, a); a = fmaf(wv[1], gv[1] * j.inv_count, a);
+    a = fmaf(wv[2], gv[2] * j.inv_count, a); a = fmaf(wv[3], gv[3] * j.inv_count, a);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
-  if (lane == 0) out[row] = a + fc_b[row];
+  if (lane == 0) j.out[row] = a + j.fc_b[row];
 }
 
 int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_w, const float* fc_b, float* out, hipStream_t stream) {
   if (!(count > 0)) return set_error(-2, "crossray_matrix: count must be positive");
-  hipLaunchKernelGGL(gram_fc_kernel, dim3(256), dim3(256), 0, stream, gram_sum, (float)(1.0 / count), fc_w, fc_b, out);
+  FcJob j{gram_sum, (float)(1.0 / count), fc_w, fc_b, out};
+  hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 1), dim3(256), 0, stream, j, j);
   return check_launch("crossray_matrix");
 }
 
@@ -209,7 +285,7 @@ __global__ __launch_bounds__(64) void fold_kernel(const float* __restrict__ sM, 
       T[i][j] = a;
     }
     __syncthreads();
-    // P = Wrgb @ Wunzip (3x32), Q = P @ T (3x32), A = Q @ Wcomp (3x64)
+    // U = Wrgb @ Wunzip (3x32), Q = U @ T (3x32), A = Q @ Wcomp (3x64)
     if (t < 32)
       for (int r = 0; r < 3; ++r) {
         float a = 0.0f;
@@ -292,6 +368,41 @@ int launch_crossray_apply(const float* x, long HW, const float* affine, float* r
   const int grid = (int)(blocks < 2048 ? blocks : 2048);
   hipLaunchKernelGGL(apply_kernel, dim3(grid), dim3(256), 0, stream, x, HW, affine, rgb, plane_stride);
   return check_launch("crossray_apply");
+}
+
+// ---------------------------------------------------------------- single-GPU decode: 6 launches, one host call
+// workspace layout (floats)
+constexpr size_t WS_SUMP0 = 0;                                         // [CROSSRAY_SUM_BLOCKS][64]
+constexpr size_t WS_SUMP1 = WS_SUMP0 + (size_t)CROSSRAY_SUM_BLOCKS * 64;
+constexpr size_t WS_GRAMP0 = WS_SUMP1 + (size_t)CROSSRAY_SUM_BLOCKS * 64;  // [CROSSRAY_GRAM_BLOCKS][1024]
+constexpr size_t WS_GRAMP1 = WS_GRAMP0 + (size_t)CROSSRAY_GRAM_BLOCKS * 1024;
+constexpr size_t WS_STATS = WS_GRAMP1 + (size_t)CROSSRAY_GRAM_BLOCKS * 1024;
+constexpr size_t ST_CMEAN = 0, ST_SMEAN = 64, ST_CGRAM = 128, ST_SGRAM = 128 + 1024, ST_CMAT = 128 + 2048, ST_SMAT = 128 + 3072,
+                 ST_AFFINE = 128 + 4096, ST_END = ST_AFFINE + 256;
+static_assert((WS_STATS + ST_END) * 4 <= CROSSRAY_WORKSPACE_BYTES, "workspace too small");
+
+int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
+  if (d.HW <= 0) return 0;
+  float* ws = (float*)d.workspace;
+  float* st = ws + WS_STATS;
+  if (!d.style) {  // type == "content"
+    if (int rc = launch_crossray_fold(nullptr, nullptr, nullptr, nullptr, d.lin, st + ST_AFFINE, stream)) return rc;
+    return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
+  }
+  if (d.HWs <= 0) return set_error(-2, "crossray_decode: empty style grid");
+  SumJob s0{d.content, d.HW, ws + WS_SUMP0, chansum_blocks(d.HW)}, s1{d.style, d.HWs, ws + WS_SUMP1, chansum_blocks(d.HWs)};
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+  GramJob g0{d.content, d.HW, nullptr, ws + WS_SUMP0, s0.nblk, (float)(1.0 / (double)d.HW), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, gram_blocks(d.HW)};
+  GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
+  if (int rc = launch_gram(g0, g1, stream)) return rc;
+  RedJob r0{ws + WS_GRAMP0, g0.nblk, st + ST_CGRAM}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 2), dim3(256), 0, stream, r0, r1, 1024);
+  FcJob f0{st + ST_CGRAM, (float)(1.0 / (double)d.HW), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
+  FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
+  hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
+  if (int rc = check_launch("crossray_decode")) return rc;
+  return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
 }
 
 }  // namespace crnerf

@@ -91,7 +91,11 @@ class style_net(nn.Module):
         if style_feature is None and type == "content":
             return self.decoder(content_feature)
         xp, (H, W) = _pixel_major(content_feature)
-        c_sum = ops.crossray_chansum(xp)
-        c_gram = self.multi_net.cnet.gram_sum(xp, (c_sum / xp.shape[0]).contiguous())
-        affine = self.affine_from_stats(c_sum, c_gram, xp.shape[0], style_feature)
-        return ops.crossray_apply(xp, affine).view(1, 3, H, W)
+        sp, _ = _pixel_major(style_feature)
+        return ops.crossray_decode(xp, sp, self.decoder_tensors()).view(1, 3, H, W)
+
+    def decoder_tensors(self):
+        """The 22 parameter tensors in state_dict order (crnerf_crossray_decode_f32's `weights`)."""
+        mn = self.multi_net
+        return (mn.snet.conv_tensors() + [mn.snet.fc.weight, mn.snet.fc.bias] + mn.cnet.conv_tensors() + [mn.cnet.fc.weight, mn.cnet.fc.bias]
+                + mn.lin_tensors() + list(self.decoder.rgb_tensors()))

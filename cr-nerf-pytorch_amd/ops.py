@@ -190,3 +190,20 @@ def crossray_apply(x, affine, out=None):
     _lib.check(lib.crnerf_crossray_apply_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(affine), _lib.dev_ptr(out), out.stride(0), _lib.stream_ptr()),
                "crnerf_crossray_apply_f32")
     return out
+
+
+def crossray_decode(content_pm, style_pm, weights, out=None):
+    """Whole style_net.forward from one host call.  content_pm [HW,64], style_pm [HWs,64] or None,
+    weights: the 22 parameter tensors in state_dict order.  Returns planar rgb [3,HW]."""
+    lib = _lib.load()
+    x = _f32c(content_pm, "content")
+    s = _f32c(style_pm, "style") if style_pm is not None else None
+    ws = crossray_workspace(x.device)
+    HW = x.shape[0]
+    if out is None:
+        out = torch.empty(3, HW, dtype=torch.float32, device=x.device)
+    arr = _lib.ptr_array([_f32c(t.detach(), "decoder weight") for t in weights], "decoder weight")
+    _lib.check(lib.crnerf_crossray_decode_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(s), s.shape[0] if s is not None else 0, arr,
+                                              ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), out.stride(0), _lib.stream_ptr()),
+               "crnerf_crossray_decode_f32")
+    return out

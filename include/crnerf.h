@@ -119,6 +119,14 @@ int crnerf_crossray_matrix_f32(const float* gram_sum, double count, const float*
  * A[3][64] then v[3].  s_matrix == NULL selects the type=="content" path (:285-287: decoder only). */
 int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const float* c_mean64, const float* s_mean64,
                              const float* const* lin, float* affine, void* stream);
+/* Single-GPU convenience: the whole of style_net.forward (chansum -> gram -> matrix -> fold -> apply for the
+ * content grid and the style grid) enqueued from one call.  weights = HOST array of the 22 parameter tensors in
+ * state_dict order: multi_net.snet.{convs.0,convs.2,convs.4,fc}.{weight,bias}, multi_net.cnet.(same),
+ * multi_net.compress.{weight,bias}, multi_net.unzip.{weight,bias}, decoder.feat_2_rgb_list.0.{weight,bias}.
+ * style == NULL selects type=="content".  rgb[c*plane_stride + px]. */
+#define CRNERF_DECODER_TENSORS 22
+int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
+                               void* workspace, float* rgb, int64_t plane_stride, void* stream);
 /* rgb[c*plane_stride + px] = sigmoid(A[c] . x[px] + v[c]) */
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
                               void* stream);
