@@ -12,11 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "render_fused.hip", "ray_kernels.hip", "crossray.hip"]
-HEADERS = ["layout.h", "mlp_core.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
+SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "ray_kernels.hip",
+           "crossray.hip"]
+HEADERS = ["layout.h", "mlp_core.h", "mlp_core16.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
 # the kernels call fmaf() explicitly wherever a fused multiply-add is wanted.
-FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-honor-nans: lets fmaxf(x, 0) be ONE v_max_f32 (otherwise hipcc canonicalises the MFMA output first).
+FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-honor-nans", "-Wall", "-Wno-unused-function"]
          + os.environ.get("CRNERF_EXTRA_FLAGS", "").split())   # tuning builds only, e.g. -DCRNERF_TIMING
 
 

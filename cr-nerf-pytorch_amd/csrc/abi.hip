@@ -1,6 +1,7 @@
 // extern "C" surface of libcrnerf_hip.so -- see include/crnerf.h for the contract of every symbol.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/crnerf.h"
 #include "crossray.h"
@@ -27,6 +28,13 @@ int check_launch(const char* what) {
 
 using namespace crnerf;
 
+// Tuning switch (not part of the ABI): CRNERF_CORE=32 selects the one-wave-per-SIMD 32x32x2 core,
+// anything else the two-waves-per-SIMD 16x16x4 core.  Packed buffers are core-specific.
+static const bool g_core16 = [] {
+  const char* e = getenv("CRNERF_CORE");
+  return !(e && strcmp(e, "32") == 0);
+}();
+
 #define REQUIRE(p, name) \
   if (!(p)) return set_error(CRNERF_ERR_NULL, name " is NULL")
 
@@ -48,7 +56,7 @@ int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* str
   t.w_sigma = tensors[18]; t.b_sigma = tensors[19];
   t.w_dir = tensors[20]; t.b_dir = tensors[21];
   t.w_rgb = tensors[22]; t.b_rgb = tensors[23];
-  return launch_pack_mlp(t, packed, (hipStream_t)stream);
+  return launch_pack_mlp(t, packed, g_core16 ? 1 : 0, (hipStream_t)stream);
 }
 
 int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream) {
@@ -65,7 +73,8 @@ int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64
   REQUIRE(x, "x");
   REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward: negative n");
-  return launch_mlp_forward(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  return g_core16 ? launch_mlp_forward16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream)
+                  : launch_mlp_forward(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
 int crnerf_composite_f32(const float* raw, const float* z, const float* noise, float noise_std, float* weights, float* feature,
@@ -100,7 +109,7 @@ int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
   r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
-  return launch_render_rays(r, (hipStream_t)stream);
+  return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
 }
 
 int crnerf_crossray_chansum_f32(const float* x, int64_t HW, float* sum64, void* workspace, void* stream) {

@@ -18,7 +18,7 @@ struct MlpTensors {  // device pointers to the 24 tensors of one NeRF_sigma (mod
   const float* w_rgb;   const float* b_rgb;    // static_rgb.0
 };
 
-int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
@@ -50,5 +50,7 @@ struct RenderArgs {
   float* z_fine;               // [R,Nc+Ni] optional (null to skip)
 };
 int launch_render_rays(const RenderArgs& a, hipStream_t stream);
+int launch_render_rays16(const RenderArgs& a, hipStream_t stream);
+int launch_mlp_forward16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 
 }  // namespace crnerf

@@ -94,4 +94,18 @@ __host__ __device__ inline int posenc_slot_to_col(int k, int F) {
   return -1;
 }
 
+// ---- "v16" fragment order for the v_mfma_f32_16x16x4_f32 core (mlp_core16.h): same layers, same
+// fragment counts and stage cuts, but a fragment is
+//     frag(layer, k-group u (16 k-values), tile T (16 rows))[lane = 16*kq + i][r] = W[16T + i][col(16u + 4kq + r)]
+// and the embedding slot order pairs (sin, cos) inside a 4-lane-group: slot k = 16v + 4g + 2p + sc
+// belongs to argument a = 8v + 2g + p (same argument -> column rule as posenc_slot_to_col).
+__host__ __device__ inline int posenc_slot_to_col16(int k, int F) {
+  const int v = k >> 4, g = (k >> 2) & 3, p = (k >> 1) & 1, sc = k & 1;
+  const int a = 8 * v + 2 * g + p;
+  if (a < 3 * F) return 3 + 6 * (a / 3) + 3 * sc + (a % 3);
+  if (a == 3 * F) return sc;
+  if (a == 3 * F + 1) return sc == 0 ? 2 : -1;
+  return -1;
+}
+
 }  // namespace crnerf

@@ -40,7 +40,7 @@ constexpr int LDS_SCRATCH = LDS_RING + RING_SLOTS * STAGE_BYTES;  // 120,832
 // per phase into crnerf_timing[]; compiled out otherwise.
 enum { T_PROLOGUE = 0, T_MMA, T_EPILOGUE, T_SIGMA, T_COMPOSITE, T_RAYLEVEL, T_TOTAL, T_COUNT };
 #ifdef CRNERF_TIMING
-extern __device__ unsigned long long crnerf_timing[T_COUNT];
+static __device__ unsigned long long crnerf_timing[T_COUNT];   // one copy per translation unit
 struct PhaseTimer {
   unsigned long long last, acc[T_COUNT];
   bool on;

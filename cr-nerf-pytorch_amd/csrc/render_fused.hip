@@ -15,10 +15,6 @@
 
 namespace crnerf {
 
-#ifdef CRNERF_TIMING
-__device__ unsigned long long crnerf_timing[T_COUNT];
-#endif
-
 struct RenderParams {
   const char* packed0;
   const char* packed1;

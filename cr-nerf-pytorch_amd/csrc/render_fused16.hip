@@ -1,0 +1,277 @@
+// Fused volumetric renderer on the v16 core (mlp_core16.h): two wavefronts per SIMD.
+// Same contract as render_fused.hip (render_rays_cross_ray, models/rendering.py:50-196).
+//
+// Work decomposition: workgroup = 8 waves = 4 rays; a ray belongs to a PAIR of waves (A = even wave,
+// B = odd wave).  The ray's samples are walked in 32-sample steps; in step k wave A owns samples
+// [32k, 32k+16), wave B [32k+16, 32k+32), each as one 16-point MFMA tile.  The pair exchanges only
+// scalars through LDS: the product of (1-alpha) over each wave's 16 samples per step (running
+// transmittance), and the per-ray feature/depth partial sums at the end of a pass.  sample_pdf and the
+// merge run on the pair's 128 lanes.  All 8 waves execute identical control flow, so plain workgroup
+// barriers order the exchanges.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "mlp_core16.h"
+#include "ray_ops.h"
+
+namespace crnerf {
+
+struct RenderParams16 {
+  const char* packed0; const char* packed1;
+  const float* rays; const float* view_dir; const float* z_coarse; const float* z_steps; const float* u; long u_stride;
+  const float* noise_c; const float* noise_f; float noise_std; int use_disp;
+  long R; int Nc, Ni, iters;
+  float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
+};
+
+constexpr int PAIR_FLOATS = 4 * MAX_NC + (MAX_NC + MAX_NI) + 128;   // zc, wc, cdf, zf(<=MAX_NI==MAX_NC), zs, exchange
+constexpr int PAIR_BYTES = PAIR_FLOATS * 4;
+static_assert(MAX_NI <= MAX_NC, "zf shares the MAX_NC sizing");
+
+struct PairScratch {
+  lds_float *zc, *wc, *cdf, *zf, *zs, *xfeat;   // xfeat[64] + depth at [64]
+  __attribute__((address_space(3))) double* xprod;  // [2]
+  __device__ __forceinline__ void bind(lds_char* b) {
+    zc = (lds_float*)b; wc = zc + MAX_NC; cdf = wc + MAX_NC; zf = cdf + MAX_NC; zs = zf + MAX_NC;
+    xfeat = zs + (MAX_NC + MAX_NI);
+    xprod = (__attribute__((address_space(3))) double*)(xfeat + 96);
+  }
+};
+
+// LDS-only exchange between the waves of the workgroup: drain this wave's LDS queue, barrier.  (A
+// workgroup-scope fence would also drain vmcnt, i.e. the LDS-DMA prefetches in flight.)
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef CRNERF_EXP_NOBARRIER  // (timing experiments only)
+  __builtin_amdgcn_s_barrier();
+#endif
+  asm volatile("" ::: "memory");
+}
+
+// sample_pdf on the pair's 128 lanes (rendering.py:7-46).  Both waves build the cdf redundantly
+// (identical values) so only the sample / merge phases need the partner.
+__device__ __forceinline__ void sample_pdf_pair(PairScratch& s, int Nc, int Ni, const float* u_row, int lane, int lane128) {
+  const int n_ = Nc - 2;
+  const float eps = 1e-5f;
+  float part = 0.0f;
+  for (int i = lane; i < n_; i += 64) part += s.wc[1 + i] + eps;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  const float wsum = part;
+  double carry = 0.0;
+  for (int base = 0; base < n_; base += 64) {
+    const int i = base + lane;
+    const float pdf = (i < n_) ? (s.wc[1 + i] + eps) / wsum : 0.0f;
+    double incl = (double)pdf;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = shfl_up_f64(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    incl += carry;
+    carry = shfl_f64(incl, 63, 64);
+    if (i < n_) s.cdf[i + 1] = (float)incl;
+  }
+  if (lane == 0) s.cdf[0] = 0.0f;
+  wave_lds_fence();
+  for (int k = lane128; k < Ni; k += 128) {
+    const float u = u_row ? u_row[k] : linspace01(k, Ni);
+    int lo = 0, hi = n_ + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s.cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 < 0 ? 0 : lo - 1;
+    const int above = lo > n_ ? n_ : lo;
+    const float c0 = s.cdf[below], c1 = s.cdf[above];
+    const float b0 = 0.5f * (s.zc[below] + s.zc[below + 1]);
+    const float b1 = 0.5f * (s.zc[above] + s.zc[above + 1]);
+    float denom = c1 - c0;
+    if (denom < eps) denom = 1.0f;
+    s.zf[k] = b0 + (u - c0) / denom * (b1 - b0);
+  }
+}
+
+__device__ __forceinline__ void merge_sort_pair(PairScratch& s, int Nc, int Ni, int lane128) {
+  const int N = Nc + Ni;
+  for (int e = lane128; e < N; e += 128) {
+    const bool is_c = e < Nc;
+    const float v = is_c ? s.zc[e] : s.zf[e - Nc];
+    int rank = 0;
+    for (int j = 0; j < Nc; ++j) {
+      const float o = s.zc[j];
+      rank += (o < v) || (o == v && (!is_c || j < e));
+    }
+    for (int j = 0; j < Ni; ++j) {
+      const float o = s.zf[j];
+      rank += (o < v) || (o == v && !is_c && j < e - Nc);
+    }
+    s.zs[rank] = v;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* lds = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const int pair = wave >> 1, half = wave & 1;
+  const int lane128 = half * 64 + lane;
+  const int Nc = a.Nc, Ni = a.Ni, Nf = Nc + Ni;
+
+  load_consts(lds, a.packed0, a.packed1);
+  PairScratch scr;
+  scr.bind(lds + LDS_SCRATCH + pair * PAIR_BYTES);
+
+  const int steps_c = (Nc + 31) >> 5, steps_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
+  WeightPipe16 pipe;
+  pipe.start(lds, (gbl_char*)(a.packed0 + CONST_BYTES), (gbl_char*)(a.packed1 + CONST_BYTES), steps_c, steps_c + steps_f, lane, wave);
+  f32x4 q[V16_AHEAD];
+  pipe.prime(q);
+  PhaseTimer tm;
+  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
+
+#pragma unroll 1
+  for (int it = 0; it < a.iters; ++it) {
+    const long rr = ((long)it * gridDim.x + blockIdx.x) * 4 + pair;
+    const bool ray_ok = rr < a.R;
+    const long r = ray_ok ? rr : a.R - 1;
+    const float* ray = a.rays + r * 8;
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float near = ray[6], far = ray[7];
+    f32x4 dv[2];
+    {
+      const float* vd = a.view_dir ? a.view_dir + r * 3 : ray + 3;       // rendering.py:155
+      posenc_regs16<DIR_FREQS, 2>(vd[0], vd[1], vd[2], g, dv);
+    }
+    for (int n = lane128; n < Nc; n += 128)
+      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    wg_barrier();
+
+    const int npass = Ni > 0 ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      const int N = pass ? Nf : Nc;
+      const lds_float* zsrc = pass ? scr.zs : scr.zc;
+      const float* noise_row = pass ? (a.noise_f ? a.noise_f + r * Nf : nullptr) : (a.noise_c ? a.noise_c + r * Nc : nullptr);
+      float* weights_row = pass ? a.weights_f + r * Nf : a.weights_c + r * Nc;
+      double carry = 1.0;
+      f32x4 facc[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) facc[T] = f32x4{0, 0, 0, 0};
+      float dacc = 0.0f;
+      const int steps = (N + 31) >> 5;
+#pragma unroll 1
+      for (int k = 0; k < steps; ++k) {
+        const int n = 32 * k + 16 * half + p;
+        const bool valid = n < N;
+        const int nc = valid ? n : N - 1;
+        const float zn = zsrc[nc];
+        const float znext = zsrc[nc + 1 < N ? nc + 1 : N - 1];
+        const float x = ox + dx * zn, y = oy + dy * zn, z = oz + dz * zn;   // rendering.py:178 / :188
+        f32x4 pe[6], feat[4];
+        posenc_regs16<XYZ_FREQS, 6>(x, y, z, g, pe);
+        float sigma;
+        mlp_tile16(pipe, pass, pe, dv, feat, sigma, g, q, tm);
+        // ---- compositing, rendering.py:121-143
+        const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        const float delta = (n == N - 1) ? 1e2f : znext - zn;
+        const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sigma + noise, 0.0f)) : 0.0f;
+        double incl = (double)(1.0f - alpha);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const double o = shfl_up_f64(incl, d, 16);
+          if (p >= d) incl *= o;
+        }
+        double excl = shfl_up_f64(incl, 1, 16);
+        if (p == 0) excl = 1.0;
+        const double tot = shfl_f64(incl, 15, 16);
+        if (lane == 0) scr.xprod[half] = tot;
+        wg_barrier();
+        const double other = scr.xprod[half ^ 1];
+        const double prod_a = half ? other : tot, prod_b = half ? tot : other;
+        const float Tr = (float)(half ? carry * prod_a * excl : carry * excl);
+        carry = carry * prod_a * prod_b;
+        const float w = alpha * Tr;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+          for (int rr2 = 0; rr2 < 4; ++rr2) facc[T][rr2] += w * feat[T][rr2];
+        dacc += w * zn;
+        if (valid && g == 0) {
+          if (ray_ok) weights_row[n] = w;
+          if (pass == 0) scr.wc[n] = w;
+        }
+        tm.tick(T_COMPOSITE);
+      }
+      // per-wave reduction over the 16 point lanes, then pair combine through LDS
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+          for (int rr2 = 0; rr2 < 4; ++rr2) facc[T][rr2] += __shfl_xor(facc[T][rr2], d);
+        dacc += __shfl_xor(dacc, d);
+      }
+      if (half == 1 && p == 0) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) *(__attribute__((address_space(3))) f32x4*)(scr.xfeat + 16 * T + 4 * g) = facc[T];
+        if (g == 0) scr.xfeat[64] = dacc;
+      }
+      wg_barrier();
+      if (half == 0 && p == 0 && ray_ok) {
+        float* frow = (pass ? a.feature_f : a.feature_c) + r * FEAT_DIM;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+          const f32x4 o = *(const __attribute__((address_space(3))) f32x4*)(scr.xfeat + 16 * T + 4 * g);
+          *(f32x4*)(frow + 16 * T + 4 * g) = facc[T] + o;
+        }
+        if (g == 0) (pass ? a.depth_f : a.depth_c)[r] = dacc + scr.xfeat[64];
+      }
+      if (pass == 0 && Ni > 0) {
+        sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128);
+        wg_barrier();
+        merge_sort_pair(scr, Nc, Ni, lane128);
+        wg_barrier();
+        if (a.z_fine && ray_ok)
+          for (int n = lane128; n < Nf; n += 128) a.z_fine[r * Nf + n] = scr.zs[n];
+      }
+      tm.tick(T_RAYLEVEL);
+    }
+    wg_barrier();   // scratch is rewritten by the next ray
+  }
+  tm.flush();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
+  if (a.R <= 0) return 0;
+  if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays: N_samples must be in [2, 256] for the fused kernel");
+  if (a.Ni < 0 || a.Ni > MAX_NI) return set_error(-2, "render_rays: N_importance must be in [0, 256] for the fused kernel");
+  if (a.Ni > 0 && a.Nc < 3) return set_error(-2, "render_rays: hierarchical sampling needs N_samples >= 3");
+  if (a.Ni > 0 && !a.packed_fine) return set_error(-3, "render_rays: N_importance > 0 but no fine model");
+  RenderParams16 k;
+  k.packed0 = (const char*)a.packed_coarse;
+  k.packed1 = (const char*)(a.packed_fine ? a.packed_fine : a.packed_coarse);
+  k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.z_steps = a.z_steps; k.u = a.u; k.u_stride = a.u_stride;
+  k.noise_c = a.noise_coarse; k.noise_f = a.noise_fine; k.noise_std = a.noise_std; k.use_disp = a.use_disp;
+  k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
+  k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
+  k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
+  const long quads = (a.R + 3) / 4;
+  const int grid = (int)(quads < 256 ? quads : 256);
+  k.iters = (int)((quads + grid - 1) / grid);
+  const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES;
+  hipError_t e = hipFuncSetAttribute((const void*)render_rays16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(render_rays16_kernel) failed");
+  hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
+  return check_launch("render_rays16_kernel");
+}
+
+#ifdef CRNERF_TIMING
+extern "C" int crnerf_debug_read_timing16(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_timing), sizeof(unsigned long long) * T_COUNT);
+}
+#endif
+
+}  // namespace crnerf

@@ -18,12 +18,13 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 7)()
-lib.crnerf_debug_read_timing.argtypes = [ctypes.c_void_p]
-assert lib.crnerf_debug_read_timing(buf) == 0
+fn = lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf) == 0
 names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"]
 tot = buf[6]
 for n, v in zip(names, buf):
     print("%-18s %12d cycles  %6.2f %%" % (n, v, 100.0 * v / tot))
-print("ideal mma cycles: %d (8 tiles x 9664 MFMA x 64)" % (8 * 9664 * 64))
+print("ideal matrix-pipe cycles per SIMD: %d (8 steps x 9664 MFMA x 64 cycles-equivalent)" % (8 * 9664 * 64))
 if not os.environ.get("CRNERF_KEEP_BUILD"):   # restore the production build
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
