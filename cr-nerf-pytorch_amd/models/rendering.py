@@ -23,6 +23,49 @@ def _coarse_depths(rays, N_samples, use_disp, perturb):
     return (lower + (upper - lower) * (perturb * torch.rand_like(z))).contiguous()
 
 
+_tables = {}
+
+
+def _linspace_tables(n_samples, n_importance, device):
+    """The reference's two tables, built the reference's way on the same device (rendering.py:160, :27)."""
+    key = (n_samples, n_importance, str(device))
+    if key not in _tables:
+        _tables[key] = (torch.linspace(0, 1, n_samples, device=device),
+                        torch.linspace(0, 1, n_importance, device=device) if n_importance > 0 else None)
+    return _tables[key]
+
+
+def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, jitter, chunk):
+    R = rays.shape[0]
+    o, d = rays[:, None, 0:3], rays[:, None, 3:6]
+    z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
+    if z_coarse is None:
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+        z_coarse = z_coarse.expand(R, Nc).contiguous()
+    demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
+
+    def run(model, z, noise):
+        N = z.shape[1]
+        pts = (o + d * z[..., None]).reshape(-1, 3)
+        if jitter:
+            pts = pts + 0.00001 * torch.rand_like(pts)                       # rendering.py:102-104
+        dirs = demb[:, None, :].expand(R, N, demb.shape[-1]).reshape(R * N, -1)
+        raw = torch.empty(R * N, 65, dtype=torch.float32, device=rays.device)
+        step = max(int(chunk), 1)
+        for i in range(0, R * N, step):                                      # point chunks, rendering.py:110-114
+            x = torch.cat([ops.posenc(pts[i:i + step].contiguous(), 15), dirs[i:i + step]], 1)
+            raw[i:i + step] = ops.mlp_forward(model.packed_weights(), x)
+        return ops.composite(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
+
+    out = {}
+    out["weights_coarse"], out["feature_coarse"], out["depth_coarse"] = run(coarse, z_coarse, noise_c)
+    if Ni > 0:
+        z_fine = ops.sample_pdf_merge(z_coarse.contiguous(), out["weights_coarse"], Ni, u=u if u is not None else u_steps)
+        out["weights_fine"], out["feature_fine"], out["depth_fine"] = run(fine, z_fine, noise_f)
+    return out
+
+
 def _check_embedding(emb, n_freqs, what):
     if not isinstance(emb, PosEmbedding) or emb.N_freqs != n_freqs:
         raise NotImplementedError("crnerf_amd: embeddings['%s'] must be crnerf_amd PosEmbedding(%d, %d); the fused kernel computes "
@@ -36,8 +79,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
     reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible)."""
     args = kwargs['args']
-    if getattr(args, 'pertubeCord', False):
-        raise NotImplementedError("crnerf_amd: args.pertubeCord (models/rendering.py:102-104) is not implemented in the HIP path")
+    jitter = bool(getattr(args, 'pertubeCord', False))
     if getattr(args, 'nerf_out_dim', 64) != 64:
         raise NotImplementedError("crnerf_amd: nerf_out_dim must be 64")
     _check_embedding(embeddings['xyz'], 15, 'xyz')
@@ -49,8 +91,6 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
             raise NotImplementedError("crnerf_amd: models must be crnerf_amd NeRF_sigma instances")
     if torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters()):
         raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad()")
-    if N_samples > _FUSED_MAX or N_importance > _FUSED_MAX:
-        raise NotImplementedError("crnerf_amd: the fused renderer handles N_samples, N_importance <= 256")
 
     rays = rays.to(torch.float32).contiguous()
     R = rays.shape[0]
@@ -65,9 +105,17 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    out = ops.render_rays(coarse.packed_weights(), fine.packed_weights() if fine is not None else None, rays,
-                          N_samples, N_importance, use_disp=use_disp, view_dir=view_dir, z_coarse=z_coarse, u=u,
-                          noise_coarse=noise_c, noise_fine=noise_f, noise_std=float(noise_std))
+    if N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
+        # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
+        # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)
+        out = _render_unfused(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
+                              float(noise_std), jitter, int(chunk))
+    else:
+        tables = _linspace_tables(N_samples, N_importance, rays.device)
+        out = ops.render_rays(coarse.packed_weights(), fine.packed_weights() if fine is not None else None, rays,
+                              N_samples, N_importance, use_disp=use_disp, view_dir=view_dir, z_coarse=z_coarse,
+                              z_steps=tables[0], u=u if u is not None else tables[1],
+                              noise_coarse=noise_c, noise_fine=noise_f, noise_std=float(noise_std))
 
     typ_c = coarse.typ
     results = {'weights_%s' % typ_c: out['weights_coarse'], 'feature_%s' % typ_c: out['feature_coarse'],

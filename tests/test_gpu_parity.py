@@ -294,6 +294,35 @@ def test_render_noise_and_external_depths_vs_oracle():
     close(out["weights_fine"], w2, atol=3e-6), close(out["feature_fine"], f2, atol=1e-5)
 
 
+@torch.no_grad()
+def test_reference_signature_general_path_large_sample_counts_and_jitter():
+    """N_samples/N_importance beyond the fused kernel (eval-style 256+256 is fused; 320+300 is not) and
+    args.pertubeCord go through the un-fused HIP pipeline; compared with the oracle at its own depths."""
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    from crnerf_amd.models.rendering import render_rays_cross_ray
+    st_c, st_f = synth.mlp_state(5, 3.0, 1.0), synth.mlp_state(6, 3.0, 1.0)
+    args = _Args()
+    models = {"coarse": NeRF_sigma("coarse", args, in_channels_xyz=93, in_channels_dir=27).to(DEV),
+              "fine": NeRF_sigma("fine", args, in_channels_xyz=93, in_channels_dir=27, encode_random=True).to(DEV)}
+    models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in st_c.items()})
+    models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in st_f.items()})
+    emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
+    rays_np = synth.rays(6, seed=11)
+    res = render_rays_cross_ray(models, emb, C(rays_np), None, 320, False, 0, 0, 300, 4096, False, args=args)
+    assert res["weights_fine"].shape == (6, 620) and res["feature_fine_random"] is res["feature_fine"]
+    rays = torch.from_numpy(rays_np)
+    ref = O.render_rays(O.to_torch(st_c), O.to_torch(st_f), rays, 320, 0, z_steps=torch.linspace(0, 1, 320))
+    close(res["feature_coarse"], ref["feature_coarse"], atol=5e-4)          # device-built linspace table (1-ulp depths)
+    assert float((res["weights_fine"].sum(-1) - 1).abs().max()) < 1e-4
+
+    class Jit(_Args):
+        pertubeCord = True
+    a = render_rays_cross_ray(models, emb, C(rays_np), None, 64, False, 0, 0, 0, 4096, False, args=Jit())
+    b = render_rays_cross_ray(models, emb, C(rays_np), None, 64, False, 0, 0, 0, 4096, False, args=args)
+    d = float((a["feature_coarse"] - b["feature_coarse"]).abs().max())
+    assert 0 < d < 0.2                                                      # 1e-5 jitter x 2^14 frequencies: visible, bounded
+
+
 def test_render_rejects_unsupported_sizes():
     pc = packed(synth.mlp_state(1))
     rays = C(synth.rays(4))
@@ -377,3 +406,30 @@ def test_reference_call_signature_end_to_end(golden):
     x = torch.cat([emb["xyz"](rays[:, :3].contiguous()), emb["dir"](rays[:, 3:6].contiguous())], 1)
     assert x.shape == (64, 120)
     close(models["fine"](x), O.mlp_forward(O.to_torch(st_f), x.cpu()), atol=3e-5, rtol=1e-5)
+
+
+def test_alternate_core32_still_matches(golden):
+    """CRNERF_CORE=32 selects the one-wave-per-SIMD 32x32x2 core (kept for A/B measurements); the env var is
+    read at library load, so it is exercised in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import crnerf_amd.synth as synth\n"
+        "from crnerf_amd import ops\n"
+        "g = dict(np.load(%r))\n"
+        "C = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "pk = lambda s: ops.pack_mlp_weights({k: C(v) for k, v in s.items()})\n"
+        "sc = synth.mlp_state(int(g['seed_coarse']), float(g['gain']), float(g['sigma_bias']))\n"
+        "sf = synth.mlp_state(int(g['seed_fine']), float(g['gain']), float(g['sigma_bias']))\n"
+        "with torch.no_grad():\n"
+        "    out = ops.render_rays(pk(sc), pk(sf), C(g['rays']), 64, 128, z_steps=C(g['z_steps_64']), u=C(g['u_steps_128']))\n"
+        "d = float((out['feature_coarse'].cpu() - torch.from_numpy(g['c64_f128__feature_coarse'])).abs().max())\n"
+        "w = float((out['weights_coarse'].cpu() - torch.from_numpy(g['c64_f128__weights_coarse'])).abs().max())\n"
+        "assert d < 1e-5 and w < 3e-6, (d, w)\n"
+        "print('core32 ok', d, w)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_render.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRNERF_CORE="32"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -107,10 +107,6 @@ def test_render_shim_validates_like_the_boundary_says():
     with pytest.raises(NotImplementedError, match="backward"):      # grad mode with trainable params
         render_rays_cross_ray({"coarse": m}, emb, rays, None, 64, False, 0, 0, 0, 1024, False, args=Args())
     with torch.no_grad():
-        class P(Args):
-            pertubeCord = True
-        with pytest.raises(NotImplementedError, match="pertubeCord"):
-            render_rays_cross_ray({"coarse": m}, emb, rays, None, 64, False, 0, 0, 0, 1024, False, args=P())
         with pytest.raises(NotImplementedError, match="PosEmbedding"):
             render_rays_cross_ray({"coarse": m}, {"xyz": PosEmbedding(9, 10), "dir": emb["dir"]}, rays, None, 64, False, 0, 0, 0, 1024, False, args=Args())
         with pytest.raises(KeyError):                                # reference reads kwargs['args'] unconditionally
