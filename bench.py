@@ -11,7 +11,7 @@ grid.  Workload = BASELINE.json configs[1]: 1024 rays x (64+128), fp32, per GPU 
 rank renders its own 1024-ray shard; the decoder's two tiny reductions and the RGB all-gather are the
 only collectives).  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel is render_rays_kernel (fp32 MFMA bound).  achieved = algorithmic MLP
+roofline: the dominant kernel is render_rays16_kernel (fp32 MFMA bound).  achieved = algorithmic MLP
 FLOPs per launch (1,233,152 FLOP/point x 256 points/ray x rays) / its average duration,
 measured live with HIP events on the launch stream.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X guide).
 cpu_baseline: the CPU oracle (plain-PyTorch restatement of the reference, oracle/cpu_ref.py) timed on
@@ -178,7 +178,7 @@ def main():
                                    "fused render_rays + cross-ray decode of the %dx%d feature grid" % (R, NC, NI, grid_hw[0], grid_hw[1]),
                        "rays_per_gpu": R, "n_samples": NC, "n_importance": NI,
                        "parallelism": "rays sharded %d-way, weights replicated" % world},
-            "roofline": {"bound": "mfma", "kernel": "render_rays_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
                          "flops_per_launch": flops},
         }
