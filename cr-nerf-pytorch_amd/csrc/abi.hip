@@ -59,6 +59,44 @@ int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* str
   return launch_pack_mlp(t, packed, g_core16 ? 1 : 0, (hipStream_t)stream);
 }
 
+static MlpTensors to_tensors(const float* const* tensors) {
+  MlpTensors t;
+  for (int i = 0; i < 8; ++i) { t.w[i] = tensors[2 * i]; t.b[i] = tensors[2 * i + 1]; }
+  t.w_final = tensors[16]; t.b_final = tensors[17];
+  t.w_sigma = tensors[18]; t.b_sigma = tensors[19];
+  t.w_dir = tensors[20]; t.b_dir = tensors[21];
+  t.w_rgb = tensors[22]; t.b_rgb = tensors[23];
+  return t;
+}
+
+size_t crnerf_packed_mlp_t_bytes(void) { return PACKEDT_BYTES; }
+size_t crnerf_mlp_train_acts_bytes(int64_t n) { return mlp_train_acts_bytes((long)n); }
+size_t crnerf_mlp_train_scratch_bytes(int64_t n) { return mlp_train_scratch_bytes((long)n); }
+
+int crnerf_pack_mlp_weights_t(const float* const* tensors, void* packed_t, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed_t, "packed_t");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_t: a tensor pointer is NULL");
+  return launch_pack_mlpT(to_tensors(tensors), packed_t, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out, void* acts, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(acts, "acts");
+  if (!g_core16) return set_error(CRNERF_ERR_CONFIG, "training kernels exist for the 16x16x4 core only (unset CRNERF_CORE)");
+  return launch_mlp_forward_train(packed, x, out, (float*)acts, (long)n, (hipStream_t)stream);
+}
+
+int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
+                            float* const* grads, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed_t, "packed_t"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
+  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward: a gradient pointer is NULL");
+  return launch_mlp_backward(packed_t, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream);
+}
+
 int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream) {
   if (n == 0) return 0;
   REQUIRE(x, "x");
@@ -83,6 +121,14 @@ int crnerf_composite_f32(const float* raw, const float* z, const float* noise, f
   REQUIRE(raw, "raw"); REQUIRE(z, "z"); REQUIRE(weights, "weights"); REQUIRE(feature, "feature"); REQUIRE(depth, "depth");
   if (R < 0) return set_error(CRNERF_ERR_SHAPE, "composite: negative R");
   return launch_composite(raw, z, noise, noise_std, weights, feature, depth, (long)R, N, (hipStream_t)stream);
+}
+
+int crnerf_composite_backward_f32(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
+                                  const float* d_depth, const float* d_weights, float* d_raw, int64_t R, int N, void* stream) {
+  if (R == 0) return 0;
+  REQUIRE(raw, "raw"); REQUIRE(z, "z"); REQUIRE(d_feature, "d_feature"); REQUIRE(d_raw, "d_raw");
+  if (R < 0) return set_error(CRNERF_ERR_SHAPE, "composite_backward: negative R");
+  return launch_composite_backward(raw, z, noise, noise_std, d_feature, d_depth, d_weights, d_raw, (long)R, N, (hipStream_t)stream);
 }
 
 int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coarse, const float* u, int64_t u_stride, float* z_sorted,

@@ -19,10 +19,18 @@ struct MlpTensors {  // device pointers to the 24 tensors of one NeRF_sigma (mod
 };
 
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream);
+int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream);
+size_t mlp_train_acts_bytes(long P);
+size_t mlp_train_scratch_bytes(long P);
+int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream);
+int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
+                        float* const* grads, long P, hipStream_t stream);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
                      float* feature, float* depth, long R, int N, hipStream_t stream);
+int launch_composite_backward(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
+                              const float* d_depth, const float* d_weights, float* d_raw, long R, int N, hipStream_t stream);
 int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, long u_stride, float* z_fine_sorted,
                             float* z_samples, long R, int Nc, int Ni, hipStream_t stream);
 

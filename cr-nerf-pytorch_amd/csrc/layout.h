@@ -108,4 +108,20 @@ __host__ __device__ inline int posenc_slot_to_col16(int k, int F) {
   return -1;
 }
 
+// ---- transposed ("WT") stream for the backward-data pass (mlp_backward16.hip), v16 fragment shape:
+//     fragT(layer, k-group u (16 OUTPUT features = the reduction), tile T (16 INPUT features))[lane = 16*kq + i][r]
+//         = W[16u + 4kq + r][in_off + 16T + i]
+// layers in backward order; only the hidden part of each input is needed (embeddings are not trainable).
+constexpr int FT_RGB = 4 * 8;      //  32: static_rgb^T      64 -> 128
+constexpr int FT_DIR = 8 * 16;     // 128: dir_encoding^T   128 -> 256 (columns 0..255 of the [128,283] weight)
+constexpr int FT_HID = 16 * 16;    // 256: xyz_encoding_final^T and xyz_encoding_{8..2}^T (layer 5: columns 93..348)
+constexpr int OFFT_RGB = 0;
+constexpr int OFFT_DIR = OFFT_RGB + FT_RGB;
+constexpr int OFFT_FIN = OFFT_DIR + FT_DIR;
+constexpr int OFFT_L8 = OFFT_FIN + FT_HID;          // L8, L7, ..., L2 contiguous
+constexpr int STREAMT_FRAGS = OFFT_L8 + 7 * FT_HID; // 2208
+constexpr int STAGEST_PER_PASS = STREAMT_FRAGS / STAGE_FRAGS;  // 138
+static_assert(STREAMT_FRAGS % STAGE_FRAGS == 0, "transposed stream must be whole stages");
+constexpr size_t PACKEDT_BYTES = (size_t)CONST_BYTES + (size_t)STREAMT_FRAGS * FRAG_BYTES;
+
 }  // namespace crnerf

@@ -36,6 +36,7 @@ struct WeightPipe16 {
   gbl_char* base[2];
   gbl_char* pf_ptr;
   int pf_left, pf_pass, passes0, passes;
+  int stages_per_pass = STAGES_PER_PASS;   // 151 forward stream, 138 transposed (backward-data) stream
   uint32_t pf_slot, rd_slot, rd_addr, lane16, wave2k;
   int stagger;          // 0/1: which of the two candidate slot sets this wave uses for its LDS-DMA issue
 
@@ -48,7 +49,7 @@ struct WeightPipe16 {
       pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
       pf_ptr += STAGE_BYTES;
       if (--pf_left == 0) {
-        pf_left = STAGES_PER_PASS;
+        pf_left = stages_per_pass;
         pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
         pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
       }
@@ -70,7 +71,7 @@ struct WeightPipe16 {
     passes0 = passes0_;
     passes = passes_;
     pf_pass = 0;
-    pf_left = STAGES_PER_PASS;
+    pf_left = stages_per_pass;
     pf_ptr = (passes0 > 0) ? base[0] : base[1];
     pf_slot = 0;
     rd_slot = 0;
@@ -159,8 +160,15 @@ __device__ __forceinline__ void store_act16(const f32x4 (&acc)[NT], f32x4 (&act)
 
 // One 16-point tile through one model.  pe[6] / dv[2]: embeddings in B-operand order (posenc16.h).
 // feat[T][r] = rgb feature 16T + 4g + r of point p (T = 0..3); sigma valid in all lanes.
+struct NoSave {   // inference: nothing is materialised
+  template <int NT>
+  __device__ __forceinline__ void operator()(int, const f32x4 (&)[NT]) const {}
+};
+
+template <class SAVE = NoSave>
 __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32x4 (&pe)[6], const f32x4 (&dv)[2],
-                                           f32x4 (&feat)[4], float& sigma, int g, f32x4 (&q)[V16_AHEAD], PhaseTimer& tm) {
+                                           f32x4 (&feat)[4], float& sigma, int g, f32x4 (&q)[V16_AHEAD], PhaseTimer& tm,
+                                           const SAVE& save = SAVE()) {
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
   f32x4 act[16], acc[16];
   tm.tick(T_PROLOGUE);
@@ -169,6 +177,7 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
   mma_layer16<16, U_XYZ, 0>(p, pe, pe, acc, q);
   tm.tick(T_MMA);
   store_act16<16, true>(acc, act);
+  save(0, act);
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4
     init_acc16<16>(acc, C + C_BIAS + l * W_HIDDEN, g);
@@ -176,12 +185,14 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
     mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
     tm.tick(T_MMA);
     store_act16<16, true>(acc, act);
+    save(l, act);
   }
   init_acc16<16>(acc, C + C_BIAS + 4 * W_HIDDEN, g);     // xyz_encoding_5 = Linear(cat[xyz, h])
   tm.tick(T_EPILOGUE);
   mma_layer16<16, U_XYZ, U_HID>(p, pe, act, acc, q);
   tm.tick(T_MMA);
   store_act16<16, true>(acc, act);
+  save(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
     init_acc16<16>(acc, C + C_BIAS + l * W_HIDDEN, g);
@@ -189,6 +200,7 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
     mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
     tm.tick(T_MMA);
     store_act16<16, true>(acc, act);
+    save(l, act);
   }
   {                                                      // static_sigma: 256 -> 1 on the VALU
     float s0 = 0.0f, s1 = 0.0f;
@@ -212,6 +224,7 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
   mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
   tm.tick(T_MMA);
   store_act16<16, false>(acc, act);
+  save(8, act);
   {
     f32x4 acc8[8];                                       // dir_encoding = relu(Linear(cat[final, dir]))
     init_acc16<8>(acc8, C + C_BDIR, g);
@@ -219,6 +232,7 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
     mma_layer16<8, U_HID, U_DIR>(p, act, dv, acc8, q);
     tm.tick(T_MMA);
     store_act16<8, true>(acc8, act);
+    save(9, act);                                        // only tiles 0..7 (128 features) are meaningful
   }
   {
     f32x4 acc4[4];                                       // static_rgb = sigmoid(Linear)

@@ -1,0 +1,328 @@
+// Training twins of NeRF_sigma.forward (models/nerf.py:157-182): forward that saves the layer
+// activations, backward-data (dgrad) on the transposed weight stream, and weight/bias gradients as
+// point-reduction GEMMs.  In the reference all of this is PyTorch autograd over 11 addmm nodes.
+//
+//   forward-train : mlp_tile16 + stores of h1..h8, final, dir_act           acts[10][P][256]
+//   backward-data : per 16-point tile, delta stays in registers exactly like the forward activations
+//                   (D[in][point] = W^T[in][out] . delta[out][point]); relu masks come from acts;
+//                   every layer's delta is stored                           deltas[10][P][256], d_rgb[P][64], d_sig[P]
+//   wgrad         : dW[m][n] = sum_p delta[p][m] * a[p][n]  (fp32 MFMA 32x32x2, k = points),
+//                   point-chunked partials + deterministic reduce, written straight in the reference
+//                   [out,in] layout (saved activations are in reference feature order, so no un-pack);
+//                   db[m] = sum_p delta[p][m]
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "mlp_core16.h"
+
+namespace crnerf {
+
+constexpr int ACT_SLOTS = 10;   // h1..h8, final, dir_act(128 used)
+constexpr int ACT_W = 256;
+
+struct ActSaver {
+  float* base; long P; long n; bool valid; int g;
+  template <int NT>
+  __device__ __forceinline__ void operator()(int slot, const f32x4 (&a)[NT]) const {
+    if (!valid) return;
+    float* row = base + ((long)slot * P + n) * ACT_W + 4 * g;
+    const int nt = slot == 9 ? 8 : NT;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+      if (T < nt) *(f32x4*)(row + 16 * T) = a[T];
+  }
+};
+
+__global__ __launch_bounds__(512, 2) void mlp_forward_train16_kernel(const char* __restrict__ packed, const float* __restrict__ x,
+                                                                     float* __restrict__ out, float* __restrict__ acts, long P, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* lds = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  load_consts(lds, packed, packed);
+  WeightPipe16 pipe;
+  pipe.start(lds, (gbl_char*)(packed + CONST_BYTES), (gbl_char*)(packed + CONST_BYTES), 1, 1, lane, wave);
+  f32x4 q[V16_AHEAD];
+  pipe.prime(q);
+  PhaseTimer tm;
+  tm.start(false);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const long tile = ((long)it * gridDim.x + blockIdx.x) * V16_WAVES + wave;
+    const long n = tile * 16 + p;
+    const bool valid = n < P;
+    const float* row = x + (valid ? n : 0) * IN_DIM;
+    f32x4 pe[6], dv[2], feat[4];
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = posenc_slot_to_col16(16 * v + 4 * g + r, XYZ_FREQS);
+        pe[v][r] = (valid && c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
+      }
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = posenc_slot_to_col16(16 * v + 4 * g + r, DIR_FREQS);
+        dv[v][r] = (valid && c >= 0) ? row[XYZ_DIM + (c < 0 ? 0 : c)] : 0.0f;
+      }
+    float sigma;
+    ActSaver sv{acts, P, n, valid, g};
+    mlp_tile16(pipe, 0, pe, dv, feat, sigma, g, q, tm, sv);
+    if (valid) {
+      float* o = out + n * OUT_DIM;
+#pragma unroll
+      for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[16 * T + 4 * g + r] = feat[T][r];
+      if (g == 0) o[FEAT_DIM] = sigma;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------- backward-data
+template <int NT>
+__device__ __forceinline__ void zero_acc16(f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int T = 0; T < NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
+}
+
+// delta_in[T] = mask(act_saved[T] > 0) * acc[T]; store to deltas slot
+template <int NT, bool MASK>
+__device__ __forceinline__ void finish_delta(const f32x4 (&acc)[NT], f32x4 (&dl)[16], const float* act_row, float* delta_row, bool valid) {
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    f32x4 d = acc[T];
+    if (MASK) {
+      const f32x4 a = valid ? *(const f32x4*)(act_row + 16 * T) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = a[r] > 0.0f ? d[r] : 0.0f;
+    }
+    dl[T] = d;
+    if (valid) *(f32x4*)(delta_row + 16 * T) = d;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __restrict__ packedT, const float* __restrict__ out,
+                                                                const float* __restrict__ d_out, const float* __restrict__ acts,
+                                                                float* __restrict__ deltas, float* __restrict__ d_rgb, float* __restrict__ d_sig,
+                                                                long P, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* lds = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  load_consts(lds, packedT, packedT);   // the consts block carries the sigma-head weights
+  const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
+  WeightPipe16 pipe;
+  pipe.stages_per_pass = STAGEST_PER_PASS;
+  pipe.start(lds, (gbl_char*)(packedT + CONST_BYTES), (gbl_char*)(packedT + CONST_BYTES), 1, 1, lane, wave);
+  f32x4 q[V16_AHEAD];
+  pipe.prime(q);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const long tile = ((long)it * gridDim.x + blockIdx.x) * V16_WAVES + wave;
+    const long n = tile * 16 + p;
+    const bool valid = n < P;
+    const long nn = valid ? n : 0;
+    const float* orow = out + nn * OUT_DIM;
+    const float* grow = d_out + nn * OUT_DIM;
+    auto act_row = [&](int slot) { return acts + ((long)slot * P + nn) * ACT_W + 4 * g; };
+    auto del_row = [&](int slot) { return deltas + ((long)slot * P + nn) * ACT_W + 4 * g; };
+
+    f32x4 dl[16], acc[16];
+    // static_rgb: sigmoid'            nerf.py:154,180
+    f32x4 drgb[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f = orow[16 * T + 4 * g + r], gf = valid ? grow[16 * T + 4 * g + r] : 0.0f;
+        drgb[T][r] = gf * f * (1.0f - f);
+      }
+      if (valid) *(f32x4*)(d_rgb + n * FEAT_DIM + 16 * T + 4 * g) = drgb[T];
+    }
+    // static_sigma: softplus' = sigmoid(pre) = 1 - exp(-sigma)      nerf.py:146,172
+    const float sg = orow[FEAT_DIM];
+    const float dsp = valid ? grow[FEAT_DIM] * (1.0f - expf(-sg)) : 0.0f;
+    if (valid && g == 0) d_sig[n] = dsp;
+
+    {  // through static_rgb^T -> dir_encoding output (relu)
+      f32x4 acc8[8];
+      zero_acc16<8>(acc8);
+      mma_layer16<8, 4, 0>(pipe, drgb, drgb, acc8, q);
+      finish_delta<8, true>(acc8, dl, act_row(9), del_row(9), valid);
+    }
+    zero_acc16<16>(acc);                               // through dir_encoding^T[:, :256] -> xyz_encoding_final output (linear)
+    mma_layer16<16, 8, 0>(pipe, dl, dl, acc, q);
+    finish_delta<16, false>(acc, dl, act_row(8), del_row(8), valid);
+    zero_acc16<16>(acc);                               // through xyz_encoding_final^T, + sigma head -> h8 (relu)
+    mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+      const f32x4 w = *(const __attribute__((address_space(3))) f32x4*)(C + C_WSIG + 16 * T + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[T][r] = fmaf(w[r], dsp, acc[T][r]);
+    }
+    finish_delta<16, true>(acc, dl, act_row(7), del_row(7), valid);
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {                     // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2
+      zero_acc16<16>(acc);
+      mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
+      finish_delta<16, true>(acc, dl, act_row(l - 1), del_row(l - 1), valid);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------- wgrad: C[m][n] = sum_p D[p][m] * A[p][n]
+struct WgradJob {
+  const float* D; int ldd; int M;      // deltas  [P, ldd], M columns used
+  const float* A; int lda; int N;      // inputs  [P, lda], N columns used
+  float* partial;                      // [nchunk][M][N]
+  long P; int chunk;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradJob j) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.y * 128 + (wave & 1) * 64, n0 = blockIdx.z * 128 + (wave >> 1) * 64;
+  const long p0 = (long)blockIdx.x * j.chunk;
+  const long p1 = p0 + j.chunk < j.P ? p0 + j.chunk : j.P;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  const bool mv0 = m0 + i < j.M, mv1 = m0 + 32 + i < j.M, nv0 = n0 + i < j.N, nv1 = n0 + 32 + i < j.N;
+  for (long pb = p0; pb < p1; pb += 8) {
+    float da[4][2], aa[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long pt = pb + 2 * s + kk;
+      const bool pv = pt < p1;
+      const float* dr = j.D + pt * j.ldd + m0 + i;
+      const float* ar = j.A + pt * j.lda + n0 + i;
+      da[s][0] = (pv && mv0) ? dr[0] : 0.0f;
+      da[s][1] = (pv && mv1) ? dr[32] : 0.0f;
+      aa[s][0] = (pv && nv0) ? ar[0] : 0.0f;
+      aa[s][1] = (pv && nv1) ? ar[32] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[s][a], aa[s][b], acc[a][b], 0, 0, 0);
+  }
+  float* out = j.partial + (long)blockIdx.x * j.M * j.N;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk, nn = n0 + 32 * b + i;
+        if (m < j.M && nn < j.N) out[(long)m * j.N + nn] = acc[a][b][r];
+      }
+}
+
+// dst[m*ldc + n] = sum_c partial[c][m][n]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * N) return;
+  float s = 0.0f;
+  for (int c = 0; c < nchunk; ++c) s += partial[(long)c * M * N + idx];
+  dst[(long)(idx / N) * ldc + idx % N] = s;
+}
+
+// partial[c][m] = sum_{p in chunk c} D[p][m]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, int ldd, int M, long P, int chunk, float* __restrict__ partial) {
+  const int m = threadIdx.x;
+  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+  if (m >= M) return;
+  float s = 0.0f;
+  for (long pt = p0; pt < p1; ++pt) s += D[pt * ldd + m];
+  partial[(long)blockIdx.x * M + m] = s;
+}
+
+constexpr int WG_CHUNK = 2048;
+
+static int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, long P, float* ws, hipStream_t st) {
+  const int nchunk = (int)((P + WG_CHUNK - 1) / WG_CHUNK);
+  WgradJob j{D, ldd, M, A, lda, N, ws, P, WG_CHUNK};
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 127) / 128, (N + 127) / 128), dim3(256), 0, st, j);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc);
+  return 0;
+}
+static int bgrad(const float* D, int ldd, int M, float* dst, long P, float* ws, hipStream_t st) {
+  const int nchunk = (int)((P + WG_CHUNK - 1) / WG_CHUNK);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk), dim3(256), 0, st, D, ldd, M, P, WG_CHUNK, ws);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, nchunk, 1, M, dst, M);
+  return 0;
+}
+
+size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float); }
+size_t mlp_train_scratch_bytes(long P) {
+  const size_t nchunk = (size_t)((P + WG_CHUNK - 1) / WG_CHUNK);
+  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + nchunk * 256 * 352 * 4;
+}
+
+static int launch_core(const void* fn, int grid, size_t shmem) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  return e == hipSuccess ? 0 : set_error(-10, "hipFuncSetAttribute(train kernel) failed");
+}
+
+int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream) {
+  if (P <= 0) return 0;
+  const long groups = (P + 127) / 128;
+  const int grid = (int)(groups < 256 ? groups : 256), iters = (int)((groups + grid - 1) / grid);
+  if (int rc = launch_core((const void*)mlp_forward_train16_kernel, grid, LDS_SCRATCH)) return rc;
+  hipLaunchKernelGGL(mlp_forward_train16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packed, x, out, acts, P, iters);
+  return check_launch("mlp_forward_train16_kernel");
+}
+
+// grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
+int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
+                        float* const* grads, long P, hipStream_t stream) {
+  if (P <= 0) return 0;
+  float* deltas = (float*)scratch;
+  float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
+  float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
+  float* ws = d_sig + P;
+  const long groups = (P + 127) / 128;
+  const int grid = (int)(groups < 256 ? groups : 256), iters = (int)((groups + grid - 1) / grid);
+  if (int rc = launch_core((const void*)mlp_backward16_kernel, grid, LDS_SCRATCH)) return rc;
+  hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
+  if (int rc = check_launch("mlp_backward16_kernel")) return rc;
+  auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
+  auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
+  // xyz_encoding_1: input x[:, :93]
+  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, P, ws, stream);
+  bgrad(D(0), ACT_W, 256, grads[1], P, ws, stream);
+  for (int l = 1; l < 8; ++l) {
+    if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
+      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, P, ws, stream);
+      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, P, ws, stream);
+    } else {
+      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, P, ws, stream);
+    }
+    bgrad(D(l), ACT_W, 256, grads[2 * l + 1], P, ws, stream);
+  }
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, P, ws, stream);          // xyz_encoding_final
+  bgrad(D(8), ACT_W, 256, grads[17], P, ws, stream);
+  wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, P, ws, stream);               // static_sigma
+  bgrad(d_sig, 1, 1, grads[19], P, ws, stream);
+  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, P, ws, stream);  // dir_encoding: cat([final, dir])
+  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, P, ws, stream);
+  bgrad(D(9), ACT_W, 128, grads[21], P, ws, stream);
+  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, P, ws, stream);   // static_rgb
+  bgrad(d_rgb, FEAT_DIM, FEAT_DIM, grads[23], P, ws, stream);
+  return check_launch("mlp_backward wgrad");
+}
+
+}  // namespace crnerf

@@ -57,6 +57,38 @@ __global__ void pack_consts_kernel(MlpTensors t, float* __restrict__ c) {
   c[i] = v;
 }
 
+// transposed stream (layout.h, "WT"); consts block = the forward one (sigma weights are read from it)
+__global__ void pack_streamT_kernel(MlpTensors t, float* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMT_FRAGS * FRAG_FLOATS) return;
+  const int frag = (int)(idx / FRAG_FLOATS);
+  const int lane = (int)(idx % FRAG_FLOATS) / 4, r = (int)(idx % 4);
+  const int i = lane & 15, kq = lane >> 4;
+  const float* W;
+  int in_dim, in_off, nt, phi;
+  if (frag < OFFT_DIR) { W = t.w_rgb; in_dim = 128; in_off = 0; nt = 8; phi = frag - OFFT_RGB; }
+  else if (frag < OFFT_FIN) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; in_off = 0; nt = 16; phi = frag - OFFT_DIR; }
+  else if (frag < OFFT_L8) { W = t.w_final; in_dim = W_HIDDEN; in_off = 0; nt = 16; phi = frag - OFFT_FIN; }
+  else {
+    const int l = 7 - (frag - OFFT_L8) / FT_HID;       // 7 = xyz_encoding_8 ... 1 = xyz_encoding_2
+    W = t.w[l]; nt = 16; phi = (frag - OFFT_L8) % FT_HID;
+    in_dim = (l == 4) ? XYZ_DIM + W_HIDDEN : W_HIDDEN;
+    in_off = (l == 4) ? XYZ_DIM : 0;                   // nerf.py:169 cat([xyz, h]): h starts at column 93
+  }
+  const int u = phi / nt, T = phi % nt;
+  const int out = 16 * u + 4 * kq + r, in = in_off + 16 * T + i;
+  stream[idx] = W[(long)out * in_dim + in];
+}
+
+int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  float* wstream = (float*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAMT_FRAGS * FRAG_FLOATS;
+  hipLaunchKernelGGL(pack_streamT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlpT");
+}
+
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);

@@ -106,3 +106,115 @@ int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, 
 }
 
 }  // namespace crnerf
+
+// ---------------------------------------------------------------- compositing backward (training)
+// Backward twin of composite_kernel: given dL/dfeature[R,64] (and optionally dL/ddepth[R], dL/dweights[R,N])
+// produces dL/draw[R,N,65] for the raw MLP outputs.  With g_n = dL/dw_n = Gf.f_n + Gd z_n + Gw_n,
+//   dL/df_n     = w_n Gf
+//   dL/dalpha_n = T_n (g_n - U_n),   U_n = sum_{m>n} g_m alpha_m prod_{n<j<m} (1 - alpha_j)
+//                 (division-free form of -sum_{m>n} g_m w_m / (1 - alpha_n); U_{N-1} = 0,
+//                  U_n = g_{n+1} alpha_{n+1} + (1 - alpha_{n+1}) U_{n+1}: an affine suffix scan)
+//   dL/dsigma_n = dL/dalpha_n * delta_n * (1 - alpha_n) * [sigma_n + noise_n > 0]
+// Reference forward being differentiated: models/rendering.py:121-143 (autograd does this in the reference).
+namespace crnerf {
+
+__global__ __launch_bounds__(256) void composite_backward_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                 const float* __restrict__ noise, float noise_std,
+                                                                 const float* __restrict__ d_feature, const float* __restrict__ d_depth,
+                                                                 const float* __restrict__ d_weights, float* __restrict__ d_raw,
+                                                                 long R, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smb[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* al = smb + (size_t)wave * 3 * N;   // alpha
+  float* Tt = al + N;                       // transmittance
+  float* gg = Tt + N;                       // g_n
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    const float* rr = raw + r * (long)N * OUT_DIM;
+    const float* zr = z + r * (long)N;
+    float* dr = d_raw + r * (long)N * OUT_DIM;
+    // phase 1: alpha, T (same arithmetic as the forward kernel)
+    double carry = 1.0;
+    for (int base = 0; base < N; base += 64) {
+      const int n = base + lane;
+      const bool valid = n < N;
+      const int nc = valid ? n : N - 1;
+      const float zn = zr[nc], znext = zr[nc + 1 < N ? nc + 1 : N - 1];
+      const float s = rr[(long)nc * OUT_DIM + FEAT_DIM] + ((noise && valid) ? noise[r * (long)N + n] * noise_std : 0.0f);
+      const float delta = (n == N - 1) ? 1e2f : znext - zn;
+      const float alpha = valid ? 1.0f - expf(-delta * fmaxf(s, 0.0f)) : 0.0f;
+      double incl = (double)(1.0f - alpha);
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_f64(incl, d, 64);
+        if (lane >= d) incl *= o;
+      }
+      double excl = shfl_up_f64(incl, 1, 64);
+      if (lane == 0) excl = 1.0;
+      if (valid) { al[n] = alpha; Tt[n] = (float)(carry * excl); }
+      carry *= shfl_f64(incl, 63, 64);
+    }
+    wave_lds_fence();
+    // phase 2: lane = channel.  g_n and dL/df_n
+    const float gf = d_feature[r * FEAT_DIM + lane];
+    const float gd = d_depth ? d_depth[r] : 0.0f;
+    for (int n = 0; n < N; ++n) {
+      float v = gf * rr[(long)n * OUT_DIM + lane];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+      const float w = al[n] * Tt[n];
+      dr[(long)n * OUT_DIM + lane] = w * gf;
+      if (lane == 0) gg[n] = v + gd * zr[n] + (d_weights ? d_weights[r * (long)N + n] : 0.0f);
+    }
+    wave_lds_fence();
+    // phase 3: reverse affine scan, lane = sample (lane 0 = LAST sample of the chunk)
+    float ucarry = 0.0f;   // U of the first (lowest-index) sample of the previously processed (later) chunk... see below
+    float a_next = 1.0f, b_next = 0.0f;  // (1-alpha, g*alpha) of the sample right after the current chunk
+    for (int top = N; top > 0; top -= 64) {
+      const int n = top - 1 - lane;                 // descending
+      const bool valid = n >= 0;
+      const int nc = valid ? n : 0;
+      // element for sample n: maps U_n = b_{n+1} + a_{n+1} U_{n+1}; shift by one so lane holds (a_{n+1}, b_{n+1})
+      const float a_self = valid ? 1.0f - al[nc] : 1.0f, b_self = valid ? gg[nc] * al[nc] : 0.0f;
+      float a = __shfl_up(a_self, 1, 64), b = __shfl_up(b_self, 1, 64);
+      if (lane == 0) { a = a_next; b = b_next; }
+      // inclusive scan of affine maps along increasing lane: F_lane = f_lane o F_{lane-1}?  U_n = b + a * U_{n+1},
+      // U_{n+1} belongs to lane-1: compose so that (A,B) maps the chunk's incoming U (ucarry) to U_n
+      float A = a, B = b;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
+        if (lane >= d) { B = fmaf(A, Bp, B); A = A * Ap; }
+      }
+      const float U = fmaf(A, ucarry, B);
+      if (valid) {
+        const float zn = zr[nc], znext = zr[nc + 1 < N ? nc + 1 : N - 1];
+        const float s = rr[(long)nc * OUT_DIM + FEAT_DIM] + (noise ? noise[r * (long)N + nc] * noise_std : 0.0f);
+        const float delta = (nc == N - 1) ? 1e2f : znext - zn;
+        const float dalpha = Tt[nc] * (gg[nc] - U);
+        dr[(long)nc * OUT_DIM + FEAT_DIM] = (s > 0.0f) ? dalpha * delta * (1.0f - al[nc]) : 0.0f;
+      }
+      // hand over to the next (earlier) chunk: its lane 0 needs (a,b) of this chunk's lowest sample and U of it
+      ucarry = __shfl(U, 63, 64);
+      a_next = __shfl(a_self, 63, 64);
+      b_next = __shfl(b_self, 63, 64);
+    }
+    wave_lds_fence();
+  }
+}
+
+int launch_composite_backward(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
+                              const float* d_depth, const float* d_weights, float* d_raw, long R, int N, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (N < 1) return set_error(-2, "composite_backward: N must be >= 1");
+  const size_t shmem = (size_t)4 * 3 * N * sizeof(float);
+  if (shmem > 160 * 1024) return set_error(-2, "composite_backward: N too large for LDS");
+  hipError_t e = hipFuncSetAttribute((const void*)composite_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(composite_backward_kernel) failed");
+  const long blocks = (R + 3) / 4;
+  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  hipLaunchKernelGGL(composite_backward_kernel, dim3(grid), dim3(256), shmem, stream, raw, z, noise, noise_std, d_feature, d_depth,
+                     d_weights, d_raw, R, N);
+  return check_launch("composite_backward_kernel");
+}
+
+}  // namespace crnerf

@@ -41,6 +41,51 @@ def pack_mlp_weights(state, out=None):
     return out
 
 
+def _mlp_tensor_list(state):
+    tensors = []
+    for name, shape in zip(MLP_TENSOR_NAMES, MLP_TENSOR_SHAPES):
+        t = state[name]
+        if tuple(t.shape) != shape:
+            raise ValueError("crnerf_amd: %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+        tensors.append(_f32c(t.detach(), name))
+    return tensors
+
+
+def pack_mlp_weights_t(state):
+    """Transposed fragment stream for the backward-data kernel."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_t_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_t(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_t")
+    return out
+
+
+def mlp_forward_train(packed, x):
+    """Forward that keeps the layer activations.  Returns (out[n,65], acts)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    n = x.shape[0]
+    out = torch.empty(n, 65, dtype=torch.float32, device=x.device)
+    acts = torch.empty(lib.crnerf_mlp_train_acts_bytes(n), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_mlp_forward_train_f32(ctypes.c_void_p(packed.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out),
+                                                ctypes.c_void_p(acts.data_ptr()), n, _lib.stream_ptr()), "crnerf_mlp_forward_train_f32")
+    return out, acts
+
+
+def mlp_backward(packed_t, x, out, d_out, acts):
+    """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order."""
+    lib = _lib.load()
+    x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
+    n = x.shape[0]
+    grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
+    scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_mlp_backward_f32(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
+                                           ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
+                                           _lib.ptr_array(grads, "grad"), n, _lib.stream_ptr()), "crnerf_mlp_backward_f32")
+    return grads
+
+
 def posenc(x, n_freqs):
     lib = _lib.load()
     x = _f32c(x, "x")
@@ -77,6 +122,18 @@ def composite(raw, z, noise=None, noise_std=0.0):
     _lib.check(lib.crnerf_composite_f32(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(noise), float(noise_std), _lib.dev_ptr(w),
                                         _lib.dev_ptr(feat), _lib.dev_ptr(depth), R, N, _lib.stream_ptr()), "crnerf_composite_f32")
     return w, feat, depth
+
+
+def composite_backward(raw, z, d_feature, d_depth=None, d_weights=None, noise=None, noise_std=0.0):
+    lib = _lib.load()
+    raw, z, d_feature = _f32c(raw, "raw"), _f32c(z, "z"), _f32c(d_feature, "d_feature")
+    R, N = z.shape
+    opt = [None if t is None else _f32c(t, n) for t, n in ((d_depth, "d_depth"), (d_weights, "d_weights"), (noise, "noise"))]
+    d_raw = torch.empty(R, N, 65, dtype=torch.float32, device=z.device)
+    _lib.check(lib.crnerf_composite_backward_f32(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(opt[2]), float(noise_std), _lib.dev_ptr(d_feature),
+                                                 _lib.dev_ptr(opt[0]), _lib.dev_ptr(opt[1]), _lib.dev_ptr(d_raw), R, N, _lib.stream_ptr()),
+               "crnerf_composite_backward_f32")
+    return d_raw
 
 
 def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samples=False):

@@ -60,10 +60,30 @@ int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* 
  * sigma_only != 0: x[n,93] -> out[n,1] (models/nerf.py:159-160,173-174). */
 int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 
+/* ---- training twins of NeRF_sigma.forward (in the reference: PyTorch autograd over the 11 addmm nodes of
+ * models/nerf.py:157-182).  Forward that keeps the layer activations, then backward = data gradient on a
+ * transposed weight stream + weight/bias gradients as point-reduction GEMMs.
+ *   acts    : crnerf_mlp_train_acts_bytes(n) bytes, written by forward_train, read by backward
+ *   scratch : crnerf_mlp_train_scratch_bytes(n) bytes (layer deltas + reduction partials)
+ *   grads   : HOST array of 24 device pointers (tensor order above), each OVERWRITTEN with d(sum(out*d_out))/d(tensor)
+ * out / d_out are [n,65] (64 features then sigma).  x is not differentiated (embeddings are inputs). */
+size_t crnerf_packed_mlp_t_bytes(void);
+int crnerf_pack_mlp_weights_t(const float* const* tensors, void* packed_t, void* stream);
+size_t crnerf_mlp_train_acts_bytes(int64_t n);
+size_t crnerf_mlp_train_scratch_bytes(int64_t n);
+int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out, void* acts, int64_t n, void* stream);
+int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
+                            float* const* grads, int64_t n, void* stream);
+
 /* Compositing part of the nested inference(), models/rendering.py:116-143:
  * raw[R,N,65], z[R,N], optional noise[R,N] (scaled by noise_std) -> weights[R,N], feature[R,64], depth[R]. */
 int crnerf_composite_f32(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
                          float* feature, float* depth, int64_t R, int N, void* stream);
+
+/* Backward of the compositing above (what autograd derives from models/rendering.py:121-143 in the reference):
+ * d_feature[R,64] (required), d_depth[R] / d_weights[R,N] (optional, NULL = zero) -> d_raw[R,N,65]. */
+int crnerf_composite_backward_f32(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
+                                  const float* d_depth, const float* d_weights, float* d_raw, int64_t R, int N, void* stream);
 
 /* sample_pdf + merge, models/rendering.py:7-46 and :183-187:
  * z_coarse[R,Nc], weights_coarse[R,Nc] (the full coarse weights; [:,1:-1] is taken inside),

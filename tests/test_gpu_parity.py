@@ -433,3 +433,57 @@ def test_alternate_core32_still_matches(golden):
          os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_render.npz"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRNERF_CORE="32"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------ backward twins (training)
+@pytest.mark.parametrize("N,with_extras", [(64, False), (192, True), (1, False), (65, True), (300, True)])
+def test_composite_backward_vs_autograd_oracle(N, with_extras):
+    """crnerf_composite_backward_f32 against torch autograd through the oracle's compositing."""
+    rng = np.random.default_rng(N)
+    R = 7
+    raw = rng.uniform(0, 1, (R, N, 65)).astype(np.float32)
+    raw[..., 64] = (rng.normal(size=(R, N)) * rng.choice([0.3, 3, 30], size=(R, 1))).astype(np.float32)   # negatives -> relu gate
+    raw[0, :, 64] = 0.0
+    if R > 1:
+        raw[1, :, 64] = 500.0                                    # alpha -> 1 after the first sample
+    z = np.sort(rng.uniform(0.2, 5, (R, N)).astype(np.float32), -1)
+    noise = rng.normal(size=(R, N)).astype(np.float32)
+    gf = rng.normal(size=(R, 64)).astype(np.float32)
+    gd = rng.normal(size=(R,)).astype(np.float32) if with_extras else None
+    gw = rng.normal(size=(R, N)).astype(np.float32) if with_extras else None
+    nstd = 0.5 if with_extras else 0.0
+    rt = torch.from_numpy(raw).requires_grad_(True)
+    w, f, d = O.composite(rt, torch.from_numpy(z), torch.from_numpy(noise), nstd)
+    loss = (f * torch.from_numpy(gf)).sum()
+    if with_extras:
+        loss = loss + (d * torch.from_numpy(gd)).sum() + (w * torch.from_numpy(gw)).sum()
+    loss.backward()
+    with torch.no_grad():
+        got = ops.composite_backward(C(raw), C(z), C(gf), None if gd is None else C(gd), None if gw is None else C(gw),
+                                     noise=C(noise), noise_std=nstd)
+    ref = rt.grad
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * scale + 1e-6
+
+
+@pytest.mark.parametrize("n,gain", [(37, 1.0), (400, 2.0)])
+def test_mlp_backward_vs_autograd_oracle(n, gain):
+    """crnerf_mlp_forward_train_f32 + crnerf_mlp_backward_f32 against torch autograd through the oracle MLP."""
+    st = synth.mlp_state(13, gain, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32))
+    w = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+    ref_out = O.mlp_forward(w, x)
+    (ref_out * d_out).sum().backward()
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        close(out, ref_out.detach(), atol=3e-5, rtol=1e-5)
+        grads = ops.mlp_backward(ops.pack_mlp_weights_t(dev_state), x.to(DEV), out, d_out.to(DEV), acts)
+    for name, gq in zip(ops.MLP_TENSOR_NAMES, grads):
+        ref = w[name].grad
+        err = float((gq.cpu() - ref).abs().max())
+        tol = 2e-4 * float(ref.abs().max()) + 1e-5
+        assert err <= tol, "%s: max|d| %.3e > %.3e (|ref|max %.3e)" % (name, err, tol, float(ref.abs().max()))
