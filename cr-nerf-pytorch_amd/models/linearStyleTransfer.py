@@ -86,12 +86,17 @@ class style_net(nn.Module):
         return k.crossray_fold(s_matrix, c_matrix, c_mean, s_mean, mn.lin_tensors() + list(self.decoder.rgb_tensors()))
 
     def forward(self, content_feature, style_feature, type=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad()")
+        train = torch.is_grad_enabled() and (content_feature.requires_grad or any(p.requires_grad for p in self.parameters()))
         if style_feature is None and type == "content":
+            if train:   # decoder only: sigmoid(1x1 conv), nerf_decoder_stylenerf.py:279-291 (n_blocks == 0)
+                w, b = self.decoder.rgb_tensors()
+                return torch.sigmoid(torch.einsum('oc,bchw->bohw', w, content_feature) + b.view(1, 3, 1, 1))
             return self.decoder(content_feature)
         xp, (H, W) = _pixel_major(content_feature)
         sp, _ = _pixel_major(style_feature)
+        if train:
+            from ..autograd import DecoderFn   # HIP forward; backward is interim (see autograd.py)
+            return DecoderFn.apply(xp, sp, *self.decoder_tensors()).view(1, 3, H, W)
         return ops.crossray_decode(xp, sp, self.decoder_tensors()).view(1, 3, H, W)
 
     def decoder_tensors(self):

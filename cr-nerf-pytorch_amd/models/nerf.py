@@ -71,6 +71,8 @@ class NeRF_sigma(nn.Module):
 
     def forward(self, x, sigma_only=False, output_random=True):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad() "
-                                      "(as eval.py:29 and appearance_modification_video.py:71 do)")
+            if sigma_only:
+                raise NotImplementedError("crnerf_amd: sigma_only has no backward twin (no reference caller uses it)")
+            from ..autograd import mlp_forward_with_grad   # training: HIP forward-with-save + HIP backward
+            return mlp_forward_with_grad(self, x.to(torch.float32).contiguous())
         return ops.mlp_forward(self.packed_weights(), x, sigma_only=sigma_only)

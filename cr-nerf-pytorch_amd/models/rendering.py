@@ -35,7 +35,7 @@ def _linspace_tables(n_samples, n_importance, device):
     return _tables[key]
 
 
-def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, jitter, chunk):
+def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, jitter, chunk, train=False):
     R = rays.shape[0]
     o, d = rays[:, None, 0:3], rays[:, None, 3:6]
     z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
@@ -51,17 +51,21 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
         if jitter:
             pts = pts + 0.00001 * torch.rand_like(pts)                       # rendering.py:102-104
         dirs = demb[:, None, :].expand(R, N, demb.shape[-1]).reshape(R * N, -1)
-        raw = torch.empty(R * N, 65, dtype=torch.float32, device=rays.device)
         step = max(int(chunk), 1)
-        for i in range(0, R * N, step):                                      # point chunks, rendering.py:110-114
-            x = torch.cat([ops.posenc(pts[i:i + step].contiguous(), 15), dirs[i:i + step]], 1)
-            raw[i:i + step] = ops.mlp_forward(model.packed_weights(), x)
+        with torch.no_grad():                                                # embeddings are inputs, not trained
+            xs = [torch.cat([ops.posenc(pts[i:i + step].contiguous(), 15), dirs[i:i + step]], 1) for i in range(0, R * N, step)]
+        if train:   # autograd.Functions over the HIP forward/backward twins (autograd.py)
+            from ..autograd import CompositeFn, mlp_forward_with_grad
+            raw = torch.cat([mlp_forward_with_grad(model, x) for x in xs], 0)
+            return CompositeFn.apply(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
+        raw = torch.cat([ops.mlp_forward(model.packed_weights(), x) for x in xs], 0)   # point chunks, rendering.py:110-114
         return ops.composite(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
 
     out = {}
     out["weights_coarse"], out["feature_coarse"], out["depth_coarse"] = run(coarse, z_coarse, noise_c)
     if Ni > 0:
-        z_fine = ops.sample_pdf_merge(z_coarse.contiguous(), out["weights_coarse"], Ni, u=u if u is not None else u_steps)
+        z_fine = ops.sample_pdf_merge(z_coarse.contiguous(), out["weights_coarse"].detach(), Ni,   # .detach(): rendering.py:184
+                                      u=u if u is not None else u_steps)
         out["weights_fine"], out["feature_fine"], out["depth_fine"] = run(fine, z_fine, noise_f)
     return out
 
@@ -89,8 +93,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     for m in (coarse, fine):
         if m is not None and not isinstance(m, NeRF_sigma):
             raise NotImplementedError("crnerf_amd: models must be crnerf_amd NeRF_sigma instances")
-    if torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters()):
-        raise NotImplementedError("crnerf_amd: backward kernels are not implemented yet -- call under torch.no_grad()")
+    train = torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters())
 
     rays = rays.to(torch.float32).contiguous()
     R = rays.shape[0]
@@ -105,11 +108,11 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    if N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
+    if train or N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
         # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
         # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)
         out = _render_unfused(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
-                              float(noise_std), jitter, int(chunk))
+                              float(noise_std), jitter, int(chunk), train)
     else:
         tables = _linspace_tables(N_samples, N_importance, rays.device)
         out = ops.render_rays(coarse.packed_weights(), fine.packed_weights() if fine is not None else None, rays,

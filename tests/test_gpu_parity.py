@@ -487,3 +487,69 @@ def test_mlp_backward_vs_autograd_oracle(n, gain):
         err = float((gq.cpu() - ref).abs().max())
         tol = 2e-4 * float(ref.abs().max()) + 1e-5
         assert err <= tol, "%s: max|d| %.3e > %.3e (|ref|max %.3e)" % (name, err, tol, float(ref.abs().max()))
+
+
+def test_training_step_gradients_vs_autograd_oracle(golden):
+    """A training-style step on the reference-signature modules (grad mode, perturb/noise inputs fixed):
+    render -> decode coarse+fine -> MSE; parameter gradients against torch autograd through the oracle."""
+    from crnerf_amd.models.linearStyleTransfer import style_net
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    from crnerf_amd.models.rendering import render_rays_cross_ray
+    R, H, W, Nc, Ni = 16, 4, 4, 64, 64
+    st_c, st_f, dst = synth.mlp_state(41, 2.0, 0.5), synth.mlp_state(42, 2.0, 0.5), synth.decoder_state(43)
+    args = _Args()
+    models = {"coarse": NeRF_sigma("coarse", args, in_channels_xyz=93, in_channels_dir=27).to(DEV),
+              "fine": NeRF_sigma("fine", args, in_channels_xyz=93, in_channels_dir=27, encode_random=True).to(DEV),
+              "decoder": style_net(args).to(DEV)}
+    models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in st_c.items()})
+    models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in st_f.items()})
+    models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
+    emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
+    rays_np = synth.rays(R, seed=21, H=H, W=W)
+    rng = np.random.default_rng(5)
+    style_np = rng.uniform(0, 1, (1, 64, 32, 32)).astype(np.float32)
+    target_np = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+    style = C(style_np).requires_grad_(True)
+    res = render_rays_cross_ray(models, emb, C(rays_np), None, Nc, False, 0, 0, Ni, 1 << 20, False, args=args)
+    assert res["feature_fine"].requires_grad and res["feature_coarse"].requires_grad
+
+    def decode(feat):
+        return models["decoder"](feat.t().reshape(1, 64, H, W), style).reshape(3, R).t()
+    loss = ((decode(res["feature_coarse"]) - C(target_np)) ** 2).mean() + ((decode(res["feature_fine"]) - C(target_np)) ** 2).mean()
+    loss.backward()
+
+    # oracle: same graph with torch autograd on the CPU (depths: device linspace tables would differ by 1 ulp -> feed the HIP z's)
+    wc = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st_c.items()}
+    wf = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st_f.items()}
+    wd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in dst.items() if not k.endswith(".f")}
+    rays = torch.from_numpy(rays_np)
+    with torch.no_grad():
+        zc = (rays[:, 6:7] * (1 - torch.linspace(0, 1, Nc)) + rays[:, 7:8] * torch.linspace(0, 1, Nc))
+        zc = (C(rays_np)[:, 6:7] * (1 - torch.linspace(0, 1, Nc, device=DEV)) + C(rays_np)[:, 7:8] * torch.linspace(0, 1, Nc, device=DEV)).cpu()
+        zf = ops.sample_pdf_merge(zc.to(DEV).contiguous(), res["weights_coarse"].detach(), Ni, u=torch.linspace(0, 1, Ni, device=DEV)).cpu()
+    demb = O.posenc(rays[:, 3:6], 4)
+    raw_c = O._run_model(wc, rays, zc, demb, 1 << 20)
+    _, fc, _ = O.composite(raw_c, zc)
+    raw_f = O._run_model(wf, rays, zf, demb, 1 << 20)
+    _, ff, _ = O.composite(raw_f, zf)
+    style_ref = torch.from_numpy(style_np).requires_grad_(True)
+
+    def decode_ref(feat):
+        return O.crossray_decode(wd, O.feature_to_grid(feat, H, W), style_ref).reshape(3, R).t()
+    loss_ref = ((decode_ref(fc) - torch.from_numpy(target_np)) ** 2).mean() + ((decode_ref(ff) - torch.from_numpy(target_np)) ** 2).mean()
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+
+    def check(named_params, ref, what):
+        for name, p in named_params:
+            if name.endswith(".f"):
+                continue
+            g, r_ = p.grad.cpu(), ref[name].grad
+            r_ = r_.reshape(g.shape)
+            tol = 5e-3 * float(r_.abs().max()) + 1e-7
+            assert float((g - r_).abs().max()) <= tol, "%s %s: %.3e > %.3e" % (what, name, float((g - r_).abs().max()), tol)
+    check(models["coarse"].named_parameters(), wc, "coarse")
+    check(models["fine"].named_parameters(), wf, "fine")
+    check(models["decoder"].named_parameters(), wd, "decoder")
+    gs, rs = style.grad.cpu(), style_ref.grad
+    assert float((gs - rs).abs().max()) <= 5e-3 * float(rs.abs().max()) + 1e-7

@@ -104,7 +104,7 @@ def test_render_shim_validates_like_the_boundary_says():
     m = NeRF_sigma('coarse', Args(), in_channels_xyz=93, in_channels_dir=27)
     rays = torch.from_numpy(synth.rays(4))
     emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
-    with pytest.raises(NotImplementedError, match="backward"):      # grad mode with trainable params
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # grad mode takes the training path -- still GPU only
         render_rays_cross_ray({"coarse": m}, emb, rays, None, 64, False, 0, 0, 0, 1024, False, args=Args())
     with torch.no_grad():
         with pytest.raises(NotImplementedError, match="PosEmbedding"):
