@@ -182,6 +182,7 @@ struct WgradJob {
   const float* D; int ldd; int M;      // deltas  [P, ldd], M columns used
   const float* A; int lda; int N;      // inputs  [P, lda], N columns used
   float* partial;                      // [nchunk][M][N]
+  float* bias_partial;                 // [nchunk][M] column sums of D (bias gradient) or null
   long P; int chunk;
 };
 
@@ -199,25 +200,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradJob j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   const bool mv0 = m0 + i < j.M, mv1 = m0 + 32 + i < j.M, nv0 = n0 + i < j.N, nv1 = n0 + 32 + i < j.N;
-  for (long pb = p0; pb < p1; pb += 8) {
-    float da[4][2], aa[4][2];
+  constexpr int KS = 8;                       // k-steps (2 points each) per iteration
+  float da[KS][2], aa[KS][2], dn[KS][2], an[KS][2];
+  auto fetch = [&](long pb, float (&d)[KS][2], float (&a)[KS][2]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const long pt = pb + 2 * s + kk;
       const bool pv = pt < p1;
       const float* dr = j.D + pt * j.ldd + m0 + i;
       const float* ar = j.A + pt * j.lda + n0 + i;
-      da[s][0] = (pv && mv0) ? dr[0] : 0.0f;
-      da[s][1] = (pv && mv1) ? dr[32] : 0.0f;
-      aa[s][0] = (pv && nv0) ? ar[0] : 0.0f;
-      aa[s][1] = (pv && nv1) ? ar[32] : 0.0f;
+      d[s][0] = (pv && mv0) ? dr[0] : 0.0f;
+      d[s][1] = (pv && mv1) ? dr[32] : 0.0f;
+      a[s][0] = (pv && nv0) ? ar[0] : 0.0f;
+      a[s][1] = (pv && nv1) ? ar[32] : 0.0f;
+    }
+  };
+  const bool do_bias = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;   // one wave column per M block
+  float bs0 = 0.0f, bs1 = 0.0f;
+  fetch(p0, da, aa);
+  for (long pb = p0; pb < p1; pb += 2 * KS) {
+    fetch(pb + 2 * KS, dn, an);               // next iteration's operands fly while this one's MFMAs run
+    if (do_bias) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { bs0 += da[s][0]; bs1 += da[s][1]; }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[s][a], aa[s][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { da[s][0] = dn[s][0]; da[s][1] = dn[s][1]; aa[s][0] = an[s][0]; aa[s][1] = an[s][1]; }
+  }
+  if (do_bias) {
+    bs0 += __shfl_xor(bs0, 32);
+    bs1 += __shfl_xor(bs1, 32);
+    if (kk == 0) {
+      if (mv0) j.bias_partial[(long)blockIdx.x * j.M + m0 + i] = bs0;
+      if (mv1) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 + i] = bs1;
+    }
   }
   float* out = j.partial + (long)blockIdx.x * j.M * j.N;
 #pragma unroll
@@ -240,36 +262,32 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
   dst[(long)(idx / N) * ldc + idx % N] = s;
 }
 
-// partial[c][m] = sum_{p in chunk c} D[p][m]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ D, int ldd, int M, long P, int chunk, float* __restrict__ partial) {
-  const int m = threadIdx.x;
-  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
-  if (m >= M) return;
-  float s = 0.0f;
-  for (long pt = p0; pt < p1; ++pt) s += D[pt * ldd + m];
-  partial[(long)blockIdx.x * M + m] = s;
+// points per wgrad workgroup: small enough to fill the chip at 1024-ray batches, large enough that the
+// partial-sum workspace (nchunk x M x N) stays ~50 MB per layer at 65k-ray batches
+static int wg_chunk(long P) {
+  long c = (P + 191) / 192;
+  c = (c + 15) / 16 * 16;
+  return (int)(c < 512 ? 512 : c);
 }
 
-constexpr int WG_CHUNK = 2048;
-
-static int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, long P, float* ws, hipStream_t st) {
-  const int nchunk = (int)((P + WG_CHUNK - 1) / WG_CHUNK);
-  WgradJob j{D, ldd, M, A, lda, N, ws, P, WG_CHUNK};
+// dW (and, when db != null, the bias gradient of the same delta) for one (delta, input-block) pair
+static int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
+                 hipStream_t st) {
+  const int chunk = wg_chunk(P);
+  const int nchunk = (int)((P + chunk - 1) / chunk);
+  float* bws = ws + (size_t)nchunk * M * N;
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk};
   hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 127) / 128, (N + 127) / 128), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc);
-  return 0;
-}
-static int bgrad(const float* D, int ldd, int M, float* dst, long P, float* ws, hipStream_t st) {
-  const int nchunk = (int)((P + WG_CHUNK - 1) / WG_CHUNK);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk), dim3(256), 0, st, D, ldd, M, P, WG_CHUNK, ws);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, nchunk, 1, M, dst, M);
+  if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, bws, nchunk, 1, M, db, M);
   return 0;
 }
 
 size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float); }
 size_t mlp_train_scratch_bytes(long P) {
-  const size_t nchunk = (size_t)((P + WG_CHUNK - 1) / WG_CHUNK);
-  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + nchunk * 256 * 352 * 4;
+  const int chunk = wg_chunk(P);
+  const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
+  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + nchunk * (256 * 256 + 256) * 4;
 }
 
 static int launch_core(const void* fn, int grid, size_t shmem) {
@@ -302,26 +320,20 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
   // xyz_encoding_1: input x[:, :93]
-  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, P, ws, stream);
-  bgrad(D(0), ACT_W, 256, grads[1], P, ws, stream);
+  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream);
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
-      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, P, ws, stream);
-      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, P, ws, stream);
+      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream);
+      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream);
     } else {
-      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, P, ws, stream);
+      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream);
     }
-    bgrad(D(l), ACT_W, 256, grads[2 * l + 1], P, ws, stream);
   }
-  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, P, ws, stream);          // xyz_encoding_final
-  bgrad(D(8), ACT_W, 256, grads[17], P, ws, stream);
-  wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, P, ws, stream);               // static_sigma
-  bgrad(d_sig, 1, 1, grads[19], P, ws, stream);
-  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, P, ws, stream);  // dir_encoding: cat([final, dir])
-  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, P, ws, stream);
-  bgrad(D(9), ACT_W, 128, grads[21], P, ws, stream);
-  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, P, ws, stream);   // static_rgb
-  bgrad(d_rgb, FEAT_DIM, FEAT_DIM, grads[23], P, ws, stream);
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream);            // xyz_encoding_final
+  wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
+  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream);  // dir_encoding: cat([final, dir])
+  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream);
+  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream);   // static_rgb
   return check_launch("mlp_backward wgrad");
 }
 

@@ -70,3 +70,26 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     parts = [torch.empty(3, width, device=dev) for _ in range(ws)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:, :s] for p, s in zip(parts, sizes)], dim=1)
+
+
+def allreduce_gradients(modules, group=None, average=True):
+    """Data-parallel training (the reference: Lightning DDP, train_mask_grid_sample.py:441-450): sum (or
+    average) every parameter gradient over the ranks with ONE flat all-reduce (~16 MB for the two MLPs +
+    decoder: a single large message suits xGMI's per-link-bound rings better than per-tensor buckets).
+    Call after loss.backward(), before optimizer.step().  Parameters without a gradient contribute zeros."""
+    params = [p for m in modules for p in m.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

@@ -103,3 +103,34 @@ def test_decode_sharded_matches_single_process(n_pixels):
     ref = O.crossray_decode(O.to_torch(synth.decoder_state(4)), O.feature_to_grid(feat, 1, n_pixels), style).reshape(3, n_pixels)
     assert np.array_equal(got[0], got[1])                               # every rank ends with the same image
     torch.testing.assert_close(torch.from_numpy(got[0]), ref, atol=2e-6, rtol=0)
+
+
+def _grad_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crnerf_amd.models.nerf import NeRF_sigma
+        from crnerf_amd.parallel import allreduce_gradients
+        m = NeRF_sigma("coarse", Args(), in_channels_xyz=93, in_channels_dir=27)
+        for i, p in enumerate(m.parameters()):
+            if i != 3:                                   # one parameter without a gradient on purpose
+                p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        allreduce_gradients([m], average=True)
+        out_q.put((rank, [float(p.grad.flatten()[0]) for p in m.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_averages_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [0.0 if i == 3 else 1.5 * (i + 1) for i in range(24)]
+    assert got[0] == want and got[1] == want
