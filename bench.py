@@ -101,8 +101,11 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # launched by torch.distributed.run (also with --nproc-per-node 1)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crnerf_amd.synth as synth
@@ -139,12 +142,12 @@ def main():
             if i is not None:
                 ev[i][1].record()
             feat = out["feature_fine"]
-            if world > 1:
+            if use_dist:
                 return decode_sharded(net, feat, style, gather=True, equal_shards=True)
             return net(feat.t().reshape(1, 64, *grid_hw), style)
 
         def fence():
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -156,7 +159,7 @@ def main():
             step(i)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -185,7 +188,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rays_np, st_c, st_f, dst, grid_hw)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -20,6 +20,8 @@ EXPORTS = [
     "crnerf_crossray_apply_f32", "crnerf_crossray_decode_f32",
     "crnerf_packed_mlp_t_bytes", "crnerf_pack_mlp_weights_t", "crnerf_mlp_train_acts_bytes", "crnerf_mlp_train_scratch_bytes",
     "crnerf_mlp_forward_train_f32", "crnerf_mlp_backward_f32",
+    "crnerf_ray_directions_f32", "crnerf_rays_from_directions_f32", "crnerf_generate_rays_f32",
+    "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -70,6 +72,11 @@ def load():
             "crnerf_mlp_forward_train_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, vp]),
             "crnerf_mlp_backward_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, pp, i64, vp]),
             "crnerf_posenc_f32": (ctypes.c_int, [vp, vp, i64, i32, vp]),
+            "crnerf_encoder_workspace_bytes": (ctypes.c_size_t, [i32, i32]),
+            "crnerf_encoder_forward_f32": (ctypes.c_int, [vp, i32, i32, pp, vp, vp, vp]),
+            "crnerf_ray_directions_f32": (ctypes.c_int, [i32, i32, f32, f32, f32, f32, vp, vp]),
+            "crnerf_rays_from_directions_f32": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_float), i64, vp, vp, vp]),
+            "crnerf_generate_rays_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), i32, i32, f32, f32, vp, vp]),
             "crnerf_mlp_forward_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, vp]),
             "crnerf_composite_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, i64, i32, vp]),
             "crnerf_composite_backward_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),

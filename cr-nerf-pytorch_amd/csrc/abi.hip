@@ -158,6 +158,32 @@ int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
   return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
 }
 
+size_t crnerf_encoder_workspace_bytes(int H, int W) { return encoder_workspace_bytes(H, W); }
+
+int crnerf_encoder_forward_f32(const float* image, int H, int W, const float* const* weights, void* workspace, float* out, void* stream) {
+  REQUIRE(image, "image"); REQUIRE(weights, "weights"); REQUIRE(workspace, "workspace"); REQUIRE(out, "out");
+  for (int i = 0; i < CRNERF_ENCODER_TENSORS; ++i)
+    if (!weights[i]) return set_error(CRNERF_ERR_NULL, "encoder_forward: a weight pointer is NULL");
+  return launch_encoder_forward(image, H, W, weights, workspace, out, (hipStream_t)stream);
+}
+
+int crnerf_ray_directions_f32(int H, int W, float fx, float fy, float cx, float cy, float* directions, void* stream) {
+  REQUIRE(directions, "directions");
+  return launch_ray_directions(fx, fy, cx, cy, H, W, directions, (hipStream_t)stream);
+}
+
+int crnerf_rays_from_directions_f32(const float* directions, const float* c2w_host, int64_t n, float* rays_o, float* rays_d, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(directions, "directions"); REQUIRE(c2w_host, "c2w"); REQUIRE(rays_o, "rays_o"); REQUIRE(rays_d, "rays_d");
+  return launch_rays_from_directions(directions, c2w_host, (long)n, rays_o, rays_d, (hipStream_t)stream);
+}
+
+int crnerf_generate_rays_f32(const float* intrinsics_host, const float* c2w_host, int H, int W, float near, float far, float* rays,
+                             void* stream) {
+  REQUIRE(intrinsics_host, "intrinsics"); REQUIRE(c2w_host, "c2w"); REQUIRE(rays, "rays");
+  return launch_generate_rays(intrinsics_host, c2w_host, H, W, near, far, rays, (hipStream_t)stream);
+}
+
 int crnerf_crossray_chansum_f32(const float* x, int64_t HW, float* sum64, void* workspace, void* stream) {
   REQUIRE(x, "x"); REQUIRE(sum64, "sum64"); REQUIRE(workspace, "workspace");
   return launch_crossray_chansum(x, (long)HW, sum64, (float*)workspace, (hipStream_t)stream);

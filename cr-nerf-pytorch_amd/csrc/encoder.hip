@@ -1,0 +1,125 @@
+// Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276
+//   conv1 1x1 3->3 | reflpad, conv2 3x3 3->64, lrelu | reflpad, conv3 3x3 64->64, lrelu | maxpool2 |
+//   reflpad, conv4 3x3 64->128, lrelu | reflpad, conv5 3x3 128->128, lrelu | maxpool2 |
+//   reflpad, conv6 3x3 128->128, lrelu | AdaptiveAvgPool2d(32) | conv7 1x1 128->64, lrelu
+// It runs once per image on the 1/8-scale photo (a few thousand pixels, ~0.6 GFLOP) and produces the
+// style operand of the cross-ray decoder, written pixel-major [1024,64] (= what crossray.hip consumes).
+// Direct convolutions, activations pixel-major (HWC) so one wave = one pixel x 64 output channels:
+// the input value is a wave-uniform broadcast, the weight row a coalesced 256-B read of the
+// [cin][tap][cout] re-layout made on the fly into the workspace.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace crnerf {
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.2f * v; }
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }   // ReflectionPad2d(1)
+
+// w[cout][cin][taps] -> wt[cin][taps][cout]
+__global__ void transpose_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int taps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cout * cin * taps) return;
+  const int o = idx / (cin * taps), r = idx % (cin * taps);
+  wt[r * cout + o] = w[idx];
+}
+
+// NCHW [C,H,W] -> HWC [H*W, C]
+__global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * HW) return;
+  const int px = idx / C, c = idx % C;
+  out[idx] = in[c * HW + px];
+}
+
+// out[px][o] = act(b[o] + sum_{c,tap} in[reflect(px+tap)][c] * wt[c][tap][o]);  TAPS = 9 (3x3, reflection pad 1) or 1
+template <int TAPS, bool ACT>
+__global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ b,
+                                                   float* __restrict__ out, int H, int W, int cin, int cout) {
+  const int o = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int px = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= H * W || o >= cout) return;
+  const int y = px / W, x = px % W;
+  float acc = b[o];
+  if (TAPS == 9) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* ip = in + ((long)reflect(y + ky - 1, H) * W + reflect(x + kx - 1, W)) * cin;
+        const float* wp = wt + (ky * 3 + kx) * cout + o;
+        for (int c = 0; c < cin; ++c) acc = fmaf(ip[c], wp[(long)c * 9 * cout], acc);
+      }
+  } else {
+    const float* ip = in + (long)px * cin;
+    for (int c = 0; c < cin; ++c) acc = fmaf(ip[c], wt[(long)c * cout + o], acc);
+  }
+  out[(long)px * cout + o] = ACT ? lrelu(acc) : acc;
+}
+
+// MaxPool2d(2,2), floor mode
+__global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Ho * Wo * C) return;
+  const int c = idx % C, px = idx / C, y = px / Wo, x = px % Wo;
+  const float* p = in + ((long)(2 * y) * W + 2 * x) * C + c;
+  out[idx] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(long)W * C], p[(long)W * C + C]));
+}
+
+// AdaptiveAvgPool2d(S): window [floor(o*in/S), ceil((o+1)*in/S))
+__global__ void adaptive_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int S) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S * S * C) return;
+  const int c = idx % C, px = idx / C, oy = px / S, ox = px % S;
+  const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S, x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+  float s = 0.0f;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) s += in[((long)y * W + x) * C + c];
+  out[idx] = s / (float)((y1 - y0) * (x1 - x0));
+}
+
+static const int ENC_CIN[7] = {3, 3, 64, 64, 128, 128, 128}, ENC_COUT[7] = {3, 64, 64, 128, 128, 128, 64}, ENC_TAPS[7] = {1, 9, 9, 9, 9, 9, 1};
+
+size_t encoder_workspace_bytes(int H, int W) {
+  size_t wt = 0;
+  for (int l = 0; l < 7; ++l) wt += (size_t)ENC_CIN[l] * ENC_COUT[l] * ENC_TAPS[l];
+  const size_t act = (size_t)H * W * 128 > (size_t)32 * 32 * 128 ? (size_t)H * W * 128 : (size_t)32 * 32 * 128;
+  return (wt + 2 * act) * sizeof(float);
+}
+
+template <int TAPS, bool ACT>
+static void conv(const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st) {
+  hipLaunchKernelGGL((conv_kernel<TAPS, ACT>), dim3((H * W + 3) / 4, (cout + 63) / 64), dim3(256), 0, st, in, wt, b, out, H, W, cin, cout);
+}
+
+// img[3,H,W] (NCHW), weights = conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias -> out[1024,64] pixel-major
+int launch_encoder_forward(const float* img, int H, int W, const float* const* w, void* workspace, float* out, hipStream_t st) {
+  if (H < 8 || W < 8) return set_error(-2, "encoder: image must be at least 8x8 (two 2x2 max-pools and reflection padding)");
+  float* wt[7];
+  float* p = (float*)workspace;
+  for (int l = 0; l < 7; ++l) {
+    wt[l] = p;
+    const int n = ENC_CIN[l] * ENC_COUT[l] * ENC_TAPS[l];
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2 * l], wt[l], ENC_COUT[l], ENC_CIN[l], ENC_TAPS[l]);
+    p += n;
+  }
+  const size_t act = (size_t)H * W * 128 > (size_t)32 * 32 * 128 ? (size_t)H * W * 128 : (size_t)32 * 32 * 128;
+  float* a = p;
+  float* b = p + act;
+  hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((3 * H * W + 255) / 256), dim3(256), 0, st, img, a, 3, H * W);
+  conv<1, false>(a, wt[0], w[1], b, H, W, 3, 3, st);            // conv1
+  conv<9, true>(b, wt[1], w[3], a, H, W, 3, 64, st);            // conv2 + relu2
+  conv<9, true>(a, wt[2], w[5], b, H, W, 64, 64, st);           // conv3 + relu3
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * 64 + 255) / 256), dim3(256), 0, st, b, a, H, W, 64);
+  const int H2 = H / 2, W2 = W / 2;
+  conv<9, true>(a, wt[3], w[7], b, H2, W2, 64, 128, st);        // conv4 + relu4
+  conv<9, true>(b, wt[4], w[9], a, H2, W2, 128, 128, st);       // conv5 + relu5
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(((H2 / 2) * (W2 / 2) * 128 + 255) / 256), dim3(256), 0, st, a, b, H2, W2, 128);
+  const int H4 = H2 / 2, W4 = W2 / 2;
+  conv<9, true>(b, wt[5], w[11], a, H4, W4, 128, 128, st);      // conv6 + relu6
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((32 * 32 * 128 + 255) / 256), dim3(256), 0, st, a, b, H4, W4, 128, 32);
+  conv<1, true>(b, wt[6], w[13], out, 32, 32, 128, 64, st);     // conv7 + relu7
+  return check_launch("encoder_forward");
+}
+
+}  // namespace crnerf

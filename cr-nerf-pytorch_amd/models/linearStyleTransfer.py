@@ -64,6 +64,56 @@ class MulLayer(nn.Module):
         return [self.compress.weight.reshape(32, 64), self.compress.bias, self.unzip.weight.reshape(64, 32), self.unzip.bias]
 
 
+class encoder_sameoutputsize(nn.Module):
+    """Appearance encoder -- reference models/linearStyleTransfer.py:208-276 (same ctor, attribute names and
+    state_dict keys conv1..conv7).  Inference runs the HIP encoder; under grad mode (enc_a is trained,
+    train_mask_grid_sample.py:95-97) the same layers run through torch ops so autograd can differentiate them
+    (the encoder is a 'next' row of the scope table, not part of the rendering hot path)."""
+
+    def __init__(self, out_channel=64):
+        super().__init__()
+        if out_channel != 64:
+            raise NotImplementedError("crnerf_amd: encoder_sameoutputsize is implemented for out_channel=64")
+        self.conv1 = nn.Conv2d(3, 3, 1, 1, 0)
+        self.reflecPad1 = nn.ReflectionPad2d((1, 1, 1, 1))
+        self.conv2 = nn.Conv2d(3, 64, 3, 1, 0)
+        self.relu2 = nn.LeakyReLU(0.2, inplace=True)
+        self.reflecPad3 = nn.ReflectionPad2d((1, 1, 1, 1))
+        self.conv3 = nn.Conv2d(64, 64, 3, 1, 0)
+        self.relu3 = nn.LeakyReLU(0.2, inplace=True)
+        self.maxPool = nn.MaxPool2d(kernel_size=2, stride=2, return_indices=True)
+        self.reflecPad4 = nn.ReflectionPad2d((1, 1, 1, 1))
+        self.conv4 = nn.Conv2d(64, 128, 3, 1, 0)
+        self.relu4 = nn.LeakyReLU(0.2, inplace=True)
+        self.reflecPad5 = nn.ReflectionPad2d((1, 1, 1, 1))
+        self.conv5 = nn.Conv2d(128, 128, 3, 1, 0)
+        self.relu5 = nn.LeakyReLU(0.2, inplace=True)
+        self.maxPool2 = nn.MaxPool2d(kernel_size=2, stride=2, return_indices=True)
+        self.reflecPad6 = nn.ReflectionPad2d((1, 1, 1, 1))
+        self.conv6 = nn.Conv2d(128, 128, 3, 1, 0)
+        self.relu6 = nn.LeakyReLU(0.2, inplace=True)
+        self.adppool = nn.AdaptiveAvgPool2d(32)
+        self.conv7 = nn.Conv2d(128, out_channel, 1, 1, 0)
+        self.relu7 = nn.LeakyReLU(0.2, inplace=True)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            out = self.conv1(x)
+            out = self.relu2(self.conv2(self.reflecPad1(out)))
+            out = self.relu3(self.conv3(self.reflecPad3(out)))
+            out, _ = self.maxPool(out)
+            out = self.relu4(self.conv4(self.reflecPad4(out)))
+            out = self.relu5(self.conv5(self.reflecPad5(out)))
+            out, _ = self.maxPool2(out)
+            out = self.relu6(self.conv6(self.reflecPad6(out)))
+            return self.relu7(self.conv7(self.adppool(out)))
+        if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3:
+            raise ValueError("encoder_sameoutputsize expects [1,3,H,W], got %s" % (tuple(x.shape),))
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7)
+        grid = ops.encoder_forward(x, [t for c in convs for t in (c.weight, c.bias)])       # [1024,64] pixel-major
+        return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)                                   # NCHW view, zero-copy for style_net
+
+
 class style_net(nn.Module):
     def __init__(self, args, residual_blocks=2):
         super().__init__()

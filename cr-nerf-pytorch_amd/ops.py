@@ -264,3 +264,16 @@ def crossray_decode(content_pm, style_pm, weights, out=None):
                                               ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), out.stride(0), _lib.stream_ptr()),
                "crnerf_crossray_decode_f32")
     return out
+
+
+def encoder_forward(image, weights):
+    """encoder_sameoutputsize.forward: image [1,3,H,W] or [3,H,W] -> pixel-major style grid [1024,64]."""
+    lib = _lib.load()
+    img = _f32c(image.reshape(3, image.shape[-2], image.shape[-1]), "image")
+    H, W = img.shape[-2], img.shape[-1]
+    ws = torch.empty(lib.crnerf_encoder_workspace_bytes(H, W), dtype=torch.uint8, device=img.device)
+    out = torch.empty(1024, 64, dtype=torch.float32, device=img.device)
+    arr = _lib.ptr_array([_f32c(t.detach(), "encoder weight") for t in weights], "encoder weight")
+    _lib.check(lib.crnerf_encoder_forward_f32(_lib.dev_ptr(img), H, W, arr, ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), _lib.stream_ptr()),
+               "crnerf_encoder_forward_f32")
+    return out

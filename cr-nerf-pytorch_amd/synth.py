@@ -55,6 +55,22 @@ def decoder_state(seed, gain=1.0):
     return out
 
 
+ENCODER_SHAPES = {}
+for _i, (_ci, _co, _k) in enumerate(((3, 3, 1), (3, 64, 3), (64, 64, 3), (64, 128, 3), (128, 128, 3), (128, 128, 3), (128, 64, 1)), start=1):
+    ENCODER_SHAPES["conv%d.weight" % _i] = (_co, _ci, _k, _k)
+    ENCODER_SHAPES["conv%d.bias" % _i] = (_co,)
+
+
+def encoder_state(seed, gain=1.0):
+    """14 tensors of encoder_sameoutputsize (models/linearStyleTransfer.py:208-276), nn.Conv2d-style uniform init."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in ENCODER_SHAPES.items():
+        w = ENCODER_SHAPES[name.replace("bias", "weight")]
+        out[name] = _uniform_linear(rng, shape, w[1] * w[2] * w[3], gain)
+    return out
+
+
 def rays(n_rays, seed=0, H=None, W=None, near=None, far=None):
     """rays[R,8]: 60-degree-fov pinhole at a jittered origin, unit directions (datasets/ray_utils.py:45),
     one (near, far) pair per image drawn from [0.3,1] x [3,5] unless given."""

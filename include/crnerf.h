@@ -120,6 +120,21 @@ typedef struct crnerf_render_args {
 } crnerf_render_args;
 int crnerf_render_rays_f32(const crnerf_render_args* args, void* stream);
 
+/* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
+ * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.
+ * weights = HOST array of 14 device pointers: conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias (reference layouts). */
+#define CRNERF_ENCODER_TENSORS 14
+size_t crnerf_encoder_workspace_bytes(int H, int W);
+int crnerf_encoder_forward_f32(const float* image, int H, int W, const float* const* weights, void* workspace, float* out, void* stream);
+
+/* Ray generation on the device.  HOST pointers: intrinsics = {fx, fy, cx, cy}, c2w = 3x4 row-major.
+ * get_ray_directions datasets/ray_utils.py:5-26 -> directions[H,W,3]; get_rays :29-52 -> rays_o/rays_d [n,3];
+ * generate_rays = both + the near/far columns of datasets/PhototourismDataset.py:17-22 -> rays[H*W,8]. */
+int crnerf_ray_directions_f32(int H, int W, float fx, float fy, float cx, float cy, float* directions, void* stream);
+int crnerf_rays_from_directions_f32(const float* directions, const float* c2w_host, int64_t n, float* rays_o, float* rays_d, void* stream);
+int crnerf_generate_rays_f32(const float* intrinsics_host, const float* c2w_host, int H, int W, float near, float far, float* rays,
+                             void* stream);
+
 /* Cross-ray transformation + decoder: style_net.forward models/linearStyleTransfer.py:284-291,
  * MulLayer.forward :58-94, CNN.forward :28-37, NeuralRenderer.forward nerf_decoder_stylenerf.py:279-291.
  * Feature grids are pixel-major x[HW,64]; split at the two global reductions (see crossray.hip). */

@@ -172,6 +172,30 @@ def feature_to_grid(feature, H, W):
     return feature.t().reshape(1, feature.shape[1], H, W)
 
 
+def encoder_forward(d, img):
+    """encoder_sameoutputsize.forward, models/linearStyleTransfer.py:252-276.  d: conv{1..7}.{weight,bias}; img [1,3,H,W]."""
+    def c3(x, i):
+        return F.leaky_relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), d["conv%d.weight" % i], d["conv%d.bias" % i]), 0.2)
+    x = F.conv2d(img, d["conv1.weight"], d["conv1.bias"])
+    x = F.max_pool2d(c3(c3(x, 2), 3), 2, 2)
+    x = F.max_pool2d(c3(c3(x, 4), 5), 2, 2)
+    x = F.adaptive_avg_pool2d(c3(x, 6), 32)
+    return F.leaky_relu(F.conv2d(x, d["conv7.weight"], d["conv7.bias"]), 0.2)
+
+
+def generate_rays(H, W, K, c2w, near=0.0, far=5.0):
+    """datasets/ray_utils.py:5-52 (get_ray_directions + get_rays) and the near/far columns of
+    datasets/PhototourismDataset.py:17-22.  Returns (directions[H,W,3], rays[H*W,8])."""
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    K = torch.as_tensor(K, dtype=torch.float64)
+    dirs = torch.stack(((i - float(K[0, 2])) / float(K[0, 0]), -(j - float(K[1, 2])) / float(K[1, 1]), -torch.ones_like(i)), -1)
+    c2w = torch.as_tensor(c2w, dtype=torch.float32)
+    d = dirs @ c2w[:, :3].t()
+    d = (d / d.norm(dim=-1, keepdim=True)).reshape(-1, 3)
+    o = c2w[:, 3].expand_as(d)
+    return dirs, torch.cat((o, d, torch.full_like(d[:, :1], near), torch.full_like(d[:, :1], far)), 1)
+
+
 def psnr(a, b):
     """metrics.py:12-13."""
     return -10.0 * math.log10(float(((a - b) ** 2).mean()))

@@ -27,7 +27,7 @@ _k.filters = _kf
 sys.modules.setdefault("kornia", _k)
 sys.modules.setdefault("kornia.filters", _kf)
 
-from models.linearStyleTransfer import style_net  # noqa: E402  (reference)
+from models.linearStyleTransfer import encoder_sameoutputsize, style_net  # noqa: E402  (reference)
 from models.nerf import NeRF_sigma, PosEmbedding  # noqa: E402  (reference)
 from models.rendering import render_rays_cross_ray, sample_pdf  # noqa: E402  (reference)
 
@@ -219,7 +219,50 @@ def main():
          rgb=net(content.clone(), style.clone()), rgb_content=net(content.clone(), None, type="content"))
 
 
+def ray_goldens():
+    """G8 ray generation: the reference's datasets/ray_utils.py loaded straight from its file (the package
+    __init__ drags in torchvision/pandas readers).  kornia.create_meshgrid is absent here; it is a pixel
+    index grid ([...,0] = x = column, [...,1] = y = row), provided by the stub below."""
+    import importlib.util
+
+    def create_meshgrid(H, W, normalized_coordinates=True):
+        assert not normalized_coordinates
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        return torch.stack([xs, ys], -1)[None]
+    sys.modules["kornia"].create_meshgrid = create_meshgrid
+    spec = importlib.util.spec_from_file_location("ref_ray_utils", "/root/reference/datasets/ray_utils.py")
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    H, W = 24, 40
+    focal = W / 2 / np.tan(np.pi / 6)                       # appearance_modification_video.py:183-189
+    K = np.array([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]])
+    c2w = np.array([[0.99702646, 0.00170214, -0.07704115, 0.03552477],   # pose_init, appearance_modification_video.py:123-125
+                    [0.01082206, -0.99294089, 0.11811554, 0.02343685],
+                    [-0.07629626, -0.11859807, -0.99000676, 0.12162088]])
+    dirs = ru.get_ray_directions(H, W, K)
+    o, d = ru.get_rays(dirs, torch.FloatTensor(c2w))
+    rays = torch.cat([o, d, 0 * torch.ones_like(o[:, :1]), 5 * torch.ones_like(o[:, :1])], 1)   # PhototourismDataset.py:17-22
+    save("g8_rays", H=H, W=W, K=K, c2w=c2w, directions=dirs, rays_o=o, rays_d=d, rays=rays)
+
+
+@torch.no_grad()
+def encoder_goldens():
+    """G9 appearance encoder: reference encoder_sameoutputsize on a small photo-like input."""
+    rng = np.random.default_rng(77)
+    st = synth.encoder_state(51, 2.0)
+    enc = encoder_sameoutputsize(64).eval()
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    out = {"seed": 51, "gain": 2.0, "wsum": checksum(st)}
+    for tag, (h, w) in (("a", (52, 76)), ("b", (130, 128))):       # 13x19 and 32x32 maps before the adaptive pool
+        img = torch.from_numpy(rng.uniform(0, 1, (1, 3, h, w)).astype(np.float32))
+        out["img_" + tag] = img
+        out["feat_" + tag] = enc(img.clone())
+    save("g9_encoder", **out)
+
+
 if __name__ == "__main__":
     import math
     math_pi = np.float32(math.pi)
     main()
+    ray_goldens()
+    encoder_goldens()

@@ -84,3 +84,19 @@ def test_g6_decoder(golden):
     # the glue the callers apply around the decoder (eval.py:291-294)
     feat = T(g["content"])[0].reshape(64, -1).t().contiguous()
     assert torch.equal(O.feature_to_grid(feat, 24, 40), T(g["content"]))
+
+
+def test_g8_ray_generation(golden):
+    g = golden("g8_rays")
+    dirs, rays = O.generate_rays(int(g["H"]), int(g["W"]), g["K"], g["c2w"])
+    assert torch.equal(dirs, T(g["directions"]))
+    torch.testing.assert_close(rays, T(g["rays"]), rtol=0, atol=1e-6)
+
+
+def test_g9_encoder(golden):
+    g = golden("g9_encoder")
+    st = synth.encoder_state(int(g["seed"]), float(g["gain"]))
+    assert _state_checksum(st) == float(g["wsum"])
+    d = O.to_torch(st)
+    for tag in ("a", "b"):
+        torch.testing.assert_close(O.encoder_forward(d, T(g["img_" + tag])), T(g["feat_" + tag]), rtol=0, atol=1e-6)
