@@ -589,3 +589,46 @@ def test_appearance_encoder_golden(golden):
     with torch.enable_grad():
         feat_t = enc(C(g["img_b"]))
     assert feat_t.requires_grad and float((feat_t.detach() - feat).abs().max()) < 1e-4
+
+
+@torch.no_grad()
+def test_orchestration_mirror_video_frame_and_checkpoint_prefixes(tmp_path):
+    """get_model / load_ckpt (Lightning prefix convention) / batched_inference / decode_image / render_frame."""
+    from crnerf_amd import pipeline
+
+    class H(_Args):
+        N_emb_xyz, N_emb_dir, N_samples, N_importance, use_disp, encode_a, encode_random, N_a = 15, 4, 64, 64, False, True, True, 48
+        img_wh = [24, 16]
+    hp = H()
+    models, emb = pipeline.get_model(hp, DEV), pipeline.get_embeddings(hp)
+    assert set(models) == {"coarse", "fine", "decoder"} and models["fine"].encode_random and not models["coarse"].encode_random
+    enc_a = pipeline.encoder_sameoutputsize(64).to(DEV)
+    # a Lightning-style checkpoint: {'state_dict': {'<attribute>.<key>': tensor}}  (utils/__init__.py:67-88)
+    sd = {}
+    for prefix, st in (("nerf_coarse", synth.mlp_state(61, 3.0, 1.0)), ("nerf_fine", synth.mlp_state(62, 3.0, 1.0)),
+                       ("decoder", synth.decoder_state(63)), ("enc_a", synth.encoder_state(64, 2.0))):
+        sd.update({"%s.%s" % (prefix, k): torch.from_numpy(v) for k, v in st.items()})
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": sd, "epoch": 3}, path)
+    pipeline.load_ckpt(models["coarse"], path, model_name="nerf_coarse")
+    pipeline.load_ckpt(models["fine"], path, model_name="nerf_fine")
+    pipeline.load_ckpt(models["decoder"], path, model_name="decoder")
+    pipeline.load_ckpt(enc_a, path, model_name="enc_a")
+    assert torch.equal(models["fine"].state_dict()["static_rgb.0.bias"].cpu(), sd["nerf_fine.static_rgb.0.bias"])
+
+    Hh, Ww = 16, 24
+    focal = Ww / 2 / np.tan(np.pi / 6)
+    K = np.array([[focal, 0, Ww / 2], [0, focal, Hh / 2], [0, 0, 1]])
+    c2w = np.array([[1, 0, 0, 0.05], [0, -1, 0, 0.02], [0, 0, -1, 0.1]], dtype=np.float32)
+    style_img = C(np.random.default_rng(3).uniform(0, 1, (1, 3, 40, 56)).astype(np.float32))
+    img = pipeline.render_frame(models, emb, enc_a, style_img, Hh, Ww, K, c2w, hp, chunk=100)   # ragged chunks
+    assert img.shape == (Hh, Ww, 3) and torch.isfinite(img).all() and 0 <= float(img.min()) and float(img.max()) <= 1
+    # same frame through the oracle, end to end (rays, encoder, render at the HIP depths' own table, decode): PSNR check
+    _, rays = O.generate_rays(Hh, Ww, K, c2w, 0.0, 5.0)
+    wc, wf = O.to_torch(synth.mlp_state(61, 3.0, 1.0)), O.to_torch(synth.mlp_state(62, 3.0, 1.0))
+    ref = O.render_rays(wc, wf, rays, 64, 64)
+    a_ref = O.encoder_forward(O.to_torch(synth.encoder_state(64, 2.0)), style_img.cpu())
+    ref_img = O.crossray_decode(O.to_torch(synth.decoder_state(63)), O.feature_to_grid(ref["feature_fine"], Hh, Ww), a_ref)
+    ref_img = ref_img.reshape(3, -1).t().reshape(Hh, Ww, 3)
+    target = ref_img + 0.05 * torch.from_numpy(np.random.default_rng(2).normal(size=ref_img.shape).astype(np.float32))
+    assert abs(O.psnr(img.cpu(), target) - O.psnr(ref_img, target)) < 0.05
