@@ -186,66 +186,80 @@ struct WgradJob {
   long P; int chunk;
 };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradJob j) {
+// Workgroup tile 256(M) x 256(N): 4 waves (one per SIMD, 512-register budget) x 128x128 = 4x4 MFMA tiles each.
+// Per k-step (2 points) a wave loads 4 delta fragments + 4 input fragments (one dword per lane: a 32-float
+// row segment per half-wave, straight from HBM/L2 in MFMA operand shape) for 16 MFMAs; the next
+// iteration's operands are in flight while the current MFMAs run.  Tiles beyond M or N are skipped.
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
-  const int m0 = blockIdx.y * 128 + (wave & 1) * 64, n0 = blockIdx.z * 128 + (wave >> 1) * 64;
+  const int m0 = blockIdx.y * 256 + (wave & 1) * 128, n0 = blockIdx.z * 256 + (wave >> 1) * 128;
   const long p0 = (long)blockIdx.x * j.chunk;
   const long p1 = p0 + j.chunk < j.P ? p0 + j.chunk : j.P;
-  f32x16 acc[2][2];
+  const int mt = (j.M - m0 + 31) / 32 < 4 ? (j.M - m0 + 31) / 32 : 4;   // live 32-row tiles of this wave (<= 0: none)
+  const int nt = (j.N - n0 + 31) / 32 < 4 ? (j.N - n0 + 31) / 32 : 4;
+  if (mt <= 0 || nt <= 0) return;
+  f32x16 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  const bool mv0 = m0 + i < j.M, mv1 = m0 + 32 + i < j.M, nv0 = n0 + i < j.N, nv1 = n0 + 32 + i < j.N;
-  constexpr int KS = 8;                       // k-steps (2 points each) per iteration
-  float da[KS][2], aa[KS][2], dn[KS][2], an[KS][2];
-  auto fetch = [&](long pb, float (&d)[KS][2], float (&a)[KS][2]) {
+  bool mv[4], nv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { mv[t] = m0 + 32 * t + i < j.M; nv[t] = n0 + 32 * t + i < j.N; }
+  constexpr int KS = 4;                       // k-steps (2 points each) per iteration
+  float da[KS][4], aa[KS][4], dn[KS][4], an[KS][4];
+  auto fetch = [&](long pb, float (&d)[KS][4], float (&a)[KS][4]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const long pt = pb + 2 * s + kk;
       const bool pv = pt < p1;
       const float* dr = j.D + pt * j.ldd + m0 + i;
       const float* ar = j.A + pt * j.lda + n0 + i;
-      d[s][0] = (pv && mv0) ? dr[0] : 0.0f;
-      d[s][1] = (pv && mv1) ? dr[32] : 0.0f;
-      a[s][0] = (pv && nv0) ? ar[0] : 0.0f;
-      a[s][1] = (pv && nv1) ? ar[32] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        d[s][t] = (pv && mv[t]) ? dr[32 * t] : 0.0f;
+        a[s][t] = (pv && nv[t]) ? ar[32 * t] : 0.0f;
+      }
     }
   };
   const bool do_bias = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;   // one wave column per M block
-  float bs0 = 0.0f, bs1 = 0.0f;
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   fetch(p0, da, aa);
   for (long pb = p0; pb < p1; pb += 2 * KS) {
     fetch(pb + 2 * KS, dn, an);               // next iteration's operands fly while this one's MFMAs run
     if (do_bias) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) { bs0 += da[s][0]; bs1 += da[s][1]; }
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bs[t] += da[s][t];
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[s][a], aa[s][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b)
+          if (a < mt && b < nt) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[s][a], aa[s][b], acc[a][b], 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { da[s][0] = dn[s][0]; da[s][1] = dn[s][1]; aa[s][0] = an[s][0]; aa[s][1] = an[s][1]; }
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { da[s][t] = dn[s][t]; aa[s][t] = an[s][t]; }
   }
   if (do_bias) {
-    bs0 += __shfl_xor(bs0, 32);
-    bs1 += __shfl_xor(bs1, 32);
-    if (kk == 0) {
-      if (mv0) j.bias_partial[(long)blockIdx.x * j.M + m0 + i] = bs0;
-      if (mv1) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 + i] = bs1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bs[t] += __shfl_xor(bs[t], 32);
+      if (kk == 0 && mv[t]) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs[t];
     }
   }
   float* out = j.partial + (long)blockIdx.x * j.M * j.N;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk, nn = n0 + 32 * b + i;
@@ -253,21 +267,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradJob j) {
       }
 }
 
-// dst[m*ldc + n] = sum_c partial[c][m][n]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc) {
+// dst[m*ldc + n] = sum_c partial[c][m][n]   (fixed summation tree: deterministic; 8 loads in flight per thread)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * N) return;
-  float s = 0.0f;
-  for (int c = 0; c < nchunk; ++c) s += partial[(long)c * M * N + idx];
-  dst[(long)(idx / N) * ldc + idx % N] = s;
+  const long stride = (long)M * N;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int c = 0;
+  for (; c + 8 <= nchunk; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += partial[(c + u) * stride + idx];
+  }
+  for (; c < nchunk; ++c) a[0] += partial[c * stride + idx];
+  dst[(long)(idx / N) * ldc + idx % N] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // points per wgrad workgroup: small enough to fill the chip at 1024-ray batches, large enough that the
 // partial-sum workspace (nchunk x M x N) stays ~50 MB per layer at 65k-ray batches
 static int wg_chunk(long P) {
-  long c = (P + 191) / 192;
+  long c = (P + 255) / 256;             // ~one 256x256 workgroup per CU
   c = (c + 15) / 16 * 16;
-  return (int)(c < 512 ? 512 : c);
+  return (int)(c < 128 ? 128 : c);
 }
 
 // dW (and, when db != null, the bias gradient of the same delta) for one (delta, input-block) pair
@@ -277,7 +297,7 @@ static int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N,
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
   WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk};
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 127) / 128, (N + 127) / 128), dim3(256), 0, st, j);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc);
   if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, bws, nchunk, 1, M, db, M);
   return 0;

@@ -67,7 +67,9 @@ def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use
 
 
 @torch.no_grad()
-def decode_image(models, results, H, W, a_embedded_from_img, key="feature_fine"):
+def decode_image(models, results, H, W, a_embedded_from_img, key=None):
+    if key is None:
+        key = "feature_fine" if "feature_fine" in results else "feature_coarse"
     feature = results[key]                                           # [H*W, 64], already pixel-major
     grid = feature.t().reshape(1, feature.shape[1], int(H), int(W))  # the reference's two rearranges: a view
     rgb = models["decoder"](grid, a_embedded_from_img)               # [1,3,H,W]
