@@ -406,3 +406,380 @@ int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
 }
 
 }  // namespace crnerf
+
+// ================================================================= backward of the decode (training)
+// What autograd derives from style_net.forward in the reference.  The forward stats (means, Grams, fc
+// outputs, folded affine) are re-created by one more forward decode into the workspace; then
+//   pre    : per pixel  d_pre = d_rgb * rgb (1-rgb),  dx = d_pre A            (direct path of x)
+//   wgrad  : dA = sum_px d_pre^T x, dv = sum_px d_pre                          (point-reduction GEMM, mlp_train16.hip)
+//   small  : dA, dv -> grads of compress / unzip / rgb convs, dT -> dsMatrix, dcMatrix, mean terms
+//   fc     : d fc_w = dm (x) g,  d fc_b = dm,  dg = fc_w^T dm   for both CNNs
+//   chain  : per pixel (content and style): recompute the 1x1-conv chain, dh3 = (dG + dG^T) h3, back through
+//            the three convs; the per-layer deltas/activations go to HBM for
+//   wgrad  : the six conv weight/bias gradients
+//   finish : dx += dxc - mean(dxc) + dmean/HW   (centering, linearStyleTransfer.py:59-65), same for the style grid
+namespace crnerf {
+
+__global__ __launch_bounds__(256) void dec_bwd_pre_kernel(const float* __restrict__ x, long HW, const float* __restrict__ affine,
+                                                          const float* __restrict__ d_rgb, long plane_stride,
+                                                          float* __restrict__ d_pre /*[HW,4]*/, float* __restrict__ dx /*[HW,64]*/) {
+  __shared__ float A[196];
+  if (threadIdx.x < 195) A[threadIdx.x] = affine[threadIdx.x];
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const long px = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
+  const bool valid = px < HW;
+  float r = 0.0f, g = 0.0f, b = 0.0f;
+  f32x4 xv[4];
+  if (valid) {
+    const float* row = x + px * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * q + 16 * k;
+      xv[k] = *(const f32x4*)(row + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r = fmaf(A[c + e], xv[k][e], r); g = fmaf(A[64 + c + e], xv[k][e], g); b = fmaf(A[128 + c + e], xv[k][e], b);
+      }
+    }
+  }
+  r += __shfl_xor(r, 1); g += __shfl_xor(g, 1); b += __shfl_xor(b, 1);
+  r += __shfl_xor(r, 2); g += __shfl_xor(g, 2); b += __shfl_xor(b, 2);
+  if (!valid) return;
+  float dp[3];
+  const float pre[3] = {r + A[192], g + A[193], b + A[194]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s = 1.0f / (1.0f + expf(-pre[c]));
+    dp[c] = d_rgb[c * plane_stride + px] * s * (1.0f - s);
+  }
+  if (q == 0) *(f32x4*)(d_pre + px * 4) = f32x4{dp[0], dp[1], dp[2], 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * q + 16 * k;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = dp[0] * A[c + e] + dp[1] * A[64 + c + e] + dp[2] * A[128 + c + e];
+    *(f32x4*)(dx + px * 64 + c) = o;
+  }
+}
+
+struct SmallBwd {
+  const float* dA; const float* dv;                  // [3,64] (ld 64), [3]
+  const float* c_mean; const float* s_mean; const float* sM; const float* cM;
+  FoldTensors w;
+  float* g_comp_w; float* g_comp_b; float* g_unz_w; float* g_unz_b; float* g_rgb_w; float* g_rgb_b;
+  float* dm_s; float* dm_c;                          // [1024] each (= d fc_b)
+  float* dc_mean; float* ds_mean;                    // [64] each: the mean terms that do not go through the Gram
+};
+
+__global__ __launch_bounds__(256) void dec_bwd_small_kernel(SmallBwd a) {
+  __shared__ float T[32][33], U[3][32], Q[3][32], Am[3][64], dAp[3][64], dQ[3][32], dU[3][32], dT[32][33], dv[3];
+  const int t = threadIdx.x;
+  if (t < 3) dv[t] = a.dv[t];
+  for (int e = t; e < 1024; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    float s = 0.0f;
+    for (int k = 0; k < 32; ++k) s = fmaf(a.sM[i * 32 + k], a.cM[k * 32 + j], s);
+    T[i][j] = s;
+  }
+  if (t < 96) {
+    const int r = t / 32, k = t % 32;
+    float s = 0.0f;
+    for (int c = 0; c < 64; ++c) s = fmaf(a.w.rgb_w[r * 64 + c], a.w.unzip_w[c * 32 + k], s);
+    U[r][k] = s;
+  }
+  __syncthreads();
+  if (t < 96) {
+    const int r = t / 32, j = t % 32;
+    float s = 0.0f;
+    for (int k = 0; k < 32; ++k) s = fmaf(U[r][k], T[k][j], s);
+    Q[r][j] = s;
+  }
+  __syncthreads();
+  if (t < 192) {
+    const int r = t / 64, c = t % 64;
+    float s = 0.0f;
+    for (int k = 0; k < 32; ++k) s = fmaf(Q[r][k], a.w.comp_w[k * 64 + c], s);
+    Am[r][c] = s;
+    dAp[r][c] = a.dA[r * 64 + c] - dv[r] * a.c_mean[c];
+  }
+  __syncthreads();
+  if (t < 96) {
+    const int r = t / 32, k = t % 32;
+    float s = dv[r] * a.w.comp_b[k];
+    for (int c = 0; c < 64; ++c) s = fmaf(dAp[r][c], a.w.comp_w[k * 64 + c], s);
+    dQ[r][k] = s;
+  }
+  for (int e = t; e < 32 * 64; e += 256) {          // d compress.weight
+    const int k = e / 64, c = e % 64;
+    a.g_comp_w[e] = Q[0][k] * dAp[0][c] + Q[1][k] * dAp[1][c] + Q[2][k] * dAp[2][c];
+  }
+  if (t < 32) a.g_comp_b[t] = Q[0][t] * dv[0] + Q[1][t] * dv[1] + Q[2][t] * dv[2];
+  if (t < 64) {
+    a.dc_mean[t] = -(Am[0][t] * dv[0] + Am[1][t] * dv[1] + Am[2][t] * dv[2]);
+    const float wv = a.w.rgb_w[t] * dv[0] + a.w.rgb_w[64 + t] * dv[1] + a.w.rgb_w[128 + t] * dv[2];
+    a.g_unz_b[t] = wv;
+    a.ds_mean[t] = wv;
+  }
+  if (t < 3) a.g_rgb_b[t] = dv[t];
+  __syncthreads();
+  if (t < 96) {
+    const int r = t / 32, k = t % 32;
+    float s = 0.0f;
+    for (int j = 0; j < 32; ++j) s = fmaf(dQ[r][j], T[k][j], s);
+    dU[r][k] = s;
+  }
+  for (int e = t; e < 1024; e += 256) {
+    const int k = e >> 5, j = e & 31;
+    dT[k][j] = U[0][k] * dQ[0][j] + U[1][k] * dQ[1][j] + U[2][k] * dQ[2][j];
+  }
+  __syncthreads();
+  if (t < 192) {                                    // d feat_2_rgb weight
+    const int r = t / 64, c = t % 64;
+    float s = dv[r] * (a.w.unzip_b[c] + a.s_mean[c]);
+    for (int k = 0; k < 32; ++k) s = fmaf(dU[r][k], a.w.unzip_w[c * 32 + k], s);
+    a.g_rgb_w[r * 64 + c] = s;
+  }
+  for (int e = t; e < 64 * 32; e += 256) {          // d unzip.weight
+    const int c = e / 32, k = e % 32;
+    a.g_unz_w[e] = a.w.rgb_w[c] * dU[0][k] + a.w.rgb_w[64 + c] * dU[1][k] + a.w.rgb_w[128 + c] * dU[2][k];
+  }
+  for (int e = t; e < 1024; e += 256) {             // T = sM cM
+    const int i = e >> 5, k = e & 31;
+    float s = 0.0f, c2 = 0.0f;
+    for (int j = 0; j < 32; ++j) {
+      s = fmaf(dT[i][j], a.cM[k * 32 + j], s);      // dsM[i][k] = sum_j dT[i][j] cM[k][j]
+      c2 = fmaf(a.sM[j * 32 + i], dT[j][k], c2);    // dcM[i][k] = sum_j sM[j][i] dT[j][k]
+    }
+    a.dm_s[e] = s;
+    a.dm_c[e] = c2;
+  }
+}
+
+struct FcBwd { const float* dm; const float* gram_sum; float inv_count; const float* fc_w; float* g_fc_w; float* g_fc_b; float* S; };
+// grid (256, 2): rows 4b..4b+3 of the outer product d fc_w = dm (x) g; blocks 0..3 also form
+// S = (dG + dG^T) * inv_count with dG = (fc_w^T dm).view(32,32): the factor the Gram backward applies per pixel
+__global__ __launch_bounds__(256) void dec_bwd_fc_kernel(FcBwd j0, FcBwd j1) {
+  const FcBwd j = blockIdx.y ? j1 : j0;
+  const int t = threadIdx.x;
+  for (int r = 0; r < 4; ++r) {
+    const int i = blockIdx.x * 4 + r;
+    const float d = j.dm[i];
+    for (int c = t; c < 1024; c += 256) j.g_fc_w[(long)i * 1024 + c] = d * (j.gram_sum[c] * j.inv_count);
+    if (t == 0) j.g_fc_b[i] = d;
+  }
+  if (blockIdx.x < 4) {
+    const int col = blockIdx.x * 256 + t;
+    float s = 0.0f;
+    for (int i = 0; i < 1024; ++i) s = fmaf(j.fc_w[(long)i * 1024 + col], j.dm[i], s);
+    j.S[1024 + col] = s;                               // raw dg, second half of the S buffer
+  }
+}
+__global__ void dec_bwd_sym_kernel(float* S0, float inv0, float* S1, float inv1) {
+  float* S = blockIdx.x ? S1 : S0;
+  const float inv = blockIdx.x ? inv1 : inv0;
+  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    const int a = e >> 5, b = e & 31;
+    S[e] = (S[1024 + a * 32 + b] + S[1024 + b * 32 + a]) * inv;   // dL/dG_sum + its transpose, G = G_sum / count
+  }
+}
+
+// per-pixel chain forward + backward; stores what wgrad needs
+struct ChainJob {
+  const float* x; long P; const float* mean; CnnTensors w; const float* S;
+  float* xc; float* h1; float* h2; float* d1; float* d2; float* d3; float* dxc; int nblk;
+};
+constexpr int CH_W1 = 0, CH_W2 = 128 * 64, CH_W3 = CH_W2 + 64 * 128, CH_B1 = CH_W3 + 32 * 64, CH_B2 = CH_B1 + 128, CH_B3 = CH_B2 + 64,
+              CH_MEAN = CH_B3 + 32, CH_S = CH_MEAN + 64, CH_FLOATS = CH_S + 1024;
+
+__device__ __forceinline__ float dlrelu(float h) { return h > 0.0f ? 1.0f : 0.2f; }
+
+__global__ __launch_bounds__(64) void dec_bwd_chain_kernel(ChainJob j0, ChainJob j1) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const bool second = (int)blockIdx.x >= j0.nblk;
+  const ChainJob J = second ? j1 : j0;
+  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 128 * 64; i += 64) { sm[CH_W1 + i] = J.w.w1[i]; sm[CH_W2 + i] = J.w.w2[i]; }
+  for (int i = tid; i < 32 * 64; i += 64) sm[CH_W3 + i] = J.w.w3[i];
+  for (int i = tid; i < 128; i += 64) sm[CH_B1 + i] = J.w.b1[i];
+  sm[CH_B2 + tid] = J.w.b2[tid];
+  sm[CH_MEAN + tid] = J.mean[tid];
+  if (tid < 32) sm[CH_B3 + tid] = J.w.b3[tid];
+  for (int i = tid; i < 1024; i += 64) sm[CH_S + i] = J.S[i];
+  __syncthreads();
+  for (long px = (long)blk * 64 + tid; px < J.P; px += (long)J.nblk * 64) {
+    float xin[64], h2[64];
+    const float* row = J.x + px * 64;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) { xin[c] = row[c] - sm[CH_MEAN + c]; J.xc[px * 64 + c] = xin[c]; }
+#pragma unroll
+    for (int o = 0; o < 64; ++o) h2[o] = sm[CH_B2 + o];
+#pragma unroll 1
+    for (int oc = 0; oc < 128; oc += 8) {               // layer 1 in chunks of 8 outputs, folded into layer 2
+      float h1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float acc = sm[CH_B1 + oc + u];
+        const float* wr = sm + CH_W1 + (oc + u) * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc = fmaf(wr[c], xin[c], acc);
+        h1[u] = lrelu02(acc);
+        J.h1[px * 128 + oc + u] = h1[u];
+      }
+#pragma unroll
+      for (int o = 0; o < 64; ++o) {
+        const float* wr = sm + CH_W2 + o * 128 + oc;
+        float acc = h2[o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(wr[u], h1[u], acc);
+        h2[o] = acc;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 64; ++o) { h2[o] = lrelu02(h2[o]); J.h2[px * 64 + o] = h2[o]; }
+    float h3[32], d3[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+      float acc = sm[CH_B3 + o];
+      const float* wr = sm + CH_W3 + o * 64;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) acc = fmaf(wr[c], h2[c], acc);
+      h3[o] = acc;
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {                      // dh3 = S h3,  S = (dG + dG^T) / count^... (see launch)
+      float acc = 0.0f;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) acc = fmaf(sm[CH_S + a * 32 + b], h3[b], acc);
+      d3[a] = acc;
+      J.d3[px * 32 + a] = acc;
+    }
+    float d2[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) d2[c] = 0.0f;
+#pragma unroll 4
+    for (int o = 0; o < 32; ++o) {
+      const float* wr = sm + CH_W3 + o * 64;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) d2[c] = fmaf(d3[o], wr[c], d2[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) { d2[c] *= dlrelu(h2[c]); J.d2[px * 64 + c] = d2[c]; }
+    float dxc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) dxc[c] = 0.0f;
+#pragma unroll 1
+    for (int kc = 0; kc < 128; kc += 8) {
+      float d1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d1[u] = 0.0f;
+#pragma unroll 4
+      for (int o = 0; o < 64; ++o) {
+        const float* wr = sm + CH_W2 + o * 128 + kc;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d1[u] = fmaf(d2[o], wr[u], d1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        d1[u] *= dlrelu(J.h1[px * 128 + kc + u]);
+        J.d1[px * 128 + kc + u] = d1[u];
+        const float* wr = sm + CH_W1 + (kc + u) * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dxc[c] = fmaf(d1[u], wr[c], dxc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) J.dxc[px * 64 + c] = dxc[c];
+  }
+}
+
+// dst[px][c] (+)= dxc[px][c] + (dmean[c] - colsum[c]) / P
+__global__ void dec_bwd_finish_kernel(float* __restrict__ dst, const float* __restrict__ dxc, const float* __restrict__ dmean,
+                                      const float* __restrict__ colsum, long P, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * 64) return;
+  const int c = (int)(idx & 63);
+  const float v = dxc[idx] + (dmean[c] - colsum[c]) / (float)P;
+  dst[idx] = accumulate ? dst[idx] + v : v;
+}
+
+size_t crossray_backward_workspace_floats(long HW, long HWs) {
+  const long P = HW + HWs;
+  size_t n = CROSSRAY_WORKSPACE_BYTES / 4;                       // forward decode workspace (stats live here)
+  n += (size_t)3 * HW + 4 * (size_t)HW;                          // scratch rgb, d_pre[HW,4]
+  n += (size_t)P * (64 + 128 + 64 + 128 + 64 + 32 + 64);         // xc, h1, h2, d1, d2, d3, dxc
+  n += 4096 + 2 * 2048 + 1024;                                   // dA/dv, dm, S/dg buffers, mean terms, column sums
+  n += wgrad_workspace_floats(P > HW ? P : HW, 128, 128) + wgrad_workspace_floats(HW, 4, 64) + 64 * (size_t)CROSSRAY_SUM_BLOCKS * 2;
+  return n;
+}
+
+int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
+                                    float* d_style, float* const* grads, hipStream_t stream) {
+  if (d.HW <= 0 || d.HWs <= 0 || !d.style) return set_error(-2, "crossray_decode_backward: needs a content and a style grid");
+  const long HW = d.HW, HWs = d.HWs;
+  float* p = workspace;
+  float* fwd_ws = p; p += CROSSRAY_WORKSPACE_BYTES / 4;
+  float* rgb = p; p += 3 * HW;
+  float* d_pre = p; p += 4 * HW;
+  auto take = [&](size_t n) { float* q = p; p += n; return q; };
+  float* xc[2] = {take(HW * 64), take(HWs * 64)};
+  float* h1[2] = {take(HW * 128), take(HWs * 128)};
+  float* h2[2] = {take(HW * 64), take(HWs * 64)};
+  float* d1[2] = {take(HW * 128), take(HWs * 128)};
+  float* d2[2] = {take(HW * 64), take(HWs * 64)};
+  float* d3[2] = {take(HW * 32), take(HWs * 32)};
+  float* dxc[2] = {take(HW * 64), take(HWs * 64)};
+  float* dA = take(256); float* dv = take(64);
+  float* dm_s = take(1024); float* dm_c = take(1024);
+  float* S_s = take(2048); float* S_c = take(2048);
+  float* dmean_c = take(64); float* dmean_s = take(64); float* cs_c = take(64); float* cs_s = take(64);
+  float* sum_ws = take(64 * (size_t)CROSSRAY_SUM_BLOCKS * 2);
+  float* wws = p;
+  // 0. forward again: stats + affine into fwd_ws
+  DecodeArgs f = d;
+  f.workspace = fwd_ws; f.rgb = rgb; f.plane_stride = HW;
+  if (int rc = launch_crossray_decode(f, stream)) return rc;
+  float* st = fwd_ws + WS_STATS;
+  // 1. d_pre, direct dx; 2. dA, dv
+  hipLaunchKernelGGL(dec_bwd_pre_kernel, dim3((unsigned)((HW * 4 + 255) / 256)), dim3(256), 0, stream, d.content, HW, st + ST_AFFINE, d_rgb,
+                     d_plane_stride, d_pre, d_content);
+  wgrad(d_pre, 4, 3, d.content, 64, 64, dA, 64, dv, HW, wws, stream);
+  // 3. small matrices
+  SmallBwd sb{dA, dv, st + ST_CMEAN, st + ST_SMEAN, st + ST_SMAT, st + ST_CMAT, d.lin,
+              grads[16], grads[17], grads[18], grads[19], grads[20], grads[21], dm_s, dm_c, dmean_c, dmean_s};
+  hipLaunchKernelGGL(dec_bwd_small_kernel, dim3(1), dim3(256), 0, stream, sb);
+  // 4. fc layers: snet = grads[6], [7]; cnet = grads[14], [15]
+  FcBwd fs{dm_s, st + ST_SGRAM, (float)(1.0 / (double)HWs), d.snet_fc_w, grads[6], grads[7], S_s};
+  FcBwd fc{dm_c, st + ST_CGRAM, (float)(1.0 / (double)HW), d.cnet_fc_w, grads[14], grads[15], S_c};
+  hipLaunchKernelGGL(dec_bwd_fc_kernel, dim3(256, 2), dim3(256), 0, stream, fs, fc);
+  // S = (dG + dG^T) / count with dG = dg.view(32,32): G = G_sum / count, G_sum = sum_px h3 h3^T
+  hipLaunchKernelGGL(dec_bwd_sym_kernel, dim3(2), dim3(256), 0, stream, S_s, (float)(1.0 / (double)HWs), S_c, (float)(1.0 / (double)HW));
+  // 5. conv chains
+  const int nb_c = (int)((HW + 63) / 64 < 1024 ? (HW + 63) / 64 : 1024), nb_s = (int)((HWs + 63) / 64 < 1024 ? (HWs + 63) / 64 : 1024);
+  ChainJob jc{d.content, HW, st + ST_CMEAN, d.cnet, S_c, xc[0], h1[0], h2[0], d1[0], d2[0], d3[0], dxc[0], nb_c};
+  ChainJob js{d.style, HWs, st + ST_SMEAN, d.snet, S_s, xc[1], h1[1], h2[1], d1[1], d2[1], d3[1], dxc[1], nb_s};
+  const size_t shmem = (size_t)CH_FLOATS * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)dec_bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(dec_bwd_chain_kernel) failed");
+  hipLaunchKernelGGL(dec_bwd_chain_kernel, dim3(nb_c + nb_s), dim3(64), shmem, stream, jc, js);
+  // 6. conv weight / bias gradients: snet = grads[0..5], cnet = grads[8..13]
+  for (int net = 0; net < 2; ++net) {
+    const long P = net ? HWs : HW;
+    float* const* g = grads + (net ? 0 : 8);
+    wgrad(d1[net], 128, 128, xc[net], 64, 64, g[0], 64, g[1], P, wws, stream);
+    wgrad(d2[net], 64, 64, h1[net], 128, 128, g[2], 128, g[3], P, wws, stream);
+    wgrad(d3[net], 32, 32, h2[net], 64, 64, g[4], 64, g[5], P, wws, stream);
+  }
+  // 7. centering terms
+  SumJob s0{dxc[0], HW, sum_ws, chansum_blocks(HW)}, s1{dxc[1], HWs, sum_ws + 64 * CROSSRAY_SUM_BLOCKS, chansum_blocks(HWs)};
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+  RedJob r0{s0.partial, s0.nblk, cs_c}, r1{s1.partial, s1.nblk, cs_s};
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 2), dim3(64), 0, stream, r0, r1, 64);
+  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HW * 64 + 255) / 256)), dim3(256), 0, stream, d_content, dxc[0], dmean_c, cs_c, HW, 1);
+  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HWs * 64 + 255) / 256)), dim3(256), 0, stream, d_style, dxc[1], dmean_s, cs_s, HWs, 0);
+  return check_launch("crossray_decode_backward");
+}
+
+}  // namespace crnerf

@@ -30,6 +30,10 @@ int launch_rays_from_directions(const float* dirs, const float* c2w_host, long n
 int launch_generate_rays(const float* intr4_host, const float* c2w_host, int H, int W, float near, float far, float* rays, hipStream_t stream);
 size_t encoder_workspace_bytes(int H, int W);
 int launch_encoder_forward(const float* img, int H, int W, const float* const* w, void* workspace, float* out, hipStream_t st);
+// dst[m*ldc + n] = sum_p D[p][m] * A[p][n] (and db[m] = sum_p D[p][m] when db != null); ws: wgrad_workspace_floats()
+size_t wgrad_workspace_floats(long P, int M, int N);
+int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
+          hipStream_t st);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,

@@ -291,8 +291,14 @@ static int wg_chunk(long P) {
 }
 
 // dW (and, when db != null, the bias gradient of the same delta) for one (delta, input-block) pair
-static int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-                 hipStream_t st) {
+size_t wgrad_workspace_floats(long P, int M, int N) {
+  const int chunk = wg_chunk(P);
+  const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
+  return nchunk * ((size_t)M * N + M);
+}
+
+int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
+          hipStream_t st) {
   const int chunk = wg_chunk(P);
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;

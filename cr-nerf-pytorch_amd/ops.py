@@ -277,3 +277,19 @@ def encoder_forward(image, weights):
     _lib.check(lib.crnerf_encoder_forward_f32(_lib.dev_ptr(img), H, W, arr, ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), _lib.stream_ptr()),
                "crnerf_encoder_forward_f32")
     return out
+
+
+def crossray_decode_backward(content_pm, style_pm, weights, d_rgb):
+    """Backward of crossray_decode: returns (d_content[HW,64], d_style[HWs,64], [22 weight gradients])."""
+    lib = _lib.load()
+    x, s, d_rgb = _f32c(content_pm, "content"), _f32c(style_pm, "style"), _f32c(d_rgb, "d_rgb")
+    HW, HWs = x.shape[0], s.shape[0]
+    ws_t = [_f32c(t.detach(), "decoder weight") for t in weights]
+    grads = [torch.empty_like(t) for t in ws_t]
+    dx, ds = torch.empty_like(x), torch.empty_like(s)
+    work = torch.empty(lib.crnerf_crossray_backward_workspace_bytes(HW, HWs), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_crossray_decode_backward_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(s), HWs, _lib.ptr_array(ws_t, "decoder weight"),
+                                                       _lib.dev_ptr(d_rgb), d_rgb.stride(0), ctypes.c_void_p(work.data_ptr()), _lib.dev_ptr(dx),
+                                                       _lib.dev_ptr(ds), _lib.ptr_array(grads, "decoder grad"), _lib.stream_ptr()),
+               "crnerf_crossray_decode_backward_f32")
+    return dx, ds, grads

@@ -162,6 +162,13 @@ int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const
 #define CRNERF_DECODER_TENSORS 22
 int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
                                void* workspace, float* rgb, int64_t plane_stride, void* stream);
+/* Backward of crnerf_crossray_decode_f32 (in the reference: autograd through style_net.forward): d_rgb[c*d_plane_stride + px]
+ * -> d_content[HW,64], d_style[HWs,64] and grads[22] (same order as `weights`, each OVERWRITTEN).
+ * workspace: crnerf_crossray_backward_workspace_bytes(HW, HWs). */
+size_t crnerf_crossray_backward_workspace_bytes(int64_t HW, int64_t HWs);
+int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
+                                        const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_style,
+                                        float* const* grads, void* stream);
 /* rgb[c*plane_stride + px] = sigmoid(A[c] . x[px] + v[c]) */
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
                               void* stream);

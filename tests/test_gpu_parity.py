@@ -632,3 +632,31 @@ def test_orchestration_mirror_video_frame_and_checkpoint_prefixes(tmp_path):
     ref_img = ref_img.reshape(3, -1).t().reshape(Hh, Ww, 3)
     target = ref_img + 0.05 * torch.from_numpy(np.random.default_rng(2).normal(size=ref_img.shape).astype(np.float32))
     assert abs(O.psnr(img.cpu(), target) - O.psnr(ref_img, target)) < 0.05
+
+
+@pytest.mark.parametrize("H,W,hs", [(8, 8, 32), (13, 21, 32), (40, 24, 16)])
+def test_decoder_backward_vs_autograd_oracle(H, W, hs):
+    """crnerf_crossray_decode_backward_f32 against torch autograd through the oracle decoder: gradients w.r.t. the
+    content grid, the style grid and all 22 parameter tensors."""
+    st = synth.decoder_state(7, 2.0)
+    rng = np.random.default_rng(H * W)
+    content = rng.uniform(0, 1, (H * W, 64)).astype(np.float32)
+    style = rng.uniform(0, 1, (hs * hs, 64)).astype(np.float32)
+    d_rgb = rng.normal(size=(3, H * W)).astype(np.float32)
+    names = [k for k in st if not k.endswith(".f")]
+    w = {k: torch.from_numpy(st[k]).clone().requires_grad_(True) for k in names}
+    xc, xs = torch.from_numpy(content).requires_grad_(True), torch.from_numpy(style).requires_grad_(True)
+    rgb = O.crossray_decode(w, O.feature_to_grid(xc, H, W), O.feature_to_grid(xs, hs, hs)).reshape(3, H * W)
+    (rgb * torch.from_numpy(d_rgb)).sum().backward()
+    with torch.no_grad():
+        dx, ds, grads = ops.crossray_decode_backward(C(content), C(style), [C(st[k]) for k in names], C(d_rgb))
+
+    def check(got, ref, what):
+        ref = ref.reshape(got.shape)
+        tol = 2e-3 * float(ref.abs().max()) + 1e-8
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= tol, "%s: %.3e > %.3e" % (what, err, tol)
+    check(dx, xc.grad, "d_content")
+    check(ds, xs.grad, "d_style")
+    for k, gq in zip(names, grads):
+        check(gq, w[k].grad, k)
