@@ -165,8 +165,23 @@ struct NoSave {   // inference: nothing is materialised
   __device__ __forceinline__ void operator()(int, const f32x4 (&)[NT]) const {}
 };
 
-template <class SAVE = NoSave>
-__device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32x4 (&pe)[6], const f32x4 (&dv)[2],
+// Where the direction embedding comes from when the dir layer needs it (late in the tile): registers
+// (module entry: it differs per point) or 8 floats per lane group parked in LDS (fused renderer: it is
+// a per-ray constant, and 8 fewer live registers across ten layers is what keeps the kernel spill-free).
+struct DirRegs {
+  f32x4 v[2];
+  __device__ __forceinline__ void get(f32x4 (&o)[2]) const { o[0] = v[0]; o[1] = v[1]; }
+};
+struct DirLds {
+  const lds_float* p;   // this lane group's 8 floats, 16-byte aligned
+  __device__ __forceinline__ void get(f32x4 (&o)[2]) const {
+    o[0] = *(const __attribute__((address_space(3))) f32x4*)(p);
+    o[1] = *(const __attribute__((address_space(3))) f32x4*)(p + 4);
+  }
+};
+
+template <class DIR, class SAVE = NoSave>
+__device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32x4 (&pe)[6], const DIR& dir,
                                            f32x4 (&feat)[4], float& sigma, int g, f32x4 (&q)[V16_AHEAD], PhaseTimer& tm,
                                            const SAVE& save = SAVE()) {
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
@@ -226,7 +241,8 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
   store_act16<16, false>(acc, act);
   save(8, act);
   {
-    f32x4 acc8[8];                                       // dir_encoding = relu(Linear(cat[final, dir]))
+    f32x4 acc8[8], dv[2];                                // dir_encoding = relu(Linear(cat[final, dir]))
+    dir.get(dv);
     init_acc16<8>(acc8, C + C_BDIR, g);
     tm.tick(T_EPILOGUE);
     mma_layer16<8, U_HID, U_DIR>(p, act, dv, acc8, q);

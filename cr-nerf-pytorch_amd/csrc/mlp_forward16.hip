@@ -28,7 +28,9 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16_kernel(const char* __res
     const bool valid = n < P;
     const int xdim = sigma_only ? XYZ_DIM : IN_DIM;
     const float* row = x + (valid ? n : 0) * xdim;
-    f32x4 pe[6], dv[2], feat[4];
+    f32x4 pe[6], feat[4];
+    DirRegs dreg;
+    f32x4 (&dv)[2] = dreg.v;
 #pragma unroll
     for (int v = 0; v < 6; ++v)
 #pragma unroll
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16_kernel(const char* __res
         dv[v][r] = (valid && !sigma_only && c >= 0) ? row[XYZ_DIM + (c < 0 ? 0 : c)] : 0.0f;
       }
     float sigma;
-    mlp_tile16(pipe, 0, pe, dv, feat, sigma, g, q, tm);
+    mlp_tile16(pipe, 0, pe, dreg, feat, sigma, g, q, tm);
     if (valid) {
       if (sigma_only) {
         if (g == 0) out[n] = sigma;

@@ -52,7 +52,9 @@ __global__ __launch_bounds__(512, 2) void mlp_forward_train16_kernel(const char*
     const long n = tile * 16 + p;
     const bool valid = n < P;
     const float* row = x + (valid ? n : 0) * IN_DIM;
-    f32x4 pe[6], dv[2], feat[4];
+    f32x4 pe[6], feat[4];
+    DirRegs dreg;
+    f32x4 (&dv)[2] = dreg.v;
 #pragma unroll
     for (int v = 0; v < 6; ++v)
 #pragma unroll
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward_train16_kernel(const char*
       }
     float sigma;
     ActSaver sv{acts, P, n, valid, g};
-    mlp_tile16(pipe, 0, pe, dv, feat, sigma, g, q, tm, sv);
+    mlp_tile16(pipe, 0, pe, dreg, feat, sigma, g, q, tm, sv);
     if (valid) {
       float* o = out + n * OUT_DIM;
 #pragma unroll

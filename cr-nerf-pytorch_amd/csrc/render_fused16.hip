@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
   load_consts(lds, a.packed0, a.packed1);
   PairScratch scr;
   scr.bind(lds + LDS_SCRATCH + pair * PAIR_BYTES);
+  lds_float* dirbuf = (lds_float*)(lds + LDS_SCRATCH + 4 * PAIR_BYTES) + wave * 32;   // 32 floats per wave
 
   const int steps_c = (Nc + 31) >> 5, steps_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
   WeightPipe16 pipe;
@@ -139,11 +140,16 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
     const float* ray = a.rays + r * 8;
     const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
     const float near = ray[6], far = ray[7];
-    f32x4 dv[2];
     {
       const float* vd = a.view_dir ? a.view_dir + r * 3 : ray + 3;       // rendering.py:155
+      f32x4 dv[2];
       posenc_regs16<DIR_FREQS, 2>(vd[0], vd[1], vd[2], g, dv);
+      if (p == 0) {                                                      // per-ray constant: park it in LDS (DirLds)
+        *(__attribute__((address_space(3))) f32x4*)(dirbuf + 8 * g) = dv[0];
+        *(__attribute__((address_space(3))) f32x4*)(dirbuf + 8 * g + 4) = dv[1];
+      }
     }
+    const DirLds dirsrc{dirbuf + 8 * g};
     for (int n = lane128; n < Nc; n += 128)
       scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
     wg_barrier();
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
         f32x4 pe[6], feat[4];
         posenc_regs16<XYZ_FREQS, 6>(x, y, z, g, pe);
         float sigma;
-        mlp_tile16(pipe, pass, pe, dv, feat, sigma, g, q, tm);
+        mlp_tile16(pipe, pass, pe, dirsrc, feat, sigma, g, q, tm);
         // ---- compositing, rendering.py:121-143
         const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
         const float delta = (n == N - 1) ? 1e2f : znext - zn;
@@ -261,7 +267,7 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   const long quads = (a.R + 3) / 4;
   const int grid = (int)(quads < 256 ? quads : 256);
   k.iters = (int)((quads + grid - 1) / grid);
-  const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES;
+  const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)render_rays16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(render_rays16_kernel) failed");
   hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
