@@ -22,7 +22,7 @@ EXPORTS = [
     "crnerf_mlp_forward_train_f32", "crnerf_mlp_backward_f32",
     "crnerf_ray_directions_f32", "crnerf_rays_from_directions_f32", "crnerf_generate_rays_f32",
     "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
-    "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32",
+    "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32", "crnerf_crossray_decode_sharded_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -90,6 +90,7 @@ def load():
             "crnerf_crossray_apply_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, vp]),
             "crnerf_crossray_backward_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
             "crnerf_crossray_decode_backward_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, i64, vp, vp, vp, pp, vp]),
+            "crnerf_crossray_decode_sharded_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, i32, vp, f64, vp, vp, i64, vp]),
             "crnerf_crossray_decode_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, vp, i64, vp]),
         }
         for name, (res, args) in sig.items():

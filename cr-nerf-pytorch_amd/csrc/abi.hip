@@ -229,6 +229,24 @@ int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* st
   return launch_crossray_decode(d, (hipStream_t)stream);
 }
 
+int crnerf_crossray_decode_sharded_f32(const float* content, int64_t HW_local, const float* style, int64_t HWs, const float* const* w,
+                                       int phase, float* xchg, double count_global, void* workspace, float* rgb, int64_t plane_stride,
+                                       void* stream) {
+  REQUIRE(style, "style"); REQUIRE(w, "weights"); REQUIRE(xchg, "xchg"); REQUIRE(workspace, "workspace");
+  if (HW_local < 0 || phase < 0 || phase > 2) return set_error(CRNERF_ERR_SHAPE, "crossray_decode_sharded: bad size or phase");
+  if (HW_local > 0) REQUIRE(content, "content");
+  if (phase == 2 && HW_local > 0) REQUIRE(rgb, "rgb");
+  for (int i = 0; i < CRNERF_DECODER_TENSORS; ++i)
+    if (!w[i]) return set_error(CRNERF_ERR_NULL, "crossray_decode_sharded: a weight pointer is NULL");
+  DecodeArgs d;
+  d.content = content; d.HW = (long)HW_local; d.style = style; d.HWs = (long)HWs;
+  d.snet = CnnTensors{w[0], w[1], w[2], w[3], w[4], w[5]}; d.snet_fc_w = w[6]; d.snet_fc_b = w[7];
+  d.cnet = CnnTensors{w[8], w[9], w[10], w[11], w[12], w[13]}; d.cnet_fc_w = w[14]; d.cnet_fc_b = w[15];
+  d.lin = FoldTensors{w[16], w[17], w[18], w[19], w[20], w[21]};
+  d.workspace = workspace; d.rgb = rgb; d.plane_stride = (long)plane_stride;
+  return launch_crossray_decode_sharded(d, phase, xchg, count_global, (hipStream_t)stream);
+}
+
 size_t crnerf_crossray_backward_workspace_bytes(int64_t HW, int64_t HWs) { return crossray_backward_workspace_floats((long)HW, (long)HWs) * sizeof(float); }
 
 int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* w,

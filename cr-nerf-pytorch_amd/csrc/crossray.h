@@ -37,6 +37,7 @@ int launch_crossray_fold(const float* sM, const float* cM, const float* c_mean, 
                          float* affine, hipStream_t stream);
 int launch_crossray_apply(const float* x, long HW, const float* affine, float* rgb, long plane_stride, hipStream_t stream);
 int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream);
+int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, double count_global, hipStream_t stream);
 size_t crossray_backward_workspace_floats(long HW, long HWs);
 int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
                                     float* d_style, float* const* grads, hipStream_t stream);

@@ -405,6 +405,50 @@ int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
   return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
 }
 
+// Ray-sharded decode (SURVEY 8e option B): three host calls around the two all-reduces of
+// parallel.decode_sharded.  xchg[0:64] = channel sums, xchg[64:1088] = Gram sums of the CONTENT grid:
+//   phase 0: local content sums -> xchg[0:64]            (style sums stay in the workspace)       | all-reduce xchg[0:64]
+//   phase 1: global sums + global count -> mean; local content Gram sums -> xchg[64:1088]; style Gram  | all-reduce xchg[64:]
+//   phase 2: global Gram -> both fc layers, fold, apply on the local pixels -> rgb
+// The style grid is replicated, so its statistics never need a collective.
+int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, double count_global, hipStream_t stream) {
+  if (!d.style || d.HWs <= 0) return set_error(-2, "crossray_decode_sharded: needs the (replicated) style grid");
+  if (!(count_global > 0) && phase > 0) return set_error(-2, "crossray_decode_sharded: global pixel count must be positive");
+  float* ws = (float*)d.workspace;
+  float* st = ws + WS_STATS;
+  const bool have = d.HW > 0;                         // a rank may hold no pixels
+  SumJob s0{d.content, d.HW, ws + WS_SUMP0, have ? chansum_blocks(d.HW) : 0}, s1{d.style, d.HWs, ws + WS_SUMP1, chansum_blocks(d.HWs)};
+  if (phase == 0) {
+    hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+    if (have) {
+      RedJob r0{ws + WS_SUMP0, s0.nblk, xchg}, rn{nullptr, 0, nullptr};
+      hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(64), 0, stream, r0, rn, 64);
+    } else if (hipMemsetAsync(xchg, 0, 64 * sizeof(float), stream) != hipSuccess) return set_error(-10, "hipMemsetAsync failed");
+    return check_launch("crossray_decode_sharded phase 0");
+  }
+  if (phase == 1) {
+    GramJob g0{d.content, d.HW, nullptr, xchg, 1, (float)(1.0 / count_global), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, have ? gram_blocks(d.HW) : 0};
+    GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
+    if (int rc = launch_gram(g0, g1, stream)) return rc;
+    RedJob r0{ws + WS_GRAMP0, g0.nblk, have ? xchg + 64 : nullptr}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 2), dim3(256), 0, stream, r0, r1, 1024);
+    if (!have) {
+      if (hipMemsetAsync(xchg + 64, 0, 1024 * sizeof(float), stream) != hipSuccess) return set_error(-10, "hipMemsetAsync failed");
+      // the mean is needed by fold on every rank
+      GramJob m0{d.style, 0, nullptr, xchg, 1, (float)(1.0 / count_global), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, 1}, none{};
+      none.nblk = 0;
+      if (int rc = launch_gram(m0, none, stream)) return rc;
+    }
+    return check_launch("crossray_decode_sharded phase 1");
+  }
+  FcJob f0{xchg + 64, (float)(1.0 / count_global), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
+  FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
+  hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
+  if (int rc = check_launch("crossray_decode_sharded phase 2")) return rc;
+  return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
+}
+
 }  // namespace crnerf
 
 // ================================================================= backward of the decode (training)

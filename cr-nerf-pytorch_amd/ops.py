@@ -293,3 +293,22 @@ def crossray_decode_backward(content_pm, style_pm, weights, d_rgb):
                                                        _lib.dev_ptr(ds), _lib.ptr_array(grads, "decoder grad"), _lib.stream_ptr()),
                "crnerf_crossray_decode_backward_f32")
     return dx, ds, grads
+
+
+def crossray_decode_sharded(content_pm, style_pm, weights, phase, xchg, count_global, rgb=None):
+    """One phase (0, 1, 2) of the ray-sharded decode; the caller all-reduces xchg[0:64] after phase 0 and
+    xchg[64:1088] after phase 1.  Returns rgb [3, HW_local] after phase 2."""
+    lib = _lib.load()
+    s = _f32c(style_pm, "style")
+    n = content_pm.shape[0]
+    x = _f32c(content_pm, "content") if n else None
+    ws = crossray_workspace(s.device)
+    arr = _lib.ptr_array([_f32c(t.detach(), "decoder weight") for t in weights], "decoder weight")
+    if phase == 2 and rgb is None:
+        rgb = torch.empty(3, n, dtype=torch.float32, device=s.device)
+    _lib.check(lib.crnerf_crossray_decode_sharded_f32(_lib.dev_ptr(x), n, _lib.dev_ptr(s), s.shape[0], arr, int(phase), _lib.dev_ptr(xchg),
+                                                      float(count_global), ctypes.c_void_p(ws.data_ptr()),
+                                                      _lib.dev_ptr(rgb) if (rgb is not None and n) else None,
+                                                      rgb.stride(0) if (rgb is not None and n) else 0, _lib.stream_ptr()),
+               "crnerf_crossray_decode_sharded_f32")
+    return rgb

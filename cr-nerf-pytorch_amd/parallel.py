@@ -39,22 +39,31 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     order = pixel order); style_feature: [1,64,h,w], replicated.  Returns RGB planar: [3, R_total] on
     every rank when gather=True (ranks may hold different R_local), else this rank's [3, R_local].
     equal_shards=True promises every rank holds the same R_local: the pixel count is then known on the
-    host and the call enqueues without any device->host synchronisation."""
+    host and the call enqueues without any device->host synchronisation.
+
+    Three kernel phases around two all-reduces (crnerf_crossray_decode_sharded_f32): channel sums ->
+    all-reduce(64 floats) -> Gram of the centred conv chain -> all-reduce(1024 floats) -> fc / fold /
+    apply on the local pixels -> all-gather of RGB."""
     k = kernels or _HipKernels()
     dev = feature_local.device
     n_local = feature_local.shape[0]
-    # reduction 1: channel sums + pixel count  -> global mean   (linearStyleTransfer.py:59-65)
-    stat = torch.cat([k.crossray_chansum(feature_local) if n_local else torch.zeros(64, device=dev),
-                      torch.tensor([float(n_local)], device=dev)])
-    dist.all_reduce(stat, group=group)
     ws = dist.get_world_size(group)
-    c_sum, count = stat[:64].contiguous(), (float(n_local * ws) if equal_shards else float(stat[64].item()))
-    # reduction 2: Gram of the centred conv chain        (linearStyleTransfer.py:29-34)
-    cnet = net.multi_net.cnet
-    gram = k.crossray_gram(feature_local, (c_sum / count).contiguous(), cnet.conv_tensors()) if n_local else torch.zeros(1024, device=dev)
-    dist.all_reduce(gram, group=group)
-    affine = net.affine_from_stats(c_sum, gram, count, style_feature, kernels=k)
-    rgb_local = k.crossray_apply(feature_local, affine) if n_local else torch.zeros(3, 0, device=dev)
+    if equal_shards:
+        count = float(n_local * ws)
+    else:
+        cnt = torch.tensor([float(n_local)], device=dev)
+        dist.all_reduce(cnt, group=group)
+        count = float(cnt.item())
+    sp = style_feature.permute(0, 2, 3, 1).reshape(-1, style_feature.shape[1]).contiguous()
+    weights = net.decoder_tensors()
+    xchg = torch.zeros(64 + 1024, dtype=torch.float32, device=dev)
+    k.crossray_decode_sharded(feature_local, sp, weights, 0, xchg, count)
+    dist.all_reduce(xchg[:64], group=group)           # reduction 1: channel sums -> global mean  (linearStyleTransfer.py:59-65)
+    k.crossray_decode_sharded(feature_local, sp, weights, 1, xchg, count)
+    dist.all_reduce(xchg[64:], group=group)           # reduction 2: Gram of the centred conv chain (linearStyleTransfer.py:29-34)
+    rgb_local = k.crossray_decode_sharded(feature_local, sp, weights, 2, xchg, count)
+    if rgb_local is None:
+        rgb_local = torch.zeros(3, 0, device=dev)
     if not gather:
         return rgb_local
     if equal_shards:
@@ -69,7 +78,7 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     pad[:, :n_local] = rgb_local
     parts = [torch.empty(3, width, device=dev) for _ in range(ws)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:, :s] for p, s in zip(parts, sizes)], dim=1)
+    return torch.cat([q[:, :s] for q, s in zip(parts, sizes)], dim=1)
 
 
 def allreduce_gradients(modules, group=None, average=True):

@@ -162,6 +162,15 @@ int crnerf_crossray_fold_f32(const float* s_matrix, const float* c_matrix, const
 #define CRNERF_DECODER_TENSORS 22
 int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
                                void* workspace, float* rgb, int64_t plane_stride, void* stream);
+/* Ray-sharded decode: the same math in three calls placed around the two all-reduces (multi-GPU, SURVEY 8e option B).
+ * xchg[1088] device floats: [0:64] channel sums, [64:1088] Gram sums of the CONTENT grid.
+ *   phase 0 writes the local channel sums into xchg[0:64]                              -> caller all-reduces xchg[0:64]
+ *   phase 1 reads the global sums (+ count_global), writes local Gram sums to xchg[64:] -> caller all-reduces xchg[64:1088]
+ *   phase 2 reads the global Gram, writes rgb for the local pixels.
+ * HW_local may be 0 (a rank without pixels); the style grid is replicated on every rank. */
+int crnerf_crossray_decode_sharded_f32(const float* content, int64_t HW_local, const float* style, int64_t HWs, const float* const* weights,
+                                       int phase, float* xchg, double count_global, void* workspace, float* rgb, int64_t plane_stride,
+                                       void* stream);
 /* Backward of crnerf_crossray_decode_f32 (in the reference: autograd through style_net.forward): d_rgb[c*d_plane_stride + px]
  * -> d_content[HW,64], d_style[HWs,64] and grads[22] (same order as `weights`, each OVERWRITTEN).
  * workspace: crnerf_crossray_backward_workspace_bytes(HW, HWs). */

@@ -50,6 +50,25 @@ class CpuKernels:
     def crossray_apply(x, affine):
         return torch.sigmoid(affine[:192].view(3, 64) @ x.t() + affine[192:195, None])
 
+    _state = {}
+
+    @classmethod
+    def crossray_decode_sharded(cls, x, sp, w, phase, xchg, count):
+        """Same three phases as crnerf_crossray_decode_sharded_f32, on CPU tensors."""
+        (s1, sb1, s2, sb2, s3, sb3, sfw, sfb, c1, cb1, c2, cb2, c3, cb3, cfw, cfb, comp_w, comp_b, unz_w, unz_b, rgb_w, rgb_b) = w
+        if phase == 0:
+            xchg[:64] = x.sum(0) if x.shape[0] else 0.0
+            return None
+        c_mean = xchg[:64] / count
+        if phase == 1:
+            xchg[64:] = cls.crossray_gram(x, c_mean, [c1, cb1, c2, cb2, c3, cb3]) if x.shape[0] else 0.0
+            return None
+        s_mean = sp.mean(0)
+        s_mat = cls.crossray_matrix(cls.crossray_gram(sp, s_mean, [s1, sb1, s2, sb2, s3, sb3]), sp.shape[0], sfw, sfb)
+        c_mat = cls.crossray_matrix(xchg[64:], count, cfw, cfb)
+        affine = cls.crossray_fold(s_mat, c_mat, c_mean, s_mean, [comp_w, comp_b, unz_w, unz_b, rgb_w, rgb_b])
+        return cls.crossray_apply(x, affine) if x.shape[0] else None
+
 
 def _free_port():
     s = socket.socket()

@@ -660,3 +660,48 @@ def test_decoder_backward_vs_autograd_oracle(H, W, hs):
     check(ds, xs.grad, "d_style")
     for k, gq in zip(names, grads):
         check(gq, w[k].grad, k)
+
+
+@torch.no_grad()
+def test_sharded_decode_phases_match_fused_decode_single_rank():
+    """parallel.decode_sharded (RCCL, world_size 1) == the single-call decode; also an uneven split of the grid
+    driven by hand through the three phases with the sums added on the host (what the all-reduces do)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from crnerf_amd.models.linearStyleTransfer import style_net
+    from crnerf_amd.parallel import decode_sharded
+    net = style_net(_Args()).to(DEV)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(9, 2.0).items()})
+    rng = np.random.default_rng(1)
+    feat = C(rng.uniform(0, 1, (37 * 29, 64)).astype(np.float32))
+    style = C(rng.uniform(0, 1, (1, 64, 32, 32)).astype(np.float32))
+    ref = net(feat.t().reshape(1, 64, 37, 29), style).reshape(3, -1)
+    # three phases by hand over an uneven 3-way split (one part empty)
+    sp = style.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
+    w = net.decoder_tensors()
+    parts = [feat[:400].contiguous(), feat[400:400].contiguous(), feat[400:].contiguous()]
+    xs = [torch.zeros(1088, device=DEV) for _ in parts]
+    for x, part in zip(xs, parts):
+        ops.crossray_decode_sharded(part, sp, w, 0, x, float(feat.shape[0]))
+    tot = sum(x[:64] for x in xs)
+    for x, part in zip(xs, parts):
+        x[:64] = tot
+        ops.crossray_decode_sharded(part, sp, w, 1, x, float(feat.shape[0]))
+    tot = sum(x[64:] for x in xs)
+    outs = []
+    for x, part in zip(xs, parts):
+        x[64:] = tot
+        o = ops.crossray_decode_sharded(part, sp, w, 2, x, float(feat.shape[0]))
+        if part.shape[0]:
+            outs.append(o)
+    close(torch.cat(outs, 1), ref.cpu(), atol=2e-6)
+    # through torch.distributed / RCCL with one rank
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        close(decode_sharded(net, feat, style, equal_shards=True), ref.cpu(), atol=2e-6)
+        close(decode_sharded(net, feat, style), ref.cpu(), atol=2e-6)
+    finally:
+        dist.destroy_process_group()
