@@ -12,5 +12,21 @@ There is no CPU or eager-PyTorch fallback: without the HIP library every compute
 """
 from . import _lib  # noqa: F401  (does not load the shared object until first use)
 
-__all__ = ["_lib"]
+__all__ = ["_lib", "set_precision", "get_precision"]
+
+_precision = "f32"
+
+
+def set_precision(precision):
+    """Default arithmetic of NeRF_sigma inside the inference paths: "f32" (exact fp32 MFMA, the reference's
+    numerics) or "bf16" (bf16 matrix cores, fp32 accumulate -- include/crnerf.h "bf16 variants").  A `precision=`
+    keyword to render_rays_cross_ray / batched_inference / NeRF_sigma.forward overrides it per call.  Training
+    (grad mode) always runs fp32."""
+    global _precision
+    from .ops import _is_bf16
+    _precision = "bf16" if _is_bf16(precision) else "f32"
+
+
+def get_precision():
+    return _precision
 __version__ = "0.1.0"

@@ -23,6 +23,7 @@ EXPORTS = [
     "crnerf_ray_directions_f32", "crnerf_rays_from_directions_f32", "crnerf_generate_rays_f32",
     "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
     "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32", "crnerf_crossray_decode_sharded_f32",
+    "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -83,6 +84,10 @@ def load():
             "crnerf_composite_backward_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
             "crnerf_sample_pdf_merge_f32": (ctypes.c_int, [vp, vp, vp, i64, vp, vp, i64, i32, i32, vp]),
             "crnerf_render_rays_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
+            "crnerf_render_rays_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
+            "crnerf_packed_mlp_bf16_bytes": (ctypes.c_size_t, []),
+            "crnerf_pack_mlp_weights_bf16": (ctypes.c_int, [pp, vp, vp]),
+            "crnerf_mlp_forward_bf16": (ctypes.c_int, [vp, vp, vp, i64, i32, vp]),
             "crnerf_crossray_chansum_f32": (ctypes.c_int, [vp, i64, vp, vp, vp]),
             "crnerf_crossray_gram_f32": (ctypes.c_int, [vp, i64, vp, pp, vp, vp, vp]),
             "crnerf_crossray_matrix_f32": (ctypes.c_int, [vp, f64, vp, vp, vp, vp]),

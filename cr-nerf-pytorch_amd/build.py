@@ -12,14 +12,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_train16.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip",
+SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "render_fused_bf16.hip", "mlp_train16.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip",
            "crossray.hip"]
-HEADERS = ["layout.h", "mlp_core.h", "mlp_core16.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
+HEADERS = ["layout.h", "mlp_core.h", "mlp_core16.h", "mlp_core_bf16.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
 # the kernels call fmaf() explicitly wherever a fused multiply-add is wanted.
 # -fno-honor-nans: lets fmaxf(x, 0) be ONE v_max_f32 (otherwise hipcc canonicalises the MFMA output first).
 FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-honor-nans", "-Wall", "-Wno-unused-function"]
          + os.environ.get("CRNERF_EXTRA_FLAGS", "").split())   # tuning builds only, e.g. -DCRNERF_TIMING
+
+
+# -fno-slp-vectorize (bf16 units): hipcc otherwise packs the epilogue's scalar adds into v_pk_add_f32 bundles placed
+# at the END of a layer -- the hand-interleaved epilogue collapses into a serial VALU burst behind the MFMAs.
+PER_FILE_FLAGS = {"mlp_forward_bf16.hip": ["-fno-slp-vectorize"], "render_fused_bf16.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -36,6 +41,7 @@ def _digest():
             h.update(name.encode())
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -52,7 +58,7 @@ def build(force=False, keep_asm=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if keep_asm:
             cmd += ["-save-temps=obj"]
         if verbose:

@@ -139,7 +139,7 @@ int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coar
   return launch_sample_pdf_merge(z_coarse, weights_coarse, u, (long)u_stride, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
 }
 
-int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
+static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16) {
   REQUIRE(a, "args");
   if (a->n_rays == 0) return 0;
   if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays: negative n_rays");
@@ -155,7 +155,27 @@ int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) {
   r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
+  if (bf16) return launch_render_rays_bf16(r, (hipStream_t)stream);
   return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
+}
+
+int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false); }
+int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
+
+size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }
+
+int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_bf16: a tensor pointer is NULL");
+  return launch_pack_mlp_bf16(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_bf16(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_bf16: negative n");
+  return launch_mlp_forward_bf16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
 size_t crnerf_encoder_workspace_bytes(int H, int W) { return encoder_workspace_bytes(H, W); }

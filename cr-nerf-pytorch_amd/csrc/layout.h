@@ -124,4 +124,44 @@ constexpr int STAGEST_PER_PASS = STREAMT_FRAGS / STAGE_FRAGS;  // 138
 static_assert(STREAMT_FRAGS % STAGE_FRAGS == 0, "transposed stream must be whole stages");
 constexpr size_t PACKEDT_BYTES = (size_t)CONST_BYTES + (size_t)STREAMT_FRAGS * FRAG_BYTES;
 
+// ---- bf16 stream for the v_mfma_f32_32x32x16_bf16 core (mlp_core_bf16.h).  A fragment is still 1 KiB = one
+// ds_read_b128 per wavefront, now the A operand of ONE MFMA (32 output rows x 16 k-values, bf16):
+//     fragB(layer, tile T (32 rows), k-step s (16 k-values))[lane = 32*hh + i][e] = bf16(W[32T + i][col(kB(s, hh, e))])
+// ordered layer-major, tile-major, k-step-minor (a tile's accumulators complete after its k-steps, so its
+// epilogue overlaps the next tile's MFMAs and only one tile of accumulators is live).
+//   * k-steps fed by hidden activations: kB = feature 32(s/2) + 16(s%2) + 4hh + (e&3) + 8(e>>2) -- exactly what
+//     lane-half hh holds in registers 8(s%2)..8(s%2)+7 of source tile s/2 after the 32x32 C/D layout.
+//   * k-steps fed by an embedding: slot 16s + 8hh + e, e = 2p + sc, belongs to argument a = 8s + 4hh + p
+//     (same argument -> column rule as posenc_slot_to_col).
+// consts block: the fp32 one (biases and the sigma head stay fp32).  The stream is padded to whole stages.
+constexpr int KS_XYZ = XYZ_PAD / 16;   // 6 k-steps
+constexpr int KS_HID = W_HIDDEN / 16;  // 16
+constexpr int KS_DIR = DIR_PAD / 16;   // 2
+constexpr int KS_HALF = 128 / 16;      // 8
+constexpr int FB_L1 = 8 * KS_XYZ;              //  48
+constexpr int FB_HID = 8 * KS_HID;             // 128
+constexpr int FB_L5 = 8 * (KS_XYZ + KS_HID);   // 176
+constexpr int FB_DIR = 4 * (KS_HID + KS_DIR);  //  72
+constexpr int FB_RGB = 2 * KS_HALF;            //  16
+constexpr int OFFB_L1 = 0;
+constexpr int OFFB_L2 = OFFB_L1 + FB_L1;       // L2, L3, L4 contiguous
+constexpr int OFFB_L5 = OFFB_L2 + 3 * FB_HID;
+constexpr int OFFB_L6 = OFFB_L5 + FB_L5;       // L6, L7, L8 contiguous
+constexpr int OFFB_FIN = OFFB_L6 + 3 * FB_HID;
+constexpr int OFFB_DIR = OFFB_FIN + FB_HID;
+constexpr int OFFB_RGB = OFFB_DIR + FB_DIR;
+constexpr int STREAMB_USED = OFFB_RGB + FB_RGB;                                             // 1208
+constexpr int STAGESB_PER_PASS = (STREAMB_USED + STAGE_FRAGS - 1) / STAGE_FRAGS;            // 76
+constexpr int STREAMB_FRAGS = STAGESB_PER_PASS * STAGE_FRAGS;                               // 1216 (8 zero fragments)
+constexpr size_t PACKEDB_BYTES = (size_t)CONST_BYTES + (size_t)STREAMB_FRAGS * FRAG_BYTES;  // 1,256,448
+
+__host__ __device__ inline int posenc_slot_to_col_b(int k, int F) {
+  const int s = k >> 4, hh = (k >> 3) & 1, p = (k >> 1) & 3, sc = k & 1;
+  const int a = 8 * s + 4 * hh + p;
+  if (a < 3 * F) return 3 + 6 * (a / 3) + 3 * sc + (a % 3);
+  if (a == 3 * F) return sc;
+  if (a == 3 * F + 1) return sc == 0 ? 2 : -1;
+  return -1;
+}
+
 }  // namespace crnerf

@@ -38,7 +38,7 @@ constexpr int LDS_SCRATCH = LDS_RING + RING_SLOTS * STAGE_BYTES;  // 120,832
 
 // Phase timer for tuning builds (-DCRNERF_TIMING): wave 0 of block 0 accumulates shader-clock cycles
 // per phase into crnerf_timing[]; compiled out otherwise.
-enum { T_PROLOGUE = 0, T_MMA, T_EPILOGUE, T_SIGMA, T_COMPOSITE, T_RAYLEVEL, T_TOTAL, T_COUNT };
+enum { T_PROLOGUE = 0, T_MMA, T_EPILOGUE, T_SIGMA, T_COMPOSITE, T_RAYLEVEL, T_TOTAL, T_X0, T_X1, T_X2, T_X3, T_X4, T_X5, T_X6, T_X7, T_COUNT };
 #ifdef CRNERF_TIMING
 static __device__ unsigned long long crnerf_timing[T_COUNT];   // one copy per translation unit
 struct PhaseTimer {
@@ -50,7 +50,9 @@ struct PhaseTimer {
     last = __builtin_readcyclecounter();
   }
   __device__ __forceinline__ void tick(int phase) {
+    __builtin_amdgcn_sched_barrier(0);   // the compiler may otherwise move MFMAs / VALU work across the clock read
     const unsigned long long t = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
     acc[phase] += t - last;
     acc[T_TOTAL] += t - last;
     last = t;

@@ -1,0 +1,414 @@
+// NeRF_sigma forward for one 64-point tile per wavefront on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate), activations register-resident as packed bf16.
+//
+// Reference semantics: NeRF_sigma.forward, models/nerf.py:157-182, evaluated in mixed precision: the
+// operands of every Linear except static_sigma (weights and input activations, incl. the two positional
+// embeddings) are rounded to bf16 (RNE); products accumulate in fp32; biases, relu, softplus, sigmoid and the
+// sigma head (fp32 weights on the un-rounded fp32 output of xyz_encoding_8) stay fp32.  oracle/cpu_ref.py
+// `mlp_forward_bf16` restates exactly this.
+//
+// MI355X design:
+//   * swapped-operand GEMM D[feature][point] = W[feature][k] * act[k][point].  A wave owns 64 points as two
+//     32-point groups; lane (p = lane&31, h = lane>>5) holds points p and 32+p.  The 32x32 C/D layout leaves the
+//     lane with features 32T + 8(r>>2) + 4h + (r&3) in accumulator register r; relu + v_cvt_pk_bf16_f32 turn
+//     registers 8j..8j+7 into the 8-element B operand of k-step 2T+j of the next layer -- no cross-lane move,
+//     no LDS round trip, no HBM (the weight pack permutes W's columns to match, layout.h "fragB").
+//   * tile-outer / k-inner order: one output tile's two accumulators (32 VGPRs) are live at a time, its
+//     epilogue overlaps the next tile's MFMAs, and the 256-feature activations of the 64 points cost
+//     2 x 128 VGPRs (ping-pong) instead of 512 as fp32.
+//   * every A fragment (1 KiB, one ds_read_b128 per lane) feeds TWO MFMAs (the two point groups): 4 waves x 1 KiB
+//     per 64 MFMA cycles = 64 B/clk/CU, half the LDS bandwidth.  Fragments are read B_AHEAD ahead of use.
+//   * weights stream L2 -> LDS through the same 6-slot x 16 KiB ring and barrier protocol as the fp32 core
+//     (mlp_core.h WeightPipe): one s_barrier per 16 fragments = 32 MFMAs = 1024 MFMA cycles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.h"
+#include "mlp_core.h"
+
+namespace crnerf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CRNERF_B_AHEAD
+#define CRNERF_B_AHEAD 4
+#endif
+constexpr int B_AHEAD = CRNERF_B_AHEAD;   // fragments read ahead of the one being multiplied (tuning: -DCRNERF_B_AHEAD=n)
+constexpr int B_TAIL = STREAMB_USED - (STAGESB_PER_PASS - 1) * STAGE_FRAGS;  // fragments in the (short) last stage: 8
+static_assert(B_TAIL % 4 == 0 && B_TAIL >= 4 && STREAMB_USED % B_AHEAD == 0, "tail stage must fit the piece schedule");
+
+// ---- compile-time schedule over the pass-relative fragment index i (0 <= i < STREAMB_USED) -------------
+// position in the padded stream (the look-ahead past the last fragment lands in the next pass)
+constexpr int b_pos(int i) { return i < STREAMB_USED ? i : i + (STREAMB_FRAGS - STREAMB_USED); }
+// stage advances executed before iteration i's read is issued (advance of stage c sits at slot 14, tail: B_TAIL-2)
+constexpr int b_last_adv() { return (STAGESB_PER_PASS - 1) * STAGE_FRAGS + B_TAIL - 2; }
+constexpr int b_cur_stage(int i) { return (i + 1) / STAGE_FRAGS + (i > b_last_adv() ? 1 : 0); }
+constexpr bool b_advance_at(int i) {
+  return i / STAGE_FRAGS < STAGESB_PER_PASS - 1 ? i % STAGE_FRAGS == STAGE_FRAGS - 2 : i == b_last_adv();
+}
+// LDS-DMA piece (0..3) issued at iteration i, or -1
+constexpr int b_piece_at(int i) {
+  const int sl = i % STAGE_FRAGS;
+  if (i / STAGE_FRAGS < STAGESB_PER_PASS - 1) return sl % 4 == 0 ? sl / 4 : -1;
+  return sl % (B_TAIL / 4) == 0 && sl < B_TAIL ? sl / (B_TAIL / 4) : -1;
+}
+constexpr bool b_schedule_ok() {
+  int pieces = 0, advances = 0;
+  for (int i = 0; i < STREAMB_USED; ++i) {
+    const int d = b_pos(i + B_AHEAD) / STAGE_FRAGS - b_cur_stage(i);
+    if (d < 0 || d > 1) return false;                 // reads stay inside stages c and c+1
+    if (b_piece_at(i) >= 0) ++pieces;
+    if (b_advance_at(i)) {
+      ++advances;
+      if (pieces != 4 * advances) return false;       // exactly 4 pieces between consecutive barriers (vmcnt counting)
+      if (b_pos(i + B_AHEAD) / STAGE_FRAGS > advances) return false;  // never reads stage c+2 before its barrier
+    }
+  }
+  return advances == STAGESB_PER_PASS && b_cur_stage(STREAMB_USED - 1) == STAGESB_PER_PASS;
+}
+static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protocol");
+
+// One LDS-DMA piece: lanes copy 16 B each, global (base + voff + imm) -> LDS (lds_addr + imm + 16 * lane).  Written as
+// asm on purpose: with the builtin, hipcc's waitcnt model stops counting LDS reads across an LDS-DMA instruction and
+// the next use of ANY prefetched fragment becomes s_waitcnt lgkmcnt(0) -- the read-ahead ring is drained every fourth
+// k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)
+__device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
+               : "memory");
+}
+
+// Weight ring for 4 waves x 4 pieces per stage; protocol documented at mlp_core.h WeightPipe.  Everything except
+// lane16 / rd_addr / nx_addr is wave-uniform (SGPRs): the stream pointers are scalar and the lane offset rides in the
+// instruction's VGPR-offset operand.  The cursor update is branch-free so the MFMA stream stays one basic block.
+struct WeightPipeB {
+  const char* base[2];   // packed streams + this wave's 4 KiB column
+  const char* pf_ptr;    // stage being fetched
+  int pf_left, pf_pass, passes0, passes;
+  uint32_t lds_ring;     // LDS byte address of the ring + this wave's 4 KiB column
+  uint32_t pf_slot, rd_slot;
+  uint32_t rd_addr, nx_addr;   // per-lane LDS byte address of fragment 0 of stage c / c+1
+  uint32_t lane16;
+  lds_char* lds;
+
+  __device__ __forceinline__ void issue_piece(int i) {
+#ifndef CRNERF_EXP_NOGLDS
+    const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    switch (i) {   // the instruction offset must be an immediate
+      case 0: glds16(dst, pf_ptr, lane16, 0); break;
+      case 1: glds16(dst, pf_ptr, lane16, 1 * FRAG_BYTES); break;
+      case 2: glds16(dst, pf_ptr, lane16, 2 * FRAG_BYTES); break;
+      default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
+    }
+#endif
+    if (i == 3) {
+      pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
+      const bool wrap = (pf_left == 1);
+      const int np = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
+      const char* nb = (np < passes0) ? base[0] : base[1];
+      pf_left = wrap ? STAGESB_PER_PASS : pf_left - 1;
+      pf_pass = wrap ? np : pf_pass;
+      pf_ptr = wrap ? nb : pf_ptr + STAGE_BYTES;
+      asm volatile("" : "+s"(pf_ptr));   // opaque: else a single-pass kernel gets 302 precomputed addresses
+    }
+  }
+  __device__ __forceinline__ void set_addrs() {
+    const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
+    nx_addr = LDS_RING + n * STAGE_BYTES + lane16;
+  }
+  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_, int lane,
+                                        int wave) {
+    lds = lds_;
+    lane16 = (uint32_t)lane * 16u;
+    lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + (uint32_t)wave * 4096u;
+    base[0] = stream0 + wave * 4096;
+    base[1] = stream1 + wave * 4096;
+    passes0 = passes0_;
+    passes = passes_;
+    pf_pass = 0;
+    pf_left = STAGESB_PER_PASS;
+    pf_ptr = (passes0 > 0) ? base[0] : base[1];
+    pf_slot = 0;
+    rd_slot = 0;
+    set_addrs();
+#pragma unroll
+    for (int s = 0; s < RING_SLOTS - 1; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issue_piece(i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory");
+#ifndef CRNERF_EXP_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    set_addrs();
+  }
+  // fragment `slot` of stage c (next == false) or c+1
+  __device__ __forceinline__ u32x4 read(bool next, int slot) const {
+    return *(const __attribute__((address_space(3))) u32x4*)(lds + (next ? nx_addr : rd_addr) + slot * FRAG_BYTES);
+  }
+  __device__ __forceinline__ void prime(u32x4 (&q)[B_AHEAD]) const {
+#pragma unroll
+    for (int j = 0; j < B_AHEAD; ++j) q[j] = read(false, j);
+  }
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};   // v_cvt_pk_bf16_f32 (RNE); element 0 = low half
+  return __builtin_bit_cast(uint32_t, v);
+}
+// ---- epilogues -------------------------------------------------------------------------------------------
+// A tile's epilogue is cut into 16 quarters (quarter qc = accumulator registers 2(qc>>1), +1 of point group qc&1,
+// ~6 VALU each) that run behind the MFMAs of the NEXT tile.  An epilogue object provides
+//     prefetch(T)       -- LDS reads (bias, ...) for tile T, issued one k-step before the first quarter
+//     run(T, qc, acc)   -- quarter qc of tile T from that group's accumulator
+// The asm statements pin each piece of work to the k-step it was written in: instruction selection may emit pure
+// arithmetic anywhere between its operands' definitions and its first use, and without them hipcc parks whole
+// layers' epilogues (256 live accumulators) behind the layer's last MFMA.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// (acc + bias) -> bf16 pair -> relu.  relu commutes with round-to-nearest-even, so it is applied to the packed pair:
+// as int16 a negative bf16 (incl. -0) is negative, and max(x, 0) per 16-bit lane is ONE v_pk_max_i16 for two values.
+// Accumulator registers 2hc, 2hc+1 are dword hc&3 of k-step 2T + (hc>>2) of the next layer's B operand.
+template <bool RELU>
+__device__ __forceinline__ uint32_t pack_pair(float v0, float v1, float b0, float b1) {
+  asm volatile("" : "+v"(v0), "+v"(v1));
+  uint32_t pk = pk_bf16(v0 + b0, v1 + b1);
+  if (RELU) {
+    asm volatile("" : "+v"(pk));   // keep the pair packed: hipcc otherwise converts the halves separately and re-packs
+    const s16x2 z = {0, 0};
+    pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), z));
+  }
+  asm volatile("" : "+v"(pk));
+  return pk;
+}
+
+__device__ __forceinline__ f32x4 lds_f4(const lds_float* p) { return *(const __attribute__((address_space(3))) f32x4*)p; }
+
+struct NoEpi {
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void run(int, int, const f32x16&) {}
+};
+
+template <bool RELU>
+struct PackEpi {   // hidden layers: next layer's B operand
+  u32x4 (&dst)[KS_HID][2];
+  const lds_float* bias;
+  int h;
+  f32x4 bv[4];
+  __device__ __forceinline__ PackEpi(u32x4 (&d)[KS_HID][2], const lds_float* b, int h_) : dst(d), bias(b), h(h_) {}
+  __device__ __forceinline__ void prefetch(int T) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
+  }
+  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+    const int hc = qc >> 1, g = qc & 1;
+    const uint32_t pk = pack_pair<RELU>(acc[2 * hc], acc[2 * hc + 1], bv[hc >> 1][2 * (hc & 1)], bv[hc >> 1][2 * (hc & 1) + 1]);
+    dst[2 * T + (hc >> 2)][g][hc & 3] = pk;
+  }
+};
+
+struct SigmaEpi {   // xyz_encoding_8: as PackEpi<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
+  u32x4 (&dst)[KS_HID][2];
+  float (&sg)[2];
+  const lds_float* bias;
+  const lds_float* wsig;
+  int h;
+  f32x4 bv[4], wv[4];
+  __device__ __forceinline__ SigmaEpi(u32x4 (&d)[KS_HID][2], float (&s)[2], const lds_float* b, const lds_float* w, int h_)
+      : dst(d), sg(s), bias(b), wsig(w), h(h_) {}
+  __device__ __forceinline__ void prefetch(int T) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
+      wv[c] = lds_f4(wsig + 32 * T + 8 * c + 4 * h);
+    }
+  }
+  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+    const int hc = qc >> 1, g = qc & 1, e = 2 * (hc & 1);
+    float x0 = acc[2 * hc], x1 = acc[2 * hc + 1];
+    const float b0 = bv[hc >> 1][e], b1 = bv[hc >> 1][e + 1];
+    dst[2 * T + (hc >> 2)][g][hc & 3] = pack_pair<true>(x0, x1, b0, b1);
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    sg[g] = fmaf(wv[hc >> 1][e], fmaxf(x0 + b0, 0.0f), sg[g]);
+    sg[g] = fmaf(wv[hc >> 1][e + 1], fmaxf(x1 + b1, 0.0f), sg[g]);
+    asm volatile("" : "+v"(sg[g]));
+  }
+};
+
+struct RgbEpi {   // static_rgb: sigmoid, fp32 out
+  f32x16 (&feat)[2][2];
+  const lds_float* bias;
+  int h;
+  f32x4 bv[4];
+  __device__ __forceinline__ RgbEpi(f32x16 (&f)[2][2], const lds_float* b, int h_) : feat(f), bias(b), h(h_) {}
+  __device__ __forceinline__ void prefetch(int T) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
+  }
+  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+    const int hc = qc >> 1, g = qc & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) feat[g][T][2 * hc + j] = sigmoid_ref(acc[2 * hc + j] + bv[hc >> 1][2 * (hc & 1) + j]);
+  }
+};
+
+// One layer.  NT output tiles; per tile NSA k-steps with B operands srcA[s][g] then NSB from srcB (g = point group).
+// FBASE: pass-relative index of the layer's first fragment; G0: index of its first tile in the pass (tile G
+// accumulates in accs[G & 1]); PT: the previous layer's last tile, whose epilogue `prev` is still pending and runs
+// behind this layer's first tile -- legal because k-step s of any layer reads source tile s/2, so the last source
+// tile is only needed by the last two k-steps.  On return this layer's tile NT-1 is pending in the same way.
+template <int NT, int NSA, int NSB, int FBASE, int G0, int PT, int NA, int NB, class PREV, class EPI>
+__device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[NA][2], const u32x4 (&srcB)[NB][2],
+                                            u32x4 (&q)[B_AHEAD], f32x16 (&accs)[2][2], PREV& prev, EPI& epi) {
+  static_assert(NSA <= NA && NSB <= NB, "source too small");
+  constexpr int NS = NSA + NSB;
+  static_assert(NS >= 14 || NS == 6 || NS == 8, "epilogue quarters must finish before the last source tile is read");
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    const int cur = (G0 + T) & 1;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int i = FBASE + T * NS + s;
+      u32x4 af = q[i % B_AHEAD];
+      asm volatile("" : "+v"(af));   // ties this k-step's MFMAs into the side-effect chain (see the epilogue notes)
+      const bf16x8 a = __builtin_bit_cast(bf16x8, af);
+      const int pos = b_pos(i + B_AHEAD);
+      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
+      const u32x4 b0 = s < NSA ? srcA[s < NSA ? s : 0][0] : srcB[s < NSA ? 0 : s - NSA][0];
+      const u32x4 b1 = s < NSA ? srcA[s < NSA ? s : 0][1] : srcB[s < NSA ? 0 : s - NSA][1];
+      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      accs[cur][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), s == 0 ? zero : accs[cur][0], 0, 0, 0);
+      accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? zero : accs[cur][1], 0, 0, 0);
+      if (b_piece_at(i) >= 0) p.issue_piece(b_piece_at(i));
+      if (b_advance_at(i)) p.advance();
+      // the previous tile's epilogue: prefetch its LDS operands behind k-step 0, then two quarters per k-step behind
+      // k-steps 1..4 and one per k-step up to 12 (<= ~6 VALU per MFMA, done before k-step 14); the short layers
+      // (K = 96, 128) take four per k-step
+      if (s == 0) {
+        if (T == 0) prev.prefetch(PT);
+        else epi.prefetch(T - 1);
+      } else {
+        const int first = NS >= 14 ? (s <= 4 ? 2 * (s - 1) : 8 + (s - 5)) : 4 * (s - 1);
+        const int count = NS >= 14 ? (s <= 4 ? 2 : (s <= 12 ? 1 : 0)) : (s <= 4 ? 4 : 0);
+#pragma unroll
+        for (int u = 0; u < count; ++u) {
+          const int qc = first + u;
+          if (T == 0) prev.run(PT, qc, accs[cur ^ 1][qc & 1]);
+          else epi.run(T - 1, qc, accs[cur ^ 1][qc & 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // pin the hand-made pipeline: hipcc otherwise bunches the epilogue into a VALU burst
+    }
+  }
+}
+
+// One 64-point tile through one model.  pe[s][g] / dv[s][g]: the embeddings as B operands (posenc_b below);
+// q carries the look-ahead fragments between layers, tiles and passes.  Returns feat[g][t][r] = rgb feature
+// 32t + 8(r>>2) + 4h + (r&3) of point 32g + p, and sigma[g] (valid in both lane halves).
+__device__ __forceinline__ void mlp_tile_b(WeightPipeB& p, int model, const u32x4 (&pe)[KS_XYZ][2], const u32x4 (&dv)[KS_DIR][2],
+                                           f32x16 (&feat)[2][2], float (&sigma)[2], int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm) {
+  // the consts block is loop-invariant LDS: launder its address once per tile, or LICM hoists all ~1,300 bias /
+  // sigma-weight reads out of the caller's tile loop and spills them to scratch
+  uint32_t c_off = model ? LDS_CONST1 : LDS_CONST0;
+  asm volatile("" : "+s"(c_off));
+  const lds_float* C = (const lds_float*)(p.lds + c_off);
+  const lds_float* B1 = C + C_BIAS;
+  u32x4 actA[KS_HID][2], actB[KS_HID][2];
+  f32x16 accs[2][2];
+  float sg[2] = {0.0f, 0.0f};
+  tm.tick(T_PROLOGUE);
+
+  // tile parity: every layer before dir has 8 tiles, so accs[G & 1] with G0 = 8 * layer; dir starts at 72, rgb at 76
+  NoEpi none;
+  PackEpi<true> e1(actA, B1, h);
+  mma_layer_b<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, none, e1);                    // xyz_encoding_1
+  tm.tick(T_X0);
+  PackEpi<true> e2(actB, B1 + 1 * W_HIDDEN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, e1, e2);                  // 2
+  tm.tick(T_X1);
+  PackEpi<true> e3(actA, B1 + 2 * W_HIDDEN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, e2, e3);        // 3
+  PackEpi<true> e4(actB, B1 + 3 * W_HIDDEN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, e3, e4);    // 4
+  tm.tick(T_X2);
+  PackEpi<true> e5(actA, B1 + 4 * W_HIDDEN, h);
+  mma_layer_b<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, e4, e5);              // 5 = Linear(cat[xyz, h])
+  tm.tick(T_X3);
+  PackEpi<true> e6(actB, B1 + 5 * W_HIDDEN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, e5, e6);                 // 6
+  PackEpi<true> e7(actA, B1 + 6 * W_HIDDEN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, e6, e7);        // 7
+  SigmaEpi e8(actB, sg, B1 + 7 * W_HIDDEN, C + C_WSIG, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, e7, e8);    // 8 (+ static_sigma)
+  PackEpi<false> efin(actA, C + C_BFIN, h);
+  mma_layer_b<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, e8, efin);              // xyz_encoding_final (no activation)
+  tm.tick(T_MMA);
+  sg[0] += __shfl_xor(sg[0], 32);
+  sg[1] += __shfl_xor(sg[1], 32);
+  sigma[0] = softplus_ref(sg[0] + C[C_BSIG]);
+  sigma[1] = softplus_ref(sg[1] + C[C_BSIG]);
+  tm.tick(T_SIGMA);
+  PackEpi<true> edir(actB, C + C_BDIR, h);
+  mma_layer_b<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, efin, edir);         // dir_encoding = relu(Linear(cat[final, dir]))
+  tm.tick(T_X4);
+  RgbEpi ergb(feat, C + C_BRGB, h);
+  mma_layer_b<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, edir, ergb);           // static_rgb = sigmoid(Linear)
+  tm.tick(T_MMA);
+  ergb.prefetch(1);                                                                           // nothing left to hide it behind
+#pragma unroll
+  for (int qc = 0; qc < 16; ++qc) ergb.run(1, qc, accs[(76 + 1) & 1][qc & 1]);
+  tm.tick(T_EPILOGUE);
+}
+
+// ---- positional embedding straight into bf16 B-operand registers ---------------------------------------
+// Reference: PosEmbedding.forward, models/nerf.py:17-30.  Lane half h, dword pp of k-step s holds
+// (sin, cos)(2^f x_d) of argument a = 8s + 4h + pp (f = a/3, d = a%3); a == 3F -> (x, y); a == 3F+1 -> (z, 0).
+// The result is rounded to bf16 (2^-9 relative), so the hardware v_sin_f32 / v_cos_f32 (inputs in revolutions)
+// are accurate enough -- PROVIDED the range reduction is done right: 2^14 |x| / 2pi reaches ~1.3e4 revolutions,
+// so x/(2pi) is formed as an unevaluated two-float sum (p + e); scaling by 2^f is exact, fract() of the high part
+// is exact, and the reduced argument carries ~1e-7 absolute error at the top frequency.
+struct Revolutions { float p, e; };
+__device__ __forceinline__ Revolutions to_revolutions(float x) {
+  const float C_HI = 0.15915494f;          // fp32(1/(2 pi))
+  const float C_LO = 6.4206382e-9f;        // 1/(2 pi) - C_HI  (1/(2 pi) = 0.15915494309189535, C_HI = 0.15915493667125702)
+  Revolutions r;
+  r.p = x * C_HI;
+  r.e = fmaf(x, C_HI, -r.p) + x * C_LO;
+  return r;
+}
+
+template <int F, int NS>
+__device__ __forceinline__ void posenc_b(float x, float y, float z, int h, u32x4 (&out)[NS]) {
+  const Revolutions rx = to_revolutions(x), ry = to_revolutions(y), rz = to_revolutions(z);
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int a0 = 8 * s + pp, a1 = a0 + 4;          // argument for h = 0 / h = 1
+      const bool trig0 = a0 < 3 * F, trig1 = a1 < 3 * F;
+      float sn = 0.0f, cs = 0.0f;
+      if (trig0 || trig1) {
+        const int d0 = trig0 ? a0 % 3 : 0, d1 = trig1 ? a1 % 3 : 0;
+        const int f0 = trig0 ? a0 / 3 : 0, f1 = trig1 ? a1 / 3 : 0;
+        const Revolutions r0 = d0 == 0 ? rx : (d0 == 1 ? ry : rz);
+        const Revolutions r1 = d1 == 0 ? rx : (d1 == 1 ? ry : rz);
+        const float P = h ? r1.p : r0.p, E = h ? r1.e : r0.e;
+        const int fe = h ? f1 : f0;
+        const float t = __builtin_amdgcn_fractf(ldexpf(P, fe)) + ldexpf(E, fe);
+        sn = __builtin_amdgcn_sinf(t);
+        cs = __builtin_amdgcn_cosf(t);
+      }
+      const float e0_0 = trig0 ? sn : (a0 == 3 * F ? x : (a0 == 3 * F + 1 ? z : 0.0f));
+      const float e0_1 = trig0 ? cs : (a0 == 3 * F ? y : 0.0f);
+      const float e1_0 = trig1 ? sn : (a1 == 3 * F ? x : (a1 == 3 * F + 1 ? z : 0.0f));
+      const float e1_1 = trig1 ? cs : (a1 == 3 * F ? y : 0.0f);
+      out[s][pp] = pk_bf16(h ? e1_0 : e0_0, h ? e1_1 : e0_1);
+    }
+}
+
+}  // namespace crnerf

@@ -89,6 +89,64 @@ int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream) {
   return check_launch("pack_mlpT");
 }
 
+// bf16 stream (layout.h "fragB"): one thread per bf16 element, round-to-nearest-even like v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ void pack_stream_bf16_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMB_FRAGS * 512) return;
+  const int frag = (int)(idx / 512);
+  const int lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+  const int i = lane & 31, hh = lane >> 5;
+  if (frag >= STREAMB_USED) { stream[idx] = 0; return; }
+
+  const float* W;
+  int in_dim, ks, phi, kind;  // kind: 0 hidden, 1 L1, 2 L5 (skip), 3 dir; ks = k-steps per tile
+  if (frag < OFFB_L2) { W = t.w[0]; in_dim = XYZ_DIM; ks = KS_XYZ; phi = frag - OFFB_L1; kind = 1; }
+  else if (frag < OFFB_L5) { const int l = (frag - OFFB_L2) / FB_HID; W = t.w[1 + l]; in_dim = W_HIDDEN; ks = KS_HID; phi = (frag - OFFB_L2) % FB_HID; kind = 0; }
+  else if (frag < OFFB_L6) { W = t.w[4]; in_dim = XYZ_DIM + W_HIDDEN; ks = KS_XYZ + KS_HID; phi = frag - OFFB_L5; kind = 2; }
+  else if (frag < OFFB_FIN) { const int l = (frag - OFFB_L6) / FB_HID; W = t.w[5 + l]; in_dim = W_HIDDEN; ks = KS_HID; phi = (frag - OFFB_L6) % FB_HID; kind = 0; }
+  else if (frag < OFFB_DIR) { W = t.w_final; in_dim = W_HIDDEN; ks = KS_HID; phi = frag - OFFB_FIN; kind = 0; }
+  else if (frag < OFFB_RGB) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; ks = KS_HID + KS_DIR; phi = frag - OFFB_DIR; kind = 3; }
+  else { W = t.w_rgb; in_dim = 128; ks = KS_HALF; phi = frag - OFFB_RGB; kind = 0; }
+
+  const int T = phi / ks, s = phi % ks;
+  const int row = 32 * T + i;
+  // hidden-activation k-step sh: the feature lane-half hh holds in element e
+  #define CRNERF_HID_FEATURE(sh) (32 * ((sh) >> 1) + 16 * ((sh) & 1) + 4 * hh + (e & 3) + 8 * (e >> 2))
+  int col;
+  switch (kind) {
+    case 1: col = posenc_slot_to_col_b(16 * s + 8 * hh + e, XYZ_FREQS); break;
+    case 2: col = s < KS_XYZ ? posenc_slot_to_col_b(16 * s + 8 * hh + e, XYZ_FREQS)
+                             : XYZ_DIM + CRNERF_HID_FEATURE(s - KS_XYZ); break;   // nerf.py:169 cat([xyz, h])
+    case 3: {
+      if (s < KS_HID) col = CRNERF_HID_FEATURE(s);
+      else {
+        const int dc = posenc_slot_to_col_b(16 * (s - KS_HID) + 8 * hh + e, DIR_FREQS);
+        col = dc < 0 ? -1 : W_HIDDEN + dc;                                          // nerf.py:177 cat([final, dir])
+      }
+      break;
+    }
+    default: col = CRNERF_HID_FEATURE(s); break;
+  }
+  #undef CRNERF_HID_FEATURE
+  stream[idx] = col >= 0 ? f32_to_bf16_rne(W[(long)row * in_dim + col]) : (unsigned short)0;
+}
+
+int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAMB_FRAGS * 512;
+  hipLaunchKernelGGL(pack_stream_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlp_bf16");
+}
+
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);

@@ -61,18 +61,26 @@ class NeRF_sigma(nn.Module):
         self._packed_key = None
 
     # ---- packed weights (kernel layout), rebuilt whenever a parameter changes
-    def packed_weights(self):
+    def packed_weights(self, precision="f32"):
+        """Packed buffer for the crnerf_*_f32 (default) or crnerf_*_bf16 entry points; re-packed when a parameter changes."""
+        bf16 = ops._is_bf16(precision)
         params = dict(self.named_parameters())
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
         if self._packed is None or key != self._packed_key:
-            self._packed = ops.pack_mlp_weights(params, out=None)
+            self._packed = {}
             self._packed_key = key
-        return self._packed
+        if bf16 not in self._packed:
+            self._packed[bf16] = ops.pack_mlp_weights(params, out=None, precision="bf16" if bf16 else "f32")
+        return self._packed[bf16]
 
-    def forward(self, x, sigma_only=False, output_random=True):
+    def forward(self, x, sigma_only=False, output_random=True, precision=None):
+        """precision: None -> crnerf_amd.get_precision(); an extension of the reference signature (nerf.py:157)."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if sigma_only:
                 raise NotImplementedError("crnerf_amd: sigma_only has no backward twin (no reference caller uses it)")
             from ..autograd import mlp_forward_with_grad   # training: HIP forward-with-save + HIP backward
             return mlp_forward_with_grad(self, x.to(torch.float32).contiguous())
-        return ops.mlp_forward(self.packed_weights(), x, sigma_only=sigma_only)
+        if precision is None:
+            from .. import get_precision
+            precision = get_precision()
+        return ops.mlp_forward(self.packed_weights(precision), x, sigma_only=sigma_only, precision=precision)

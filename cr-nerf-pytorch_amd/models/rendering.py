@@ -35,7 +35,8 @@ def _linspace_tables(n_samples, n_importance, device):
     return _tables[key]
 
 
-def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, jitter, chunk, train=False):
+def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, jitter, chunk, train=False,
+                    precision="f32"):
     R = rays.shape[0]
     o, d = rays[:, None, 0:3], rays[:, None, 3:6]
     z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
@@ -58,7 +59,7 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
             from ..autograd import CompositeFn, mlp_forward_with_grad
             raw = torch.cat([mlp_forward_with_grad(model, x) for x in xs], 0)
             return CompositeFn.apply(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
-        raw = torch.cat([ops.mlp_forward(model.packed_weights(), x) for x in xs], 0)   # point chunks, rendering.py:110-114
+        raw = torch.cat([ops.mlp_forward(model.packed_weights(precision), x, precision=precision) for x in xs], 0)   # point chunks, rendering.py:110-114
         return ops.composite(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
 
     out = {}
@@ -81,7 +82,9 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     """Same contract as the reference: returns weights_/feature_/depth_ for 'coarse' and, when
     N_importance > 0, 'fine' (+ 'feature_fine_random', the SAME tensor object as 'feature_fine',
     models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
-    reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible)."""
+    reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible).
+    One keyword beyond the reference's: precision="f32"|"bf16" (default crnerf_amd.get_precision()) selects the
+    matrix-core arithmetic of NeRF_sigma at inference (include/crnerf.h); grad mode always trains in fp32."""
     args = kwargs['args']
     jitter = bool(getattr(args, 'pertubeCord', False))
     if getattr(args, 'nerf_out_dim', 64) != 64:
@@ -94,6 +97,11 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if m is not None and not isinstance(m, NeRF_sigma):
             raise NotImplementedError("crnerf_amd: models must be crnerf_amd NeRF_sigma instances")
     train = torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters())
+    precision = kwargs.get('precision', None)
+    if precision is None:
+        from .. import get_precision
+        precision = get_precision()
+    precision = "bf16" if (ops._is_bf16(precision) and not train) else "f32"
 
     rays = rays.to(torch.float32).contiguous()
     R = rays.shape[0]
@@ -112,13 +120,13 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
         # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)
         out = _render_unfused(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
-                              float(noise_std), jitter, int(chunk), train)
+                              float(noise_std), jitter, int(chunk), train, precision)
     else:
         tables = _linspace_tables(N_samples, N_importance, rays.device)
-        out = ops.render_rays(coarse.packed_weights(), fine.packed_weights() if fine is not None else None, rays,
+        out = ops.render_rays(coarse.packed_weights(precision), fine.packed_weights(precision) if fine is not None else None, rays,
                               N_samples, N_importance, use_disp=use_disp, view_dir=view_dir, z_coarse=z_coarse,
                               z_steps=tables[0], u=u if u is not None else tables[1],
-                              noise_coarse=noise_c, noise_fine=noise_f, noise_std=float(noise_std))
+                              noise_coarse=noise_c, noise_fine=noise_f, noise_std=float(noise_std), precision=precision)
 
     typ_c = coarse.typ
     results = {'weights_%s' % typ_c: out['weights_coarse'], 'feature_%s' % typ_c: out['feature_coarse'],

@@ -23,8 +23,9 @@ def _f32c(t, name):
     return t
 
 
-def pack_mlp_weights(state, out=None):
-    """state: mapping name -> device tensor with the 24 NeRF_sigma tensors (models/nerf.py:137-154)."""
+def pack_mlp_weights(state, out=None, precision="f32"):
+    """state: mapping name -> device tensor with the 24 NeRF_sigma tensors (models/nerf.py:137-154).
+    precision "f32" -> buffer for the *_f32 entry points, "bf16" -> for the *_bf16 ones (different layouts)."""
     lib = _lib.load()
     tensors = []
     for name, shape in zip(MLP_TENSOR_NAMES, MLP_TENSOR_SHAPES):
@@ -33,12 +34,22 @@ def pack_mlp_weights(state, out=None):
             raise ValueError("crnerf_amd: %s has shape %s, the HIP kernels are built for %s "
                              "(D=8, W=256, N_emb_xyz=15, N_emb_dir=4, nerf_out_dim=64)" % (name, tuple(t.shape), shape))
         tensors.append(_f32c(t.detach(), name))
-    nbytes = lib.crnerf_packed_mlp_bytes()
+    bf16 = _is_bf16(precision)
+    nbytes = lib.crnerf_packed_mlp_bf16_bytes() if bf16 else lib.crnerf_packed_mlp_bytes()
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
     arr = _lib.ptr_array(tensors, "mlp tensor")
-    _lib.check(lib.crnerf_pack_mlp_weights(arr, ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()), "crnerf_pack_mlp_weights")
+    fn = lib.crnerf_pack_mlp_weights_bf16 if bf16 else lib.crnerf_pack_mlp_weights
+    _lib.check(fn(arr, ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()), "crnerf_pack_mlp_weights" + ("_bf16" if bf16 else ""))
     return out
+
+
+def _is_bf16(precision):
+    if precision in ("bf16", "bfloat16", torch.bfloat16):
+        return True
+    if precision in ("f32", "fp32", "float32", torch.float32, None):
+        return False
+    raise ValueError("crnerf_amd: precision must be 'f32' or 'bf16', got %r" % (precision,))
 
 
 def _mlp_tensor_list(state):
@@ -96,16 +107,28 @@ def posenc(x, n_freqs):
     return out
 
 
-def mlp_forward(packed, x, sigma_only=False):
+def mlp_forward(packed, x, sigma_only=False, precision="f32"):
     lib = _lib.load()
     x = _f32c(x, "x")
     want = 93 if sigma_only else 120
     if x.dim() != 2 or x.shape[1] != want:
         raise ValueError("mlp_forward expects [n,%d], got %s" % (want, tuple(x.shape)))
     out = torch.empty(x.shape[0], 1 if sigma_only else 65, dtype=torch.float32, device=x.device)
-    _lib.check(lib.crnerf_mlp_forward_f32(ctypes.c_void_p(packed.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0],
-                                          int(bool(sigma_only)), _lib.stream_ptr()), "crnerf_mlp_forward_f32")
+    bf16 = _is_bf16(precision)
+    _check_packed(packed, bf16)
+    fn = lib.crnerf_mlp_forward_bf16 if bf16 else lib.crnerf_mlp_forward_f32
+    _lib.check(fn(ctypes.c_void_p(packed.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], int(bool(sigma_only)), _lib.stream_ptr()),
+               "crnerf_mlp_forward_bf16" if bf16 else "crnerf_mlp_forward_f32")
     return out
+
+
+def _check_packed(packed, bf16):
+    """The two packed layouts differ in size, so a mix-up is caught here instead of rendering garbage."""
+    lib = _lib.load()
+    want = lib.crnerf_packed_mlp_bf16_bytes() if bf16 else lib.crnerf_packed_mlp_bytes()
+    if packed is not None and packed.numel() * packed.element_size() != want:
+        raise ValueError("crnerf_amd: packed weights are %d bytes, the %s entry points need %d (pack with precision=%r)"
+                         % (packed.numel() * packed.element_size(), "bf16" if bf16 else "f32", want, "bf16" if bf16 else "f32"))
 
 
 def composite(raw, z, noise=None, noise_std=0.0):
@@ -152,9 +175,12 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
 
 
 def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
-                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False):
+                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32"):
     """Fused renderer.  Returns a dict of freshly allocated tensors."""
     lib = _lib.load()
+    bf16 = _is_bf16(precision)
+    _check_packed(packed_coarse, bf16)
+    _check_packed(packed_fine, bf16)
     rays = _f32c(rays, "rays")
     if rays.dim() != 2 or rays.shape[1] != 8:
         raise ValueError("rays must be [R,8], got %s" % (tuple(rays.shape),))
@@ -182,7 +208,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine"):
         setattr(a, k, out[k].data_ptr() if k in out else None)
-    _lib.check(lib.crnerf_render_rays_f32(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32")
+    fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
+    _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
     return out
 
 

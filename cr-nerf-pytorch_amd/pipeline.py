@@ -77,13 +77,13 @@ def decode_image(models, results, H, W, a_embedded_from_img, key=None):
 
 
 @torch.no_grad()
-def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, near=0.0, far=5.0, chunk=32768):
+def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, near=0.0, far=5.0, chunk=32768, precision=None):
     """One frame of the appearance-hallucination video path (appearance_modification_video.py:224-262):
     style image -> appearance embedding, camera -> rays on the device, render, decode.  Returns [H,W,3] in [0,1]."""
     a_emb = enc_a(style_img)
     rays = generate_rays(H, W, K, c2w, near, far, device=style_img.device)
     res = batched_inference(models, embeddings, rays, None, hparams_.N_samples, hparams_.N_importance, hparams_.use_disp,
-                            chunk, False, args=hparams_, a_embedded_from_img=a_emb)
+                            chunk, False, args=hparams_, a_embedded_from_img=a_emb, precision=precision)
     return decode_image(models, res, H, W, a_emb).reshape(int(H), int(W), 3).clamp(0, 1)
 
 

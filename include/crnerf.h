@@ -120,6 +120,20 @@ typedef struct crnerf_render_args {
 } crnerf_render_args;
 int crnerf_render_rays_f32(const crnerf_render_args* args, void* stream);
 
+/* ---- bf16 matrix-core variants (BASELINE config 3: "1x MI355X bf16"; SURVEY 8b minimum export set
+ * crnerf_mlp_forward_{f32,bf16} / crnerf_render_rays_{f32,bf16}).  Same reference functions, mixed precision:
+ * the operands of every nn.Linear of NeRF_sigma except static_sigma -- weights and input activations, including the
+ * two positional embeddings -- are rounded to bf16 (round-to-nearest-even); products accumulate in fp32; biases,
+ * ReLU, Softplus, Sigmoid, the sigma head (fp32 weights on the un-rounded output of xyz_encoding_8), ray geometry,
+ * compositing, sample_pdf and the z merge stay fp32.  I/O tensors are fp32 exactly as in the _f32 entry points.
+ * The packed buffer is a different layout (fp32 consts + bf16 fragments): pack with crnerf_pack_mlp_weights_bf16. */
+size_t crnerf_packed_mlp_bf16_bytes(void);
+int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed_bf16, void* stream);
+/* NeRF_sigma.forward, models/nerf.py:157-182: x[n,120] -> out[n,65]; sigma_only != 0: x[n,93] -> out[n,1]. */
+int crnerf_mlp_forward_bf16(const void* packed_bf16, const float* x, float* out, int64_t n, int sigma_only, void* stream);
+/* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are bf16 packs. */
+int crnerf_render_rays_bf16(const crnerf_render_args* args, void* stream);
+
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.
  * weights = HOST array of 14 device pointers: conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias (reference layouts). */

@@ -46,6 +46,34 @@ def mlp_forward(w, x, sigma_only=False):
     return torch.cat((feat, sigma), dim=-1)                                                  # :181
 
 
+def bf16_round(t):
+    """Round-to-nearest-even to bfloat16, returned as fp32 (what v_cvt_pk_bf16_f32 does to an MFMA operand)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def mlp_forward_bf16(w, x, sigma_only=False):
+    """NeRF_sigma.forward, models/nerf.py:157-182, in the mixed precision of the crnerf_*_bf16 entry points
+    (include/crnerf.h): operands of every Linear except static_sigma -- weights and input activations, incl. the
+    embedded input x -- rounded to bf16, fp32 accumulation; biases / activations / the sigma head in fp32, the latter
+    on the UN-rounded output of xyz_encoding_8.  Products of two bf16 values are exact in fp32, so F.linear on the
+    rounded operands differs from the MFMA only in summation order."""
+    q = bf16_round
+    lin = lambda h, name: F.linear(q(h), q(w[name + ".weight"]), w[name + ".bias"])  # noqa: E731
+    xyz = x if sigma_only else x[:, :93]
+    h = xyz
+    for layer in range(1, 9):
+        if layer == 5:
+            h = torch.cat((xyz, h), dim=1)
+        h = F.relu(lin(h, "xyz_encoding_%d.0" % layer))
+    sigma = F.softplus(F.linear(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))
+    if sigma_only:
+        return sigma
+    final = lin(h, "xyz_encoding_final")
+    g = F.relu(lin(torch.cat((final, x[:, 93:]), dim=1), "dir_encoding.0"))
+    feat = torch.sigmoid(lin(g, "static_rgb.0"))
+    return torch.cat((feat, sigma), dim=-1)
+
+
 # ------------------------------------------------------------------ models/rendering.py
 def composite(raw, z, noise=None, noise_std=0.0):
     """Compositing half of inference(), models/rendering.py:116-143.
@@ -102,30 +130,35 @@ def fine_depths(z_coarse, weights_coarse, n_importance, det=True, u=None):
     return torch.sort(torch.cat((z_coarse, extra), dim=-1), dim=-1)[0], extra
 
 
-def _run_model(w, rays, z, dir_emb, chunk):
+def _run_model(w, rays, z, dir_emb, chunk, mlp=None):
     """Point-chunk loop of inference(), models/rendering.py:100-116."""
+    mlp = mlp or mlp_forward
     R, N = z.shape
     pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)          # :178 / :188
     dirs = dir_emb[:, None, :].expand(R, N, dir_emb.shape[-1]).reshape(R * N, -1)           # :108
     outs = []
     for i in range(0, R * N, chunk):
-        outs.append(mlp_forward(w, torch.cat((posenc(pts[i:i + chunk], 15), dirs[i:i + chunk]), dim=1)))
+        outs.append(mlp(w, torch.cat((posenc(pts[i:i + chunk], 15), dirs[i:i + chunk]), dim=1)))
     return torch.cat(outs, dim=0).view(R, N, 65)
 
 
 def render_rays(w_coarse, w_fine, rays, n_samples, n_importance, use_disp=False, chunk=32768, view_dir=None,
-                z_coarse=None, u=None, noise_coarse=None, noise_fine=None, noise_std=0.0, return_raw=False, z_steps=None):
-    """render_rays_cross_ray, models/rendering.py:50-196, with perturb == 0 unless z_coarse/u are supplied."""
+                z_coarse=None, u=None, noise_coarse=None, noise_fine=None, noise_std=0.0, return_raw=False, z_steps=None,
+                precision="f32", z_fine=None):
+    """render_rays_cross_ray, models/rendering.py:50-196, with perturb == 0 unless z_coarse/u are supplied.
+    precision="bf16": NeRF_sigma through mlp_forward_bf16, everything else unchanged.  z_fine: evaluate the fine
+    pass at these depths instead of sampling them (used to compare fine outputs at identical depths)."""
+    mlp = mlp_forward_bf16 if precision == "bf16" else mlp_forward
     dir_emb = posenc(rays[:, 3:6] if view_dir is None else view_dir, 4)                     # :155
     z = coarse_depths(rays, n_samples, use_disp, z_steps) if z_coarse is None else z_coarse
     out = {}
-    raw_c = _run_model(w_coarse, rays, z, dir_emb, chunk)
+    raw_c = _run_model(w_coarse, rays, z, dir_emb, chunk, mlp)
     out["weights_coarse"], out["feature_coarse"], out["depth_coarse"] = composite(raw_c, z, noise_coarse, noise_std)
     if return_raw:
         out["raw_coarse"], out["z_coarse"] = raw_c, z
     if n_importance > 0:
-        z_f, _ = fine_depths(z, out["weights_coarse"], n_importance, det=(u is None), u=u)
-        raw_f = _run_model(w_fine, rays, z_f, dir_emb, chunk)
+        z_f = fine_depths(z, out["weights_coarse"], n_importance, det=(u is None), u=u)[0] if z_fine is None else z_fine
+        raw_f = _run_model(w_fine, rays, z_f, dir_emb, chunk, mlp)
         out["weights_fine"], out["feature_fine"], out["depth_fine"] = composite(raw_f, z_f, noise_fine, noise_std)
         out["z_fine"] = z_f
         if return_raw:

@@ -11,20 +11,25 @@ import crnerf_amd.synth as synth
 from crnerf_amd import ops, _lib
 dev = torch.device("cuda:0")
 C = lambda s: {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
-pc, pf = ops.pack_mlp_weights(C(synth.mlp_state(1, 3.0, 1.0))), ops.pack_mlp_weights(C(synth.mlp_state(2, 3.0, 1.0)))
+PREC = os.environ.get("CRNERF_PRECISION", "f32")   # bf16 -> the bf16 fused kernel
+pc, pf = ops.pack_mlp_weights(C(synth.mlp_state(1, 3.0, 1.0)), precision=PREC), ops.pack_mlp_weights(C(synth.mlp_state(2, 3.0, 1.0)), precision=PREC)
 rays = torch.from_numpy(synth.rays(1024)).to(dev)
 for _ in range(3):
-    ops.render_rays(pc, pf, rays, 64, 128)
+    ops.render_rays(pc, pf, rays, 64, 128, precision=PREC)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = (ctypes.c_ulonglong * 7)()
-fn = lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16
+buf = (ctypes.c_ulonglong * 15)()
+fn = (lib.crnerf_debug_read_timing_bf16 if PREC == "bf16" else
+      lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16)
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
-names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"]
+names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"] + ["x%d" % i for i in range(8)]
 tot = buf[6]
 for n, v in zip(names, buf):
     print("%-18s %12d cycles  %6.2f %%" % (n, v, 100.0 * v / tot))
-print("ideal matrix-pipe cycles per SIMD: %d (8 steps x 9664 MFMA x 64 cycles-equivalent)" % (8 * 9664 * 64))
+if PREC == "bf16":
+    print("ideal matrix-pipe cycles per wave: %d (4 tiles x 2416 MFMA x 32 cycles)" % (4 * 2416 * 32))
+else:
+    print("ideal matrix-pipe cycles per SIMD: %d (8 steps x 9664 MFMA x 64 cycles-equivalent)" % (8 * 9664 * 64))
 if not os.environ.get("CRNERF_KEEP_BUILD"):   # restore the production build
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
