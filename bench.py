@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 2 * 616576          # SURVEY 8a A4 / BASELINE.md section 2
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), --precision bf16 only
 NC, NI = 64, 128
 
 
@@ -40,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]")
     return ap.parse_args()
 
 
@@ -126,7 +129,7 @@ def main():
         nerf_out_dim, img_wh = 64, [grid_hw[1], grid_hw[0]]
 
     with torch.no_grad():
-        pc, pf = ops.pack_mlp_weights(to_dev(st_c)), ops.pack_mlp_weights(to_dev(st_f))
+        pc, pf = ops.pack_mlp_weights(to_dev(st_c), precision=a.precision), ops.pack_mlp_weights(to_dev(st_f), precision=a.precision)
         net = style_net(Args()).to(dev)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
         rays = torch.from_numpy(rays_np).to(dev)
@@ -138,7 +141,7 @@ def main():
         def step(i=None):
             if i is not None:
                 ev[i][0].record()
-            out = ops.render_rays(pc, pf, rays, NC, NI, z_steps=z_steps, u=u_steps)
+            out = ops.render_rays(pc, pf, rays, NC, NI, z_steps=z_steps, u=u_steps, precision=a.precision)
             if i is not None:
                 ev[i][1].record()
             feat = out["feature_fine"]
@@ -168,6 +171,9 @@ def main():
     if rank == 0:
         flops = FLOP_PER_POINT * (NC + NC + NI) * R
         achieved = flops / (kern_ms * 1e-3) / 1e12
+        bf16 = a.precision == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        kernel = "render_rays_bf16_kernel" if bf16 else ("render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "render_rays_hbm_bytes.json")   # written from a rocprofv3 --pmc pass (profiles/README.md)
         if os.path.exists(pmc):
@@ -176,13 +182,15 @@ def main():
         line = {
             "metric": "rays/sec (64+128 samples, 8-layer W=256 MLP)", "value": world * R * a.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d rays x (%d coarse + %d fine) per GPU, NeRF_sigma 8x256 coarse+fine, "
-                                   "fused render_rays + cross-ray decode of the %dx%d feature grid" % (R, NC, NI, grid_hw[0], grid_hw[1]),
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]%s: %d rays x (%d coarse + %d fine) per GPU, NeRF_sigma 8x256 coarse+fine, "
+                                   "fused render_rays + cross-ray decode of the %dx%d feature grid"
+                                   % (2 if bf16 else 1, " arithmetic (bf16 MFMA operands, fp32 accumulate) on the configs[1] ray batch" if bf16 else "",
+                                      R, NC, NI, grid_hw[0], grid_hw[1]),
                        "rays_per_gpu": R, "n_samples": NC, "n_importance": NI,
                        "parallelism": "rays sharded %d-way, weights replicated" % world},
-            "roofline": {"bound": "mfma", "kernel": "render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "kernel_ms": kern_ms,
                          "flops_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -36,7 +36,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int B_AHEAD = CRNERF_B_AHEAD;   // fragments read ahead of the one being multiplied (tuning: -DCRNERF_B_AHEAD=n)
 constexpr int B_TAIL = STREAMB_USED - (STAGESB_PER_PASS - 1) * STAGE_FRAGS;  // fragments in the (short) last stage: 8
-static_assert(B_TAIL % 4 == 0 && B_TAIL >= 4 && STREAMB_USED % B_AHEAD == 0, "tail stage must fit the piece schedule");
+static_assert(B_TAIL == 8 && STREAMB_USED % B_AHEAD == 0, "tail stage must fit the piece schedule");
 
 // ---- compile-time schedule over the pass-relative fragment index i (0 <= i < STREAMB_USED) -------------
 // position in the padded stream (the look-ahead past the last fragment lands in the next pass)
@@ -47,25 +47,37 @@ constexpr int b_cur_stage(int i) { return (i + 1) / STAGE_FRAGS + (i > b_last_ad
 constexpr bool b_advance_at(int i) {
   return i / STAGE_FRAGS < STAGESB_PER_PASS - 1 ? i % STAGE_FRAGS == STAGE_FRAGS - 2 : i == b_last_adv();
 }
-// LDS-DMA piece (0..3) issued at iteration i, or -1
+// LDS-DMA piece (0..3) issued at iteration i, or -1: slots 1, 5, 9, 13 of a stage (k-steps that carry one epilogue
+// quarter in the 16-k-step layers, so piece + quarter + fragment read stay within 4 fillers per MFMA gap)
 constexpr int b_piece_at(int i) {
   const int sl = i % STAGE_FRAGS;
-  if (i / STAGE_FRAGS < STAGESB_PER_PASS - 1) return sl % 4 == 0 ? sl / 4 : -1;
-  return sl % (B_TAIL / 4) == 0 && sl < B_TAIL ? sl / (B_TAIL / 4) : -1;
+  if (i / STAGE_FRAGS < STAGESB_PER_PASS - 1) return sl % 4 == 1 ? sl / 4 : -1;
+  return sl == 0 ? 0 : (sl == 1 ? 1 : (sl == 3 ? 2 : (sl == 5 ? 3 : -1)));   // tail stage (B_TAIL = 8 fragments)
+}
+// prefetch-cursor bookkeeping (SALU only) sits in the stage's last k-step, which carries no epilogue work
+constexpr bool b_cursor_at(int i) {
+  return i / STAGE_FRAGS < STAGESB_PER_PASS - 1 ? i % STAGE_FRAGS == STAGE_FRAGS - 1 : i == STREAMB_USED - 1;
 }
 constexpr bool b_schedule_ok() {
-  int pieces = 0, advances = 0;
+  int pieces = 0, advances = 0, cursors = 0;
   for (int i = 0; i < STREAMB_USED; ++i) {
     const int d = b_pos(i + B_AHEAD) / STAGE_FRAGS - b_cur_stage(i);
     if (d < 0 || d > 1) return false;                 // reads stay inside stages c and c+1
-    if (b_piece_at(i) >= 0) ++pieces;
+    if (b_piece_at(i) >= 0) {
+      if (b_piece_at(i) != pieces % 4 || cursors != pieces / 4) return false;   // in order, cursor moved before piece 0
+      ++pieces;
+    }
+    if (b_cursor_at(i)) {
+      ++cursors;
+      if (pieces != 4 * cursors) return false;
+    }
     if (b_advance_at(i)) {
       ++advances;
       if (pieces != 4 * advances) return false;       // exactly 4 pieces between consecutive barriers (vmcnt counting)
       if (b_pos(i + B_AHEAD) / STAGE_FRAGS > advances) return false;  // never reads stage c+2 before its barrier
     }
   }
-  return advances == STAGESB_PER_PASS && b_cur_stage(STREAMB_USED - 1) == STAGESB_PER_PASS;
+  return advances == STAGESB_PER_PASS && cursors == STAGESB_PER_PASS && b_cur_stage(STREAMB_USED - 1) == STAGESB_PER_PASS;
 }
 static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protocol");
 
@@ -101,16 +113,17 @@ struct WeightPipeB {
       default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
     }
 #endif
-    if (i == 3) {
-      pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
-      const bool wrap = (pf_left == 1);
-      const int np = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
-      const char* nb = (np < passes0) ? base[0] : base[1];
-      pf_left = wrap ? STAGESB_PER_PASS : pf_left - 1;
-      pf_pass = wrap ? np : pf_pass;
-      pf_ptr = wrap ? nb : pf_ptr + STAGE_BYTES;
-      asm volatile("" : "+s"(pf_ptr));   // opaque: else a single-pass kernel gets 302 precomputed addresses
-    }
+  }
+  // after the 4th piece of a stage: move the fetch cursor to the next stage
+  __device__ __forceinline__ void cursor_update() {
+    pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
+    const bool wrap = (pf_left == 1);
+    const int np = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
+    const char* nb = (np < passes0) ? base[0] : base[1];
+    pf_left = wrap ? STAGESB_PER_PASS : pf_left - 1;
+    pf_pass = wrap ? np : pf_pass;
+    pf_ptr = wrap ? nb : pf_ptr + STAGE_BYTES;
+    asm volatile("" : "+s"(pf_ptr));   // opaque: else a single-pass kernel gets 302 precomputed addresses
   }
   __device__ __forceinline__ void set_addrs() {
     const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
@@ -133,9 +146,11 @@ struct WeightPipeB {
     rd_slot = 0;
     set_addrs();
 #pragma unroll
-    for (int s = 0; s < RING_SLOTS - 1; ++s)
+    for (int s = 0; s < RING_SLOTS - 1; ++s) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_piece(i);
+      cursor_update();
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -162,22 +177,44 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 // ---- epilogues -------------------------------------------------------------------------------------------
-// A tile's epilogue is cut into 16 quarters (quarter qc = accumulator registers 2(qc>>1), +1 of point group qc&1,
-// ~6 VALU each) that run behind the MFMAs of the NEXT tile.  An epilogue object provides
-//     prefetch(T)       -- LDS reads (bias, ...) for tile T, issued one k-step before the first quarter
-//     run(T, qc, acc)   -- quarter qc of tile T from that group's accumulator
-// The asm statements pin each piece of work to the k-step it was written in: instruction selection may emit pure
+// Issue budget (tools/ubench/gen_mfma_stream.py, one wave per SIMD): beside a v_mfma_f32_32x32x16_bf16 up to FOUR
+// other instructions per MFMA gap are free (32.7 cycles/MFMA with 8 fillers per k-step split 4 + 4); 10 per k-step cost
+// 35.9, 12 cost 38.0, and 6 all in ONE gap 36.7.  So the epilogue of a tile is cut into 16 quarters (quarter qc =
+// accumulator registers 2(qc>>1), +1 of point group qc&1) of 4 VALU each -- two accumulator reads in the first gap of
+// a k-step, convert + relu in the second -- that run behind the MFMAs of the NEXT tile, one quarter per k-step.  The
+// bias costs nothing: it is the C operand of a tile's first two MFMAs (one f32x16 read from LDS, shared by both groups).
+// An epilogue object provides
+//     prefetch(T)               LDS reads for tile T's epilogue (only the sigma head has any)
+//     load(slot, T, qc, acc)    first half of quarter qc: fetch its two accumulator registers
+//     finish(slot, T, qc)       second half: convert / activate / store
+// The asm statements pin each piece of work to the gap it was written in: instruction selection may emit pure
 // arithmetic anywhere between its operands' definitions and its first use, and without them hipcc parks whole
 // layers' epilogues (256 live accumulators) behind the layer's last MFMA.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// (acc + bias) -> bf16 pair -> relu.  relu commutes with round-to-nearest-even, so it is applied to the packed pair:
-// as int16 a negative bf16 (incl. -0) is negative, and max(x, 0) per 16-bit lane is ONE v_pk_max_i16 for two values.
-// Accumulator registers 2hc, 2hc+1 are dword hc&3 of k-step 2T + (hc>>2) of the next layer's B operand.
+__device__ __forceinline__ f32x4 lds_f4(const lds_float* p) { return *(const __attribute__((address_space(3))) f32x4*)p; }
+
+struct EpiTemps {
+  float t[4][2];
+  __device__ __forceinline__ void fetch(int slot, int qc, const f32x16& acc) {
+    float v0 = acc[2 * (qc >> 1)], v1 = acc[2 * (qc >> 1) + 1];
+    asm volatile("" : "+v"(v0), "+v"(v1));
+    t[slot][0] = v0;
+    t[slot][1] = v1;
+  }
+};
+
+struct NoEpi {
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void load(int, int, int, const f32x16&) {}
+  __device__ __forceinline__ void finish(int, int, int) {}
+};
+
+// bf16 pair -> relu.  relu commutes with round-to-nearest-even, so it is applied to the packed pair: as int16 a negative
+// bf16 (incl. -0) is negative, and max(x, 0) per 16-bit lane is ONE v_pk_max_i16 for two values.
 template <bool RELU>
-__device__ __forceinline__ uint32_t pack_pair(float v0, float v1, float b0, float b1) {
-  asm volatile("" : "+v"(v0), "+v"(v1));
-  uint32_t pk = pk_bf16(v0 + b0, v1 + b1);
+__device__ __forceinline__ uint32_t pack_pair(float v0, float v1) {
+  uint32_t pk = pk_bf16(v0, v1);
   if (RELU) {
     asm volatile("" : "+v"(pk));   // keep the pair packed: hipcc otherwise converts the halves separately and re-packs
     const s16x2 z = {0, 0};
@@ -187,122 +224,135 @@ __device__ __forceinline__ uint32_t pack_pair(float v0, float v1, float b0, floa
   return pk;
 }
 
-__device__ __forceinline__ f32x4 lds_f4(const lds_float* p) { return *(const __attribute__((address_space(3))) f32x4*)p; }
-
-struct NoEpi {
-  __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void run(int, int, const f32x16&) {}
-};
-
+// hidden layers: accumulator registers 2hc, 2hc+1 become dword hc&3 of k-step 2T + (hc>>2) of the next layer's B operand
 template <bool RELU>
-struct PackEpi {   // hidden layers: next layer's B operand
+struct PackEpi : EpiTemps {
   u32x4 (&dst)[KS_HID][2];
-  const lds_float* bias;
-  int h;
-  f32x4 bv[4];
-  __device__ __forceinline__ PackEpi(u32x4 (&d)[KS_HID][2], const lds_float* b, int h_) : dst(d), bias(b), h(h_) {}
-  __device__ __forceinline__ void prefetch(int T) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
-  }
-  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+  __device__ __forceinline__ explicit PackEpi(u32x4 (&d)[KS_HID][2]) : dst(d) {}
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void load(int slot, int, int qc, const f32x16& acc) { fetch(slot, qc, acc); }
+  __device__ __forceinline__ void finish(int slot, int T, int qc) {
     const int hc = qc >> 1, g = qc & 1;
-    const uint32_t pk = pack_pair<RELU>(acc[2 * hc], acc[2 * hc + 1], bv[hc >> 1][2 * (hc & 1)], bv[hc >> 1][2 * (hc & 1) + 1]);
-    dst[2 * T + (hc >> 2)][g][hc & 3] = pk;
+    dst[2 * T + (hc >> 2)][g][hc & 3] = pack_pair<RELU>(t[slot][0], t[slot][1]);
   }
 };
 
-struct SigmaEpi {   // xyz_encoding_8: as PackEpi<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
+// xyz_encoding_8: as PackEpi<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
+struct SigmaEpi : EpiTemps {
   u32x4 (&dst)[KS_HID][2];
   float (&sg)[2];
-  const lds_float* bias;
   const lds_float* wsig;
   int h;
-  f32x4 bv[4], wv[4];
-  __device__ __forceinline__ SigmaEpi(u32x4 (&d)[KS_HID][2], float (&s)[2], const lds_float* b, const lds_float* w, int h_)
-      : dst(d), sg(s), bias(b), wsig(w), h(h_) {}
+  f32x4 wv[4];
+  __device__ __forceinline__ SigmaEpi(u32x4 (&d)[KS_HID][2], float (&s)[2], const lds_float* w, int h_) : dst(d), sg(s), wsig(w), h(h_) {}
   __device__ __forceinline__ void prefetch(int T) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
-      wv[c] = lds_f4(wsig + 32 * T + 8 * c + 4 * h);
-    }
+    for (int c = 0; c < 4; ++c) wv[c] = lds_f4(wsig + 32 * T + 8 * c + 4 * h);
   }
-  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+  __device__ __forceinline__ void load(int slot, int, int qc, const f32x16& acc) { fetch(slot, qc, acc); }
+  __device__ __forceinline__ void finish(int slot, int T, int qc) {
     const int hc = qc >> 1, g = qc & 1, e = 2 * (hc & 1);
-    float x0 = acc[2 * hc], x1 = acc[2 * hc + 1];
-    const float b0 = bv[hc >> 1][e], b1 = bv[hc >> 1][e + 1];
-    dst[2 * T + (hc >> 2)][g][hc & 3] = pack_pair<true>(x0, x1, b0, b1);
-    asm volatile("" : "+v"(x0), "+v"(x1));
-    sg[g] = fmaf(wv[hc >> 1][e], fmaxf(x0 + b0, 0.0f), sg[g]);
-    sg[g] = fmaf(wv[hc >> 1][e + 1], fmaxf(x1 + b1, 0.0f), sg[g]);
+    const float x0 = t[slot][0], x1 = t[slot][1];
+    dst[2 * T + (hc >> 2)][g][hc & 3] = pack_pair<true>(x0, x1);
+    sg[g] = fmaf(wv[hc >> 1][e], fmaxf(x0, 0.0f), sg[g]);
+    sg[g] = fmaf(wv[hc >> 1][e + 1], fmaxf(x1, 0.0f), sg[g]);
     asm volatile("" : "+v"(sg[g]));
   }
 };
 
-struct RgbEpi {   // static_rgb: sigmoid, fp32 out
+// 1 / (1 + 2^(-x log2 e)) on the hardware exp2 / rcp (1 ulp each): 4 instructions instead of ~22 for expf + IEEE
+// division, 64 of them per lane per tile; the relative error (~2e-7) is far below this path's bf16 noise
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+
+struct RgbEpi : EpiTemps {   // static_rgb: sigmoid, fp32 out
   f32x16 (&feat)[2][2];
-  const lds_float* bias;
-  int h;
-  f32x4 bv[4];
-  __device__ __forceinline__ RgbEpi(f32x16 (&f)[2][2], const lds_float* b, int h_) : feat(f), bias(b), h(h_) {}
-  __device__ __forceinline__ void prefetch(int T) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bv[c] = lds_f4(bias + 32 * T + 8 * c + 4 * h);
-  }
-  __device__ __forceinline__ void run(int T, int qc, const f32x16& acc) {
+  __device__ __forceinline__ explicit RgbEpi(f32x16 (&f)[2][2]) : feat(f) {}
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void load(int slot, int, int qc, const f32x16& acc) { fetch(slot, qc, acc); }
+  __device__ __forceinline__ void finish(int slot, int T, int qc) {
     const int hc = qc >> 1, g = qc & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) feat[g][T][2 * hc + j] = sigmoid_ref(acc[2 * hc + j] + bv[hc >> 1][2 * (hc & 1) + j]);
+    feat[g][T][2 * hc] = sigmoid_fast(t[slot][0]);
+    feat[g][T][2 * hc + 1] = sigmoid_fast(t[slot][1]);
   }
 };
+
+// acc-layout bias of output tile T: element 4c + j = bias[32T + 8c + 4h + j]
+__device__ __forceinline__ void load_bias_half(f32x16& bv, const lds_float* bias, int T, int h, int half) {
+#pragma unroll
+  for (int c = 2 * half; c < 2 * half + 2; ++c) {
+    const f32x4 b = lds_f4(bias + 32 * T + 8 * c + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[4 * c + j] = b[j];
+  }
+}
 
 // One layer.  NT output tiles; per tile NSA k-steps with B operands srcA[s][g] then NSB from srcB (g = point group).
 // FBASE: pass-relative index of the layer's first fragment; G0: index of its first tile in the pass (tile G
 // accumulates in accs[G & 1]); PT: the previous layer's last tile, whose epilogue `prev` is still pending and runs
 // behind this layer's first tile -- legal because k-step s of any layer reads source tile s/2, so the last source
 // tile is only needed by the last two k-steps.  On return this layer's tile NT-1 is pending in the same way.
+// biasv: on entry the bias of tile 0 (acc layout); reloaded for each following tile -- and from next_bias for the next
+// layer's tile 0 -- a few k-steps before it is needed.  (next_bias must be a readable address even for the last layer:
+// the consts block sits at LDS address 0, so a null sentinel would alias the first layer's bias.)
 template <int NT, int NSA, int NSB, int FBASE, int G0, int PT, int NA, int NB, class PREV, class EPI>
 __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[NA][2], const u32x4 (&srcB)[NB][2],
-                                            u32x4 (&q)[B_AHEAD], f32x16 (&accs)[2][2], PREV& prev, EPI& epi) {
+                                            u32x4 (&q)[B_AHEAD], f32x16 (&accs)[2][2], f32x16& biasv, const lds_float* bias,
+                                            const lds_float* next_bias, int h, PREV& prev, EPI& epi) {
   static_assert(NSA <= NA && NSB <= NB, "source too small");
   constexpr int NS = NSA + NSB;
-  static_assert(NS >= 14 || NS == 6 || NS == 8, "epilogue quarters must finish before the last source tile is read");
+  static_assert(NS >= 16 || NS == 6 || NS == 8, "epilogue quarters must finish before the last source tile is read");
+  constexpr bool LONG = NS >= 16;
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     const int cur = (G0 + T) & 1;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int i = FBASE + T * NS + s;
+      // quarters of the previous tile's epilogue carried by this k-step.  Long layers: one per k-step from k-step 1,
+      // a second one every fourth k-step, done after k-step 13 (k-step 14 of a layer's first tile reads the result);
+      // the short layers (K = 96, 128) take four per k-step in k-steps 1..4.
+      const int first = LONG ? (s - 1) + (s - 1) / 4 : 4 * (s - 1);
+      const int count = s < 1 ? 0 : (LONG ? (s <= 13 ? (s % 4 == 0 ? 2 : 1) : 0) : (s <= 4 ? 4 : 0));
+      const f32x16& pa0 = accs[cur ^ 1][0];
+      const f32x16& pa1 = accs[cur ^ 1][1];
+
       u32x4 af = q[i % B_AHEAD];
       asm volatile("" : "+v"(af));   // ties this k-step's MFMAs into the side-effect chain (see the epilogue notes)
       const bf16x8 a = __builtin_bit_cast(bf16x8, af);
-      const int pos = b_pos(i + B_AHEAD);
-      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
       const u32x4 b0 = s < NSA ? srcA[s < NSA ? s : 0][0] : srcB[s < NSA ? 0 : s - NSA][0];
       const u32x4 b1 = s < NSA ? srcA[s < NSA ? s : 0][1] : srcB[s < NSA ? 0 : s - NSA][1];
-      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      accs[cur][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), s == 0 ? zero : accs[cur][0], 0, 0, 0);
-      accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? zero : accs[cur][1], 0, 0, 0);
+      // ---- gap 1
+      accs[cur][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), s == 0 ? biasv : accs[cur][0], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < count; ++u) {
+        const int qc = first + u;
+        if (T == 0) prev.load(u, PT, qc, (qc & 1) ? pa1 : pa0);
+        else epi.load(u, T - 1, qc, (qc & 1) ? pa1 : pa0);
+      }
       if (b_piece_at(i) >= 0) p.issue_piece(b_piece_at(i));
-      if (b_advance_at(i)) p.advance();
-      // the previous tile's epilogue: prefetch its LDS operands behind k-step 0, then two quarters per k-step behind
-      // k-steps 1..4 and one per k-step up to 12 (<= ~6 VALU per MFMA, done before k-step 14); the short layers
-      // (K = 96, 128) take four per k-step
+      __builtin_amdgcn_sched_barrier(0);   // pin the hand-made pipeline (hipcc would bunch the fillers)
+      // ---- gap 2
+      accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? biasv : accs[cur][1], 0, 0, 0);
+      const int pos = b_pos(i + B_AHEAD);
+      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
+#pragma unroll
+      for (int u = 0; u < count; ++u) {
+        const int qc = first + u;
+        if (T == 0) prev.finish(u, PT, qc);
+        else epi.finish(u, T - 1, qc);
+      }
       if (s == 0) {
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);
-      } else {
-        const int first = NS >= 14 ? (s <= 4 ? 2 * (s - 1) : 8 + (s - 5)) : 4 * (s - 1);
-        const int count = NS >= 14 ? (s <= 4 ? 2 : (s <= 12 ? 1 : 0)) : (s <= 4 ? 4 : 0);
-#pragma unroll
-        for (int u = 0; u < count; ++u) {
-          const int qc = first + u;
-          if (T == 0) prev.run(PT, qc, accs[cur ^ 1][qc & 1]);
-          else epi.run(T - 1, qc, accs[cur ^ 1][qc & 1]);
-        }
       }
-      __builtin_amdgcn_sched_barrier(0);   // pin the hand-made pipeline: hipcc otherwise bunches the epilogue into a VALU burst
+      if (s == NS - 4 || s == NS - 3) {   // the next tile's bias, half per k-step (biasv was consumed at s == 0); early enough that
+                                          // the wait for it leaves the two newest fragment reads in flight
+        const lds_float* nb = (T + 1 < NT) ? bias : next_bias;
+        load_bias_half(biasv, nb, (T + 1 < NT) ? T + 1 : 0, h, s - (NS - 4));
+      }
+      if (b_advance_at(i)) p.advance();
+      if (b_cursor_at(i)) p.cursor_update();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -319,49 +369,46 @@ __device__ __forceinline__ void mlp_tile_b(WeightPipeB& p, int model, const u32x
   const lds_float* C = (const lds_float*)(p.lds + c_off);
   const lds_float* B1 = C + C_BIAS;
   u32x4 actA[KS_HID][2], actB[KS_HID][2];
-  f32x16 accs[2][2];
+  f32x16 accs[2][2], biasv;
   float sg[2] = {0.0f, 0.0f};
+  load_bias_half(biasv, B1, 0, h, 0);
+  load_bias_half(biasv, B1, 0, h, 1);
   tm.tick(T_PROLOGUE);
 
   // tile parity: every layer before dir has 8 tiles, so accs[G & 1] with G0 = 8 * layer; dir starts at 72, rgb at 76
   NoEpi none;
-  PackEpi<true> e1(actA, B1, h);
-  mma_layer_b<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, none, e1);                    // xyz_encoding_1
+  PackEpi<true> eA(actA), eB(actB);
+  PackEpi<false> efin(actA);
+  SigmaEpi e8(actB, sg, C + C_WSIG, h);
+  RgbEpi ergb(feat);
+  mma_layer_b<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, biasv, B1, B1 + 1 * W_HIDDEN, h, none, eA);                           // xyz_encoding_1
   tm.tick(T_X0);
-  PackEpi<true> e2(actB, B1 + 1 * W_HIDDEN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, e1, e2);                  // 2
+  mma_layer_b<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, biasv, B1 + 1 * W_HIDDEN, B1 + 2 * W_HIDDEN, h, eA, eB);          // 2
   tm.tick(T_X1);
-  PackEpi<true> e3(actA, B1 + 2 * W_HIDDEN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, e2, e3);        // 3
-  PackEpi<true> e4(actB, B1 + 3 * W_HIDDEN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, e3, e4);    // 4
+  mma_layer_b<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, biasv, B1 + 2 * W_HIDDEN, B1 + 3 * W_HIDDEN, h, eB, eA);      // 3
+  mma_layer_b<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, biasv, B1 + 3 * W_HIDDEN, B1 + 4 * W_HIDDEN, h, eA, eB);  // 4
   tm.tick(T_X2);
-  PackEpi<true> e5(actA, B1 + 4 * W_HIDDEN, h);
-  mma_layer_b<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, e4, e5);              // 5 = Linear(cat[xyz, h])
+  mma_layer_b<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, biasv, B1 + 4 * W_HIDDEN, B1 + 5 * W_HIDDEN, h, eB, eA);      // 5 = Linear(cat[xyz, h])
   tm.tick(T_X3);
-  PackEpi<true> e6(actB, B1 + 5 * W_HIDDEN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, e5, e6);                 // 6
-  PackEpi<true> e7(actA, B1 + 6 * W_HIDDEN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, e6, e7);        // 7
-  SigmaEpi e8(actB, sg, B1 + 7 * W_HIDDEN, C + C_WSIG, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, e7, e8);    // 8 (+ static_sigma)
-  PackEpi<false> efin(actA, C + C_BFIN, h);
-  mma_layer_b<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, e8, efin);              // xyz_encoding_final (no activation)
+  mma_layer_b<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, biasv, B1 + 5 * W_HIDDEN, B1 + 6 * W_HIDDEN, h, eA, eB);         // 6
+  mma_layer_b<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, biasv, B1 + 6 * W_HIDDEN, B1 + 7 * W_HIDDEN, h, eB, eA);      // 7
+  mma_layer_b<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, biasv, B1 + 7 * W_HIDDEN, C + C_BFIN, h, eA, e8);   // 8 (+ static_sigma)
+  mma_layer_b<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, biasv, C + C_BFIN, C + C_BDIR, h, e8, efin);                    // xyz_encoding_final (no activation)
   tm.tick(T_MMA);
   sg[0] += __shfl_xor(sg[0], 32);
   sg[1] += __shfl_xor(sg[1], 32);
   sigma[0] = softplus_ref(sg[0] + C[C_BSIG]);
   sigma[1] = softplus_ref(sg[1] + C[C_BSIG]);
   tm.tick(T_SIGMA);
-  PackEpi<true> edir(actB, C + C_BDIR, h);
-  mma_layer_b<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, efin, edir);         // dir_encoding = relu(Linear(cat[final, dir]))
+  mma_layer_b<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, biasv, C + C_BDIR, C + C_BRGB, h, efin, eB);                 // dir_encoding = relu(Linear(cat[final, dir]))
   tm.tick(T_X4);
-  RgbEpi ergb(feat, C + C_BRGB, h);
-  mma_layer_b<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, edir, ergb);           // static_rgb = sigmoid(Linear)
+  mma_layer_b<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, biasv, C + C_BRGB, C + C_BRGB, h, eB, ergb);                      // static_rgb = sigmoid(Linear)
   tm.tick(T_MMA);
-  ergb.prefetch(1);                                                                           // nothing left to hide it behind
 #pragma unroll
-  for (int qc = 0; qc < 16; ++qc) ergb.run(1, qc, accs[(76 + 1) & 1][qc & 1]);
+  for (int qc = 0; qc < 16; ++qc) {   // rgb's last tile: nothing left to hide it behind
+    ergb.load(0, 1, qc, accs[(76 + 1) & 1][qc & 1]);
+    ergb.finish(0, 1, qc);
+  }
   tm.tick(T_EPILOGUE);
 }
 

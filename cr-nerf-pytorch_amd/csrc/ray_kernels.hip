@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void sample_pdf_merge_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   RayScratch s;
-  s.bind((lds_char*)smem, Nc, Ni);
+  s.bind((lds_char*)smem, (Nc + 3) & ~3, (Ni + 3) & ~3);   // 16-byte aligned arrays: merge_sort_wave reads them as float4
   for (long r = blockIdx.x; r < R; r += gridDim.x) {
     for (int n = lane; n < Nc; n += 64) {
       s.zc[n] = z_coarse[r * Nc + n];
@@ -95,7 +95,7 @@ int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, 
                             float* z_samples, long R, int Nc, int Ni, hipStream_t stream) {
   if (R <= 0) return 0;
   if (Nc < 3 || Ni < 1) return set_error(-2, "sample_pdf_merge: need N_samples >= 3 and N_importance >= 1");
-  const size_t shmem = (size_t)(3 * Nc + 2 * Ni) * 4;
+  const size_t shmem = (size_t)(3 * ((Nc + 3) & ~3) + 2 * ((Ni + 3) & ~3)) * 4;
   if (shmem > 160 * 1024) return set_error(-2, "sample_pdf_merge: 3*N_samples + 2*N_importance exceeds LDS");
   hipError_t e = hipFuncSetAttribute((const void*)sample_pdf_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(sample_pdf_merge_kernel) failed");

@@ -28,6 +28,7 @@ struct RayScratch {
   lds_float* wc;   // [Nc] coarse weights, then reused as the cdf [Nc-1]
   lds_float* zf;   // [Ni] importance samples
   lds_float* zs;   // [Nc+Ni] merged, ascending
+  // base 16-byte aligned, caps multiples of 4 (merge_sort_wave reads zc / zf as float4)
   __device__ __forceinline__ void bind(lds_char* base, int nc_cap = MAX_NC, int ni_cap = MAX_NI) {
     zc = (lds_float*)base;
     wc = zc + nc_cap;
@@ -106,6 +107,47 @@ __device__ __forceinline__ float composite_tile(CompositeState& st, const f32x16
   return w;
 }
 
+// One 64-sample tile held as two 32-point groups (lane (p, h) owns points p and 32 + p, bf16 core): ONE 64-lane scan
+// instead of two 32-lane ones.  Lane 32h + p evaluates alpha of sample 32h + p (= its group-h point), the scan runs
+// over lanes in sample order, and the two halves swap weights at the end.  sigma / noise / zn / znext / is_last /
+// valid are indexed by group.  Returns this lane's two weights.
+struct Weights2 { float w[2]; };
+__device__ __forceinline__ Weights2 composite_tile64(CompositeState& st, const f32x16 (&feat)[2][2], const float (&sigma)[2],
+                                                     const float (&noise)[2], const float (&zn)[2], const float (&znext)[2],
+                                                     const bool (&is_last)[2], const bool (&valid)[2], int lane) {
+  const int h = lane >> 5;
+  const float sg = h ? sigma[1] : sigma[0], ns = h ? noise[1] : noise[0];
+  const float z0 = h ? zn[1] : zn[0], z1 = h ? znext[1] : znext[0];
+  const bool last = h ? is_last[1] : is_last[0], ok = h ? valid[1] : valid[0];
+  const float delta = last ? 1e2f : z1 - z0;
+  const float alpha = ok ? 1.0f - expf(-delta * fmaxf(sg + ns, 0.0f)) : 0.0f;
+  double incl = (double)(1.0f - alpha);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = shfl_up_f64(incl, d, 64);
+    if (lane >= d) incl *= o;
+  }
+  double excl = shfl_up_f64(incl, 1, 64);
+  if (lane == 0) excl = 1.0;
+  const float T = (float)(st.t_carry * excl);
+  st.t_carry *= shfl_f64(incl, 63, 64);
+  const float mine = alpha * T;
+  const float other = __shfl_xor(mine, 32);
+  Weights2 r;
+  r.w[0] = h ? other : mine;
+  r.w[1] = h ? mine : other;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      st.facc[t][k] += r.w[0] * feat[0][t][k];
+      st.facc[t][k] += r.w[1] * feat[1][t][k];
+    }
+  st.dacc += r.w[0] * zn[0];
+  st.dacc += r.w[1] * zn[1];
+  return r;
+}
+
 // Cross-lane reduction of the accumulators over the 32 point-lanes of each half; afterwards every
 // lane holds the totals (features 32t+8q+4h+j of the ray in facc[t][4q+j]).
 __device__ __forceinline__ void composite_finish(CompositeState& st) {
@@ -182,22 +224,56 @@ __device__ __forceinline__ void sample_pdf_wave(RayScratch& s, int Nc, int Ni, c
   wave_lds_fence();
 }
 
-// zs = sort(cat(zc, zf)) by rank counting (stable: coarse before fine, then by index); O(N^2/64)
-// compares per lane, negligible beside the MLP and valid for unsorted zf (perturb > 0).
+// number of entries of arr[0..n) that sort before a value v: (o < v), plus ties (o == v) at positions j < tie_below.
+// All lanes walk the same addresses (LDS broadcast), four entries per ds_read_b128 and several reads in flight --
+// the scalar one-entry-per-iteration form is bound by LDS latency (58k cycles per ray at 64+128 samples).
+__device__ __forceinline__ int count_before(const lds_float* arr, int n, float v, int tie_below) {
+  int rank = 0, j = 0;
+#pragma unroll 4
+  for (; j + 4 <= n; j += 4) {
+    const f32x4 o = *(const __attribute__((address_space(3))) f32x4*)(arr + j);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rank += (int)(o[t] < v) | ((int)(o[t] == v) & (int)(j + t < tie_below));   // branch-free
+  }
+  for (; j < n; ++j) {
+    const float o = arr[j];
+    rank += (int)(o < v) | ((int)(o == v) & (int)(j < tie_below));
+  }
+  return rank;
+}
+
+__device__ __forceinline__ bool wave_ascending(const lds_float* a, int n, int lane) {
+  bool bad = false;
+  for (int i = lane; i + 1 < n; i += 64) bad |= a[i] > a[i + 1];
+  return __ballot(bad) == 0;
+}
+// first index with a[idx] >= v (STRICT = true) / a[idx] > v (STRICT = false) in an ascending array
+template <bool STRICT>
+__device__ __forceinline__ int bound_lds(const lds_float* a, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const float o = a[mid];
+    if (STRICT ? (o < v) : (o <= v)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// zs = sort(cat(zc, zf)), stable with coarse entries before equal fine ones (what torch.sort returns for the values).
+// Both inputs ascending (always, unless the caller supplies unsorted depths / uniforms): a two-way merge by binary
+// search, rank = own index + number of entries of the OTHER array that precede -- ~8 dependent LDS reads per entry.
+// Otherwise: rank counting over all entries, O(N^2/64) compares per lane.
 __device__ __forceinline__ void merge_sort_wave(RayScratch& s, int Nc, int Ni, int lane) {
   const int N = Nc + Ni;
+  const bool sorted = wave_ascending(s.zc, Nc, lane) && wave_ascending(s.zf, Ni, lane);
   for (int e = lane; e < N; e += 64) {
     const bool is_c = e < Nc;
     const float v = is_c ? s.zc[e] : s.zf[e - Nc];
-    int rank = 0;
-    for (int j = 0; j < Nc; ++j) {
-      const float o = s.zc[j];
-      rank += (o < v) || (o == v && (!is_c || j < e));
-    }
-    for (int j = 0; j < Ni; ++j) {
-      const float o = s.zf[j];
-      rank += (o < v) || (o == v && !is_c && j < e - Nc);
-    }
+    int rank;
+    if (sorted)
+      rank = is_c ? e + bound_lds<true>(s.zf, Ni, v) : (e - Nc) + bound_lds<false>(s.zc, Nc, v);
+    else   // ties: a coarse entry precedes every equal fine entry; equal entries of one array keep their order
+      rank = count_before(s.zc, Nc, v, is_c ? e : Nc) + count_before(s.zf, Ni, v, is_c ? 0 : e - Nc);
     s.zs[rank] = v;
   }
   wave_lds_fence();

@@ -112,15 +112,22 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
         f32x16 feat[2][2];
         float sigma[2];
         mlp_tile_b(pipe, pass, pe, dv, feat, sigma, h, q, tm);
+        float noise[2];
+        bool is_last[2], valid[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const int n = tile * 64 + 32 * g + p;
-          const bool valid = n < N;
-          const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
-          const float w = composite_tile(st, feat[g], sigma[g], noise, zn[g], znext[g], n == N - 1, valid, p);
-          if (valid && h == 0) {
-            if (ray_ok) weights_row[n] = w;
-            if (pass == 0) scr.wc[n] = w;
+          valid[g] = n < N;
+          is_last[g] = n == N - 1;
+          noise[g] = (noise_row && valid[g]) ? noise_row[n] * a.noise_std : 0.0f;
+        }
+        const Weights2 w = composite_tile64(st, feat, sigma, noise, zn, znext, is_last, valid, lane);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int n = tile * 64 + 32 * g + p;
+          if (valid[g] && h == 0) {
+            if (ray_ok) weights_row[n] = w.w[g];
+            if (pass == 0) scr.wc[n] = w.w[g];
           }
         }
         tm.tick(T_COMPOSITE);
@@ -128,10 +135,13 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
       composite_finish(st);
       if (ray_ok)
         store_ray_feature(st, (pass ? a.feature_f : a.feature_c) + r * FEAT_DIM, (pass ? a.depth_f : a.depth_c) + r, p, h);
+      tm.tick(T_X5);
       if (pass == 0 && Ni > 0) {
         wave_lds_fence();
         sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane);
+        tm.tick(T_X6);
         merge_sort_wave(scr, Nc, Ni, lane);
+        tm.tick(T_X7);
         if (a.z_fine && ray_ok)
           for (int n = lane; n < Nf; n += 64) a.z_fine[r * Nf + n] = scr.zs[n];
       }

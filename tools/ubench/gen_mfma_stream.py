@@ -1,0 +1,87 @@
+"""Generates + builds a micro-benchmark of the bf16 core's k-step shape (one wave per SIMD, 4 waves per workgroup):
+  per k-step: 1 ds_read_b128 (A fragment, read 4 k-steps ahead) + 2 x v_mfma_f32_32x32x16_bf16 (two accumulators)
+  + F filler instructions of a chosen kind.  Prints shader cycles per MFMA for each variant.
+Usage (GPU box): python tools/ubench/gen_mfma_stream.py
+"""
+import os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KSTEPS = 32          # per asm block (2 "tiles" of 16)
+def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None):
+    L = []
+    acc0, acc1 = ("a[0:15]", "a[16:31]") if acc == "a" else ("v[128:143]", "v[144:159]")
+    b0, b1 = ("v[16:19]", "v[20:23]") if bsrc == "v" else ("a[64:67]", "a[68:71]")
+    fills = []
+    if fill_kind == "valu":
+        fills = ["v_add_f32 v%d, v%d, v%d" % (100 + (i % 8), 110 + (i % 8), 120 + (i % 8)) for i in range(per_kstep)]
+    elif fill_kind == "accread":
+        fills = ["v_accvgpr_read_b32 v%d, a%d" % (100 + (i % 8), 32 + (i % 16)) for i in range(per_kstep)]
+    elif fill_kind == "epi":     # realistic quarter(s): 2 accread, 2 add, cvt_pk, pk_max per 6
+        for qd in range(per_kstep // 6):
+            r = 100 + 2 * (qd % 4)
+            fills += ["v_accvgpr_read_b32 v%d, a%d" % (r, 32 + 2 * (qd % 8)), "v_accvgpr_read_b32 v%d, a%d" % (r + 1, 33 + 2 * (qd % 8)),
+                      "v_add_f32 v%d, v%d, v110" % (r, r), "v_add_f32 v%d, v%d, v111" % (r + 1, r + 1),
+                      "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r, r, r + 1), "v_pk_max_i16 v%d, v%d, 0" % (112 + qd % 4, r)]
+    elif fill_kind == "epi_v":   # same work but the accumulators being read live in VGPRs (no accvgpr_read)
+        for qd in range(per_kstep // 4):
+            r = 100 + 2 * (qd % 4)
+            fills += ["v_add_f32 v%d, v%d, v110" % (r, 160 + 2 * (qd % 8)), "v_add_f32 v%d, v%d, v111" % (r + 1, 161 + 2 * (qd % 8)),
+                      "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r, r, r + 1), "v_pk_max_i16 v%d, v%d, 0" % (112 + qd % 4, r)]
+    half = (len(fills) + 1) // 2 if first_gap is None else first_gap
+    for s in range(KSTEPS):
+        q = 4 * (s % 4)
+        if dsread:
+            L.append("s_waitcnt lgkmcnt(3)")
+        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc0, q, q + 3, b0, acc0))
+        L += fills[:half]
+        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc1, q, q + 3, b1, acc1))
+        if dsread:
+            L.append("ds_read_b128 v[%d:%d], %%0 offset:%d" % (q, q + 3, 1024 * (s % 16)))
+        L += fills[half:]
+    return "\\n\\t".join(L)
+
+VARIANTS = [
+    ("mfma only (acc AGPR)", dict(fill_kind=None, per_kstep=0, dsread=False)),
+    ("mfma only (acc VGPR)", dict(fill_kind=None, per_kstep=0, dsread=False, acc="v")),
+    ("+ ds_read", dict(fill_kind=None, per_kstep=0)),
+    ("+ ds_read, B from AGPR", dict(fill_kind=None, per_kstep=0, bsrc="a")),
+    ("+ ds_read + 6 valu/kstep", dict(fill_kind="valu", per_kstep=6)),
+    ("+ ds_read + 8 valu/kstep", dict(fill_kind="valu", per_kstep=8)),
+    ("+ ds_read + 10 valu/kstep", dict(fill_kind="valu", per_kstep=10)),
+    ("+ ds_read + 12 valu/kstep", dict(fill_kind="valu", per_kstep=12)),
+    ("+ ds_read + 6 accread/kstep", dict(fill_kind="accread", per_kstep=6)),
+    ("+ ds_read + 1 quarter (6)/kstep", dict(fill_kind="epi", per_kstep=6)),
+    ("+ ds_read + 2 quarters (12)/kstep", dict(fill_kind="epi", per_kstep=12)),
+    ("+ ds_read + 1 quarter, acc VGPR (4)/kstep", dict(fill_kind="epi_v", per_kstep=4, acc="v")),
+    ("+ ds_read + 2 quarters, acc VGPR (8)/kstep", dict(fill_kind="epi_v", per_kstep=8, acc="v")),
+    ("+ ds_read + 1 quarter all in 2nd gap", dict(fill_kind="epi", per_kstep=6, first_gap=0)),
+]
+
+clob = ", ".join('"v%d"' % i for i in range(0, 24)) + ", " + ", ".join('"v%d"' % i for i in range(100, 180)) + ", " + ", ".join('"a%d"' % i for i in range(0, 72))
+src = ['#include <hip/hip_runtime.h>', '#include <stdio.h>', 'typedef __attribute__((address_space(3))) char lds_char;']
+for k, (name, kw) in enumerate(VARIANTS):
+    src.append('''__global__ __launch_bounds__(256, 1) void k%d(unsigned long long* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned addr = (unsigned)(size_t)(lds_char*)smem + (threadIdx.x & 63) * 16;
+  for (int i = threadIdx.x; i < 4096; i += 256) ((float*)smem)[i] = 0.f;
+  __syncthreads();
+  unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("%s" ::"v"(addr) : %s, "memory");
+  }
+  asm volatile("s_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15" ::: "memory");
+  unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}''' % (k, body(**kw), clob))
+src.append('int main() { unsigned long long* d; hipMalloc(&d, 8); unsigned long long h; const int iters = 200;')
+for k, (name, kw) in enumerate(VARIANTS):
+    src.append('  hipFuncSetAttribute((const void*)k%d, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);' % k)
+    src.append('  for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(k%d, dim3(256), dim3(256), 65536, 0, d, iters); hipDeviceSynchronize(); }' % k)
+    src.append('  hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); printf("%%-46s %%6.2f cycles/MFMA\\n", "%s", (double)h / (iters * %d.0));' % (name, 2 * KSTEPS))
+src.append('  return 0; }')
+path = os.path.join(HERE, "mfma_stream_gen.hip")
+open(path, "w").write("\n".join(src))
+exe = os.path.join(HERE, "mfma_stream")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", exe, path])
+if "--build-only" not in sys.argv:
+    subprocess.check_call([exe])
