@@ -224,16 +224,27 @@ __device__ __forceinline__ uint32_t pack_pair(float v0, float v1) {
   return pk;
 }
 
-// hidden layers: accumulator registers 2hc, 2hc+1 become dword hc&3 of k-step 2T + (hc>>2) of the next layer's B operand
+// hidden layers: accumulator registers 2hc, 2hc+1 become dword hc&3 of k-step 2T + (hc>>2) of the next layer's B operand.
+// Both halves are real asm: an empty `asm volatile("" : "+v"(x))` pin right after a VALU instruction costs an s_nop
+// (hipcc's inline-asm hazard rule), i.e. two more issue slots per quarter in a gap that has none to spare.
 template <bool RELU>
 struct PackEpi : EpiTemps {
   u32x4 (&dst)[KS_HID][2];
   __device__ __forceinline__ explicit PackEpi(u32x4 (&d)[KS_HID][2]) : dst(d) {}
   __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void load(int slot, int, int qc, const f32x16& acc) { fetch(slot, qc, acc); }
+  __device__ __forceinline__ void load(int slot, int, int qc, const f32x16& acc) {
+    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3"
+                 : "=v"(t[slot][0]), "=v"(t[slot][1])
+                 : "a"(acc[2 * (qc >> 1)]), "a"(acc[2 * (qc >> 1) + 1]));
+  }
   __device__ __forceinline__ void finish(int slot, int T, int qc) {
     const int hc = qc >> 1, g = qc & 1;
-    dst[2 * T + (hc >> 2)][g][hc & 3] = pack_pair<RELU>(t[slot][0], t[slot][1]);
+    uint32_t pk;
+    if (RELU)
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(pk) : "v"(t[slot][0]), "v"(t[slot][1]));
+    else
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(t[slot][0]), "v"(t[slot][1]));
+    dst[2 * T + (hc >> 2)][g][hc & 3] = pk;
   }
 };
 
@@ -323,6 +334,7 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
       const u32x4 b1 = s < NSA ? srcA[s < NSA ? s : 0][1] : srcB[s < NSA ? 0 : s - NSA][1];
       // ---- gap 1
       accs[cur][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), s == 0 ? biasv : accs[cur][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // MFMA first, its fillers behind it (hipcc would hoist the fillers above the MFMA)
 #pragma unroll
       for (int u = 0; u < count; ++u) {
         const int qc = first + u;
@@ -333,14 +345,16 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
       __builtin_amdgcn_sched_barrier(0);   // pin the hand-made pipeline (hipcc would bunch the fillers)
       // ---- gap 2
       accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? biasv : accs[cur][1], 0, 0, 0);
-      const int pos = b_pos(i + B_AHEAD);
-      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < count; ++u) {
         const int qc = first + u;
         if (T == 0) prev.finish(u, PT, qc);
         else epi.finish(u, T - 1, qc);
       }
+      __builtin_amdgcn_sched_barrier(0);   // VALU first, then the LDS read: a VALU instruction right before the next k-step's asm pin costs an s_nop
+      const int pos = b_pos(i + B_AHEAD);
+      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
       if (s == 0) {
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);
