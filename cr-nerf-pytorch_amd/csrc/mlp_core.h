@@ -72,6 +72,16 @@ struct PhaseTimer {
 
 #define CRNERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// One LDS-DMA piece: lanes copy 16 B each, global (base + voff + imm) -> LDS (lds_addr + imm + 16 * lane).  Written as
+// asm on purpose: with the builtin, hipcc's waitcnt model stops counting LDS reads across an LDS-DMA instruction and
+// the next use of ANY prefetched fragment becomes s_waitcnt lgkmcnt(0) -- the read-ahead ring is drained every fourth
+// k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)
+__device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
+               : "memory");
+}
+
+
 // Streams packed weights into the LDS ring.  All members except pf_ptr / rd_addr are wave-uniform.
 //
 // Protocol (c = stage being consumed):  fragments of stage c AND of stage c+1 may be read (the

@@ -33,17 +33,20 @@ constexpr int U_HALF = 128 / 16;      // 8
 // Same ring protocol as WeightPipe (mlp_core.h), 8 waves x 2 pieces per stage.
 struct WeightPipe16 {
   lds_char* lds;
-  gbl_char* base[2];
-  gbl_char* pf_ptr;
+  const char* base[2];   // wave-uniform: packed streams + this wave's 2 KiB column (the lane offset rides in the VGPR-offset operand)
+  const char* pf_ptr;
   int pf_left, pf_pass, passes0, passes;
   int stages_per_pass = STAGES_PER_PASS;   // 151 forward stream, 138 transposed (backward-data) stream
-  uint32_t pf_slot, rd_slot, rd_addr, lane16, wave2k;
+  uint32_t pf_slot, rd_slot, rd_addr, lane16, wave2k, lds_ring;
   int stagger;          // 0/1: which of the two candidate slot sets this wave uses for its LDS-DMA issue
 
   __device__ __forceinline__ void issue_piece(int i) {
-    lds_char* dst = lds + LDS_RING + pf_slot * STAGE_BYTES + wave2k;
 #ifndef CRNERF_EXP_NOGLDS   // (timing experiments only)
-    __builtin_amdgcn_global_load_lds(pf_ptr + i * FRAG_BYTES, dst + i * FRAG_BYTES, 16, 0, 0);
+    // asm, not the builtin: see glds16 (mlp_core.h) -- with the builtin every fragment prefetch is drained
+    // (s_waitcnt lgkmcnt(0)) at the first use after each LDS-DMA instruction
+    const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    if (i == 0) glds16(dst, pf_ptr, lane16, 0);
+    else glds16(dst, pf_ptr, lane16, FRAG_BYTES);
 #endif
     if (i == V16_PIECES - 1) {
       pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
@@ -56,18 +59,20 @@ struct WeightPipe16 {
     }
   }
 
-  __device__ __forceinline__ void start(lds_char* lds_, gbl_char* stream0, gbl_char* stream1, int passes0_, int passes_,
+  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_,
                                         int lane, int wave) {
+    static_assert(V16_PIECES == 2, "issue_piece hard-codes the two instruction offsets");
     lds = lds_;
     lane16 = (uint32_t)lane * 16u;
     wave2k = (uint32_t)wave * (V16_PIECES * FRAG_BYTES);
+    lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + wave2k;
 #ifdef CRNERF_EXP_STAGGER_ODD
     stagger = wave & 1;
 #else
     stagger = (wave >> 2) & 1;   // waves w and w+4 of a 512-thread workgroup share a SIMD
 #endif
-    base[0] = stream0 + wave2k + lane16;
-    base[1] = stream1 + wave2k + lane16;
+    base[0] = stream0 + wave2k;
+    base[1] = stream1 + wave2k;
     passes0 = passes0_;
     passes = passes_;
     pf_pass = 0;

@@ -81,15 +81,6 @@ constexpr bool b_schedule_ok() {
 }
 static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protocol");
 
-// One LDS-DMA piece: lanes copy 16 B each, global (base + voff + imm) -> LDS (lds_addr + imm + 16 * lane).  Written as
-// asm on purpose: with the builtin, hipcc's waitcnt model stops counting LDS reads across an LDS-DMA instruction and
-// the next use of ANY prefetched fragment becomes s_waitcnt lgkmcnt(0) -- the read-ahead ring is drained every fourth
-// k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)
-__device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
-               : "memory");
-}
-
 // Weight ring for 4 waves x 4 pieces per stage; protocol documented at mlp_core.h WeightPipe.  Everything except
 // lane16 / rd_addr / nx_addr is wave-uniform (SGPRs): the stream pointers are scalar and the lane offset rides in the
 // instruction's VGPR-offset operand.  The cursor update is branch-free so the MFMA stream stays one basic block.

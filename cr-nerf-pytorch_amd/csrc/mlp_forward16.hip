@@ -15,7 +15,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16_kernel(const char* __res
 
   load_consts(lds, packed, packed);
   WeightPipe16 pipe;
-  pipe.start(lds, (gbl_char*)(packed + CONST_BYTES), (gbl_char*)(packed + CONST_BYTES), 1, 1, lane, wave);
+  pipe.start(lds, packed + CONST_BYTES, packed + CONST_BYTES, 1, 1, lane, wave);
   f32x4 q[V16_AHEAD];
   pipe.prime(q);
   PhaseTimer tm;

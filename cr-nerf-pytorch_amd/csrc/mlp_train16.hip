@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward_train16_kernel(const char*
   const int p = lane & 15, g = lane >> 4;
   load_consts(lds, packed, packed);
   WeightPipe16 pipe;
-  pipe.start(lds, (gbl_char*)(packed + CONST_BYTES), (gbl_char*)(packed + CONST_BYTES), 1, 1, lane, wave);
+  pipe.start(lds, packed + CONST_BYTES, packed + CONST_BYTES, 1, 1, lane, wave);
   f32x4 q[V16_AHEAD];
   pipe.prime(q);
   PhaseTimer tm;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
   const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
   WeightPipe16 pipe;
   pipe.stages_per_pass = STAGEST_PER_PASS;
-  pipe.start(lds, (gbl_char*)(packedT + CONST_BYTES), (gbl_char*)(packedT + CONST_BYTES), 1, 1, lane, wave);
+  pipe.start(lds, packedT + CONST_BYTES, packedT + CONST_BYTES, 1, 1, lane, wave);
   f32x4 q[V16_AHEAD];
   pipe.prime(q);
 #pragma unroll 1

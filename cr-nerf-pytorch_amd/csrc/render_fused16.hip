@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
 
   const int steps_c = (Nc + 31) >> 5, steps_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
   WeightPipe16 pipe;
-  pipe.start(lds, (gbl_char*)(a.packed0 + CONST_BYTES), (gbl_char*)(a.packed1 + CONST_BYTES), steps_c, steps_c + steps_f, lane, wave);
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, steps_c, steps_c + steps_f, lane, wave);
   f32x4 q[V16_AHEAD];
   pipe.prime(q);
   PhaseTimer tm;
