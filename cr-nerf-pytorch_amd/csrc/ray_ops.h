@@ -14,6 +14,7 @@
 // then round to fp32.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "mlp_core.h"
 
 namespace crnerf {
@@ -150,15 +151,26 @@ __device__ __forceinline__ Weights2 composite_tile64(CompositeState& st, const f
 
 // Cross-lane reduction of the accumulators over the 32 point-lanes of each half; afterwards every
 // lane holds the totals (features 32t+8q+4h+j of the ray in facc[t][4q+j]).
+// sum over the 32 lanes of each wave half, result in every lane: four DPP steps inside a 16-lane row (quad xor 1,
+// quad xor 2, half-row mirror, row mirror) and one ds_swizzle across the two rows -- no address registers and a
+// fraction of the latency of five ds_bpermute round trips per value
+__device__ __forceinline__ float half_wave_sum(float v) {
+  auto dpp_add = [](float x, auto ctrl) __attribute__((always_inline)) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+}
+
 __device__ __forceinline__ void composite_finish(CompositeState& st) {
 #pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) {
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st.facc[t][r] += __shfl_xor(st.facc[t][r], d);
-    st.dacc += __shfl_xor(st.dacc, d);
-  }
+    for (int r = 0; r < 16; ++r) st.facc[t][r] = half_wave_sum(st.facc[t][r]);
+  st.dacc = half_wave_sum(st.dacc);
 }
 
 __device__ __forceinline__ void store_ray_feature(const CompositeState& st, float* feature_row, float* depth, int p, int h) {

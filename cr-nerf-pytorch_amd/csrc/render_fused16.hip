@@ -93,18 +93,17 @@ __device__ __forceinline__ void sample_pdf_pair(PairScratch& s, int Nc, int Ni, 
 
 __device__ __forceinline__ void merge_sort_pair(PairScratch& s, int Nc, int Ni, int lane128) {
   const int N = Nc + Ni;
+  // both inputs ascending (always, unless the caller supplies unsorted depths / uniforms): two-way merge by binary
+  // search (ray_ops.h merge_sort_wave); each wave of the pair checks the whole arrays, so both take the same branch
+  const bool sorted = wave_ascending(s.zc, Nc, lane128 & 63) && wave_ascending(s.zf, Ni, lane128 & 63);
   for (int e = lane128; e < N; e += 128) {
     const bool is_c = e < Nc;
     const float v = is_c ? s.zc[e] : s.zf[e - Nc];
-    int rank = 0;
-    for (int j = 0; j < Nc; ++j) {
-      const float o = s.zc[j];
-      rank += (o < v) || (o == v && (!is_c || j < e));
-    }
-    for (int j = 0; j < Ni; ++j) {
-      const float o = s.zf[j];
-      rank += (o < v) || (o == v && !is_c && j < e - Nc);
-    }
+    int rank;
+    if (sorted)
+      rank = is_c ? e + bound_lds<true>(s.zf, Ni, v) : (e - Nc) + bound_lds<false>(s.zc, Nc, v);
+    else
+      rank = count_before(s.zc, Nc, v, is_c ? e : Nc) + count_before(s.zf, Ni, v, is_c ? 0 : e - Nc);
     s.zs[rank] = v;
   }
 }
