@@ -178,7 +178,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "render_rays_hbm_bytes.json")   # written from a rocprofv3 --pmc pass (profiles/README.md)
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch_%d_rays" % R)
+                traffic = json.load(f).get(a.precision, {}).get("hbm_bytes_per_launch_%d_rays" % R)
         line = {
             "metric": "rays/sec (64+128 samples, 8-layer W=256 MLP)", "value": world * R * a.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
