@@ -133,7 +133,8 @@ def main():
         net = style_net(Args()).to(dev)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
         rays = torch.from_numpy(rays_np).to(dev)
-        style = torch.rand(1, 64, 32, 32, generator=torch.Generator().manual_seed(0)).to(dev)
+        # the appearance encoder hands the decoder a pixel-major [1024,64] grid viewed as NCHW (zero-copy, models/linearStyleTransfer.py)
+        style = torch.rand(1024, 64, generator=torch.Generator().manual_seed(0)).to(dev).view(1, 32, 32, 64).permute(0, 3, 1, 2)
         z_steps, u_steps = torch.linspace(0, 1, NC, device=dev), torch.linspace(0, 1, NI, device=dev)  # rendering.py:160, :27
 
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

@@ -24,6 +24,7 @@ EXPORTS = [
     "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
     "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32", "crnerf_crossray_decode_sharded_f32",
     "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16",
+    "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -39,6 +40,40 @@ class RenderArgs(ctypes.Structure):
         ("n_rays", ctypes.c_int64), ("n_samples", ctypes.c_int32), ("n_importance", ctypes.c_int32),
         ("weights_coarse", _c_fp), ("feature_coarse", _c_fp), ("depth_coarse", _c_fp),
         ("weights_fine", _c_fp), ("feature_fine", _c_fp), ("depth_fine", _c_fp), ("z_fine", _c_fp),
+    ]
+
+
+class LossArgs(ctypes.Structure):
+    """struct crnerf_loss_args (include/crnerf.h)."""
+    _fields_ = [
+        ("rgb_coarse", _c_fp), ("rgb_coarse_row_stride", ctypes.c_int64), ("rgb_coarse_chan_stride", ctypes.c_int64),
+        ("rgb_fine", _c_fp), ("rgb_fine_row_stride", ctypes.c_int64), ("rgb_fine_chan_stride", ctypes.c_int64),
+        ("targets", _c_fp), ("targets_row_stride", ctypes.c_int64), ("targets_chan_stride", ctypes.c_int64),
+        ("mask", _c_fp),
+        ("a_embedded", _c_fp), ("n_a", ctypes.c_int64),
+        ("a_embedded_random", _c_fp), ("a_embedded_random_rec", _c_fp), ("n_rec", ctypes.c_int64),
+        ("content_wo", _c_fp), ("content_with", _c_fp), ("n_content", ctypes.c_int64),
+        ("n_rays", ctypes.c_int64),
+        ("mse_on_appearance", ctypes.c_int32),
+        ("coef", ctypes.c_float), ("weight_kl", ctypes.c_float), ("weight_rec_a", ctypes.c_float), ("weight_content", ctypes.c_float),
+        ("mask_size_weight", ctypes.c_float), ("mask_digit_weight", ctypes.c_float),
+    ]
+
+
+class LossGrads(ctypes.Structure):
+    """struct crnerf_loss_grads."""
+    _fields_ = [(n, _c_fp) for n in ("d_rgb_coarse", "d_rgb_fine", "d_mask", "d_a_embedded", "d_a_embedded_random_rec",
+                                     "d_content_wo", "d_content_with")]
+
+
+class BatchArgs(ctypes.Structure):
+    """struct crnerf_batch_args."""
+    _fields_ = [
+        ("all_rays", _c_fp), ("ray_stride", ctypes.c_int64), ("all_rgbs", _c_fp), ("row_offset", ctypes.c_int64),
+        ("img_w", ctypes.c_int32), ("img_h", ctypes.c_int32), ("side", ctypes.c_int32),
+        ("w_lin", _c_fp), ("h_lin", _c_fp),
+        ("scale", ctypes.c_float), ("h_offset", ctypes.c_float), ("w_offset", ctypes.c_float),
+        ("rays", _c_fp), ("ts", ctypes.c_void_p), ("rgbs", _c_fp), ("rgb_idx", ctypes.c_void_p), ("uv_sample", _c_fp),
     ]
 
 
@@ -97,6 +132,10 @@ def load():
             "crnerf_crossray_decode_backward_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, i64, vp, vp, vp, pp, vp]),
             "crnerf_crossray_decode_sharded_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, i32, vp, f64, vp, vp, i64, vp]),
             "crnerf_crossray_decode_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, vp, i64, vp]),
+            "crnerf_loss_workspace_bytes": (ctypes.c_size_t, []),
+            "crnerf_loss_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, vp, vp]),
+            "crnerf_loss_backward_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, ctypes.POINTER(LossGrads), vp]),
+            "crnerf_grid_sample_batch_f32": (ctypes.c_int, [ctypes.POINTER(BatchArgs), vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h

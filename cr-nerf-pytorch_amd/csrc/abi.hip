@@ -292,4 +292,60 @@ int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, f
   return launch_crossray_apply(x, (long)HW, affine, rgb, (long)plane_stride, (hipStream_t)stream);
 }
 
+
+static bool to_loss_args(const crnerf_loss_args* a, LossArgs& k, LossScales& sc) {
+  k.rgb_c = a->rgb_coarse; k.rgb_f = a->rgb_fine; k.tgt = a->targets; k.mask = a->mask;
+  k.a = a->a_embedded; k.a_rand = a->a_embedded_random; k.a_rec = a->a_embedded_random_rec; k.c_wo = a->content_wo; k.c_with = a->content_with;
+  k.R = (long)a->n_rays; k.n_a = a->a_embedded ? (long)a->n_a : 0; k.n_rec = a->a_embedded_random_rec ? (long)a->n_rec : 0;
+  k.n_c = a->content_wo ? (long)a->n_content : 0;
+  k.rc_sr = (long)a->rgb_coarse_row_stride; k.rc_sc = (long)a->rgb_coarse_chan_stride;
+  k.rf_sr = (long)a->rgb_fine_row_stride; k.rf_sc = (long)a->rgb_fine_chan_stride;
+  k.tg_sr = (long)a->targets_row_stride; k.tg_sc = (long)a->targets_chan_stride;
+  k.mse_a = a->mse_on_appearance;
+  const double c = a->coef, R = (double)a->n_rays;
+  sc.s[0] = k.n_a ? (float)(c * a->weight_kl / (double)k.n_a) : 0.0f;
+  sc.s[1] = k.n_rec ? (float)(c * a->weight_rec_a / (double)k.n_rec) : 0.0f;
+  sc.s[2] = (float)(c * 0.5 / (3.0 * R));
+  sc.s[3] = k.n_c ? (float)(c * a->weight_content / (double)k.n_c) : 0.0f;
+  const bool reg = a->mask && a->rgb_fine;                    // r_ms / r_md exist with rgb_fine AND out_mask only (losses.py:67-69)
+  sc.s[4] = reg ? (float)(c * a->mask_size_weight / R) : 0.0f;
+  sc.s[5] = reg ? (float)(c * a->mask_digit_weight / R) : 0.0f;
+  sc.s[6] = a->rgb_fine ? (float)(c * 0.5 / (3.0 * R)) : 0.0f;
+  return true;
+}
+
+size_t crnerf_loss_workspace_bytes(void) { return loss_workspace_bytes(); }
+
+int crnerf_loss_f32(const crnerf_loss_args* a, float* losses, void* workspace, void* stream) {
+  REQUIRE(a, "args"); REQUIRE(losses, "losses"); REQUIRE(workspace, "workspace");
+  if (a->n_rays <= 0) return set_error(CRNERF_ERR_SHAPE, "loss: n_rays must be positive");
+  REQUIRE(a->rgb_coarse, "rgb_coarse"); REQUIRE(a->targets, "targets");
+  if (a->a_embedded_random_rec && !a->a_embedded_random) return set_error(CRNERF_ERR_NULL, "loss: a_embedded_random_rec without a_embedded_random");
+  if ((a->content_wo == nullptr) != (a->content_with == nullptr)) return set_error(CRNERF_ERR_NULL, "loss: content_wo and content_with come as a pair");
+  LossArgs k; LossScales sc;
+  to_loss_args(a, k, sc);
+  return launch_loss_forward(k, sc, losses, workspace, (hipStream_t)stream);
+}
+
+int crnerf_loss_backward_f32(const crnerf_loss_args* a, const float* upstream, const crnerf_loss_grads* g, void* stream) {
+  REQUIRE(a, "args"); REQUIRE(upstream, "upstream"); REQUIRE(g, "grads");
+  if (a->n_rays <= 0) return set_error(CRNERF_ERR_SHAPE, "loss_backward: n_rays must be positive");
+  REQUIRE(a->rgb_coarse, "rgb_coarse"); REQUIRE(a->targets, "targets");
+  LossArgs k; LossScales sc;
+  to_loss_args(a, k, sc);
+  LossGrads kg{g->d_rgb_coarse, g->d_rgb_fine, g->d_mask, g->d_a_embedded, g->d_a_embedded_random_rec, g->d_content_wo, g->d_content_with};
+  return launch_loss_backward(k, sc, upstream, kg, (hipStream_t)stream);
+}
+
+int crnerf_grid_sample_batch_f32(const crnerf_batch_args* a, void* stream) {
+  REQUIRE(a, "args");
+  if (a->side <= 0) return 0;
+  REQUIRE(a->all_rays, "all_rays"); REQUIRE(a->all_rgbs, "all_rgbs"); REQUIRE(a->w_lin, "w_lin"); REQUIRE(a->h_lin, "h_lin");
+  REQUIRE(a->rays, "rays"); REQUIRE(a->ts, "ts"); REQUIRE(a->rgbs, "rgbs"); REQUIRE(a->rgb_idx, "rgb_idx"); REQUIRE(a->uv_sample, "uv_sample");
+  if (a->img_w <= 0 || a->img_h <= 0 || a->ray_stride < 9) return set_error(CRNERF_ERR_SHAPE, "grid_sample_batch: bad image size or ray_stride < 9");
+  BatchArgs k{a->all_rays, (long)a->ray_stride, a->all_rgbs, (long)a->row_offset, a->img_w, a->img_h, a->side, a->w_lin, a->h_lin,
+              a->scale, a->h_offset, a->w_offset, a->rays, (long*)a->ts, a->rgbs, (long*)a->rgb_idx, a->uv_sample};
+  return launch_grid_batch(k, (hipStream_t)stream);
+}
+
 }  // extern "C"

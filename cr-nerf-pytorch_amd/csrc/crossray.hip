@@ -136,15 +136,23 @@ __global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 31, h = lane >> 5;
 
-  // fragments: frag(v,t)[lane = 32kk + i][j] = W[32t + i][8v + 4kk + j]
-  for (int idx = tid; idx < GF_B1; idx += 256) {
-    const int frag = idx >> 8, l = (idx & 255) >> 2, j = idx & 3, i = l & 31, kk = l >> 5;
-    float val;
-    if (frag < 32) { const int v = frag >> 2, t = frag & 3; val = J.w.w1[(32 * t + i) * 64 + 8 * v + 4 * kk + j]; }
-    else if (frag < 64) { const int f = frag - 32, v = f >> 1, t = f & 1; val = J.w.w2[(32 * t + i) * 128 + 8 * v + 4 * kk + j]; }
-    else { const int v = frag - 64; val = J.w.w3[i * 64 + 8 * v + 4 * kk + j]; }
-    sm[idx] = val;
+  // fragments: frag(v,t)[lane = 32kk + i][j] = W[32t + i][8v + 4kk + j]; the four j are contiguous in W, so one 16-byte
+  // load per lane-slot, all 18 of a thread in flight at once (one element per loop iteration was 36 us of serialized
+  // global-load latency -- as long as the render kernel of a 32x32 bf16 batch)
+  static_assert(GF_B1 == 72 * 256, "fragment area");
+  f32x4 stage[18];
+#pragma unroll
+  for (int it = 0; it < 18; ++it) {
+    const int idx4 = tid + 256 * it;
+    const int frag = idx4 >> 6, l = idx4 & 63, i = l & 31, kk = l >> 5;
+    const float* src;
+    if (frag < 32) { const int v = frag >> 2, t = frag & 3; src = J.w.w1 + (32 * t + i) * 64 + 8 * v + 4 * kk; }
+    else if (frag < 64) { const int f = frag - 32, v = f >> 1, t = f & 1; src = J.w.w2 + (32 * t + i) * 128 + 8 * v + 4 * kk; }
+    else { const int v = frag - 64; src = J.w.w3 + i * 64 + 8 * v + 4 * kk; }
+    stage[it] = *(const f32x4*)src;
   }
+#pragma unroll
+  for (int it = 0; it < 18; ++it) *(f32x4*)(sm + 4 * (tid + 256 * it)) = stage[it];
   if (tid < 128) sm[GF_B1 + tid] = J.w.b1[tid];
   if (tid < 64) {
     sm[GF_B2 + tid] = J.w.b2[tid];
@@ -271,40 +279,47 @@ int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_
   return check_launch("crossray_matrix");
 }
 
-// ---------------------------------------------------------------- fold: A[3][64], v[3]  (single 64-thread block)
-__global__ __launch_bounds__(64) void fold_kernel(const float* __restrict__ sM, const float* __restrict__ cM, const float* __restrict__ c_mean,
-                                                  const float* __restrict__ s_mean, FoldTensors w, float* __restrict__ affine) {
-  __shared__ float T[32][33], U[3][32], P[3][64], Q[3][32];
+// ---------------------------------------------------------------- fold: A[3][64], v[3]  (single 256-thread block)
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ sM, const float* __restrict__ cM, const float* __restrict__ c_mean,
+                                                   const float* __restrict__ s_mean, FoldTensors w, float* __restrict__ affine) {
+  __shared__ float S[32][33], Cm[32][33], T[32][33], U[3][32], P[3][64], Q[3][32];
   const int t = threadIdx.x;
   if (sM) {
+    // operands into LDS first (coalesced); the weight-only product U = Wrgb @ Wunzip (3x32) rides along
+    for (int e = t; e < 1024; e += 256) {
+      S[e >> 5][e & 31] = sM[e];
+      Cm[e >> 5][e & 31] = cM[e];
+    }
+    if (t < 96) {
+      const int r = t >> 5, c = t & 31;
+      float a = 0.0f;
+      for (int k = 0; k < 64; ++k) a = fmaf(w.rgb_w[r * 64 + k], w.unzip_w[k * 32 + c], a);
+      U[r][c] = a;
+    }
+    __syncthreads();
     // T = sMatrix @ cMatrix                                   linearStyleTransfer.py:86
-    for (int e = t; e < 1024; e += 64) {
+    for (int e = t; e < 1024; e += 256) {
       const int i = e >> 5, j = e & 31;
       float a = 0.0f;
-      for (int k = 0; k < 32; ++k) a = fmaf(sM[i * 32 + k], cM[k * 32 + j], a);
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) a = fmaf(S[i][k], Cm[k][j], a);
       T[i][j] = a;
     }
     __syncthreads();
-    // U = Wrgb @ Wunzip (3x32), Q = U @ T (3x32), A = Q @ Wcomp (3x64)
-    if (t < 32)
-      for (int r = 0; r < 3; ++r) {
-        float a = 0.0f;
-        for (int k = 0; k < 64; ++k) a = fmaf(w.rgb_w[r * 64 + k], w.unzip_w[k * 32 + t], a);
-        U[r][t] = a;
-      }
-    __syncthreads();
-    if (t < 32)
-      for (int r = 0; r < 3; ++r) {
-        float a = 0.0f;
-        for (int k = 0; k < 32; ++k) a = fmaf(U[r][k], T[k][t], a);
-        Q[r][t] = a;
-      }
-    __syncthreads();
-    for (int r = 0; r < 3; ++r) {
+    // Q = U @ T (3x32), A = Q @ Wcomp (3x64)
+    if (t < 96) {
+      const int r = t >> 5, c = t & 31;
       float a = 0.0f;
-      for (int k = 0; k < 32; ++k) a = fmaf(Q[r][k], w.comp_w[k * 64 + t], a);
-      P[r][t] = a;
-      affine[r * 64 + t] = a;
+      for (int k = 0; k < 32; ++k) a = fmaf(U[r][k], T[k][c], a);
+      Q[r][c] = a;
+    }
+    __syncthreads();
+    if (t < 192) {
+      const int r = t >> 6, c = t & 63;
+      float a = 0.0f;
+      for (int k = 0; k < 32; ++k) a = fmaf(Q[r][k], w.comp_w[k * 64 + c], a);
+      P[r][c] = a;
+      affine[r * 64 + c] = a;
     }
     __syncthreads();
     // v = Q (bcomp) - A cMean + Wrgb (bunzip + sMean) + brgb
@@ -317,14 +332,14 @@ __global__ __launch_bounds__(64) void fold_kernel(const float* __restrict__ sM, 
     }
   } else {
     // type == "content": decoder only                          linearStyleTransfer.py:285-287
-    for (int r = 0; r < 3; ++r) affine[r * 64 + t] = w.rgb_w[r * 64 + t];
+    if (t < 192) affine[t] = w.rgb_w[t];
     if (t < 3) affine[192 + t] = w.rgb_b[t];
   }
 }
 
 int launch_crossray_fold(const float* sM, const float* cM, const float* c_mean, const float* s_mean, const FoldTensors& w,
                          float* affine, hipStream_t stream) {
-  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, stream, sM, cM, c_mean, s_mean, w, affine);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, sM, cM, c_mean, s_mean, w, affine);
   return check_launch("crossray_fold");
 }
 
@@ -400,7 +415,7 @@ int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
   FcJob f0{st + ST_CGRAM, (float)(1.0 / (double)d.HW), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
   FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
   hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
-  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
   if (int rc = check_launch("crossray_decode")) return rc;
   return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
 }
@@ -444,7 +459,7 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
   FcJob f0{xchg + 64, (float)(1.0 / count_global), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
   FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
   hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
-  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
   if (int rc = check_launch("crossray_decode_sharded phase 2")) return rc;
   return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
 }

@@ -73,4 +73,27 @@ int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);
 
+
+// ---- training-side neighbours (train_aux.hip)
+struct LossArgs {
+  const float* rgb_c; const float* rgb_f; const float* tgt; const float* mask;   // [R,3] strided, [R,3] or null, [R,3], [R] or null
+  const float* a; const float* a_rand; const float* a_rec; const float* c_wo; const float* c_with;
+  long R, n_a, n_rec, n_c;
+  long rc_sr, rc_sc, rf_sr, rf_sc, tg_sr, tg_sc;   // element strides (row, channel)
+  int mse_a;
+};
+struct LossScales { float s[7]; };                 // loss_k = s[k] * sum_k
+struct LossGrads { float *d_rgb_c, *d_rgb_f, *d_mask, *d_a, *d_a_rec, *d_c_wo, *d_c_with; };   // contiguous, any may be null
+size_t loss_workspace_bytes();
+int launch_loss_forward(const LossArgs& a, const LossScales& sc, float* losses, void* workspace, hipStream_t stream);
+int launch_loss_backward(const LossArgs& a, const LossScales& sc, const float* upstream, const LossGrads& g, hipStream_t stream);
+struct BatchArgs {
+  const float* all_rays; long ray_stride; const float* all_rgbs; long row_offset;
+  int img_w, img_h, side;
+  const float* w_lin; const float* h_lin;          // [side] linspace tables (host-built like the reference's)
+  float scale, h_offset, w_offset;
+  float* rays; long* ts; float* rgbs; long* rgb_idx; float* uv;
+};
+int launch_grid_batch(const BatchArgs& a, hipStream_t stream);
+
 }  // namespace crnerf

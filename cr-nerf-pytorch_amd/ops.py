@@ -339,3 +339,105 @@ def crossray_decode_sharded(content_pm, style_pm, weights, phase, xchg, count_gl
                                                       rgb.stride(0) if (rgb is not None and n) else 0, _lib.stream_ptr()),
                "crnerf_crossray_decode_sharded_f32")
     return rgb
+
+
+# ---------------------------------------------------------------- training-side neighbours
+LOSS_KEYS = ("kl_a", "rec_a_random", "c_l", "content_constraint", "r_ms", "r_md", "f_l")
+
+
+def _rgb2d(t, name):
+    if t.dim() != 2 or t.shape[1] != 3:
+        raise ValueError("crnerf_amd: %s must be [R,3], got %s" % (name, tuple(t.shape)))
+    if not t.is_cuda:
+        raise RuntimeError("crnerf_amd: %s is on %s; the HIP path needs GPU tensors and has no CPU fallback" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("crnerf_amd: %s must be float32" % name)
+    return t
+
+
+def loss_args(rgb_coarse, targets, rgb_fine=None, mask=None, a_embedded=None, a_embedded_random=None, a_embedded_random_rec=None,
+              content_wo=None, content_with=None, mse_on_appearance=False, coef=1.0, weight_kl=0.0, weight_rec_a=0.0,
+              weight_content=0.0, mask_size_weight=0.0, mask_digit_weight=0.0):
+    """Fill struct crnerf_loss_args.  rgb tensors may be any strided [R,3] view (e.g. the decoder's planar output
+    rearranged the reference's way); everything else is made contiguous.  Returns (struct, keep-alive list)."""
+    a = _lib.LossArgs()
+    keep = []
+    R = rgb_coarse.shape[0]
+    for name, t in (("rgb_coarse", rgb_coarse), ("rgb_fine", rgb_fine), ("targets", targets)):
+        if t is None:
+            setattr(a, name, None)
+            continue
+        t = _rgb2d(t.detach(), name)
+        if t.shape[0] != R:
+            raise ValueError("crnerf_amd: %s has %d rows, rgb_coarse %d" % (name, t.shape[0], R))
+        keep.append(t)
+        setattr(a, name, t.data_ptr())
+        setattr(a, name + "_row_stride", t.stride(0))
+        setattr(a, name + "_chan_stride", t.stride(1))
+    flat = lambda t, n: None if t is None else _f32c(t.detach(), n).reshape(-1)  # noqa: E731
+    m, ae, ar, arr, cw, cwi = (flat(t, n) for t, n in ((mask, "out_mask"), (a_embedded, "a_embedded"), (a_embedded_random, "a_embedded_random"),
+                                                        (a_embedded_random_rec, "a_embedded_random_rec"), (content_wo, "content_wo_a_embed"),
+                                                        (content_with, "content_with_a_embed")))
+    if m is not None and m.numel() != R:
+        raise ValueError("crnerf_amd: out_mask must have one value per ray")
+    if arr is not None and (ar is None or ar.numel() != arr.numel()):
+        raise ValueError("crnerf_amd: a_embedded_random and a_embedded_random_rec must have the same size")
+    if (cw is None) != (cwi is None) or (cw is not None and cw.numel() != cwi.numel()):
+        raise ValueError("crnerf_amd: content_wo_a_embed and content_with_a_embed come as a same-sized pair")
+    keep += [t for t in (m, ae, ar, arr, cw, cwi) if t is not None]
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    a.mask, a.a_embedded, a.a_embedded_random, a.a_embedded_random_rec, a.content_wo, a.content_with = p(m), p(ae), p(ar), p(arr), p(cw), p(cwi)
+    a.n_a = ae.numel() if ae is not None else 0
+    a.n_rec = arr.numel() if arr is not None else 0
+    a.n_content = cw.numel() if cw is not None else 0
+    a.n_rays = R
+    a.mse_on_appearance = int(bool(mse_on_appearance))
+    a.coef, a.weight_kl, a.weight_rec_a, a.weight_content = float(coef), float(weight_kl), float(weight_rec_a), float(weight_content)
+    a.mask_size_weight, a.mask_digit_weight = float(mask_size_weight), float(mask_digit_weight)
+    return a, keep
+
+
+_loss_ws = {}
+
+
+def loss_forward(args):
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if dev not in _loss_ws:
+        _loss_ws[dev] = torch.empty(lib.crnerf_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
+    losses = torch.empty(7, dtype=torch.float32, device=dev)
+    _lib.check(lib.crnerf_loss_f32(ctypes.byref(args), _lib.dev_ptr(losses), ctypes.c_void_p(_loss_ws[dev].data_ptr()), _lib.stream_ptr()),
+               "crnerf_loss_f32")
+    return losses
+
+
+def loss_backward(args, upstream, want):
+    """want: dict name -> shape of the gradients to produce (names of struct crnerf_loss_grads without the d_ prefix)."""
+    lib = _lib.load()
+    g = _lib.LossGrads()
+    out = {}
+    for name, shape in want.items():
+        out[name] = torch.empty(shape, dtype=torch.float32, device=upstream.device)
+        setattr(g, "d_" + name, out[name].data_ptr())
+    _lib.check(lib.crnerf_loss_backward_f32(ctypes.byref(args), _lib.dev_ptr(_f32c(upstream, "upstream")), ctypes.byref(g), _lib.stream_ptr()),
+               "crnerf_loss_backward_f32")
+    return out
+
+
+def grid_sample_batch(all_rays, all_rgbs, row_offset, img_w, img_h, side, w_lin, h_lin, scale, h_offset, w_offset):
+    lib = _lib.load()
+    all_rays, all_rgbs = _f32c(all_rays, "all_rays"), _f32c(all_rgbs, "all_rgbs")
+    if all_rays.dim() != 2 or all_rays.shape[1] < 9 or all_rgbs.dim() != 2 or all_rgbs.shape[1] != 3:
+        raise ValueError("crnerf_amd: all_rays must be [N,>=9] and all_rgbs [N,3]")
+    w_lin, h_lin = _f32c(w_lin, "w_lin"), _f32c(h_lin, "h_lin")
+    dev, n = all_rays.device, side * side
+    out = {"rays": torch.empty(n, 8, device=dev), "ts": torch.empty(n, dtype=torch.int64, device=dev), "rgbs": torch.empty(n, 3, device=dev),
+           "rgb_idx": torch.empty(n, dtype=torch.int64, device=dev), "uv_sample": torch.empty(n, 2, device=dev)}
+    a = _lib.BatchArgs()
+    a.all_rays, a.ray_stride, a.all_rgbs, a.row_offset = all_rays.data_ptr(), all_rays.stride(0), all_rgbs.data_ptr(), int(row_offset)
+    a.img_w, a.img_h, a.side = int(img_w), int(img_h), int(side)
+    a.w_lin, a.h_lin = w_lin.data_ptr(), h_lin.data_ptr()
+    a.scale, a.h_offset, a.w_offset = float(scale), float(h_offset), float(w_offset)
+    a.rays, a.ts, a.rgbs, a.rgb_idx, a.uv_sample = (out[k].data_ptr() for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"))
+    _lib.check(lib.crnerf_grid_sample_batch_f32(ctypes.byref(a), _lib.stream_ptr()), "crnerf_grid_sample_batch_f32")
+    return out

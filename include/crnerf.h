@@ -196,6 +196,51 @@ int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const 
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
                               void* stream);
 
+/* ---- training-side neighbours of the path ------------------------------------------------------
+ * CRNeRFLoss.forward, losses.py:49-78 (mask_regularize :80-91, _l2_regularize :93-96).  The seven terms, in the
+ * order losses[0..6] = kl_a, rec_a_random, c_l, content_constraint, r_ms, r_md, f_l; a term whose inputs are absent
+ * (NULL pointers) is 0 and must be left out of the dict by the caller, as the reference does.  rgb tensors are [R,3]
+ * with explicit element strides (row, channel), so the decoder's planar [3,R] output is consumed in place.
+ * mask: out_mask[R] (it is .detach()-ed inside c_l only, losses.py:63 vs :70). */
+typedef struct crnerf_loss_args {
+  const float* rgb_coarse; int64_t rgb_coarse_row_stride, rgb_coarse_chan_stride;
+  const float* rgb_fine;   int64_t rgb_fine_row_stride, rgb_fine_chan_stride;      /* NULL: no 'rgb_fine' */
+  const float* targets;    int64_t targets_row_stride, targets_chan_stride;
+  const float* mask;                                                               /* NULL: no 'out_mask' */
+  const float* a_embedded; int64_t n_a;                                            /* NULL: no 'a_embedded' */
+  const float* a_embedded_random; const float* a_embedded_random_rec; int64_t n_rec;
+  const float* content_wo; const float* content_with; int64_t n_content;
+  int64_t n_rays;
+  int32_t mse_on_appearance;
+  float coef, weight_kl, weight_rec_a, weight_content;   /* CRNeRFLoss.coef, hparams.weightKL / weightRecA / weightcontent */
+  float mask_size_weight;                                 /* ExponentialAnnealingWeight.getWeight(global_step), losses.py:38-39 */
+  float mask_digit_weight;                                /* hparams.maskrd */
+} crnerf_loss_args;
+typedef struct crnerf_loss_grads {                        /* contiguous outputs; any may be NULL */
+  float* d_rgb_coarse; float* d_rgb_fine; float* d_mask;  /* [R,3] [R,3] [R] */
+  float* d_a_embedded; float* d_a_embedded_random_rec; float* d_content_wo; float* d_content_with;
+} crnerf_loss_grads;
+#define CRNERF_LOSS_TERMS 7
+size_t crnerf_loss_workspace_bytes(void);
+int crnerf_loss_f32(const crnerf_loss_args* args, float* losses, void* workspace, void* stream);
+/* upstream[7] (device): d total / d losses[k] -- what autograd hands back for the seven scalars */
+int crnerf_loss_backward_f32(const crnerf_loss_args* args, const float* upstream, const crnerf_loss_grads* grads, void* stream);
+
+/* Grid-sample batcher: PhototourismDataset.__getitem__ (train), datasets/phototourism_mask_grid_sample.py:241-275.
+ * Cuts a side x side lattice batch out of image `row_offset / (w*h)` of the flat, HBM-resident buffers all_rays[N,
+ * ray_stride >= 9] (o, d, near, far, image id) and all_rgbs[N,3].  w_lin / h_lin: the reference's two linspace
+ * tables (torch.linspace(0, 1-1/w, side), :249-250); scale / offsets: its three uniform draws (:255-257), made by the
+ * host so that the RNG stream is the reference's.  Outputs: rays[side^2,8], ts[side^2] (int64), rgbs[side^2,3],
+ * rgb_idx[side^2] (int64, pixel index inside the image), uv_sample[side^2,2] = (h, w) lattice coordinates. */
+typedef struct crnerf_batch_args {
+  const float* all_rays; int64_t ray_stride; const float* all_rgbs; int64_t row_offset;
+  int32_t img_w, img_h, side;
+  const float* w_lin; const float* h_lin;
+  float scale, h_offset, w_offset;
+  float* rays; int64_t* ts; float* rgbs; int64_t* rgb_idx; float* uv_sample;
+} crnerf_batch_args;
+int crnerf_grid_sample_batch_f32(const crnerf_batch_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,6 +229,72 @@ def generate_rays(H, W, K, c2w, near=0.0, far=5.0):
     return dirs, torch.cat((o, d, torch.full_like(d[:, :1], near), torch.full_like(d[:, :1], far)), 1)
 
 
+# ------------------------------------------------------------------ losses.py, datasets/phototourism_mask_grid_sample.py
+LOSS_KEYS = ("kl_a", "rec_a_random", "c_l", "content_constraint", "r_ms", "r_md", "f_l")
+
+
+def annealing_weight(step, vmax, vmin, k):
+    """ExponentialAnnealingWeight.getWeight, losses.py:30-39."""
+    return max(vmin, vmax * math.exp(-step * k))
+
+
+def crnerf_loss(inputs, targets, hp, global_step, coef=1.0):
+    """CRNeRFLoss.forward, losses.py:49-78 (+ mask_regularize :80-91, _l2_regularize :93-96).  inputs: dict of tensors
+    with the reference's keys; hp: object with maskrs_max/min/k, maskrd, weightKL, weightRecA, weightcontent,
+    mse_on_appearance.  Returns (dict in the reference's insertion order, annealing weight)."""
+    ret = {}
+    ann = annealing_weight(global_step, hp.maskrs_max, hp.maskrs_min, hp.maskrs_k)
+    if "a_embedded" in inputs:
+        ret["kl_a"] = (inputs["a_embedded"] ** 2).mean() * hp.weightKL
+        if "a_embedded_random_rec" in inputs:
+            d = inputs["a_embedded_random"].detach() - inputs["a_embedded_random_rec"]
+            ret["rec_a_random"] = ((d ** 2).mean() if hp.mse_on_appearance else d.abs().mean()) * hp.weightRecA
+    if "out_mask" in inputs:
+        mask = inputs["out_mask"]
+        ret["c_l"] = 0.5 * ((1 - mask.detach()) * (inputs["rgb_coarse"] - targets) ** 2).mean()
+    else:
+        ret["c_l"] = 0.5 * ((inputs["rgb_coarse"] - targets) ** 2).mean()
+    if "content_wo_a_embed" in inputs and "content_with_a_embed" in inputs:
+        ret["content_constraint"] = ((inputs["content_wo_a_embed"] - inputs["content_with_a_embed"]) ** 2).mean() * hp.weightcontent
+    if "rgb_fine" in inputs:
+        if "out_mask" in inputs:
+            ret["r_ms"] = (mask ** 2).mean() * ann
+            ret["r_md"] = (1 / ((mask - 0.5) ** 2 + 0.02)).mean() * hp.maskrd
+            ret["f_l"] = 0.5 * ((1 - mask) * (inputs["rgb_fine"] - targets) ** 2).mean()
+        else:
+            ret["f_l"] = 0.5 * ((inputs["rgb_fine"] - targets) ** 2).mean()
+    return {k: coef * v for k, v in ret.items()}, ann
+
+
+def grid_sample_indices(img_w, img_h, side, scale, h_offset, w_offset):
+    """The index arithmetic of PhototourismDataset.__getitem__ (train), phototourism_mask_grid_sample.py:247-262:
+    a side x side lattice over [0, 1-1/w) x [0, 1-1/h), shrunk by `scale` and shifted, floor-ed to pixels.
+    scale / offsets are the three torch.Tensor(1).uniform_ draws (fp32).  Returns (img_sample_points int64 [side^2],
+    uv_sample fp32 [side^2, 2])."""
+    # img_w / img_h are elements of the int64 tensor all_imgs_wh in the reference, so 1 - 1/img_w is an fp32 TENSOR
+    # expression (not Python double arithmetic) -- the lattice end points carry that rounding
+    img_w, img_h = torch.as_tensor(img_w, dtype=torch.int64), torch.as_tensor(img_h, dtype=torch.int64)
+    w_lin = torch.linspace(0, 1 - 1 / img_w, side)
+    h_lin = torch.linspace(0, 1 - 1 / img_h, side)
+    w_samples, h_samples = torch.meshgrid([w_lin, h_lin], indexing="ij")
+    scale, h_offset, w_offset = (torch.as_tensor(v, dtype=torch.float32).reshape(1) for v in (scale, h_offset, w_offset))
+    h_sb = h_samples * scale + h_offset
+    w_sb = w_samples * scale + w_offset
+    h = (h_sb * img_h).floor()
+    w = (w_sb * img_w).floor()
+    pts = (w + h * img_w).permute(1, 0).contiguous().view(-1).long()
+    uv = torch.cat((h_sb.permute(1, 0).contiguous().view(-1, 1), w_sb.permute(1, 0).contiguous().view(-1, 1)), -1)
+    return pts, uv
+
+
+def grid_sample_batch(all_rays, all_rgbs, wh, sample_ts, side, scale, h_offset, w_offset):
+    """The gathers of the same method, :264-275: rows of the flat ray / rgb buffers at image `sample_ts`."""
+    img_w, img_h = int(wh[sample_ts][0]), int(wh[sample_ts][1])
+    pts, uv = grid_sample_indices(img_w, img_h, side, scale, h_offset, w_offset)
+    rows = pts + int((wh[:sample_ts, 0] * wh[:sample_ts, 1]).sum())
+    return {"rays": all_rays[rows, :8], "ts": all_rays[rows, 8].long(), "rgbs": all_rgbs[rows], "rgb_idx": pts, "uv_sample": uv}
+
+
 def psnr(a, b):
     """metrics.py:12-13."""
     return -10.0 * math.log10(float(((a - b) ** 2).mean()))

@@ -1,0 +1,99 @@
+"""GPU parity of the training-side neighbours: the fused CRNeRF loss (value and gradient) against the
+reference's own outputs and autograd gradients (golden g10), and the grid-sample batcher against the reference's
+__getitem__ (golden g11, bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from crnerf_amd.losses import ColorLoss, CRNeRFLoss, loss_dict
+from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class HP:
+    maskrs_max, maskrs_min, maskrs_k, maskrd = 5e-2, 6e-3, 1e-3, 1e-3
+    weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
+
+
+def _inputs(g, tag, planar=False):
+    t = lambda k: torch.from_numpy(g[tag + "__" + k]).to(DEV).requires_grad_(True)  # noqa: E731
+    keys = list(g[tag + "__keys"])
+    leaves = {"rgb_coarse": t("rgb_coarse"), "a_embedded": t("a"), "a_embedded_random_rec": t("a_rand_rec"), "content_wo_a_embed": t("c_wo"),
+              "content_with_a_embed": t("c_with")}
+    if "f_l" in keys:
+        leaves["rgb_fine"] = t("rgb_fine")
+    if tag in ("full", "mse_a"):
+        leaves["out_mask"] = t("mask")
+    inputs = dict(leaves)
+    inputs["a_embedded_random"] = torch.from_numpy(g[tag + "__a_rand"]).to(DEV)
+    if planar:   # the decoder's planar [3,R] output rearranged the reference's way ('1 n h w -> (h w) n'): a strided view
+        for k in ("rgb_coarse", "rgb_fine"):
+            if k in inputs:
+                inputs[k] = leaves[k].t().contiguous().t()
+                assert not inputs[k].is_contiguous()
+    return leaves, inputs, torch.from_numpy(g[tag + "__targets"]).to(DEV), keys
+
+
+@pytest.mark.parametrize("planar", [False, True])
+@pytest.mark.parametrize("tag", ["full", "mse_a", "nomask", "coarse_only"])
+def test_crnerf_loss_value_and_gradient_vs_reference(golden, tag, planar):
+    g = golden("g10_loss")
+    hp = HP()
+    hp.mse_on_appearance = tag == "mse_a"
+    leaves, inputs, targets, keys = _inputs(g, tag, planar)
+    crit = loss_dict['crnerf'](hp, coef=1)
+    ret, ann = crit(inputs, targets, hp, int(g[tag + "__step"]))
+    assert list(ret.keys()) == keys                                    # same keys, same insertion order as the reference
+    assert abs(ann - float(g[tag + "__ann"])) < 1e-12
+    for k in keys:
+        want = float(g[tag + "__loss_" + k])
+        assert abs(float(ret[k]) - want) <= 2e-6 * abs(want) + 1e-12, (k, float(ret[k]), want)   # fp32 sums in another order
+    sum(l for l in ret.values()).backward()                            # train_mask_grid_sample.py:285
+    for name, key in (("rgb_coarse", "d_rgb_coarse"), ("rgb_fine", "d_rgb_fine"), ("out_mask", "d_mask"), ("a_embedded", "d_a"),
+                      ("a_embedded_random_rec", "d_a_rand_rec"), ("content_wo_a_embed", "d_c_wo"), ("content_with_a_embed", "d_c_with")):
+        if name in leaves:
+            got = leaves[name].grad
+            want = g[tag + "__" + key]
+            if got is None:
+                assert not want.any(), name
+            else:
+                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-10, err_msg=name)   # d_mask sums three terms of either sign
+
+
+def test_loss_upstream_weights_and_color_loss():
+    """backward honours arbitrary upstream gradients per term (not only the plain sum), and ColorLoss is the same kernel."""
+    gen = torch.Generator().manual_seed(1)
+    R = 1000
+    rc, rf = (torch.rand(R, 3, generator=gen).to(DEV).requires_grad_() for _ in range(2))
+    tg, mask = torch.rand(R, 3, generator=gen).to(DEV), torch.rand(R, 1, generator=gen).to(DEV).requires_grad_()
+    hp = HP()
+    ret, _ = CRNeRFLoss(hp)({"rgb_coarse": rc, "rgb_fine": rf, "out_mask": mask}, tg, hp, 10)
+    (3.0 * ret["c_l"] + 0.5 * ret["f_l"] - 2.0 * ret["r_ms"] + 7.0 * ret["r_md"]).backward()
+    rc2, rf2, m2 = (t.detach().cpu().double().requires_grad_() for t in (rc, rf, mask))
+    t2 = tg.cpu().double()
+    ann = max(hp.maskrs_min, hp.maskrs_max * np.exp(-10 * hp.maskrs_k))
+    ref = (3.0 * 0.5 * ((1 - m2.detach()) * (rc2 - t2) ** 2).mean() + 0.5 * 0.5 * ((1 - m2) * (rf2 - t2) ** 2).mean()
+           - 2.0 * (m2 ** 2).mean() * ann + 7.0 * (1 / ((m2 - 0.5) ** 2 + 0.02)).mean() * hp.maskrd)
+    ref.backward()
+    for a, b in ((rc, rc2), (rf, rf2), (mask, m2)):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-5, atol=1e-10)
+    col = loss_dict['color'](coef=1)({"rgb_coarse": rc.detach(), "rgb_fine": rf.detach()}, tg)
+    want = ((rc.detach() - tg) ** 2).mean() + ((rf.detach() - tg) ** 2).mean()
+    assert abs(float(col) - float(want)) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_grid_sample_batcher_vs_reference(golden, tag):
+    g = golden("g11_batcher")
+    v = lambda k: g[tag + "__" + k]  # noqa: E731
+    b = GridSampleBatcher(torch.from_numpy(g["all_rays"]).to(DEV), torch.from_numpy(g["all_rgbs"]).to(DEV), g["wh"], batch_size=int(v("batch")),
+                          scale_anneal=float(v("anneal")), min_scale=float(v("min_scale")))
+    b.iterations = int(v("iterations"))
+    torch.manual_seed(int(v("torch_seed")))
+    s = b.__getitem__(int(v("idx")), current_epoch=int(v("epoch")))
+    assert s["min_scale_cur"] == float(v("min_scale_cur")) and list(s["img_wh"]) == list(v("img_wh"))
+    for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"):
+        assert np.array_equal(s[k].cpu().numpy(), v(k)), k            # a gather and fp32 index arithmetic: bit-exact
+        assert s[k].dtype == (torch.int64 if k in ("ts", "rgb_idx") else torch.float32)

@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/cpu_ref.py) against the golden vectors produced by the reference itself
 (tests/golden/make_golden.py).  This is what pins the oracle -- SURVEY 8c."""
 import numpy as np
+import pytest
 import torch
 
 import crnerf_amd.synth as synth
@@ -100,3 +101,56 @@ def test_g9_encoder(golden):
     d = O.to_torch(st)
     for tag in ("a", "b"):
         torch.testing.assert_close(O.encoder_forward(d, T(g["img_" + tag])), T(g["feat_" + tag]), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ loss and grid-sample batcher
+class _HP:
+    maskrs_max, maskrs_min, maskrs_k, maskrd = 5e-2, 6e-3, 1e-3, 1e-3
+    weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
+
+
+def _loss_inputs(g, tag, grad=False):
+    t = lambda k: torch.from_numpy(g[tag + "__" + k]).clone().requires_grad_(grad)  # noqa: E731
+    keys = list(g[tag + "__keys"])
+    inputs = {"rgb_coarse": t("rgb_coarse"), "a_embedded": t("a"), "a_embedded_random": torch.from_numpy(g[tag + "__a_rand"]),
+              "a_embedded_random_rec": t("a_rand_rec"), "content_wo_a_embed": t("c_wo"), "content_with_a_embed": t("c_with")}
+    if "f_l" in keys:
+        inputs["rgb_fine"] = t("rgb_fine")
+    if "r_ms" in keys or tag in ("full", "mse_a"):
+        inputs["out_mask"] = t("mask")
+    return inputs, torch.from_numpy(g[tag + "__targets"]), keys
+
+
+@pytest.mark.parametrize("tag", ["full", "mse_a", "nomask", "coarse_only"])
+def test_oracle_loss_matches_reference(golden, tag):
+    g = golden("g10_loss")
+    hp = _HP()
+    hp.mse_on_appearance = tag == "mse_a"
+    inputs, targets, keys = _loss_inputs(g, tag, grad=True)
+    ret, ann = O.crnerf_loss(inputs, targets, hp, int(g[tag + "__step"]))
+    assert list(ret.keys()) == keys and abs(ann - float(g[tag + "__ann"])) < 1e-12
+    for k in keys:
+        assert abs(float(ret[k]) - float(g[tag + "__loss_" + k])) <= 1e-7 * max(1.0, abs(float(g[tag + "__loss_" + k]))), k
+    sum(ret.values()).backward()
+    for name, key in (("rgb_coarse", "d_rgb_coarse"), ("rgb_fine", "d_rgb_fine"), ("out_mask", "d_mask"), ("a_embedded", "d_a"),
+                      ("a_embedded_random_rec", "d_a_rand_rec"), ("content_wo_a_embed", "d_c_wo"), ("content_with_a_embed", "d_c_with")):
+        if name in inputs and inputs[name].grad is not None:
+            np.testing.assert_allclose(inputs[name].grad.numpy(), g[tag + "__" + key], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_batcher_draws_and_oracle_gather_match_reference(golden, tag):
+    """The product's host-side draws (GridSampleBatcher.draw: numpy seed per (epoch, idx), torch's CPU generator) fed to
+    the oracle's index arithmetic reproduce the reference's own __getitem__ bit for bit."""
+    from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
+    g = golden("g11_batcher")
+    v = lambda k: g[tag + "__" + k]  # noqa: E731
+    rays, rgbs, wh = torch.from_numpy(g["all_rays"]), torch.from_numpy(g["all_rgbs"]), torch.from_numpy(g["wh"])
+    b = GridSampleBatcher(rays, rgbs, wh, batch_size=int(v("batch")), scale_anneal=float(v("anneal")), min_scale=float(v("min_scale")))
+    b.iterations = int(v("iterations"))
+    torch.manual_seed(int(v("torch_seed")))
+    ts, w, h, msc, scale, ho, wo = b.draw(int(v("idx")), int(v("epoch")))
+    assert msc == float(v("min_scale_cur")) and [w, h] == list(v("img_wh"))
+    s = O.grid_sample_batch(rays, rgbs, wh, ts, int(np.sqrt(int(v("batch")))), scale, ho, wo)
+    for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"):
+        assert np.array_equal(s[k].numpy(), v(k)), k
