@@ -188,6 +188,78 @@ struct WgradJob {
   long P; int chunk;
 };
 
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
+                                                    int wave) {
+  constexpr int KS = 4;                       // k-steps (2 points each) per iteration
+  int dcol[MT], acol[NT];
+  float dmask[MT], amask[NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { const int c = m0 + 32 * t + i; dcol[t] = c < j.M ? c : j.M - 1; dmask[t] = c < j.M ? 1.0f : 0.0f; }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { const int c = n0 + 32 * t + i; acol[t] = c < j.N ? c : j.N - 1; amask[t] = c < j.N ? 1.0f : 0.0f; }
+  const long plast = p1 - 1;
+  float dc[KS][MT], ac[KS][NT], dn[KS][MT], an[KS][NT];
+  auto fetch = [&](long pb, float (&d)[KS][MT], float (&a)[KS][NT]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const long pt = pb + 2 * s + kk;
+      const long pc = pt < plast ? pt : plast;
+      const float keep = pt < p1 ? 1.0f : 0.0f;
+      const float* dr = j.D + pc * j.ldd;
+      const float* ar = j.A + pc * j.lda;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) d[s][t] = dr[dcol[t]] * (dmask[t] * keep);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[s][t] = ar[acol[t]] * amask[t];
+    }
+  };
+  const bool do_bias = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;   // one wave column per M block
+  float bs[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) bs[t] = 0.0f;
+  fetch(p0, dc, ac);
+  for (long pb = p0; pb < p1; pb += 2 * KS) {
+    fetch(pb + 2 * KS, dn, an);               // next iteration's operands fly while this one's MFMAs run
+    if (do_bias) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) bs[t] += dc[s][t];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[s][a], ac[s][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) dc[s][t] = dn[s][t];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ac[s][t] = an[s][t];
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      bs[t] += __shfl_xor(bs[t], 32);
+      if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs[t];
+    }
+  }
+  float* out = j.partial + (long)blockIdx.x * j.M * j.N;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk, nn = n0 + 32 * b + i;
+        if (m < j.M && nn < j.N) out[(long)m * j.N + nn] = acc[a][b][r];
+      }
+}
+
 // Workgroup tile 256(M) x 256(N): 4 waves (one per SIMD, 512-register budget) x 128x128 = 4x4 MFMA tiles each.
 // Per k-step (2 points) a wave loads 4 delta fragments + 4 input fragments (one dword per lane: a 32-float
 // row segment per half-wave, straight from HBM/L2 in MFMA operand shape) for 16 MFMAs; the next
@@ -208,65 +280,69 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  bool mv[4], nv[4];
+  if (mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
+    // ---- full 128x128 wave tile (every 256-wide layer): branch-free stream.  Column mapping: MFMA tile t, lane i <->
+    // column 4i + t, so a lane's four operands of a point are ONE 16-byte load (512 contiguous bytes per half-wave) and
+    // the whole k-step is 2 x global_load_dwordx4 + 16 MFMAs.  (The guarded generic loop below puts a branch around
+    // every load and MFMA; hipcc then waits vmcnt(0) at each join, i.e. for the prefetch it has just issued.)
+    constexpr int KF = 4;
+    const float* dbase = j.D + m0 + 4 * i;
+    const float* abase = j.A + n0 + 4 * i;
+    const long plast = p1 - 1;
+    f32x4 dc[KF], ac[KF], dnx[KF], anx[KF];
+    auto fetch4 = [&](long pb, f32x4 (&d)[KF], f32x4 (&a)[KF]) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { mv[t] = m0 + 32 * t + i < j.M; nv[t] = n0 + 32 * t + i < j.N; }
-  constexpr int KS = 4;                       // k-steps (2 points each) per iteration
-  float da[KS][4], aa[KS][4], dn[KS][4], an[KS][4];
-  auto fetch = [&](long pb, float (&d)[KS][4], float (&a)[KS][4]) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const long pt = pb + 2 * s + kk;
-      const bool pv = pt < p1;
-      const float* dr = j.D + pt * j.ldd + m0 + i;
-      const float* ar = j.A + pt * j.lda + n0 + i;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        d[s][t] = (pv && mv[t]) ? dr[32 * t] : 0.0f;
-        a[s][t] = (pv && nv[t]) ? ar[32 * t] : 0.0f;
+      for (int s = 0; s < KF; ++s) {
+        const long pt = pb + 2 * s + kk;
+        const long pc = pt < plast ? pt : plast;                      // clamped: always a readable row
+        const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
+        const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
+        const float keep = pt < p1 ? 1.0f : 0.0f;                     // rows past the chunk contribute nothing
+        d[s] = dv * keep;
+        a[s] = av;
       }
+    };
+    const bool do_bias4 = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;
+    f32x4 bs4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    fetch4(p0, dc, ac);
+    for (long pb = p0; pb < p1; pb += 2 * KF) {
+      fetch4(pb + 2 * KF, dnx, anx);
+      if (do_bias4) {
+#pragma unroll
+        for (int s = 0; s < KF; ++s) bs4 += dc[s];
+      }
+#pragma unroll
+      for (int s = 0; s < KF; ++s)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[s][a], ac[s][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < KF; ++s) { dc[s] = dnx[s]; ac[s] = anx[s]; }
     }
-  };
-  const bool do_bias = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;   // one wave column per M block
-  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  fetch(p0, da, aa);
-  for (long pb = p0; pb < p1; pb += 2 * KS) {
-    fetch(pb + 2 * KS, dn, an);               // next iteration's operands fly while this one's MFMAs run
-    if (do_bias) {
+    if (do_bias4) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bs[t] += da[s][t];
+      for (int t = 0; t < 4; ++t) bs4[t] += __shfl_xor(bs4[t], 32);
+      if (kk == 0) *(f32x4*)(j.bias_partial + (long)blockIdx.x * j.M + m0 + 4 * i) = bs4;
     }
+    float* outp = j.partial + (long)blockIdx.x * j.M * j.N;
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (a < mt && b < nt) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[s][a], aa[s][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { da[s][t] = dn[s][t]; aa[s][t] = an[s][t]; }
-  }
-  if (do_bias) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bs[t] += __shfl_xor(bs[t], 32);
-      if (kk == 0 && mv[t]) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs[t];
-    }
-  }
-  float* out = j.partial + (long)blockIdx.x * j.M * j.N;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk, nn = n0 + 32 * b + i;
-        if (m < j.M && nn < j.N) out[(long)m * j.N + nn] = acc[a][b][r];
+        const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
+        const f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+        *(f32x4*)(outp + (long)m * j.N + n0 + 4 * i) = v;
       }
+    return;
+  }
+  // ---- partial tiles (N = 93 / 27 embedding blocks, M = 128 / 64 / 1 heads): the same stream with MT x NT live MFMA
+  // tiles, MT in {1,2,4}, NT in {1,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
+  // so no control flow sits between a prefetch and the MFMAs that hide it
+  const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt <= 3 ? 3 : 4);
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, wave); return; }
+  CRNERF_WG(1, 1) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 3) CRNERF_WG(2, 4) CRNERF_WG(4, 1) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
+#undef CRNERF_WG
 }
 
 // dst[m*ldc + n] = sum_c partial[c][m][n]   (fixed summation tree: deterministic; 8 loads in flight per thread)

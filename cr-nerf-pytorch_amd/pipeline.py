@@ -6,6 +6,8 @@ reference's drivers can be re-created without Lightning / imageio / torchvision:
     batched_inference(...)        eval.py:29-59 / appearance_modification_video.py:71-102 (ray-chunk loop, dict concat)
     decode_image(...)             eval.py:288-295 (feature -> [1,64,H,W] view -> decoder -> [H*W,3])
     render_frame(...)             one video frame: rays generated on the device, style from the appearance encoder
+    TrainingSystem                NeRFSystem.decode / forward / training_step, train_mask_grid_sample.py:127-226, :268-290
+                                  (encode_a / encode_random configuration; use_mask needs the CGNet mask network, not built)
 """
 from collections import defaultdict
 
@@ -87,5 +89,83 @@ def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, n
     return decode_image(models, res, H, W, a_emb).reshape(int(H), int(W), 3).clamp(0, 1)
 
 
+class TrainingSystem:
+    """The training-side orchestration of the reference's NeRFSystem without Lightning: same dict keys, same order of
+    operations, autograd through the HIP twins (models/rendering.py grad path, autograd.py) and the fused loss."""
+
+    def __init__(self, hparams_, models=None, embeddings=None, enc_a=None, device="cuda"):
+        from .losses import loss_dict
+        if getattr(hparams_, "use_mask", False):
+            raise NotImplementedError("crnerf_amd: use_mask needs the CGNet mask network (models/lightweight_seg.py), which is not built")
+        if getattr(hparams_, "encode_c", False):
+            raise NotImplementedError("crnerf_amd: encode_c (content encoder) is not built")
+        self.hparams_ = hparams_
+        self.loss = loss_dict['crnerf'](hparams_, coef=1)                                   # :74
+        self.models = models or get_model(hparams_, device)
+        self.embeddings = embeddings or get_embeddings(hparams_)
+        self.enc_a = enc_a if enc_a is not None else encoder_sameoutputsize(out_channel=hparams_.nerf_out_dim).to(device)   # :95
+        self.embedding_a_list = [None] * getattr(hparams_, "N_vocab", 1500)                 # :98
+        self.models_to_train = list(self.models.values()) + [self.enc_a]                    # :84-97
+        self.global_step = 0
+
+    def parameters(self):
+        return [p for m in self.models_to_train for p in m.parameters()]
+
+    def decode(self, results, type, **kwargs):                                              # :127-149
+        feature = results['feature_' + type]
+        H, W = int(kwargs['H']), int(kwargs['W'])
+        grid = feature.t().reshape(1, feature.shape[-1], H, W)                              # 'n1 n3 -> n3 n1' then ' n3 (h w) -> 1 n3 h w'
+        style = kwargs['a_embedded_random'] if type == "fine_random" else kwargs['a_embedded_from_img']
+        rgbs_pred = self.models['decoder'](grid, style)
+        if type == "fine":
+            results['rgb_fine_img'] = rgbs_pred
+        if type != "fine_random":                                                           # fine_random is rearranged later (:221)
+            rgbs_pred = rgbs_pred.reshape(3, H * W).t()                                     # ' 1 n1 h w -> (h w) n1' (a strided view)
+        results['rgb_' + type] = rgbs_pred
+        return results
+
+    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None):                             # :151-226
+        import random
+        hp = self.hparams_
+        results = defaultdict(list)
+        kwargs = {'args': hp}
+        whole_img = (whole_img + 1) / 2                                                     # [-1,1] -> [0,1]  :156
+        kwargs['a_embedded_from_img'] = self.enc_a(whole_img)
+        if hp.encode_random:
+            idexlist = [k for k, v in enumerate(self.embedding_a_list) if v is not None]
+            kwargs['a_embedded_random'] = kwargs['a_embedded_from_img'] if len(idexlist) == 0 else self.embedding_a_list[random.choice(idexlist)]
+        kwargs["H"], kwargs["W"] = H, W
+        B = rays.shape[0]
+        ray_chunk = max(int(hp.chunk), 1 << 16)   # the reference's 8,192-ray chunks (:185-197) only bound its memory; rays are independent
+        for i in range(0, B, ray_chunk):
+            part = render_rays_cross_ray(self.models, self.embeddings, rays[i:i + ray_chunk], ts[i:i + ray_chunk], hp.N_samples, hp.use_disp,
+                                         hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, False, **kwargs)
+            for k, v in part.items():
+                results[k] += [v]
+        for k, v in results.items():
+            results[k] = torch.cat(v, 0)
+        results = self.decode(results, "coarse", **kwargs)
+        if hp.N_importance > 0:
+            results = self.decode(results, "fine", **kwargs)
+        results['a_embedded'] = kwargs['a_embedded_from_img']
+        results['whole_img'] = whole_img
+        if hp.encode_random:
+            results['a_embedded_random'] = kwargs['a_embedded_random']
+            results = self.decode(results, "fine_random", **kwargs)
+            results['a_embedded_random_rec'] = self.enc_a(results['rgb_fine_random'])       # :219
+            results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
+            self.embedding_a_list[int(ts[0])] = kwargs['a_embedded_from_img'].clone().detach()
+        return results
+
+    def training_step(self, batch):                                                         # :268-290
+        rays, ts, rgbs = batch['rays'], batch['ts'], batch['rgbs']
+        side = int(round(rays.shape[0] ** 0.5))
+        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'))
+        loss_d, annealing = self.loss(results, rgbs, self.hparams_, self.global_step)
+        loss = sum(l for l in loss_d.values())
+        self.global_step += 1
+        return loss, loss_d, results
+
+
 __all__ = ["get_model", "get_embeddings", "load_ckpt", "extract_model_state_dict", "batched_inference", "decode_image", "render_frame",
-           "encoder_sameoutputsize"]
+           "encoder_sameoutputsize", "TrainingSystem"]

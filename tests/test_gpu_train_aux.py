@@ -97,3 +97,51 @@ def test_grid_sample_batcher_vs_reference(golden, tag):
     for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"):
         assert np.array_equal(s[k].cpu().numpy(), v(k)), k            # a gather and fp32 index arithmetic: bit-exact
         assert s[k].dtype == (torch.int64 if k in ("ts", "rgb_idx") else torch.float32)
+
+
+def test_training_system_mirrors_nerfsystem_step():
+    """NeRFSystem.forward / training_step (train_mask_grid_sample.py:151-226, :268-290) on the drop-in modules: result keys,
+    loss keys, gradients reaching every trained module, the fused loss agreeing with the oracle on the same results, and a
+    few optimiser steps reducing the loss."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import pipeline
+    from oracle import cpu_ref as O
+
+    class HPT(HP):
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [16, 16], 32, 32, 1.0, 1.0, 128, 8
+        use_mask = encode_c = False
+    hp = HPT()
+    torch.manual_seed(0)
+    sys_ = pipeline.TrainingSystem(hp, device=DEV)
+    sys_.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
+    sys_.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
+    sys_.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    sys_.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+    R = 256
+    batch = {"rays": torch.from_numpy(synth.rays(R, H=16, W=16)).to(DEV), "ts": torch.full((R,), 3, dtype=torch.int64, device=DEV),
+             "rgbs": torch.rand(R, 3, device=DEV), "whole_img": torch.rand(1, 3, 64, 80, device=DEV) * 2 - 1}
+    opt = torch.optim.Adam(sys_.parameters(), lr=5e-4)
+    losses = []
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss, loss_d, results = sys_.training_step(batch)
+        if it == 0:
+            assert list(loss_d.keys()) == ["kl_a", "rec_a_random", "c_l", "f_l"]
+            for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "feature_fine_random", "depth_fine",
+                      "rgb_coarse", "rgb_fine_img", "rgb_fine", "a_embedded", "whole_img", "a_embedded_random", "rgb_fine_random",
+                      "a_embedded_random_rec"):
+                assert k in results, k
+            assert results["rgb_fine"].shape == (R, 3) and results["rgb_fine_img"].shape == (1, 3, 16, 16)
+            ref, _ = O.crnerf_loss({k: v.detach().cpu() for k, v in results.items() if torch.is_tensor(v)}, batch["rgbs"].cpu(), hp, 0)
+            for k in loss_d:
+                assert abs(float(loss_d[k]) - float(ref[k])) <= 1e-5 * abs(float(ref[k])) + 1e-10, k
+            assert sys_.embedding_a_list[3] is not None and sys_.embedding_a_list[0] is None      # :222
+        loss.backward()
+        if it == 0:
+            for name, mod in (("coarse", sys_.models["coarse"]), ("fine", sys_.models["fine"]), ("decoder", sys_.models["decoder"]), ("enc_a", sys_.enc_a)):
+                got = [p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0 for p in mod.parameters()]
+                assert all(got), (name, got)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses

@@ -1,0 +1,67 @@
+"""Measurement tool (GPU box): BASELINE configs[3] shaped training step on ONE MI355X -- a grid-sample batch cut from
+HBM-resident ray/rgb buffers (GridSampleBatcher), NeRFSystem.forward mirror (TrainingSystem: appearance encoder,
+render in grad mode with perturb=1 / noise_std=1, three decodes, encoder on the re-rendered image), the fused CRNeRF
+loss, backward through the HIP twins, Adam.  usage: python tools/train_config4_bench.py [rays=65536] [Nc=64] [Ni=64]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import crnerf_amd.synth as synth
+from crnerf_amd import pipeline
+from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+NI = int(sys.argv[3]) if len(sys.argv) > 3 else 64      # command/train.sh: N_importance 64
+side = int(R ** 0.5)
+dev = "cuda:0"
+
+
+class HP:
+    maskrs_max, maskrs_min, maskrs_k, maskrd = 5e-2, 6e-3, 1e-3, 0.0
+    weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
+    nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+    img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [side, side], NC, NI, 1.0, 1.0, 8 * 1024, 1500
+    use_mask = encode_c = False
+
+
+hp = HP()
+torch.manual_seed(0)
+sysm = pipeline.TrainingSystem(hp, device=dev)
+sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
+sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
+sysm.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+sysm.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+
+# synthetic "scene": 8 images of 512 x 384, rays of a pinhole camera each, buffers resident in HBM
+n_img, iw, ih = 8, 512, 384
+rays = torch.cat([torch.cat([torch.from_numpy(synth.rays(iw * ih, seed=i, H=ih, W=iw)), torch.full((iw * ih, 1), float(i))], 1) for i in range(n_img)]).to(dev)
+rgbs = torch.rand(n_img * iw * ih, 3, device=dev)
+imgs = [torch.rand(1, 3, ih // 8, iw // 8, device=dev) * 2 - 1 for _ in range(n_img)]     # 1/8-scale appearance images, in [-1, 1]
+wh = np.array([[iw, ih]] * n_img)
+batcher = GridSampleBatcher(rays, rgbs, wh, batch_size=R, all_imgs=imgs)
+opt = torch.optim.Adam(sysm.parameters(), lr=5e-4)
+
+
+def step(i):
+    batch = batcher.__getitem__(i, 0)
+    opt.zero_grad(set_to_none=True)
+    loss, loss_d, _ = sysm.training_step(batch)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for i in range(2):
+    step(i)
+torch.cuda.synchronize()
+torch.cuda.reset_peak_memory_stats()
+n = 3
+t0 = time.perf_counter()
+for i in range(n):
+    l = step(2 + i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+pts = R * (NC + NC + NI)
+print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.1f ms -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
+      % (R, side, side, NC, NI, dt * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
