@@ -337,15 +337,17 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
       // ---- gap 2
       accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? biasv : accs[cur][1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // the LDS read goes FIRST behind the MFMA (tools/ubench: 32.5 cycles/MFMA; with the VALU pair first and the read last
+      // the s_nop hipcc puts before the next k-step's MFMA becomes visible: 34.5)
+      const int pos = b_pos(i + B_AHEAD);
+      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < count; ++u) {
         const int qc = first + u;
         if (T == 0) prev.finish(u, PT, qc);
         else epi.finish(u, T - 1, qc);
       }
-      __builtin_amdgcn_sched_barrier(0);   // VALU first, then the LDS read: a VALU instruction right before the next k-step's asm pin costs an s_nop
-      const int pos = b_pos(i + B_AHEAD);
-      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
       if (s == 0) {
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);

@@ -7,7 +7,8 @@ import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 KSTEPS = 32          # per asm block (2 "tiles" of 16)
-def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None):
+def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None, rotate_b=False, bias_c=False, glds=False, barrier=False,
+         real_order=False, nop=True, ds_first=False):
     L = []
     acc0, acc1 = ("a[0:15]", "a[16:31]") if acc == "a" else ("v[128:143]", "v[144:159]")
     b0, b1 = ("v[16:19]", "v[20:23]") if bsrc == "v" else ("a[64:67]", "a[68:71]")
@@ -22,6 +23,10 @@ def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None):
             fills += ["v_accvgpr_read_b32 v%d, a%d" % (r, 32 + 2 * (qd % 8)), "v_accvgpr_read_b32 v%d, a%d" % (r + 1, 33 + 2 * (qd % 8)),
                       "v_add_f32 v%d, v%d, v110" % (r, r), "v_add_f32 v%d, v%d, v111" % (r + 1, r + 1),
                       "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r, r, r + 1), "v_pk_max_i16 v%d, v%d, 0" % (112 + qd % 4, r)]
+    elif fill_kind == "epi4":    # the shipped quarter: 2 accread | cvt_pk, pk_max
+        r = 100
+        fills = ["v_accvgpr_read_b32 v%d, a%d" % (r, 32), "v_accvgpr_read_b32 v%d, a%d" % (r + 1, 33),
+                 "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r + 2, r, r + 1), "v_pk_max_i16 v%d, v%d, 0" % (112, r + 2)]
     elif fill_kind == "epi_v":   # same work but the accumulators being read live in VGPRs (no accvgpr_read)
         for qd in range(per_kstep // 4):
             r = 100 + 2 * (qd % 4)
@@ -30,14 +35,31 @@ def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None):
     half = (len(fills) + 1) // 2 if first_gap is None else first_gap
     for s in range(KSTEPS):
         q = 4 * (s % 4)
+        if rotate_b:     # a different B operand every k-step, as the real layer loop (activations of 16 k-steps x 2 groups)
+            b0 = "v[%d:%d]" % (24 + 8 * (s % 8), 27 + 8 * (s % 8))
+            b1 = "v[%d:%d]" % (28 + 8 * (s % 8), 31 + 8 * (s % 8))
+        c0, c1 = acc0, acc1
+        if bias_c and s % 16 == 0:   # a tile's first MFMAs take the bias as C from another register set
+            c0 = c1 = "a[72:87]"
         if dsread:
             L.append("s_waitcnt lgkmcnt(3)")
-        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc0, q, q + 3, b0, acc0))
+        if real_order and nop:
+            L.append("s_nop 0")
+        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc0, q, q + 3, b0, c0))
         L += fills[:half]
-        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc1, q, q + 3, b1, acc1))
-        if dsread:
-            L.append("ds_read_b128 v[%d:%d], %%0 offset:%d" % (q, q + 3, 1024 * (s % 16)))
-        L += fills[half:]
+        if glds and s % 4 == 1:
+            L += ["s_mov_b32 m0, %2", "s_nop 0", "global_load_lds_dwordx4 %3, %1 offset:0"]
+        L.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], %s, %s" % (acc1, q, q + 3, b1, c1))
+        if real_order and not ds_first:
+            L += fills[half:]
+            if dsread:
+                L.append("ds_read_b128 v[%d:%d], %%0 offset:%d" % (q, q + 3, 1024 * (s % 16)))
+        else:
+            if dsread:
+                L.append("ds_read_b128 v[%d:%d], %%0 offset:%d" % (q, q + 3, 1024 * (s % 16)))
+            L += fills[half:]
+        if barrier and s % 16 == 14:
+            L += ["s_waitcnt vmcnt(8)", "s_barrier"]
     return "\\n\\t".join(L)
 
 VARIANTS = [
@@ -55,28 +77,40 @@ VARIANTS = [
     ("+ ds_read + 1 quarter, acc VGPR (4)/kstep", dict(fill_kind="epi_v", per_kstep=4, acc="v")),
     ("+ ds_read + 2 quarters, acc VGPR (8)/kstep", dict(fill_kind="epi_v", per_kstep=8, acc="v")),
     ("+ ds_read + 1 quarter all in 2nd gap", dict(fill_kind="epi", per_kstep=6, first_gap=0)),
+    ("real k-step order, quarter of 4 (2+2)", dict(fill_kind="epi4", per_kstep=4, real_order=True)),
+    ("real order without the s_nop", dict(fill_kind="epi4", per_kstep=4, real_order=True, nop=False)),
+    ("real order, ds_read first in gap 2", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True)),
+    ("real order, no nop, ds_read first", dict(fill_kind="epi4", per_kstep=4, real_order=True, nop=False, ds_first=True)),
+    ("  + B operand rotates over 64 regs", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True)),
+    ("  + bias as C of a tile's first MFMAs", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True)),
+    ("  + LDS-DMA piece every 4th k-step", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True, glds=True)),
+    ("  + vmcnt wait + s_barrier every 16th", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True, glds=True, barrier=True)),
 ]
 
-clob = ", ".join('"v%d"' % i for i in range(0, 24)) + ", " + ", ".join('"v%d"' % i for i in range(100, 180)) + ", " + ", ".join('"a%d"' % i for i in range(0, 72))
+clob = ", ".join('"v%d"' % i for i in range(0, 96)) + ", " + ", ".join('"v%d"' % i for i in range(100, 196)) + ", " + ", ".join('"a%d"' % i for i in range(0, 88))
 src = ['#include <hip/hip_runtime.h>', '#include <stdio.h>', 'typedef __attribute__((address_space(3))) char lds_char;']
 for k, (name, kw) in enumerate(VARIANTS):
-    src.append('''__global__ __launch_bounds__(256, 1) void k%d(unsigned long long* out, int iters) {
+    src.append('''__global__ __launch_bounds__(256, 1) void k%d(unsigned long long* out, int iters, const char* gsrc0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned addr = (unsigned)(size_t)(lds_char*)smem + (threadIdx.x & 63) * 16;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* gsrc = gsrc0 + wv * 4096;
+  unsigned ldsdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem) + 32768 + wv * 4096;
+  unsigned voff = (threadIdx.x & 63) * 16;
   for (int i = threadIdx.x; i < 4096; i += 256) ((float*)smem)[i] = 0.f;
   __syncthreads();
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
-    asm volatile("%s" ::"v"(addr) : %s, "memory");
+    asm volatile("%s" ::"v"(addr), "s"(gsrc), "s"(ldsdst), "v"(voff) : %s, "memory");
   }
   asm volatile("s_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15" ::: "memory");
   unsigned long long t1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }''' % (k, body(**kw), clob))
-src.append('int main() { unsigned long long* d; hipMalloc(&d, 8); unsigned long long h; const int iters = 200;')
+src.append('int main() { unsigned long long* d; hipMalloc(&d, 8); char* g; hipMalloc(&g, 1 << 20); hipMemset(g, 0, 1 << 20); unsigned long long h; const int iters = 200;')
 for k, (name, kw) in enumerate(VARIANTS):
     src.append('  hipFuncSetAttribute((const void*)k%d, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);' % k)
-    src.append('  for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(k%d, dim3(256), dim3(256), 65536, 0, d, iters); hipDeviceSynchronize(); }' % k)
+    src.append('  for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(k%d, dim3(256), dim3(256), 65536, 0, d, iters, g); hipDeviceSynchronize(); }' % k)
     src.append('  hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); printf("%%-46s %%6.2f cycles/MFMA\\n", "%s", (double)h / (iters * %d.0));' % (name, 2 * KSTEPS))
 src.append('  return 0; }')
 path = os.path.join(HERE, "mfma_stream_gen.hip")
