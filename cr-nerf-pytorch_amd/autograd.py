@@ -5,6 +5,7 @@ path is one autograd.Function whose backward calls the HIP backward twins.
     MlpFn        NeRF_sigma.forward           fwd: crnerf_mlp_forward_train_f32   bwd: crnerf_mlp_backward_f32
     CompositeFn  inference() compositing      fwd: crnerf_composite_f32           bwd: crnerf_composite_backward_f32
     DecoderFn    style_net.forward            fwd: crnerf_crossray_decode_f32     bwd: crnerf_crossray_decode_backward_f32
+    EncoderFn    encoder_sameoutputsize.forward   fwd: crnerf_encoder_forward_train_f32   bwd: crnerf_encoder_backward_f32
 
 Inputs that the reference does not train through this path (ray geometry, embeddings, hierarchical
 depths -- the latter are .detach()ed at models/rendering.py:184) get no gradient.
@@ -71,3 +72,20 @@ class DecoderFn(torch.autograd.Function):
         xp, sp, *w = ctx.saved_tensors
         dx, ds, grads = ops.crossray_decode_backward(xp, sp, w, d_rgb.contiguous())
         return (dx, ds) + tuple(g.view_as(t) for g, t in zip(grads, w))
+
+
+class EncoderFn(torch.autograd.Function):
+    """encoder_sameoutputsize.forward with gradients: fwd crnerf_encoder_forward_train_f32, bwd crnerf_encoder_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, image, *w):
+        out, saved, hw = ops.encoder_forward_train(image, w)
+        ctx.save_for_backward(out, saved, *w)
+        ctx.hw, ctx.image_shape = hw, image.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, saved, *w = ctx.saved_tensors
+        grads, d_img = ops.encoder_backward(w, saved, ctx.hw, out, d_out.contiguous(), want_d_image=ctx.needs_input_grad[0])
+        return (d_img.view(ctx.image_shape) if d_img is not None else None,) + tuple(g.view_as(t) for g, t in zip(grads, w))

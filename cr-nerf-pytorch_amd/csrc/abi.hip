@@ -293,6 +293,25 @@ int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, f
 }
 
 
+size_t crnerf_encoder_train_saved_bytes(int H, int W) { return encoder_train_saved_bytes(H, W); }
+size_t crnerf_encoder_train_scratch_bytes(int H, int W) { return encoder_train_scratch_bytes(H, W); }
+
+int crnerf_encoder_forward_train_f32(const float* image, int H, int W, const float* const* weights, void* saved, float* out, void* stream) {
+  REQUIRE(image, "image"); REQUIRE(weights, "weights"); REQUIRE(saved, "saved"); REQUIRE(out, "out");
+  for (int i = 0; i < CRNERF_ENCODER_TENSORS; ++i)
+    if (!weights[i]) return set_error(CRNERF_ERR_NULL, "encoder_forward_train: a weight pointer is NULL");
+  return launch_encoder_forward_train(image, H, W, weights, saved, out, (hipStream_t)stream);
+}
+
+int crnerf_encoder_backward_f32(int H, int W, const float* const* weights, const void* saved, const float* out, const float* d_out, void* scratch,
+                                float* const* grads, float* d_image, void* stream) {
+  REQUIRE(weights, "weights"); REQUIRE(saved, "saved"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  if (H < 8 || W < 8) return set_error(CRNERF_ERR_SHAPE, "encoder_backward: image must be at least 8x8");
+  for (int i = 0; i < CRNERF_ENCODER_TENSORS; ++i)
+    if (!weights[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "encoder_backward: a weight or gradient pointer is NULL");
+  return launch_encoder_backward(H, W, weights, saved, out, d_out, scratch, grads, d_image, (hipStream_t)stream);
+}
+
 static bool to_loss_args(const crnerf_loss_args* a, LossArgs& k, LossScales& sc) {
   k.rgb_c = a->rgb_coarse; k.rgb_f = a->rgb_fine; k.tgt = a->targets; k.mask = a->mask;
   k.a = a->a_embedded; k.a_rand = a->a_embedded_random; k.a_rec = a->a_embedded_random_rec; k.c_wo = a->content_wo; k.c_with = a->content_with;

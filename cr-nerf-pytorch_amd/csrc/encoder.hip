@@ -78,6 +78,29 @@ __global__ void adaptive_avgpool_kernel(const float* __restrict__ in, float* __r
   out[idx] = s / (float)((y1 - y0) * (x1 - x0));
 }
 
+template <int TAPS, bool ACT>
+static void conv(const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st);
+
+// thin launch wrappers shared with encoder_train.hip
+void enc_conv(int taps, bool act, const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st) {
+  if (taps == 9) conv<9, true>(in, wt, b, out, H, W, cin, cout, st);
+  else if (act) conv<1, true>(in, wt, b, out, H, W, cin, cout, st);
+  else conv<1, false>(in, wt, b, out, H, W, cin, cout, st);
+}
+void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st) {
+  const int n = cout * cin * taps;
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, wt, cout, cin, taps);
+}
+void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, in, out, C, HW);
+}
+void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * C + 255) / 256), dim3(256), 0, st, in, out, H, W, C);
+}
+void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st) {
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((S * S * C + 255) / 256), dim3(256), 0, st, in, out, H, W, C, S);
+}
+
 static const int ENC_CIN[7] = {3, 3, 64, 64, 128, 128, 128}, ENC_COUT[7] = {3, 64, 64, 128, 128, 128, 64}, ENC_TAPS[7] = {1, 9, 9, 9, 9, 9, 1};
 
 size_t encoder_workspace_bytes(int H, int W) {

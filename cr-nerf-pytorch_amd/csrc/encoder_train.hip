@@ -1,0 +1,246 @@
+// Training twins of the appearance encoder: forward that keeps every layer output, and the backward
+// pass -- weight / bias gradients of the seven convolutions and the gradient w.r.t. the input image (the encoder is also
+// applied to the re-rendered image, train_mask_grid_sample.py:219, so d_img flows on into the decoder).
+// Reference: encoder_sameoutputsize, models/linearStyleTransfer.py:208-276, differentiated by PyTorch autograd there.
+// Same data layout as encoder.hip: activations pixel-major (HWC), one wave = one pixel x 64 channels.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace crnerf {
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }   // ReflectionPad2d(1)
+__device__ __forceinline__ float lrelu_grad(float y) { return y > 0.0f ? 1.0f : 0.2f; }                       // y = lrelu(pre): same sign
+
+// forward kernels are encoder.hip's; redeclared here through small wrappers in that file
+void enc_conv(int taps, bool act, const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st);
+void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st);
+void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st);
+void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st);
+void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st);
+
+static const int TCIN[7] = {3, 3, 64, 64, 128, 128, 128}, TCOUT[7] = {3, 64, 64, 128, 128, 128, 64}, TTAPS[7] = {1, 9, 9, 9, 9, 9, 1};
+
+struct EncLayout {   // float offsets of the saved activations
+  size_t a0, y1, y2, y3, p3, y4, y5, p5, y6, p6, end;
+  int H, W, H2, W2, H4, W4;
+};
+static EncLayout enc_layout(int H, int W) {
+  EncLayout L;
+  L.H = H; L.W = W; L.H2 = H / 2; L.W2 = W / 2; L.H4 = L.H2 / 2; L.W4 = L.W2 / 2;
+  const size_t n0 = (size_t)H * W, n2 = (size_t)L.H2 * L.W2, n4 = (size_t)L.H4 * L.W4;
+  size_t o = 0;
+  L.a0 = o; o += n0 * 3;   L.y1 = o; o += n0 * 3;   L.y2 = o; o += n0 * 64;  L.y3 = o; o += n0 * 64;
+  L.p3 = o; o += n2 * 64;  L.y4 = o; o += n2 * 128; L.y5 = o; o += n2 * 128;
+  L.p5 = o; o += n4 * 128; L.y6 = o; o += n4 * 128; L.p6 = o; o += (size_t)1024 * 128;
+  L.end = o;
+  return L;
+}
+static size_t enc_weight_floats() {
+  size_t n = 0;
+  for (int l = 0; l < 7; ++l) n += (size_t)TCIN[l] * TCOUT[l] * TTAPS[l];
+  return n;
+}
+size_t encoder_train_saved_bytes(int H, int W) { return (enc_layout(H, W).end + enc_weight_floats()) * sizeof(float); }
+struct ScratchLayout { size_t ga, gb, g, X, wd, ws, end; };
+static ScratchLayout enc_scratch(int H, int W) {
+  const size_t n0 = (size_t)H * W, n2 = (size_t)(H / 2) * (W / 2), n4 = (size_t)(H / 4) * (W / 4);
+  const size_t gmap = n0 * 64 > (size_t)1024 * 128 ? n0 * 64 : (size_t)1024 * 128;   // largest gradient map (>= n2*128, n4*128)
+  size_t xcol = n0 * 64 * 9;                                                           // conv3's patch matrix is the largest
+  if (n2 * 128 * 9 > xcol) xcol = n2 * 128 * 9;
+  size_t ws = 0;                                                                       // MFMA wgrad partial sums
+  const size_t cand[7] = {wgrad_workspace_floats((long)n0, 3, 3), wgrad_workspace_floats((long)n0, 64, 27), wgrad_workspace_floats((long)n0, 64, 576),
+                          wgrad_workspace_floats((long)n2, 128, 576), wgrad_workspace_floats((long)n2, 128, 1152),
+                          wgrad_workspace_floats((long)n4, 128, 1152), wgrad_workspace_floats(1024, 64, 128)};
+  for (size_t c : cand) ws = c > ws ? c : ws;
+  ScratchLayout L;
+  size_t o = 0;
+  L.ga = o; o += gmap; L.gb = o; o += gmap; L.g = o; o += gmap; L.X = o; o += xcol; L.wd = o; o += 128 * 128 * 9; L.ws = o; o += ws;
+  L.end = o;
+  return L;
+}
+size_t encoder_train_scratch_bytes(int H, int W) { return enc_scratch(H, W).end * sizeof(float); }
+
+int launch_encoder_forward_train(const float* img, int H, int W, const float* const* w, void* saved, float* out, hipStream_t st) {
+  if (H < 8 || W < 8) return set_error(-2, "encoder: image must be at least 8x8 (two 2x2 max-pools and reflection padding)");
+  const EncLayout L = enc_layout(H, W);
+  float* s = (float*)saved;
+  float* wt[7];
+  float* p = s + L.end;
+  for (int l = 0; l < 7; ++l) { wt[l] = p; enc_transpose_weights(w[2 * l], wt[l], TCOUT[l], TCIN[l], TTAPS[l], st); p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
+  enc_chw_to_hwc(img, s + L.a0, 3, H * W, st);
+  enc_conv(1, false, s + L.a0, wt[0], w[1], s + L.y1, H, W, 3, 3, st);
+  enc_conv(9, true, s + L.y1, wt[1], w[3], s + L.y2, H, W, 3, 64, st);
+  enc_conv(9, true, s + L.y2, wt[2], w[5], s + L.y3, H, W, 64, 64, st);
+  enc_maxpool2(s + L.y3, s + L.p3, H, W, 64, st);
+  enc_conv(9, true, s + L.p3, wt[3], w[7], s + L.y4, L.H2, L.W2, 64, 128, st);
+  enc_conv(9, true, s + L.y4, wt[4], w[9], s + L.y5, L.H2, L.W2, 128, 128, st);
+  enc_maxpool2(s + L.y5, s + L.p5, L.H2, L.W2, 128, st);
+  enc_conv(9, true, s + L.p5, wt[5], w[11], s + L.y6, L.H4, L.W4, 128, 128, st);
+  enc_adaptive_avgpool(s + L.y6, s + L.p6, L.H4, L.W4, 128, 32, st);
+  enc_conv(1, true, s + L.p6, wt[6], w[13], out, 32, 32, 128, 64, st);
+  return check_launch("encoder_forward_train");
+}
+
+// ---------------------------------------------------------------- backward kernels
+// g[px][o] = d_out[px][o] * lrelu'(y[px][o])  (y = null: plain copy)
+__global__ void enc_act_grad_kernel(const float* __restrict__ d_out, const float* __restrict__ y, float* __restrict__ g, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  g[idx] = y ? d_out[idx] * lrelu_grad(y[idx]) : d_out[idx];
+}
+
+// X[px][c * 9 + tap] = in[reflect(px + tap)][c]: the reflection-padded 3x3 patches as a [HW, 9 cin] matrix, so that the
+// weight gradient is the point-reduction GEMM dW[o][c*9+tap] = sum_px g[px][o] X[px][c*9+tap] -- exactly the shape (and
+// the output layout, [cout][cin][3][3]) of the MLP's MFMA wgrad kernel (mlp_train16.hip), which is reused as is.
+__global__ void enc_im2col_kernel(const float* __restrict__ in, float* __restrict__ X, int H, int W, int cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)H * W * cin * 9;
+  if (idx >= n) return;
+  const int col = (int)(idx % (cin * 9)), c = col / 9, tap = col % 9;
+  const long px = idx / (cin * 9);
+  const int py = (int)(px / W), pxx = (int)(px % W);
+  X[idx] = in[((long)reflect1(py + tap / 3 - 1, H) * W + reflect1(pxx + tap % 3 - 1, W)) * cin + c];
+}
+
+// w[o][c][tap] -> wd[tap][o][c]
+__global__ void enc_weights_for_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int cout, int cin, int taps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cout * cin * taps) return;
+  const int o = idx / (cin * taps), c = (idx / taps) % cin, t = idx % taps;
+  wd[((long)t * cout + o) * cin + c] = w[idx];
+}
+
+// d_in[px][c] = sum over (output pixel q, tap) with reflect(q + tap) == px of sum_o g[q][o] * w[o][c][tap]   (g already carries lrelu')
+// (the adjoint of the reflection-padded gather: pixels in row / column 1 and n-2 also collect what the padding mirrored)
+template <int TAPS>
+__global__ __launch_bounds__(256) void enc_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ wd,
+                                                        float* __restrict__ d_in, int H, int W, int cin, int cout) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int px = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= H * W) return;
+  const int py = px / W, pxx = px % W;
+  float acc = 0.0f;
+  if (TAPS == 9) {
+    int ty[3], tx[3], nty = 0, ntx = 0;                    // padded coordinates that map onto (py, pxx)
+    ty[nty++] = py; if (py == 1) ty[nty++] = -1; if (py == H - 2) ty[nty++] = H;
+    tx[ntx++] = pxx; if (pxx == 1) tx[ntx++] = -1; if (pxx == W - 2) tx[ntx++] = W;
+    for (int a = 0; a < nty; ++a)
+      for (int ky = 0; ky < 3; ++ky) {
+        const int qy = ty[a] - ky + 1;
+        if (qy < 0 || qy >= H) continue;
+        for (int b = 0; b < ntx; ++b)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int qx = tx[b] - kx + 1;
+            if (qx < 0 || qx >= W) continue;
+            const long q = (long)qy * W + qx;
+            const float* wp = wd + (long)(ky * 3 + kx) * cout * cin + c;
+            const float* gq = g + q * cout;
+            const int cc = c < cin ? c : cin - 1;
+#pragma unroll 8
+            for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], wp[(long)o * cin + (cc - c)], acc);
+          }
+      }
+  } else {
+    const float* gq = g + (long)px * cout;
+    const int cc = c < cin ? c : cin - 1;
+#pragma unroll 8
+    for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], wd[(long)o * cin + cc], acc);
+  }
+  if (c < cin) d_in[(long)px * cin + c] = acc;
+}
+
+// MaxPool2d(2,2) backward: the gradient goes to the first maximum of the window in scan order (ATen's tie rule)
+__global__ void enc_maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Ho * Wo * C) return;
+  const int c = idx % C, px = idx / C, yy = px / Wo, xx = px % Wo;
+  const long base = ((long)(2 * yy) * W + 2 * xx) * C + c;
+  const long off[4] = {0, C, (long)W * C, (long)W * C + C};
+  int best = 0;
+  float bv = in[base];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float v = in[base + off[k]];
+    if (v > bv) { bv = v; best = k; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d_in[base + off[k]] = k == best ? d_out[idx] : 0.0f;
+}
+
+// AdaptiveAvgPool2d(S) backward: every input position collects d_out / window_area from the windows that contain it
+__global__ void enc_avgpool_bwd_kernel(const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C, int S) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W * C) return;
+  const int c = idx % C, px = idx / C, yy = px / W, xx = px % W;
+  float acc = 0.0f;
+  for (int oy = 0; oy < S; ++oy) {
+    const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
+    if (yy < y0 || yy >= y1) continue;
+    for (int ox = 0; ox < S; ++ox) {
+      const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+      if (xx < x0 || xx >= x1) continue;
+      acc += d_out[((long)oy * S + ox) * C + c] / (float)((y1 - y0) * (x1 - x0));
+    }
+  }
+  d_in[idx] = acc;
+}
+
+// HWC [HW,C] -> NCHW [C,HW]
+__global__ void enc_hwc_to_chw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * HW) return;
+  const int c = idx / HW, px = idx % HW;
+  out[idx] = in[(long)px * C + c];
+}
+
+struct BwdBufs { float* g; float* X; float* wd; float* ws; };
+
+template <int TAPS>
+static void conv_bwd(const float* d_out, const float* y, const float* in, const float* w, const BwdBufs& B, float* dW, float* db, float* d_in, int H,
+                     int W, int cin, int cout, hipStream_t st) {
+  const long n = (long)H * W * cout;
+  hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, y, B.g, n);
+  const float* X = in;
+  if (TAPS == 9) {
+    const long nx = (long)H * W * cin * 9;
+    hipLaunchKernelGGL(enc_im2col_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, in, B.X, H, W, cin);
+    X = B.X;
+  }
+  wgrad(B.g, cout, cout, X, cin * TAPS, cin * TAPS, dW, cin * TAPS, db, (long)H * W, B.ws, st);   // MFMA point-reduction GEMM (+ bias sums)
+  if (d_in) {
+    const int nw = cout * cin * TAPS;
+    hipLaunchKernelGGL(enc_weights_for_dgrad_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, w, B.wd, cout, cin, TAPS);
+    hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, B.g, B.wd, d_in, H, W, cin, cout);
+  }
+}
+
+// saved: from launch_encoder_forward_train; out: its output (for lrelu7'); d_out[1024,64]; grads[14] in weight order;
+// d_img[3,H,W] (NCHW) or null
+int launch_encoder_backward(int H, int W, const float* const* w, const void* saved, const float* out, const float* d_out, void* scratch,
+                            float* const* grads, float* d_img, hipStream_t st) {
+  const EncLayout L = enc_layout(H, W);
+  const float* s = (const float*)saved;
+  const ScratchLayout SL = enc_scratch(H, W);
+  float* base = (float*)scratch;
+  float* ga = base + SL.ga;
+  float* gb = base + SL.gb;
+  const BwdBufs B{base + SL.g, base + SL.X, base + SL.wd, base + SL.ws};
+  const int n0 = H * W, n2 = L.H2 * L.W2, n4 = L.H4 * L.W4;
+  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, grads[12], grads[13], ga, 32, 32, 128, 64, st);                    // conv7 -> d p6
+  hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, gb, L.H4, L.W4, 128, 32); // -> d y6
+  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st);              // conv6 -> d p5
+  (void)hipMemsetAsync(gb, 0, (size_t)n2 * 128 * sizeof(float), st);
+  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, gb, L.H2, L.W2, 128);  // -> d y5
+  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st);                 // conv5 -> d y4
+  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st);                  // conv4 -> d p3
+  (void)hipMemsetAsync(ga, 0, (size_t)n0 * 64 * sizeof(float), st);
+  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, ga, H, W, 64);  // -> d y3
+  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, grads[4], grads[5], gb, H, W, 64, 64, st);                         // conv3 -> d y2
+  conv_bwd<9>(gb, s + L.y2, s + L.y1, w[2], B, grads[2], grads[3], ga, H, W, 3, 64, st);                          // conv2 -> d y1
+  conv_bwd<1>(ga, nullptr, s + L.a0, w[0], B, grads[0], grads[1], d_img ? gb : nullptr, H, W, 3, 3, st);         // conv1 -> d a0
+  if (d_img) hipLaunchKernelGGL(enc_hwc_to_chw_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, st, gb, d_img, 3, n0);
+  return check_launch("encoder_backward");
+}
+
+}  // namespace crnerf

@@ -74,6 +74,12 @@ int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);
 
 
+size_t encoder_train_saved_bytes(int H, int W);
+size_t encoder_train_scratch_bytes(int H, int W);
+int launch_encoder_forward_train(const float* img, int H, int W, const float* const* w, void* saved, float* out, hipStream_t st);
+int launch_encoder_backward(int H, int W, const float* const* w, const void* saved, const float* out, const float* d_out, void* scratch,
+                            float* const* grads, float* d_img, hipStream_t st);
+
 // ---- training-side neighbours (train_aux.hip)
 struct LossArgs {
   const float* rgb_c; const float* rgb_f; const float* tgt; const float* mask;   // [R,3] strided, [R,3] or null, [R,3], [R] or null

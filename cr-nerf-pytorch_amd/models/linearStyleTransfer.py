@@ -66,9 +66,8 @@ class MulLayer(nn.Module):
 
 class encoder_sameoutputsize(nn.Module):
     """Appearance encoder -- reference models/linearStyleTransfer.py:208-276 (same ctor, attribute names and
-    state_dict keys conv1..conv7).  Inference runs the HIP encoder; under grad mode (enc_a is trained,
-    train_mask_grid_sample.py:95-97) the same layers run through torch ops so autograd can differentiate them
-    (the encoder is a 'next' row of the scope table, not part of the rendering hot path)."""
+    state_dict keys conv1..conv7).  Inference and training both run the HIP kernels (csrc/encoder.hip,
+    csrc/encoder_train.hip); the nn.Conv2d / pooling members only hold the parameters under the reference's names."""
 
     def __init__(self, out_channel=64):
         super().__init__()
@@ -97,19 +96,13 @@ class encoder_sameoutputsize(nn.Module):
         self.relu7 = nn.LeakyReLU(0.2, inplace=True)
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            out = self.conv1(x)
-            out = self.relu2(self.conv2(self.reflecPad1(out)))
-            out = self.relu3(self.conv3(self.reflecPad3(out)))
-            out, _ = self.maxPool(out)
-            out = self.relu4(self.conv4(self.reflecPad4(out)))
-            out = self.relu5(self.conv5(self.reflecPad5(out)))
-            out, _ = self.maxPool2(out)
-            out = self.relu6(self.conv6(self.reflecPad6(out)))
-            return self.relu7(self.conv7(self.adppool(out)))
         if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3:
             raise ValueError("encoder_sameoutputsize expects [1,3,H,W], got %s" % (tuple(x.shape),))
         convs = (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..autograd import EncoderFn   # training: HIP forward-with-save + HIP backward (csrc/encoder_train.hip)
+            grid = EncoderFn.apply(x.to(torch.float32).contiguous(), *[t for c in convs for t in (c.weight, c.bias)])
+            return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)
         grid = ops.encoder_forward(x, [t for c in convs for t in (c.weight, c.bias)])       # [1024,64] pixel-major
         return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)                                   # NCHW view, zero-copy for style_net
 

@@ -306,6 +306,35 @@ def encoder_forward(image, weights):
     return out
 
 
+def encoder_forward_train(image, weights):
+    """Forward of the appearance encoder that keeps the layer outputs: returns (grid [1024,64], saved, (H, W))."""
+    lib = _lib.load()
+    img = _f32c(image, "image")
+    if img.dim() == 4:
+        img = img[0]
+    _, H, W = img.shape
+    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    saved = torch.empty(lib.crnerf_encoder_train_saved_bytes(H, W), dtype=torch.uint8, device=img.device)
+    out = torch.empty(1024, 64, dtype=torch.float32, device=img.device)
+    _lib.check(lib.crnerf_encoder_forward_train_f32(_lib.dev_ptr(img), H, W, _lib.ptr_array(ws, "encoder weight"), ctypes.c_void_p(saved.data_ptr()),
+                                                    _lib.dev_ptr(out), _lib.stream_ptr()), "crnerf_encoder_forward_train_f32")
+    return out, saved, (H, W)
+
+
+def encoder_backward(weights, saved, hw, out, d_out, want_d_image=True):
+    lib = _lib.load()
+    H, W = hw
+    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    grads = [torch.empty_like(t) for t in ws]
+    d_img = torch.empty(3, H, W, dtype=torch.float32, device=out.device) if want_d_image else None
+    scratch = torch.empty(lib.crnerf_encoder_train_scratch_bytes(H, W), dtype=torch.uint8, device=out.device)
+    _lib.check(lib.crnerf_encoder_backward_f32(H, W, _lib.ptr_array(ws, "encoder weight"), ctypes.c_void_p(saved.data_ptr()), _lib.dev_ptr(out),
+                                               _lib.dev_ptr(_f32c(d_out, "d_out")), ctypes.c_void_p(scratch.data_ptr()),
+                                               _lib.ptr_array(grads, "encoder grad"), _lib.dev_ptr(d_img), _lib.stream_ptr()),
+               "crnerf_encoder_backward_f32")
+    return grads, d_img
+
+
 def crossray_decode_backward(content_pm, style_pm, weights, d_rgb):
     """Backward of crossray_decode: returns (d_content[HW,64], d_style[HWs,64], [22 weight gradients])."""
     lib = _lib.load()

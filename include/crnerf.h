@@ -196,6 +196,16 @@ int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const 
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
                               void* stream);
 
+/* Training twins of the appearance encoder (the reference trains enc_a through PyTorch autograd,
+ * train_mask_grid_sample.py:95-97, :160, :219): a forward that keeps every layer output in `saved`, and the backward:
+ * grads[14] in the order of `weights`, d_image[3,H,W] optional (NULL to skip; needed where the encoder reads the
+ * re-rendered image).  `out` is the forward's output (its sign carries the last LeakyReLU's derivative). */
+size_t crnerf_encoder_train_saved_bytes(int H, int W);
+size_t crnerf_encoder_train_scratch_bytes(int H, int W);
+int crnerf_encoder_forward_train_f32(const float* image, int H, int W, const float* const* weights, void* saved, float* out, void* stream);
+int crnerf_encoder_backward_f32(int H, int W, const float* const* weights, const void* saved, const float* out, const float* d_out,
+                                void* scratch, float* const* grads, float* d_image, void* stream);
+
 /* ---- training-side neighbours of the path ------------------------------------------------------
  * CRNeRFLoss.forward, losses.py:49-78 (mask_regularize :80-91, _l2_regularize :93-96).  The seven terms, in the
  * order losses[0..6] = kl_a, rec_a_random, c_l, content_constraint, r_ms, r_md, f_l; a term whose inputs are absent

@@ -145,3 +145,39 @@ def test_training_system_mirrors_nerfsystem_step():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("H,W", [(52, 76), (16, 16), (130, 128), (9, 23)])
+def test_encoder_backward_vs_autograd_oracle(H, W):
+    """Training twins of the appearance encoder: output, all 14 parameter gradients and the image gradient against torch
+    autograd through the oracle's restatement of encoder_sameoutputsize (itself pinned by golden g9)."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd.models.linearStyleTransfer import encoder_sameoutputsize
+    from oracle import cpu_ref as O
+    st = synth.encoder_state(51, 2.0)
+    enc = encoder_sameoutputsize(64).to(DEV)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    img = torch.rand(1, 3, H, W, generator=g)
+    cot = torch.randn(1, 64, 32, 32, generator=g)
+    x = img.to(DEV).requires_grad_()
+    out = enc(x)
+    (out * cot.to(DEV)).sum().backward()
+    ref_w = {k: v.clone().requires_grad_() for k, v in O.to_torch(st).items()}
+    xr = img.clone().requires_grad_()
+    ref = O.encoder_forward(ref_w, xr)
+    (ref * cot).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=2e-5, rtol=1e-5)
+    # A max-pool window whose two largest entries differ by less than the forward's rounding error (the convolutions sum
+    # in another order than ATen's) routes its gradient to the other entry: a handful of isolated elements differ, which
+    # is the reference's own ill-conditioning.  So: relative L2 tight, and all but 1 % of the elements tight pointwise.
+    def check(got, want, name):
+        got, want = got.detach().cpu().double(), want.detach().double()
+        d = (got - want).abs()
+        scale = float(want.abs().max()) + 1e-12
+        assert float(d.norm() / (want.norm() + 1e-30)) < 3e-3, (name, float(d.norm() / want.norm()))
+        assert float((d > 3e-4 * scale).double().mean()) < 1e-2, (name, float((d > 3e-4 * scale).double().mean()))   # one flip touches a 5x5x3 patch of d_image
+    check(x.grad, xr.grad, "d_image")
+    for (name, p) in enc.named_parameters():
+        assert p.grad is not None, name
+        check(p.grad, ref_w[name].grad, name)
