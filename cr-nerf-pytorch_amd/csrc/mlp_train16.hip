@@ -2,9 +2,9 @@
 // activations, backward-data (dgrad) on the transposed weight stream, and weight/bias gradients as
 // point-reduction GEMMs.  In the reference all of this is PyTorch autograd over 11 addmm nodes.
 //
-//   forward-train : mlp_tile16 + stores of h1..h8, final, dir_act           acts[10][P][256]
+//   forward-train : mlp_tile16 + stores of h1..h8, final, dir_act           acts[10][P][256] (+ 256 relu bits per point and layer)
 //   backward-data : per 16-point tile, delta stays in registers exactly like the forward activations
-//                   (D[in][point] = W^T[in][out] . delta[out][point]); relu masks come from acts;
+//                   (D[in][point] = W^T[in][out] . delta[out][point]); relu masks come from the saved bits;
 //                   every layer's delta is stored                           deltas[10][P][256], d_rgb[P][64], d_sig[P]
 //   wgrad         : dW[m][n] = sum_p delta[p][m] * a[p][n]  (fp32 MFMA 32x32x2, k = points),
 //                   point-chunked partials + deterministic reduce, written straight in the reference
@@ -19,6 +19,14 @@ namespace crnerf {
 constexpr int ACT_SLOTS = 10;   // h1..h8, final, dir_act(128 used)
 constexpr int ACT_W = 256;
 
+// relu-activity bits of the saved activations: masks[slot][point][g] = 64 bits, bit 4T + r <-> feature 16T + 4g + r.
+// The backward-data kernel reads these 32 B per point and layer (all ten layers in ONE load batch per tile) instead of
+// re-reading the 1 KiB activation row behind every layer -- each of those reads was consumed on the spot, i.e. a
+// s_waitcnt vmcnt(0) that also drained the weight prefetch, ten times per tile.
+__device__ __forceinline__ unsigned long long* mask_slot(float* acts, long P, int slot, long n, int g) {
+  return (unsigned long long*)(acts + (size_t)ACT_SLOTS * P * ACT_W) + ((size_t)slot * P + n) * 4 + g;
+}
+
 struct ActSaver {
   float* base; long P; long n; bool valid; int g;
   template <int NT>
@@ -26,9 +34,21 @@ struct ActSaver {
     if (!valid) return;
     float* row = base + ((long)slot * P + n) * ACT_W + 4 * g;
     const int nt = slot == 9 ? 8 : NT;
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int T = 0; T < NT; ++T)
-      if (T < nt) *(f32x4*)(row + 16 * T) = a[T];
+      if (T < nt) {
+        *(f32x4*)(row + 16 * T) = a[T];
+        if (slot != 8) {   // xyz_encoding_final is linear: no mask
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t bit = a[T][r] > 0.0f ? 1u : 0u;       // post-relu values: > 0 <=> pre-activation > 0
+            const int k = 4 * T + r;
+            if (k < 32) lo |= bit << k; else hi |= bit << (k - 32);
+          }
+        }
+      }
+    if (slot != 8) *mask_slot(base, P, slot, n, g) = ((unsigned long long)hi << 32) | lo;
   }
 };
 
@@ -55,18 +75,20 @@ __global__ __launch_bounds__(512, 2) void mlp_forward_train16_kernel(const char*
     f32x4 pe[6], feat[4];
     DirRegs dreg;
     f32x4 (&dv)[2] = dreg.v;
+    int gg = g;
+    asm volatile("" : "+v"(gg));   // keep the 32 lane-group-dependent column selects inside the loop (hoisted, they are spilled)
 #pragma unroll
     for (int v = 0; v < 6; ++v)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int c = posenc_slot_to_col16(16 * v + 4 * g + r, XYZ_FREQS);
+        const int c = posenc_slot_to_col16(16 * v + 4 * gg + r, XYZ_FREQS);
         pe[v][r] = (valid && c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
       }
 #pragma unroll
     for (int v = 0; v < 2; ++v)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int c = posenc_slot_to_col16(16 * v + 4 * g + r, DIR_FREQS);
+        const int c = posenc_slot_to_col16(16 * v + 4 * gg + r, DIR_FREQS);
         dv[v][r] = (valid && c >= 0) ? row[XYZ_DIM + (c < 0 ? 0 : c)] : 0.0f;
       }
     float sigma;
@@ -91,16 +113,20 @@ __device__ __forceinline__ void zero_acc16(f32x4 (&acc)[NT]) {
   for (int T = 0; T < NT; ++T) acc[T] = f32x4{0, 0, 0, 0};
 }
 
-// delta_in[T] = mask(act_saved[T] > 0) * acc[T]; store to deltas slot
+// delta_in[T] = mask * acc[T] (mask: this layer's relu-activity bits, see mask_slot); store to the deltas slot
 template <int NT, bool MASK>
-__device__ __forceinline__ void finish_delta(const f32x4 (&acc)[NT], f32x4 (&dl)[16], const float* act_row, float* delta_row, bool valid) {
+__device__ __forceinline__ void finish_delta(const f32x4 (&acc)[NT], f32x4 (&dl)[16], unsigned long long bits, float* delta_row, bool valid) {
+  const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     f32x4 d = acc[T];
     if (MASK) {
-      const f32x4 a = valid ? *(const f32x4*)(act_row + 16 * T) : f32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d[r] = a[r] > 0.0f ? d[r] : 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * T + r;
+        const uint32_t on = ((k < 32 ? lo >> k : hi >> (k - 32)) & 1u);
+        d[r] = on ? d[r] : 0.0f;
+      }
     }
     dl[T] = d;
     if (valid) *(f32x4*)(delta_row + 16 * T) = d;
@@ -131,7 +157,9 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
     const long nn = valid ? n : 0;
     const float* orow = out + nn * OUT_DIM;
     const float* grow = d_out + nn * OUT_DIM;
-    auto act_row = [&](int slot) { return acts + ((long)slot * P + nn) * ACT_W + 4 * g; };
+    unsigned long long bits[ACT_SLOTS];   // all ten layers' relu bits of this lane's 64 features: one load batch per tile
+#pragma unroll
+    for (int sl = 0; sl < ACT_SLOTS; ++sl) bits[sl] = (valid && sl != 8) ? *mask_slot((float*)acts, P, sl, nn, g) : 0ull;
     auto del_row = [&](int slot) { return deltas + ((long)slot * P + nn) * ACT_W + 4 * g; };
 
     f32x4 dl[16], acc[16];
@@ -155,11 +183,11 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
       f32x4 acc8[8];
       zero_acc16<8>(acc8);
       mma_layer16<8, 4, 0>(pipe, drgb, drgb, acc8, q);
-      finish_delta<8, true>(acc8, dl, act_row(9), del_row(9), valid);
+      finish_delta<8, true>(acc8, dl, bits[9], del_row(9), valid);
     }
     zero_acc16<16>(acc);                               // through dir_encoding^T[:, :256] -> xyz_encoding_final output (linear)
     mma_layer16<16, 8, 0>(pipe, dl, dl, acc, q);
-    finish_delta<16, false>(acc, dl, act_row(8), del_row(8), valid);
+    finish_delta<16, false>(acc, dl, 0ull, del_row(8), valid);
     zero_acc16<16>(acc);                               // through xyz_encoding_final^T, + sigma head -> h8 (relu)
     mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
 #pragma unroll
@@ -168,12 +196,12 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[T][r] = fmaf(w[r], dsp, acc[T][r]);
     }
-    finish_delta<16, true>(acc, dl, act_row(7), del_row(7), valid);
+    finish_delta<16, true>(acc, dl, bits[7], del_row(7), valid);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                     // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2
       zero_acc16<16>(acc);
       mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
-      finish_delta<16, true>(acc, dl, act_row(l - 1), del_row(l - 1), valid);
+      finish_delta<16, true>(acc, dl, bits[l - 1], del_row(l - 1), valid);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -387,7 +415,7 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
   return 0;
 }
 
-size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float); }
+size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float) + (size_t)ACT_SLOTS * P * 32; }   // activations + relu bits
 size_t mlp_train_scratch_bytes(long P) {
   const int chunk = wg_chunk(P);
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
