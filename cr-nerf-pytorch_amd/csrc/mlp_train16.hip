@@ -218,7 +218,7 @@ struct WgradJob {
 
 template <int MT, int NT>
 __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
-                                                    int wave) {
+                                                    bool bias_wave) {
   constexpr int KS = 4;                       // k-steps (2 points each) per iteration
   int dcol[MT], acol[NT];
   float dmask[MT], amask[NT];
@@ -242,7 +242,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
       for (int t = 0; t < NT; ++t) a[s][t] = ar[acol[t]] * amask[t];
     }
   };
-  const bool do_bias = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;   // one wave column per M block
+  const bool do_bias = j.bias_partial && blockIdx.z == 0 && bias_wave;
   float bs[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) bs[t] = 0.0f;
@@ -295,11 +295,17 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
-  const int m0 = blockIdx.y * 256 + (wave & 1) * 128, n0 = blockIdx.z * 256 + (wave >> 1) * 128;
+  // wave tiles: 2 (M) x 2 (N) of 128 x 128 -- or, for the narrow heads (M <= 128: dir_encoding, static_rgb, static_sigma),
+  // 1 x 4 of 128 x 64, so that all four waves have columns to work on instead of two (or one) of them
+  const bool nsplit = j.M <= 128;
+  const int m0 = blockIdx.y * 256 + (nsplit ? 0 : (wave & 1) * 128);
+  const int n0 = blockIdx.z * 256 + (nsplit ? wave * 64 : (wave >> 1) * 128);
+  const int ncap = nsplit ? 2 : 4;
   const long p0 = (long)blockIdx.x * j.chunk;
   const long p1 = p0 + j.chunk < j.P ? p0 + j.chunk : j.P;
   const int mt = (j.M - m0 + 31) / 32 < 4 ? (j.M - m0 + 31) / 32 : 4;   // live 32-row tiles of this wave (<= 0: none)
-  const int nt = (j.N - n0 + 31) / 32 < 4 ? (j.N - n0 + 31) / 32 : 4;
+  const int nt = (j.N - n0 + 31) / 32 < ncap ? (j.N - n0 + 31) / 32 : ncap;
+  const bool bias_wave = nsplit ? wave == 0 : (wave >> 1) == 0;          // one wave per M block sums the bias gradient
   if (mt <= 0 || nt <= 0) return;
   f32x16 acc[4][4];
 #pragma unroll
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  if (mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
+  if (!nsplit && mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
     // ---- full 128x128 wave tile (every 256-wide layer): branch-free stream.  Column mapping: MFMA tile t, lane i <->
     // column 4i + t, so a lane's four operands of a point are ONE 16-byte load (512 contiguous bytes per half-wave) and
     // the whole k-step is 2 x global_load_dwordx4 + 16 MFMAs.  (The guarded generic loop below puts a branch around
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
         a[s] = av;
       }
     };
-    const bool do_bias4 = j.bias_partial && blockIdx.z == 0 && (wave >> 1) == 0;
+    const bool do_bias4 = j.bias_partial && blockIdx.z == 0 && bias_wave;
     f32x4 bs4 = {0.0f, 0.0f, 0.0f, 0.0f};
     fetch4(p0, dc, ac);
     for (long pb = p0; pb < p1; pb += 2 * KF) {
@@ -365,11 +371,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     return;
   }
   // ---- partial tiles (N = 93 / 27 embedding blocks, M = 128 / 64 / 1 heads): the same stream with MT x NT live MFMA
-  // tiles, MT in {1,2,4}, NT in {1,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
+  // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
-  const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt <= 3 ? 3 : 4);
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, wave); return; }
-  CRNERF_WG(1, 1) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 3) CRNERF_WG(2, 4) CRNERF_WG(4, 1) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
+  const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, bias_wave); return; }
+  CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
+  CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
 }
 
