@@ -75,7 +75,9 @@ struct PhaseTimer {
 // One LDS-DMA piece: lanes copy 16 B each, global (base + voff + imm) -> LDS (lds_addr + imm + 16 * lane).  Written as
 // asm on purpose: with the builtin, hipcc's waitcnt model stops counting LDS reads across an LDS-DMA instruction and
 // the next use of ANY prefetched fragment becomes s_waitcnt lgkmcnt(0) -- the read-ahead ring is drained every fourth
-// k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)
+// k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)  The asm rewrites M0 without telling
+// the compiler (M0 is a reserved register, clang rejects it as a clobber): kernels that contain it must not index
+// register arrays dynamically (s_set_gpr_idx / v_movrel keep their index in M0) -- checked by grepping the ISA.
 __device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
                : "memory");

@@ -201,7 +201,10 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
     for (int l = 7; l >= 1; --l) {                     // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2
       zero_acc16<16>(acc);
       mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
-      finish_delta<16, true>(acc, dl, bits[l - 1], del_row(l - 1), valid);
+      unsigned long long bl = bits[0];   // bits[l - 1] by selects: a dynamic register index would go through M0, which the
+#pragma unroll                           // LDS-DMA asm (glds16) rewrites behind the compiler's back
+      for (int t = 1; t < 7; ++t) bl = (l - 1 == t) ? bits[t] : bl;
+      finish_delta<16, true>(acc, dl, bl, del_row(l - 1), valid);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
