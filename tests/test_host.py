@@ -148,3 +148,26 @@ def test_shard_bounds_cover_without_overlap():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_kernels_with_asm_lds_dma_do_not_use_m0_indexing(tmp_path):
+    """glds16 (csrc/mlp_core.h) rewrites M0 inside inline asm, which the compiler cannot be told (M0 is reserved).  That is
+    safe as long as the compiler itself never parks state in M0 in those kernels: dynamic register indexing
+    (s_set_gpr_idx_* / v_movrel*) is the one construct that would.  Checked on the generated gfx950 ISA."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "cr-nerf-pytorch_amd", "csrc")
+    units = ["render_fused16.hip", "mlp_forward16.hip", "mlp_train16.hip", "render_fused_bf16.hip", "mlp_forward_bf16.hip"]
+    procs = [(u, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-S",
+                                   "--cuda-device-only", "-I", csrc, os.path.join(csrc, u), "-o", str(tmp_path / (u + ".s"))],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)) for u in units]
+    for u, p in procs:
+        out, _ = p.communicate()
+        assert p.returncode == 0, out.decode(errors="replace")[-2000:]
+        isa = open(tmp_path / (u + ".s")).read()
+        assert "global_load_lds_dwordx4" in isa, u
+        for bad in ("s_set_gpr_idx", "v_movrel"):
+            assert bad not in isa, "%s: %s found -- a dynamic register index would collide with the LDS-DMA asm's use of M0" % (u, bad)
