@@ -83,49 +83,52 @@ static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protoco
 
 // Weight ring for 4 waves x 4 pieces per stage; protocol documented at mlp_core.h WeightPipe.  Everything except
 // lane16 / rd_addr / nx_addr is wave-uniform (SGPRs): the stream pointers are scalar and the lane offset rides in the
-// instruction's VGPR-offset operand.  The cursor update is branch-free so the MFMA stream stays one basic block.
+// instruction's VGPR-offset operand.
 struct WeightPipeB {
+  // Scalar instructions are NOT free beside the MFMA stream (tools/ubench: ~3.5 cycles each wherever they are placed,
+  // i.e. the first version's ~27 SALU of ring bookkeeping per stage cost 2.4 cycles per MFMA), so the state is kept in
+  // the form that needs the fewest of them: LDS byte addresses that are bumped and wrapped instead of slot indices that
+  // are scaled, per-lane read addresses updated with VALU instructions (free up to four per MFMA gap), M0 written once
+  // per stage, and the once-per-pass stream switch behind a (uniform, almost never taken) branch.
   const char* base[2];   // packed streams + this wave's 4 KiB column
   const char* pf_ptr;    // stage being fetched
   int pf_left, pf_pass, passes0, passes;
-  uint32_t lds_ring;     // LDS byte address of the ring + this wave's 4 KiB column
-  uint32_t pf_slot, rd_slot;
+  uint32_t pf_dst;       // LDS byte address the stage being fetched goes to (+ this wave's 4 KiB column)
+  uint32_t ring_lo, ring_hi;   // pf_dst range
   uint32_t rd_addr, nx_addr;   // per-lane LDS byte address of fragment 0 of stage c / c+1
   uint32_t lane16;
   lds_char* lds;
 
   __device__ __forceinline__ void issue_piece(int i) {
 #ifndef CRNERF_EXP_NOGLDS
-    const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    // piece 0 writes M0 (= LDS base of the stage); pieces 1..3 reuse it with their instruction offset.  Nothing else in
+    // these kernels touches M0 (tests/test_host.py checks the ISA).
     switch (i) {   // the instruction offset must be an immediate
-      case 0: glds16(dst, pf_ptr, lane16, 0); break;
-      case 1: glds16(dst, pf_ptr, lane16, 1 * FRAG_BYTES); break;
-      case 2: glds16(dst, pf_ptr, lane16, 2 * FRAG_BYTES); break;
-      default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
+      case 0: glds16(pf_dst, pf_ptr, lane16, 0); break;
+      case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(1 * FRAG_BYTES) : "memory"); break;
+      case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(2 * FRAG_BYTES) : "memory"); break;
+      default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(3 * FRAG_BYTES) : "memory"); break;
     }
 #endif
   }
   // after the 4th piece of a stage: move the fetch cursor to the next stage
   __device__ __forceinline__ void cursor_update() {
-    pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
-    const bool wrap = (pf_left == 1);
-    const int np = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
-    const char* nb = (np < passes0) ? base[0] : base[1];
-    pf_left = wrap ? STAGESB_PER_PASS : pf_left - 1;
-    pf_pass = wrap ? np : pf_pass;
-    pf_ptr = wrap ? nb : pf_ptr + STAGE_BYTES;
+    pf_dst = (pf_dst + STAGE_BYTES == ring_hi) ? ring_lo : pf_dst + STAGE_BYTES;
+    pf_ptr += STAGE_BYTES;
+    if (__builtin_expect(--pf_left == 0, 0)) {   // end of a pass: switch stream (once per 76 stages)
+      pf_left = STAGESB_PER_PASS;
+      pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
+      pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
+    }
     asm volatile("" : "+s"(pf_ptr));   // opaque: else a single-pass kernel gets 302 precomputed addresses
-  }
-  __device__ __forceinline__ void set_addrs() {
-    const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
-    rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
-    nx_addr = LDS_RING + n * STAGE_BYTES + lane16;
   }
   __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_, int lane,
                                         int wave) {
     lds = lds_;
     lane16 = (uint32_t)lane * 16u;
-    lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + (uint32_t)wave * 4096u;
+    ring_lo = (uint32_t)(uintptr_t)lds_ + LDS_RING + (uint32_t)wave * 4096u;
+    ring_hi = ring_lo + RING_SLOTS * STAGE_BYTES;
+    pf_dst = ring_lo;
     base[0] = stream0 + wave * 4096;
     base[1] = stream1 + wave * 4096;
     passes0 = passes0_;
@@ -133,9 +136,8 @@ struct WeightPipeB {
     pf_pass = 0;
     pf_left = STAGESB_PER_PASS;
     pf_ptr = (passes0 > 0) ? base[0] : base[1];
-    pf_slot = 0;
-    rd_slot = 0;
-    set_addrs();
+    rd_addr = LDS_RING + lane16;
+    nx_addr = LDS_RING + STAGE_BYTES + lane16;
 #pragma unroll
     for (int s = 0; s < RING_SLOTS - 1; ++s) {
 #pragma unroll
@@ -150,8 +152,9 @@ struct WeightPipeB {
 #ifndef CRNERF_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
-    rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
-    set_addrs();
+    rd_addr = nx_addr;                                           // per-lane, VALU only
+    const uint32_t n = nx_addr + STAGE_BYTES;
+    nx_addr = n >= LDS_RING + RING_SLOTS * STAGE_BYTES + lane16 ? n - RING_SLOTS * STAGE_BYTES : n;
   }
   // fragment `slot` of stage c (next == false) or c+1
   __device__ __forceinline__ u32x4 read(bool next, int slot) const {

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 KSTEPS = 32          # per asm block (2 "tiles" of 16)
 def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None, rotate_b=False, bias_c=False, glds=False, barrier=False,
-         real_order=False, nop=True, ds_first=False):
+         real_order=False, nop=True, ds_first=False, tile_extras=False, x_doubles=True, x_bias=True, x_salu=True):
     L = []
     acc0, acc1 = ("a[0:15]", "a[16:31]") if acc == "a" else ("v[128:143]", "v[144:159]")
     b0, b1 = ("v[16:19]", "v[20:23]") if bsrc == "v" else ("a[64:67]", "a[68:71]")
@@ -58,6 +58,25 @@ def body(fill_kind, per_kstep, acc="a", bsrc="v", dsread=True, first_gap=None, r
             if dsread:
                 L.append("ds_read_b128 v[%d:%d], %%0 offset:%d" % (q, q + 3, 1024 * (s % 16)))
             L += fills[half:]
+        if tile_extras:   # what a 16-k-step tile of the real layer loop carries besides the steady-state k-step
+            sl = s % 16
+            if x_doubles and sl in (4, 8, 12):      # second quarter of the double k-steps
+                L += fills
+            if x_bias and sl in (12, 13):        # next tile's bias, two 16-byte LDS reads per k-step straight into AGPRs
+                L += ["ds_read_b128 a[72:75], %0 offset:16384", "ds_read_b128 a[76:79], %0 offset:16400"]
+            if x_salu == "spread":    # the same bookkeeping cut into pieces over k-steps 14, 15, 0, 2, 3
+                sal = lambda n, b: ["s_add_u32 s%d, s%d, %d" % (40 + (b + i) % 7, 40 + (b + i) % 7, i + 1) for i in range(n)]
+                if sl == 14: L += sal(4, 0) + ["v_mov_b32 v124, v126", "v_mov_b32 v126, v127"]
+                if sl == 15: L += sal(6, 1)
+                if sl == 0: L += sal(6, 2)
+                if sl == 2: L += sal(3, 3)
+                if sl == 3: L += sal(2, 4) + ["v_add_u32 v127, s41, v125"]
+            if x_salu is True and sl == 14:              # advance(): ring-slot bookkeeping
+                L += ["s_add_u32 s40, s40, 1", "s_cmp_eq_u32 s40, 6", "s_cselect_b32 s40, 0, s40", "s_lshl_b32 s41, s40, 14", "s_add_u32 s41, s41, 0x5800",
+                      "v_add_u32 v124, s41, v125", "v_add_u32 v126, s41, v125"]
+            if x_salu is True and sl == 15:              # cursor_update(): ~10 scalar instructions
+                L += ["s_add_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 6", "s_cselect_b32 s42, 0, s42", "s_cmp_eq_u32 s43, 1", "s_cselect_b32 s44, 1, 0",
+                      "s_sub_u32 s43, s43, 1", "s_add_u32 s45, s45, 0x4000", "s_addc_u32 s46, s46, 0", "s_cmp_lg_u32 s44, 0", "s_cselect_b32 s43, 76, s43"]
         if barrier and s % 16 == 14:
             L += ["s_waitcnt vmcnt(8)", "s_barrier"]
     return "\\n\\t".join(L)
@@ -85,9 +104,16 @@ VARIANTS = [
     ("  + bias as C of a tile's first MFMAs", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True)),
     ("  + LDS-DMA piece every 4th k-step", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True, glds=True)),
     ("  + vmcnt wait + s_barrier every 16th", dict(fill_kind="epi4", per_kstep=4, real_order=True, rotate_b=True, bias_c=True, glds=True, barrier=True)),
+    ("shipped order (ds_read first) + DMA + barrier", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True)),
+    ("  + per-tile extras (doubles, bias reads, SALU)", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True)),
+    ("    extras: only the double quarters", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True, x_bias=False, x_salu=False)),
+    ("    extras: only the bias reads", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True, x_doubles=False, x_salu=False)),
+    ("    extras: SALU bookkeeping spread over 5 k-steps", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True, x_doubles=False, x_bias=False, x_salu="spread")),
+    ("    all extras, SALU spread", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True, x_salu="spread")),
+    ("    extras: only the SALU bookkeeping", dict(fill_kind="epi4", per_kstep=4, real_order=True, ds_first=True, rotate_b=True, bias_c=True, glds=True, barrier=True, tile_extras=True, x_doubles=False, x_bias=False)),
 ]
 
-clob = ", ".join('"v%d"' % i for i in range(0, 96)) + ", " + ", ".join('"v%d"' % i for i in range(100, 196)) + ", " + ", ".join('"a%d"' % i for i in range(0, 88))
+clob = '"s40", "s41", "s42", "s43", "s44", "s45", "s46", "scc", ' + ", ".join('"v%d"' % i for i in range(0, 96)) + ", " + ", ".join('"v%d"' % i for i in range(100, 196)) + ", " + ", ".join('"a%d"' % i for i in range(0, 88))
 src = ['#include <hip/hip_runtime.h>', '#include <stdio.h>', 'typedef __attribute__((address_space(3))) char lds_char;']
 for k, (name, kw) in enumerate(VARIANTS):
     src.append('''__global__ __launch_bounds__(256, 1) void k%d(unsigned long long* out, int iters, const char* gsrc0) {
