@@ -181,3 +181,31 @@ def test_encoder_backward_vs_autograd_oracle(H, W):
     for (name, p) in enc.named_parameters():
         assert p.grad is not None, name
         check(p.grad, ref_w[name].grad, name)
+
+
+@torch.no_grad()
+def test_video_frames_shard_across_ranks_without_exchange():
+    """appearance_modification_video.py:224-262 through crnerf_amd.video: the frame list is cut rank-wise; the union of two
+    'ranks' equals the single-rank run frame for frame (frames are independent: no collective)."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import pipeline, video
+
+    class HPV(HP):
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance = [40, 24], 32, 32
+    hp = HPV()
+    m, emb = pipeline.get_model(hp, DEV), pipeline.get_embeddings(hp)
+    m["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 3.0, 1.0).items()})
+    m["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 3.0, 1.0).items()})
+    m["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    enc = pipeline.encoder_sameoutputsize(64).to(DEV)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+    style = torch.rand(1, 3, 40, 56, device=DEV)
+    whole = video.render_video(m, emb, enc, style, hp, "trevi_fountain", n_frames=6)
+    parts = {}
+    for r in range(2):
+        parts.update(video.render_video(m, emb, enc, style, hp, "trevi_fountain", n_frames=6, rank=r, world_size=2))
+    assert sorted(whole) == sorted(parts) == list(range(6))
+    for i in range(6):
+        assert whole[i].shape == (24, 40, 3) and whole[i].dtype == np.uint8
+        assert np.array_equal(whole[i], parts[i])

@@ -154,3 +154,15 @@ def test_batcher_draws_and_oracle_gather_match_reference(golden, tag):
     s = O.grid_sample_batch(rays, rgbs, wh, ts, int(np.sqrt(int(v("batch")))), scale, ho, wo)
     for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"):
         assert np.array_equal(s[k].numpy(), v(k)), k
+
+
+def test_video_camera_path_matches_reference(golden):
+    """crnerf_amd.video (table-driven fly-throughs) against the reference's define_poses_* / define_camera outputs."""
+    from crnerf_amd import video
+    g = golden("g12_video")
+    for scene, key in (("brandenburg_gate", "poses_gate"), ("trevi_fountain", "poses_fountain")):
+        got = video.define_poses(scene)
+        assert got.shape == g[key].shape == (240, 3, 4)
+        np.testing.assert_allclose(got, g[key], rtol=0, atol=1e-14)
+    for wh in ((320, 240), (800, 800)):
+        np.testing.assert_allclose(video.define_camera(wh), g["K_%dx%d" % wh], rtol=0, atol=1e-12)
