@@ -154,19 +154,24 @@ __global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j
 #pragma unroll
   for (int it = 0; it < 18; ++it) *(f32x4*)(sm + 4 * (tid + 256 * it)) = stage[it];
   if (tid < 128) sm[GF_B1 + tid] = J.w.b1[tid];
+  if (tid < 64) sm[GF_B2 + tid] = J.w.b2[tid];
+  if (tid < 32) sm[GF_B3 + tid] = J.w.b3[tid];
+  // channel means from the partial rows: four row-interleaved partial sums per channel with the loads of a partial in
+  // flight together (a plain row loop is chan_rows dependent L2 round trips -- 64 of them, ~25 us, for a 32x32 grid)
+  float part = 0.0f;
+  if (!J.mean) {
+    const int c = tid & 63, q = tid >> 6;
+#pragma unroll 8
+    for (int r = q; r < J.chan_rows; r += 4) part += J.chan_partial[r * 64 + c];
+    sm[GF_HB + q * 64 + c] = part;     // the transpose buffers are idle until the tile loop
+  }
+  __syncthreads();
   if (tid < 64) {
-    sm[GF_B2 + tid] = J.w.b2[tid];
-    float m;
-    if (J.mean) m = J.mean[tid];
-    else {
-      float s = 0.0f;
-      for (int r = 0; r < J.chan_rows; ++r) s += J.chan_partial[r * 64 + tid];
-      m = s * J.inv_count;
-    }
+    const float m = J.mean ? J.mean[tid]
+                           : ((sm[GF_HB + tid] + sm[GF_HB + 64 + tid]) + (sm[GF_HB + 128 + tid] + sm[GF_HB + 192 + tid])) * J.inv_count;
     sm[GF_MEAN + tid] = m;
     if (blk == 0 && J.mean_out) J.mean_out[tid] = m;
   }
-  if (tid < 32) sm[GF_B3 + tid] = J.w.b3[tid];
   __syncthreads();
 
   float* hb = sm + GF_HB + wave * 32 * 33;
@@ -282,22 +287,26 @@ int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_
 // ---------------------------------------------------------------- fold: A[3][64], v[3]  (single 256-thread block)
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ sM, const float* __restrict__ cM, const float* __restrict__ c_mean,
                                                    const float* __restrict__ s_mean, FoldTensors w, float* __restrict__ affine) {
+  // Everything this kernel reads (two 32x32 matrices, ~4.6k weights) goes to LDS in ONE batch of coalesced loads; the
+  // chain of small products then runs out of LDS.  (Read on demand, the last step alone was 160 dependent global loads
+  // in three threads: 8 us for 0.1 MFLOP.)
   __shared__ float S[32][33], Cm[32][33], T[32][33], U[3][32], P[3][64], Q[3][32];
+  __shared__ float Wrgb[3][64], Wun[64][33], Wcomp[32][65], bun[64], bcomp[32], cmean[64];
   const int t = threadIdx.x;
   if (sM) {
-    // operands into LDS first (coalesced); the weight-only product U = Wrgb @ Wunzip (3x32) rides along
     for (int e = t; e < 1024; e += 256) {
       S[e >> 5][e & 31] = sM[e];
       Cm[e >> 5][e & 31] = cM[e];
     }
-    if (t < 96) {
-      const int r = t >> 5, c = t & 31;
-      float a = 0.0f;
-      for (int k = 0; k < 64; ++k) a = fmaf(w.rgb_w[r * 64 + k], w.unzip_w[k * 32 + c], a);
-      U[r][c] = a;
+    for (int e = t; e < 2048; e += 256) {
+      Wun[e >> 5][e & 31] = w.unzip_w[e];         // [64][32]
+      Wcomp[e >> 6][e & 63] = w.comp_w[e];        // [32][64]
     }
+    if (t < 192) Wrgb[t >> 6][t & 63] = w.rgb_w[t];
+    if (t < 64) { bun[t] = w.unzip_b[t] + s_mean[t]; cmean[t] = c_mean[t]; }
+    if (t < 32) bcomp[t] = w.comp_b[t];
     __syncthreads();
-    // T = sMatrix @ cMatrix                                   linearStyleTransfer.py:86
+    // T = sMatrix @ cMatrix (linearStyleTransfer.py:86) and, alongside, U = Wrgb @ Wunzip (3x32)
     for (int e = t; e < 1024; e += 256) {
       const int i = e >> 5, j = e & 31;
       float a = 0.0f;
@@ -305,30 +314,38 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ sM,
       for (int k = 0; k < 32; ++k) a = fmaf(S[i][k], Cm[k][j], a);
       T[i][j] = a;
     }
-    __syncthreads();
-    // Q = U @ T (3x32), A = Q @ Wcomp (3x64)
     if (t < 96) {
       const int r = t >> 5, c = t & 31;
       float a = 0.0f;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) a = fmaf(Wrgb[r][k], Wun[k][c], a);
+      U[r][c] = a;
+    }
+    __syncthreads();
+    if (t < 96) {                                   // Q = U @ T (3x32)
+      const int r = t >> 5, c = t & 31;
+      float a = 0.0f;
+#pragma unroll 8
       for (int k = 0; k < 32; ++k) a = fmaf(U[r][k], T[k][c], a);
       Q[r][c] = a;
     }
     __syncthreads();
-    if (t < 192) {
+    if (t < 192) {                                  // A = Q @ Wcomp (3x64)
       const int r = t >> 6, c = t & 63;
       float a = 0.0f;
-      for (int k = 0; k < 32; ++k) a = fmaf(Q[r][k], w.comp_w[k * 64 + c], a);
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) a = fmaf(Q[r][k], Wcomp[k][c], a);
       P[r][c] = a;
       affine[r * 64 + c] = a;
     }
     __syncthreads();
-    // v = Q (bcomp) - A cMean + Wrgb (bunzip + sMean) + brgb
-    if (t < 3) {
-      float a = w.rgb_b[t];
-      for (int k = 0; k < 32; ++k) a = fmaf(Q[t][k], w.comp_b[k], a);
-      for (int k = 0; k < 64; ++k) a = fmaf(-P[t][k], c_mean[k], a);
-      for (int k = 0; k < 64; ++k) a = fmaf(w.rgb_w[t * 64 + k], w.unzip_b[k] + s_mean[k], a);
-      affine[192 + t] = a;
+    // v = Q bcomp - A cMean + Wrgb (bunzip + sMean) + brgb: wave r sums row r, one term per lane
+    if (t < 192) {
+      const int r = t >> 6, k = t & 63;
+      float a = (k < 32 ? Q[r][k] * bcomp[k] : 0.0f) - P[r][k] * cmean[k] + Wrgb[r][k] * bun[k];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+      if (k == 0) affine[192 + r] = a + w.rgb_b[r];
     }
   } else {
     // type == "content": decoder only                          linearStyleTransfer.py:285-287
