@@ -112,6 +112,14 @@ __device__ __forceinline__ float composite_tile(CompositeState& st, const f32x16
 // instead of two 32-lane ones.  Lane 32h + p evaluates alpha of sample 32h + p (= its group-h point), the scan runs
 // over lanes in sample order, and the two halves swap weights at the end.  sigma / noise / zn / znext / is_last /
 // valid are indexed by group.  Returns this lane's two weights.
+// source lane's value through the DPP network, 1.0 where the control selects no source lane / the row is masked out
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0x3ff00000, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 struct Weights2 { float w[2]; };
 __device__ __forceinline__ Weights2 composite_tile64(CompositeState& st, const f32x16 (&feat)[2][2], const float (&sigma)[2],
                                                      const float (&noise)[2], const float (&zn)[2], const float (&znext)[2],
@@ -122,16 +130,19 @@ __device__ __forceinline__ Weights2 composite_tile64(CompositeState& st, const f
   const bool last = h ? is_last[1] : is_last[0], ok = h ? valid[1] : valid[0];
   const float delta = last ? 1e2f : z1 - z0;
   const float alpha = ok ? 1.0f - expf(-delta * fmaxf(sg + ns, 0.0f)) : 0.0f;
+  // inclusive prefix product over the 64 lanes on the DPP network (no LDS crossbar round trips): four shifts inside the
+  // 16-lane rows, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3.  A lane without a source
+  // keeps the identity 1.0 it passes as `old`.
   double incl = (double)(1.0f - alpha);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double o = shfl_up_f64(incl, d, 64);
-    if (lane >= d) incl *= o;
-  }
-  double excl = shfl_up_f64(incl, 1, 64);
-  if (lane == 0) excl = 1.0;
+  incl *= dpp_f64<0x111, 0xf>(incl);   // row_shr:1
+  incl *= dpp_f64<0x112, 0xf>(incl);   // row_shr:2
+  incl *= dpp_f64<0x114, 0xf>(incl);   // row_shr:4
+  incl *= dpp_f64<0x118, 0xf>(incl);   // row_shr:8
+  incl *= dpp_f64<0x142, 0xa>(incl);   // row_bcast:15 -> rows 1, 3
+  incl *= dpp_f64<0x143, 0xc>(incl);   // row_bcast:31 -> rows 2, 3
+  const double excl = dpp_f64<0x138, 0xf>(incl);   // wave_shr:1; lane 0 keeps 1.0
   const float T = (float)(st.t_carry * excl);
-  st.t_carry *= shfl_f64(incl, 63, 64);
+  st.t_carry *= __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incl), 63), __builtin_amdgcn_readlane(__double2loint(incl), 63));
   const float mine = alpha * T;
   const float other = __shfl_xor(mine, 32);
   Weights2 r;
