@@ -24,6 +24,7 @@ EXPORTS = [
     "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
     "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32", "crnerf_crossray_decode_sharded_f32",
     "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16",
+    "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
 ]
@@ -133,6 +134,8 @@ def load():
             "crnerf_crossray_decode_backward_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, i64, vp, vp, vp, pp, vp]),
             "crnerf_crossray_decode_sharded_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, i32, vp, f64, vp, vp, i64, vp]),
             "crnerf_crossray_decode_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, vp, i64, vp]),
+            "crnerf_decoder_content_backward_workspace_bytes": (ctypes.c_size_t, [i64]),
+            "crnerf_decoder_content_backward_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp]),
             "crnerf_encoder_train_saved_bytes": (ctypes.c_size_t, [i32, i32]),
             "crnerf_encoder_train_scratch_bytes": (ctypes.c_size_t, [i32, i32]),
             "crnerf_encoder_forward_train_f32": (ctypes.c_int, [vp, i32, i32, pp, vp, vp, vp]),

@@ -89,3 +89,21 @@ class EncoderFn(torch.autograd.Function):
         out, saved, *w = ctx.saved_tensors
         grads, d_img = ops.encoder_backward(w, saved, ctx.hw, out, d_out.contiguous(), want_d_image=ctx.needs_input_grad[0])
         return (d_img.view(ctx.image_shape) if d_img is not None else None,) + tuple(g.view_as(t) for g, t in zip(grads, w))
+
+
+class ContentDecoderFn(torch.autograd.Function):
+    """style_net.forward(content, None, type='content'): fwd crnerf_crossray_decode_f32 (style == NULL),
+    bwd crnerf_decoder_content_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, xp, rgb_w, rgb_b, all_weights):
+        out = ops.crossray_decode(xp, None, all_weights)          # planar [3,HW]
+        ctx.save_for_backward(xp, rgb_w, out)
+        ctx.w_shape = rgb_w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        xp, rgb_w, out = ctx.saved_tensors
+        dx, dw, db = ops.decoder_content_backward(xp, rgb_w, out, d_rgb.contiguous())
+        return dx, dw.view(ctx.w_shape), db, None

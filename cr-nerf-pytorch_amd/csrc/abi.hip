@@ -293,6 +293,19 @@ int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, f
 }
 
 
+size_t crnerf_decoder_content_backward_workspace_bytes(int64_t HW) { return content_backward_workspace_floats((long)HW) * sizeof(float); }
+
+int crnerf_decoder_content_backward_f32(const float* content, int64_t HW, const float* rgb_w, const float* rgb, int64_t rgb_plane_stride,
+                                        const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_w, float* d_b,
+                                        void* stream) {
+  if (HW == 0) return 0;
+  REQUIRE(content, "content"); REQUIRE(rgb_w, "rgb_w"); REQUIRE(rgb, "rgb"); REQUIRE(d_rgb, "d_rgb"); REQUIRE(workspace, "workspace");
+  REQUIRE(d_content, "d_content"); REQUIRE(d_w, "d_w"); REQUIRE(d_b, "d_b");
+  if (HW < 0) return set_error(CRNERF_ERR_SHAPE, "decoder_content_backward: negative HW");
+  return launch_content_backward(content, (long)HW, rgb_w, rgb, (long)rgb_plane_stride, d_rgb, (long)d_plane_stride, (float*)workspace, d_content,
+                                 d_w, d_b, (hipStream_t)stream);
+}
+
 size_t crnerf_encoder_train_saved_bytes(int H, int W) { return encoder_train_saved_bytes(H, W); }
 size_t crnerf_encoder_train_scratch_bytes(int H, int W) { return encoder_train_scratch_bytes(H, W); }
 

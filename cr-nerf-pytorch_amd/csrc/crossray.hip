@@ -858,4 +858,37 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   return check_launch("crossray_decode_backward");
 }
 
+
+// ---------------------------------------------------------------- decoder-only ("content") backward
+// style_net.forward(content, None, type="content") = NeuralRenderer alone: rgb = sigmoid(W x + b), W [3,64]
+// (linearStyleTransfer.py:285-287, nerf_decoder_stylenerf.py:279-291).  d_pre = d_rgb * rgb (1 - rgb);
+// d_x = W^T d_pre; dW = sum_px d_pre (x) x and db = sum_px d_pre through the MFMA point-reduction GEMM.
+__global__ __launch_bounds__(256) void content_bwd_kernel(const float* __restrict__ rgb, long rgb_stride, const float* __restrict__ d_rgb,
+                                                          long d_stride, const float* __restrict__ W, long HW, float* __restrict__ d_pre,
+                                                          float* __restrict__ d_x) {
+  const long px = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (px >= HW) return;
+  float g[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float y = rgb[o * rgb_stride + px];
+    g[o] = d_rgb[o * d_stride + px] * y * (1.0f - y);
+  }
+  if (c < 3) d_pre[px * 4 + c] = g[c];
+  if (c == 3) d_pre[px * 4 + 3] = 0.0f;
+  d_x[px * 64 + c] = fmaf(g[0], W[c], fmaf(g[1], W[64 + c], g[2] * W[128 + c]));
+}
+
+size_t content_backward_workspace_floats(long HW) { return (size_t)HW * 4 + wgrad_workspace_floats(HW, 3, 64); }
+
+int launch_content_backward(const float* content, long HW, const float* W, const float* rgb, long rgb_stride, const float* d_rgb, long d_stride,
+                            float* workspace, float* d_content, float* dW, float* db, hipStream_t stream) {
+  if (HW <= 0) return 0;
+  float* d_pre = workspace;                     // [HW,4], column 3 zero
+  hipLaunchKernelGGL(content_bwd_kernel, dim3((unsigned)((HW + 3) / 4)), dim3(256), 0, stream, rgb, rgb_stride, d_rgb, d_stride, W, HW, d_pre, d_content);
+  wgrad(d_pre, 4, 3, content, 64, 64, dW, 64, db, HW, workspace + (size_t)HW * 4, stream);
+  return check_launch("content_backward");
+}
+
 }  // namespace crnerf

@@ -74,6 +74,9 @@ int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);
 
 
+size_t content_backward_workspace_floats(long HW);
+int launch_content_backward(const float* content, long HW, const float* W, const float* rgb, long rgb_stride, const float* d_rgb, long d_stride,
+                            float* workspace, float* d_content, float* dW, float* db, hipStream_t stream);
 size_t encoder_train_saved_bytes(int H, int W);
 size_t encoder_train_scratch_bytes(int H, int W);
 int launch_encoder_forward_train(const float* img, int H, int W, const float* const* w, void* saved, float* out, hipStream_t st);

@@ -132,8 +132,10 @@ class style_net(nn.Module):
         train = torch.is_grad_enabled() and (content_feature.requires_grad or any(p.requires_grad for p in self.parameters()))
         if style_feature is None and type == "content":
             if train:   # decoder only: sigmoid(1x1 conv), nerf_decoder_stylenerf.py:279-291 (n_blocks == 0)
+                from ..autograd import ContentDecoderFn
                 w, b = self.decoder.rgb_tensors()
-                return torch.sigmoid(torch.einsum('oc,bchw->bohw', w, content_feature) + b.view(1, 3, 1, 1))
+                xp, (H, W) = _pixel_major(content_feature)
+                return ContentDecoderFn.apply(xp, w, b, self.decoder_tensors()).view(1, 3, H, W)
             return self.decoder(content_feature)
         xp, (H, W) = _pixel_major(content_feature)
         sp, _ = _pixel_major(style_feature)

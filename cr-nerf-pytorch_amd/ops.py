@@ -306,6 +306,20 @@ def encoder_forward(image, weights):
     return out
 
 
+def decoder_content_backward(content_pm, rgb_w, rgb, d_rgb):
+    """Backward of the decoder-only ('content') call: returns (d_content[HW,64], d_w[3,64], d_b[3])."""
+    lib = _lib.load()
+    x, w = _f32c(content_pm, "content"), _f32c(rgb_w.detach(), "rgb_w").reshape(3, 64)
+    rgb, d_rgb = _f32c(rgb, "rgb"), _f32c(d_rgb, "d_rgb")
+    HW = x.shape[0]
+    dx, dw, db = torch.empty_like(x), torch.empty(3, 64, device=x.device), torch.empty(3, device=x.device)
+    work = torch.empty(lib.crnerf_decoder_content_backward_workspace_bytes(HW), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_decoder_content_backward_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(w), _lib.dev_ptr(rgb), rgb.stride(0), _lib.dev_ptr(d_rgb),
+                                                       d_rgb.stride(0), ctypes.c_void_p(work.data_ptr()), _lib.dev_ptr(dx), _lib.dev_ptr(dw),
+                                                       _lib.dev_ptr(db), _lib.stream_ptr()), "crnerf_decoder_content_backward_f32")
+    return dx, dw, db
+
+
 def encoder_forward_train(image, weights):
     """Forward of the appearance encoder that keeps the layer outputs: returns (grid [1024,64], saved, (H, W))."""
     lib = _lib.load()

@@ -7,7 +7,7 @@ reference's drivers can be re-created without Lightning / imageio / torchvision:
     decode_image(...)             eval.py:288-295 (feature -> [1,64,H,W] view -> decoder -> [H*W,3])
     render_frame(...)             one video frame: rays generated on the device, style from the appearance encoder
     TrainingSystem                NeRFSystem.decode / forward / training_step, train_mask_grid_sample.py:127-226, :268-290
-                                  (encode_a / encode_random configuration; use_mask needs the CGNet mask network, not built)
+                                  (encode_a / encode_random / encode_c configuration; use_mask needs the CGNet mask network, not built)
 """
 from collections import defaultdict
 
@@ -97,24 +97,27 @@ class TrainingSystem:
         from .losses import loss_dict
         if getattr(hparams_, "use_mask", False):
             raise NotImplementedError("crnerf_amd: use_mask needs the CGNet mask network (models/lightweight_seg.py), which is not built")
-        if getattr(hparams_, "encode_c", False):
-            raise NotImplementedError("crnerf_amd: encode_c (content encoder) is not built")
         self.hparams_ = hparams_
         self.loss = loss_dict['crnerf'](hparams_, coef=1)                                   # :74
         self.models = models or get_model(hparams_, device)
         self.embeddings = embeddings or get_embeddings(hparams_)
         self.enc_a = enc_a if enc_a is not None else encoder_sameoutputsize(out_channel=hparams_.nerf_out_dim).to(device)   # :95
+        self.enc_cont = encoder_sameoutputsize(out_channel=hparams_.nerf_out_dim).to(device) if getattr(hparams_, "encode_c", False) else None   # :84
         self.embedding_a_list = [None] * getattr(hparams_, "N_vocab", 1500)                 # :98
-        self.models_to_train = list(self.models.values()) + [self.enc_a]                    # :84-97
+        self.models_to_train = list(self.models.values()) + [self.enc_a] + ([self.enc_cont] if self.enc_cont is not None else [])   # :84-97
         self.global_step = 0
 
     def parameters(self):
         return [p for m in self.models_to_train for p in m.parameters()]
 
     def decode(self, results, type, **kwargs):                                              # :127-149
-        feature = results['feature_' + type]
+        feature = results['feature_' + type] if type != 'content' else results['feature_fine']
         H, W = int(kwargs['H']), int(kwargs['W'])
         grid = feature.t().reshape(1, feature.shape[-1], H, W)                              # 'n1 n3 -> n3 n1' then ' n3 (h w) -> 1 n3 h w'
+        if type == "content":                                                               # decoder only, no appearance transfer (:145-148)
+            results['rgb_content_img'] = self.models['decoder'](grid, None, type="content")
+            results['rgb_content'] = None
+            return results
         style = kwargs['a_embedded_random'] if type == "fine_random" else kwargs['a_embedded_from_img']
         rgbs_pred = self.models['decoder'](grid, style)
         if type == "fine":
@@ -147,6 +150,8 @@ class TrainingSystem:
         results = self.decode(results, "coarse", **kwargs)
         if hp.N_importance > 0:
             results = self.decode(results, "fine", **kwargs)
+        if getattr(hp, "encode_c", False):
+            results = self.decode(results, "content", **kwargs)                             # :207-208
         results['a_embedded'] = kwargs['a_embedded_from_img']
         results['whole_img'] = whole_img
         if hp.encode_random:
@@ -155,6 +160,9 @@ class TrainingSystem:
             results['a_embedded_random_rec'] = self.enc_a(results['rgb_fine_random'])       # :219
             results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
             self.embedding_a_list[int(ts[0])] = kwargs['a_embedded_from_img'].clone().detach()
+        if getattr(hp, "encode_c", False):                                                  # :222-224
+            results['content_with_a_embed'] = self.enc_cont(results['rgb_fine_img'])
+            results['content_wo_a_embed'] = self.enc_cont(results['rgb_content_img'])
         return results
 
     def training_step(self, batch):                                                         # :268-290

@@ -192,6 +192,13 @@ size_t crnerf_crossray_backward_workspace_bytes(int64_t HW, int64_t HWs);
 int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
                                         const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_style,
                                         float* const* grads, void* stream);
+/* Backward of the decoder-only call style_net.forward(content, None, type="content") (linearStyleTransfer.py:285-287;
+ * forward = crnerf_crossray_decode_f32 with style == NULL): rgb = sigmoid(W x + b) with W = decoder.feat_2_rgb_list.0.weight
+ * [3,64].  rgb / d_rgb planar with their strides -> d_content[HW,64], d_w[3,64], d_b[3]. */
+size_t crnerf_decoder_content_backward_workspace_bytes(int64_t HW);
+int crnerf_decoder_content_backward_f32(const float* content, int64_t HW, const float* rgb_w, const float* rgb, int64_t rgb_plane_stride,
+                                        const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_w, float* d_b,
+                                        void* stream);
 /* rgb[c*plane_stride + px] = sigmoid(A[c] . x[px] + v[c]) */
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride,
                               void* stream);

@@ -110,10 +110,11 @@ def test_training_system_mirrors_nerfsystem_step():
     class HPT(HP):
         nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
         img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [16, 16], 32, 32, 1.0, 1.0, 128, 8
-        use_mask = encode_c = False
+        use_mask, encode_c = False, True          # command/train.sh:24 trains with --encode_c
     hp = HPT()
     torch.manual_seed(0)
     sys_ = pipeline.TrainingSystem(hp, device=DEV)
+    sys_.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
     sys_.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
     sys_.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
     sys_.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
@@ -127,10 +128,10 @@ def test_training_system_mirrors_nerfsystem_step():
         opt.zero_grad(set_to_none=True)
         loss, loss_d, results = sys_.training_step(batch)
         if it == 0:
-            assert list(loss_d.keys()) == ["kl_a", "rec_a_random", "c_l", "f_l"]
+            assert list(loss_d.keys()) == ["kl_a", "rec_a_random", "c_l", "content_constraint", "f_l"]
             for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "feature_fine_random", "depth_fine",
                       "rgb_coarse", "rgb_fine_img", "rgb_fine", "a_embedded", "whole_img", "a_embedded_random", "rgb_fine_random",
-                      "a_embedded_random_rec"):
+                      "a_embedded_random_rec", "rgb_content_img", "content_with_a_embed", "content_wo_a_embed"):
                 assert k in results, k
             assert results["rgb_fine"].shape == (R, 3) and results["rgb_fine_img"].shape == (1, 3, 16, 16)
             ref, _ = O.crnerf_loss({k: v.detach().cpu() for k, v in results.items() if torch.is_tensor(v)}, batch["rgbs"].cpu(), hp, 0)
@@ -139,7 +140,8 @@ def test_training_system_mirrors_nerfsystem_step():
             assert sys_.embedding_a_list[3] is not None and sys_.embedding_a_list[0] is None      # :222
         loss.backward()
         if it == 0:
-            for name, mod in (("coarse", sys_.models["coarse"]), ("fine", sys_.models["fine"]), ("decoder", sys_.models["decoder"]), ("enc_a", sys_.enc_a)):
+            for name, mod in (("coarse", sys_.models["coarse"]), ("fine", sys_.models["fine"]), ("decoder", sys_.models["decoder"]), ("enc_a", sys_.enc_a),
+                              ("enc_cont", sys_.enc_cont)):
                 got = [p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0 for p in mod.parameters()]
                 assert all(got), (name, got)
         opt.step()
@@ -209,3 +211,29 @@ def test_video_frames_shard_across_ranks_without_exchange():
     for i in range(6):
         assert whole[i].shape == (24, 40, 3) and whole[i].dtype == np.uint8
         assert np.array_equal(whole[i], parts[i])
+
+
+def test_content_decoder_backward_vs_autograd():
+    """style_net(content, None, type='content') under grad: HIP forward + crnerf_decoder_content_backward_f32 vs torch autograd."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd.models.linearStyleTransfer import style_net
+
+    class A:
+        nerf_out_dim, img_wh = 64, [13, 7]
+    net = style_net(A()).to(DEV)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 64, 7, 13, generator=g)
+    cot = torch.randn(1, 3, 7, 13, generator=g)
+    xd = x.to(DEV).requires_grad_()
+    out = net(xd, None, type="content")
+    (out * cot.to(DEV)).sum().backward()
+    w = net.decoder.feat_2_rgb_list[0].weight.detach().cpu().reshape(3, 64).requires_grad_()
+    b = net.decoder.feat_2_rgb_list[0].bias.detach().cpu().requires_grad_()
+    xr = x.clone().requires_grad_()
+    ref = torch.sigmoid(torch.einsum('oc,bchw->bohw', w, xr) + b.view(1, 3, 1, 1))
+    (ref * cot).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(net.decoder.feat_2_rgb_list[0].weight.grad.cpu().reshape(3, 64), w.grad, atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(net.decoder.feat_2_rgb_list[0].bias.grad.cpu(), b.grad, atol=1e-5, rtol=1e-4)

@@ -22,7 +22,7 @@ class HP:
     weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
     nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
     img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [side, side], NC, NI, 1.0, 1.0, 8 * 1024, 1500
-    use_mask = encode_c = False
+    use_mask, encode_c = False, True       # command/train.sh:24 (--encode_c; --use_mask needs the CGNet mask network)
 
 
 hp = HP()
@@ -32,6 +32,7 @@ sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.
 sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
 sysm.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
 sysm.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+sysm.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
 
 # synthetic "scene": 8 images of 512 x 384, rays of a pinhole camera each, buffers resident in HBM
 n_img, iw, ih = 8, 512, 384
