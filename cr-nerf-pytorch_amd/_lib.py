@@ -27,6 +27,8 @@ EXPORTS = [
     "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
+    "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
+    "crnerf_fglo_f32", "crnerf_fglo_backward_f32", "crnerf_bilinear_gather_f32", "crnerf_bilinear_gather_backward_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -77,6 +79,11 @@ class BatchArgs(ctypes.Structure):
         ("scale", ctypes.c_float), ("h_offset", ctypes.c_float), ("w_offset", ctypes.c_float),
         ("rays", _c_fp), ("ts", ctypes.c_void_p), ("rgbs", _c_fp), ("rgb_idx", ctypes.c_void_p), ("uv_sample", _c_fp),
     ]
+
+
+class ConvGeom(ctypes.Structure):
+    """struct crnerf_conv_geom."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("cin", "cout", "H", "W", "k", "stride", "pad", "dil", "depthwise")]
 
 
 _lib = None
@@ -144,6 +151,15 @@ def load():
             "crnerf_loss_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, vp, vp]),
             "crnerf_loss_backward_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, ctypes.POINTER(LossGrads), vp]),
             "crnerf_grid_sample_batch_f32": (ctypes.c_int, [ctypes.POINTER(BatchArgs), vp]),
+            "crnerf_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp]),
+            "crnerf_conv2d_backward_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp, vp, vp]),
+            "crnerf_bn_prelu_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, vp]),
+            "crnerf_bn_prelu_backward_f32": (ctypes.c_int, [vp] * 11 + [i32, i64, i32, vp]),
+            "crnerf_avgpool3s2_f32": (ctypes.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+            "crnerf_fglo_f32": (ctypes.c_int, [vp] * 7 + [i32, i32, i64, vp]),
+            "crnerf_fglo_backward_f32": (ctypes.c_int, [vp] * 11 + [i32, i32, i64, vp]),
+            "crnerf_bilinear_gather_f32": (ctypes.c_int, [vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
+            "crnerf_bilinear_gather_backward_f32": (ctypes.c_int, [vp, vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h

@@ -107,3 +107,85 @@ class ContentDecoderFn(torch.autograd.Function):
         xp, rgb_w, out = ctx.saved_tensors
         dx, dw, db = ops.decoder_content_backward(xp, rgb_w, out, d_rgb.contiguous())
         return dx, dw.view(ctx.w_shape), db, None
+
+
+# ---------------------------------------------------------------- transient-mask network (models/lightweight_seg.py)
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d(..., bias=False) on one image: csrc/cgnet.hip forward, dgrad and wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation, groups)
+        return ops.conv2d(x, w, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, w = ctx.saved_tensors
+        dx, dw = ops.conv2d_backward(x, w, d_y, *ctx.cfg, want_dx=ctx.needs_input_grad[0])
+        return dx, dw, None, None, None, None
+
+
+class BNPReLUFn(torch.autograd.Function):
+    """BatchNorm2d(eps) -> PReLU in one pass; `bn` supplies mode, momentum and the running buffers (updated here)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, bn):
+        training = bn.training or bn.running_mean is None
+        y, mean, invstd, var_u = ops.bn_prelu(x, gamma, beta, alpha, bn.eps, training, bn.running_mean, bn.running_var)
+        if training and bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1.0 - m).add_(var_u, alpha=m)
+        ctx.save_for_backward(x, gamma, beta, alpha, mean, invstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, gamma, beta, alpha, mean, invstd = ctx.saved_tensors
+        dx, dg, db, da = ops.bn_prelu_backward(x, gamma, beta, alpha, mean, invstd, d_y, ctx.training)
+        return dx, dg, db, da, None
+
+
+class AvgPool3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape[-3:])
+        return ops.avgpool3s2(x)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        return ops.avgpool3s2_backward(d_y, ctx.shape)
+
+
+class FGloFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        y, stats = ops.fglo(x, w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1, w2, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, w1, w2, stats = ctx.saved_tensors
+        return ops.fglo_backward(x, w1, w2, stats, d_y)
+
+
+class BilinearGatherFn(torch.autograd.Function):
+    """F.interpolate(bilinear, align_corners=False) [+ sigmoid] read at `idx` (None = every pixel)."""
+
+    @staticmethod
+    def forward(ctx, x, size, idx, sigmoid):
+        out = ops.bilinear_gather(x, size, idx, sigmoid)
+        ctx.cfg = (tuple(x.shape[-2:]), tuple(size), sigmoid)
+        ctx.save_for_backward(out if sigmoid else None, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, idx = ctx.saved_tensors
+        in_hw, size, sigmoid = ctx.cfg
+        return ops.bilinear_gather_backward(out, d_out, in_hw, size, idx, sigmoid), None, None, None

@@ -380,4 +380,83 @@ int crnerf_grid_sample_batch_f32(const crnerf_batch_args* a, void* stream) {
   return launch_grid_batch(k, (hipStream_t)stream);
 }
 
+static int to_geom(const crnerf_conv_geom* a, ConvGeom& g) {
+  if (a->cin <= 0 || a->cout <= 0 || a->H <= 0 || a->W <= 0 || a->k <= 0 || a->stride <= 0 || a->dil <= 0 || a->pad < 0)
+    return set_error(CRNERF_ERR_SHAPE, "conv2d: non-positive geometry");
+  if (a->depthwise && a->cin != a->cout) return set_error(CRNERF_ERR_SHAPE, "conv2d: depth-wise needs cin == cout");
+  const int Ho = (a->H + 2 * a->pad - a->dil * (a->k - 1) - 1) / a->stride + 1, Wo = (a->W + 2 * a->pad - a->dil * (a->k - 1) - 1) / a->stride + 1;
+  if (Ho <= 0 || Wo <= 0) return set_error(CRNERF_ERR_SHAPE, "conv2d: empty output");
+  g = ConvGeom{a->cin, a->cout, a->H, a->W, Ho, Wo, a->k, a->stride, a->pad, a->dil, a->depthwise ? 1 : 0};
+  return 0;
+}
+
+int crnerf_conv2d_f32(const crnerf_conv_geom* geom, const float* x, const float* w, float* y, void* stream) {
+  REQUIRE(geom, "geom"); REQUIRE(x, "x"); REQUIRE(w, "w"); REQUIRE(y, "y");
+  ConvGeom g;
+  if (int e = to_geom(geom, g)) return e;
+  return launch_cg_conv_forward(g, x, w, y, (hipStream_t)stream);
+}
+
+int crnerf_conv2d_backward_f32(const crnerf_conv_geom* geom, const float* x, const float* w, const float* d_y, float* d_x, float* d_w, void* stream) {
+  REQUIRE(geom, "geom"); REQUIRE(x, "x"); REQUIRE(w, "w"); REQUIRE(d_y, "d_y"); REQUIRE(d_w, "d_w");
+  ConvGeom g;
+  if (int e = to_geom(geom, g)) return e;
+  return launch_cg_conv_backward(g, x, w, d_y, d_x, d_w, (hipStream_t)stream);
+}
+
+int crnerf_bn_prelu_f32(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
+                        float* y, int C, int64_t HW, float eps, int training, void* stream) {
+  REQUIRE(x, "x"); REQUIRE(gamma, "gamma"); REQUIRE(beta, "beta"); REQUIRE(alpha, "alpha"); REQUIRE(mean, "mean"); REQUIRE(invstd, "invstd"); REQUIRE(y, "y");
+  if (training) REQUIRE(var_unbiased, "var_unbiased");
+  if (C <= 0 || HW <= 0 || HW > (1 << 30)) return set_error(CRNERF_ERR_SHAPE, "bn_prelu: C and HW must be positive");
+  return launch_cg_bn_prelu_forward(x, gamma, beta, alpha, mean, invstd, var_unbiased, y, C, (int)HW, eps, training, (hipStream_t)stream);
+}
+
+int crnerf_bn_prelu_backward_f32(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean, const float* invstd,
+                                 const float* d_y, float* d_x, float* d_gamma, float* d_beta, float* d_alpha, int C, int64_t HW, int training,
+                                 void* stream) {
+  REQUIRE(x, "x"); REQUIRE(gamma, "gamma"); REQUIRE(beta, "beta"); REQUIRE(alpha, "alpha"); REQUIRE(mean, "mean"); REQUIRE(invstd, "invstd");
+  REQUIRE(d_y, "d_y"); REQUIRE(d_x, "d_x"); REQUIRE(d_gamma, "d_gamma"); REQUIRE(d_beta, "d_beta"); REQUIRE(d_alpha, "d_alpha");
+  if (C <= 0 || HW <= 0 || HW > (1 << 30)) return set_error(CRNERF_ERR_SHAPE, "bn_prelu_backward: C and HW must be positive");
+  return launch_cg_bn_prelu_backward(x, gamma, beta, alpha, mean, invstd, d_y, d_x, d_gamma, d_beta, d_alpha, C, (int)HW, training, (hipStream_t)stream);
+}
+
+int crnerf_avgpool3s2_f32(const float* in, float* out, int C, int H, int W, int backward, void* stream) {
+  REQUIRE(in, "in"); REQUIRE(out, "out");
+  if (C <= 0 || H <= 0 || W <= 0) return set_error(CRNERF_ERR_SHAPE, "avgpool3s2: non-positive shape");
+  return launch_cg_avgpool(in, out, C, H, W, backward, (hipStream_t)stream);
+}
+
+int crnerf_fglo_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R, int64_t HW,
+                    void* stream) {
+  REQUIRE(x, "x"); REQUIRE(w1, "w1"); REQUIRE(b1, "b1"); REQUIRE(w2, "w2"); REQUIRE(b2, "b2"); REQUIRE(stats, "stats"); REQUIRE(y, "y");
+  if (C <= 0 || R <= 0 || HW <= 0 || HW > (1 << 22)) return set_error(CRNERF_ERR_SHAPE, "fglo: non-positive shape");
+  return launch_cg_fglo_forward(x, w1, b1, w2, b2, stats, y, C, R, (int)HW, (hipStream_t)stream);
+}
+
+int crnerf_fglo_backward_f32(const float* x, const float* w1, const float* w2, const float* stats, const float* d_y, float* scratch, float* d_x,
+                             float* d_w1, float* d_b1, float* d_w2, float* d_b2, int C, int R, int64_t HW, void* stream) {
+  REQUIRE(x, "x"); REQUIRE(w1, "w1"); REQUIRE(w2, "w2"); REQUIRE(stats, "stats"); REQUIRE(d_y, "d_y"); REQUIRE(scratch, "scratch"); REQUIRE(d_x, "d_x");
+  REQUIRE(d_w1, "d_w1"); REQUIRE(d_b1, "d_b1"); REQUIRE(d_w2, "d_w2"); REQUIRE(d_b2, "d_b2");
+  if (C <= 0 || C > 256 || R <= 0 || R > 64 || HW <= 0 || HW > (1 << 22)) return set_error(CRNERF_ERR_SHAPE, "fglo_backward: bad shape");
+  return launch_cg_fglo_backward(x, w1, w2, stats, d_y, scratch, d_x, d_w1, d_b1, d_w2, d_b2, C, R, (int)HW, (hipStream_t)stream);
+}
+
+int crnerf_bilinear_gather_f32(const float* in, int h, int w, int Ho, int Wo, const int64_t* idx, int64_t n, int sigmoid, float* out, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(in, "in"); REQUIRE(out, "out");
+  if (h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0 || n < 0) return set_error(CRNERF_ERR_SHAPE, "bilinear_gather: non-positive shape");
+  if (!idx && n != (int64_t)Ho * Wo) return set_error(CRNERF_ERR_SHAPE, "bilinear_gather: idx == NULL means every output pixel (n = Ho*Wo)");
+  return launch_cg_bilinear(in, (const long*)idx, out, (long)n, h, w, Ho, Wo, sigmoid, (hipStream_t)stream);
+}
+
+int crnerf_bilinear_gather_backward_f32(const float* out, const float* d_out, int h, int w, int Ho, int Wo, const int64_t* idx, int64_t n, int sigmoid,
+                                        float* d_in, void* stream) {
+  REQUIRE(d_in, "d_in");
+  if (h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0 || n < 0) return set_error(CRNERF_ERR_SHAPE, "bilinear_gather_backward: non-positive shape");
+  if (n > 0) { REQUIRE(d_out, "d_out"); if (sigmoid) REQUIRE(out, "out"); }
+  if (!idx && n != (int64_t)Ho * Wo) return set_error(CRNERF_ERR_SHAPE, "bilinear_gather_backward: idx == NULL means every output pixel");
+  return launch_cg_bilinear_backward(out, d_out, (const long*)idx, d_in, (long)n, h, w, Ho, Wo, sigmoid, (hipStream_t)stream);
+}
+
 }  // extern "C"

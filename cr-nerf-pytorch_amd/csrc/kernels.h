@@ -83,6 +83,23 @@ int launch_encoder_forward_train(const float* img, int H, int W, const float* co
 int launch_encoder_backward(int H, int W, const float* const* w, const void* saved, const float* out, const float* d_out, void* scratch,
                             float* const* grads, float* d_img, hipStream_t st);
 
+// ---- transient-mask network operators (cgnet.hip)
+struct ConvGeom { int cin, cout, H, W, Ho, Wo, k, stride, pad, dil, depthwise; };
+int launch_cg_conv_forward(const ConvGeom& g, const float* x, const float* w, float* y, hipStream_t st);
+int launch_cg_conv_backward(const ConvGeom& g, const float* x, const float* w, const float* dy, float* dx, float* dw, hipStream_t st);
+int launch_cg_bn_prelu_forward(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
+                               float* y, int C, int HW, float eps, int training, hipStream_t st);
+int launch_cg_bn_prelu_backward(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean, const float* invstd,
+                                const float* dy, float* dx, float* dgamma, float* dbeta, float* dalpha, int C, int HW, int training, hipStream_t st);
+int launch_cg_avgpool(const float* in, float* out, int C, int H, int W, int backward, hipStream_t st);
+int launch_cg_fglo_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R, int HW,
+                           hipStream_t st);
+int launch_cg_fglo_backward(const float* x, const float* w1, const float* w2, const float* stats, const float* dy, float* scratch, float* dx, float* dw1,
+                            float* db1, float* dw2, float* db2, int C, int R, int HW, hipStream_t st);
+int launch_cg_bilinear(const float* in, const long* idx, float* out, long n, int h, int w, int Ho, int Wo, int sigmoid, hipStream_t st);
+int launch_cg_bilinear_backward(const float* out, const float* d_out, const long* idx, float* d_in, long n, int h, int w, int Ho, int Wo, int sigmoid,
+                                hipStream_t st);
+
 // ---- training-side neighbours (train_aux.hip)
 struct LossArgs {
   const float* rgb_c; const float* rgb_f; const float* tgt; const float* mask;   // [R,3] strided, [R,3] or null, [R,3], [R] or null

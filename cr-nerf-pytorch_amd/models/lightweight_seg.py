@@ -1,0 +1,184 @@
+"""Transient-mask network: Context_Guided_Network as CR-NeRF instantiates it (classes=1, M=2, N=2, input_channel=3;
+train_mask_grid_sample.py:99-101), on the HIP operators of csrc/cgnet.hip.
+
+Mirror of models/lightweight_seg.py:12-368: the same module tree, so the same parameter and buffer names
+(`level2_0.F_glo.fc.0.weight`, `b1.bn.running_mean`, ...) and a reference checkpoint's `implicit_mask.*` entries load
+unchanged; each module's forward is one fused HIP call (conv, BatchNorm+PReLU, FGlo, pooling, upsample+sigmoid), with
+the backward in HIP too.  torch supplies only the parameter containers, the channel concatenations and the residual
+add.  One image per call (batch 1) -- that is the only way the reference uses it.
+"""
+import torch
+from torch import nn
+
+from ..autograd import AvgPool3s2Fn, BilinearGatherFn, BNPReLUFn, Conv2dFn, FGloFn
+
+__all__ = ["Context_Guided_Network", "mask_at_pixels"]
+
+
+class _ConvParam(nn.Module):
+    """Holds `weight` under the name nn.Conv2d would give it (the reference wraps nn.Conv2d as `.conv`)."""
+
+    def __init__(self, n_in, n_out, k, stride=1, dilation=1, groups=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in // groups, k, k))
+        nn.init.kaiming_normal_(self.weight)            # lightweight_seg.py:318-321
+        self.stride, self.padding, self.dilation, self.groups = stride, (k - 1) // 2 * dilation, dilation, groups
+
+    def forward(self, x):
+        return Conv2dFn.apply(x, self.weight, self.stride, self.padding, self.dilation, self.groups)
+
+
+def _bn_prelu(x, bn, act):
+    return BNPReLUFn.apply(x, bn.weight, bn.bias, act.weight, bn)
+
+
+class ConvBNPReLU(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1):
+        super().__init__()
+        self.conv = _ConvParam(nIn, nOut, kSize, stride)
+        self.bn = nn.BatchNorm2d(nOut, eps=1e-03)
+        self.act = nn.PReLU(nOut)
+
+    def forward(self, input):
+        return _bn_prelu(self.conv(input), self.bn, self.act)
+
+
+class BNPReLU(nn.Module):
+    def __init__(self, nOut):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(nOut, eps=1e-03)
+        self.act = nn.PReLU(nOut)
+
+    def forward(self, input):
+        return _bn_prelu(input, self.bn, self.act)
+
+
+class Conv(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1):
+        super().__init__()
+        self.conv = _ConvParam(nIn, nOut, kSize, stride)
+
+    def forward(self, input):
+        return self.conv(input)
+
+
+class ChannelWiseConv(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1):
+        super().__init__()
+        self.conv = _ConvParam(nIn, nOut, kSize, stride, groups=nIn)
+
+    def forward(self, input):
+        return self.conv(input)
+
+
+class ChannelWiseDilatedConv(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, d=1):
+        super().__init__()
+        self.conv = _ConvParam(nIn, nOut, kSize, stride, dilation=d, groups=nIn)
+
+    def forward(self, input):
+        return self.conv(input)
+
+
+class FGlo(nn.Module):
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction), nn.ReLU(inplace=True), nn.Linear(channel // reduction, channel),
+                                nn.Sigmoid())     # containers for fc.0 / fc.2; evaluated fused
+
+    def forward(self, x):
+        return FGloFn.apply(x, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias)
+
+
+class ContextGuidedBlock_Down(nn.Module):
+    def __init__(self, nIn, nOut, dilation_rate=2, reduction=16):
+        super().__init__()
+        self.conv1x1 = ConvBNPReLU(nIn, nOut, 3, 2)
+        self.F_loc = ChannelWiseConv(nOut, nOut, 3, 1)
+        self.F_sur = ChannelWiseDilatedConv(nOut, nOut, 3, 1, dilation_rate)
+        self.bn = nn.BatchNorm2d(2 * nOut, eps=1e-3)
+        self.act = nn.PReLU(2 * nOut)
+        self.reduce = Conv(2 * nOut, nOut, 1, 1)
+        self.F_glo = FGlo(nOut, reduction)
+
+    def forward(self, input):
+        output = self.conv1x1(input)
+        joi_feat = torch.cat([self.F_loc(output), self.F_sur(output)], 1)
+        joi_feat = self.reduce(_bn_prelu(joi_feat, self.bn, self.act))
+        return self.F_glo(joi_feat)
+
+
+class ContextGuidedBlock(nn.Module):
+    def __init__(self, nIn, nOut, dilation_rate=2, reduction=16, add=True):
+        super().__init__()
+        n = int(nOut / 2)
+        self.conv1x1 = ConvBNPReLU(nIn, n, 1, 1)
+        self.F_loc = ChannelWiseConv(n, n, 3, 1)
+        self.F_sur = ChannelWiseDilatedConv(n, n, 3, 1, dilation_rate)
+        self.bn_prelu = BNPReLU(nOut)
+        self.add = add
+        self.F_glo = FGlo(nOut, reduction)
+
+    def forward(self, input):
+        output = self.conv1x1(input)
+        joi_feat = self.bn_prelu(torch.cat([self.F_loc(output), self.F_sur(output)], 1))
+        output = self.F_glo(joi_feat)
+        return input + output if self.add else output
+
+
+class InputInjection(nn.Module):
+    def __init__(self, downsamplingRatio):
+        super().__init__()
+        self.ratio = downsamplingRatio
+
+    def forward(self, input):
+        for _ in range(self.ratio):
+            input = AvgPool3s2Fn.apply(input)
+        return input
+
+
+class Context_Guided_Network(nn.Module):
+    """CGNet; forward(image[1,C,H,W]) -> mask[1,classes,H,W] in (0,1)  (lightweight_seg.py:274-368)."""
+
+    def __init__(self, classes=19, M=3, N=21, input_channel=64, dropout_flag=False):
+        super().__init__()
+        if dropout_flag:
+            raise NotImplementedError("crnerf_amd: dropout_flag is never set by CR-NeRF and is not built")
+        if classes != 1:
+            raise NotImplementedError("crnerf_amd: the upsample operator handles the single-channel mask CR-NeRF uses (classes=1)")
+        self.level1_0 = ConvBNPReLU(input_channel, 32, 3, 2)
+        self.level1_1 = ConvBNPReLU(32, 32, 3, 1)
+        self.level1_2 = ConvBNPReLU(32, 32, 3, 1)
+        self.sample1 = InputInjection(1)
+        self.sample2 = InputInjection(2)
+        self.b1 = BNPReLU(32 + input_channel)
+        self.level2_0 = ContextGuidedBlock_Down(32 + input_channel, 64, dilation_rate=2, reduction=8)
+        self.level2 = nn.ModuleList(ContextGuidedBlock(64, 64, dilation_rate=2, reduction=8) for _ in range(M - 1))
+        self.bn_prelu_2 = BNPReLU(128 + input_channel)
+        self.level3_0 = ContextGuidedBlock_Down(128 + input_channel, 128, dilation_rate=4, reduction=16)
+        self.level3 = nn.ModuleList(ContextGuidedBlock(128, 128, dilation_rate=4, reduction=16) for _ in range(N - 1))
+        self.bn_prelu_3 = BNPReLU(256)
+        self.classifier = nn.Sequential(Conv(256, classes, 1, 1))
+
+    def forward(self, input):
+        if not input.is_cuda:
+            raise RuntimeError("crnerf_amd: Context_Guided_Network runs on the HIP operators only; input is on %s" % input.device)
+        output0 = self.level1_2(self.level1_1(self.level1_0(input)))
+        inp1 = self.sample1(input)
+        inp2 = self.sample2(input)
+        output1_0 = self.level2_0(self.b1(torch.cat([output0, inp1], 1)))
+        output1 = output1_0
+        for layer in self.level2:
+            output1 = layer(output1)
+        output2_0 = self.level3_0(self.bn_prelu_2(torch.cat([output1, output1_0, inp2], 1)))
+        output2 = output2_0
+        for layer in self.level3:
+            output2 = layer(output2)
+        classifier = self.classifier(self.bn_prelu_3(torch.cat([output2_0, output2], 1)))
+        return BilinearGatherFn.apply(classifier, tuple(input.shape[2:]), None, True)
+
+
+def mask_at_pixels(pred_mask, hw_whole, rgb_idx):
+    """interpolate(pred_mask, size=hw_whole)[rgb_idx] without forming the full-resolution mask
+    (train_mask_grid_sample.py:172-175: interpolate -> rearrange('b c h w -> (b h w) c') -> [rgb_idx]).  -> [n,1]"""
+    return BilinearGatherFn.apply(pred_mask, (int(hw_whole[0]), int(hw_whole[1])), rgb_idx, False).unsqueeze(1)

@@ -484,3 +484,158 @@ def grid_sample_batch(all_rays, all_rgbs, row_offset, img_w, img_h, side, w_lin,
     a.rays, a.ts, a.rgbs, a.rgb_idx, a.uv_sample = (out[k].data_ptr() for k in ("rays", "ts", "rgbs", "rgb_idx", "uv_sample"))
     _lib.check(lib.crnerf_grid_sample_batch_f32(ctypes.byref(a), _lib.stream_ptr()), "crnerf_grid_sample_batch_f32")
     return out
+
+
+# ---------------------------------------------------------------- transient-mask network operators (csrc/cgnet.hip)
+def _chw(t, name):
+    """[1,C,H,W] or [C,H,W] fp32 device tensor -> contiguous, with its (C, H, W)."""
+    t = _f32c(t, name)
+    if t.dim() == 4:
+        if t.shape[0] != 1:
+            raise ValueError("crnerf_amd: %s: the mask network runs on one image (batch 1), got batch %d" % (name, t.shape[0]))
+    elif t.dim() != 3:
+        raise ValueError("crnerf_amd: %s must be [1,C,H,W] or [C,H,W]" % name)
+    return t, tuple(t.shape[-3:])
+
+
+def _geom(x_shape, w, stride, padding, dilation, groups):
+    C, H, W = x_shape
+    cout, cpg, k, k2 = w.shape
+    if k != k2:
+        raise ValueError("crnerf_amd: conv2d: square kernels only")
+    if groups == 1:
+        if cpg != C:
+            raise ValueError("crnerf_amd: conv2d: weight expects %d input channels, got %d" % (cpg, C))
+    elif not (groups == C == cout and cpg == 1):
+        raise ValueError("crnerf_amd: conv2d: groups must be 1 or depth-wise (groups = cin = cout)")
+    g = _lib.ConvGeom(C, cout, H, W, k, stride, padding, dilation, int(groups != 1))
+    Ho = (H + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    return g, Ho, Wo
+
+
+def conv2d(x, w, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d(x, w, None, stride, padding, dilation, groups) for batch 1 (groups = 1 or depth-wise)."""
+    lib = _lib.load()
+    x, shp = _chw(x, "x")
+    w = _f32c(w, "weight")
+    g, Ho, Wo = _geom(shp, w, stride, padding, dilation, groups)
+    y = torch.empty(1, w.shape[0], Ho, Wo, device=x.device)
+    _lib.check(lib.crnerf_conv2d_f32(ctypes.byref(g), _lib.dev_ptr(x), _lib.dev_ptr(w), _lib.dev_ptr(y), _lib.stream_ptr()), "crnerf_conv2d_f32")
+    return y
+
+
+def conv2d_backward(x, w, d_y, stride=1, padding=0, dilation=1, groups=1, want_dx=True):
+    lib = _lib.load()
+    x, shp = _chw(x, "x")
+    w, d_y = _f32c(w, "weight"), _f32c(d_y, "d_y")
+    g, _, _ = _geom(shp, w, stride, padding, dilation, groups)
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty_like(w)
+    _lib.check(lib.crnerf_conv2d_backward_f32(ctypes.byref(g), _lib.dev_ptr(x), _lib.dev_ptr(w), _lib.dev_ptr(d_y), _lib.dev_ptr(dx), _lib.dev_ptr(dw),
+                                              _lib.stream_ptr()), "crnerf_conv2d_backward_f32")
+    return dx, dw
+
+
+def bn_prelu(x, gamma, beta, alpha, eps, training, running_mean=None, running_var=None):
+    """BatchNorm2d + PReLU.  Returns (y, mean, invstd, var_unbiased); eval mode reads the running statistics."""
+    lib = _lib.load()
+    x, (C, H, W) = _chw(x, "x")
+    y = torch.empty_like(x)
+    if training:
+        mean, invstd, var_u = (torch.empty(C, device=x.device) for _ in range(3))
+    else:
+        mean, invstd, var_u = _f32c(running_mean, "running_mean"), torch.rsqrt(_f32c(running_var, "running_var") + eps), None
+    _lib.check(lib.crnerf_bn_prelu_f32(_lib.dev_ptr(x), _lib.dev_ptr(_f32c(gamma, "bn.weight")), _lib.dev_ptr(_f32c(beta, "bn.bias")),
+                                       _lib.dev_ptr(_f32c(alpha, "act.weight")), _lib.dev_ptr(mean), _lib.dev_ptr(invstd), _lib.dev_ptr(var_u),
+                                       _lib.dev_ptr(y), C, H * W, float(eps), int(bool(training)), _lib.stream_ptr()), "crnerf_bn_prelu_f32")
+    return y, mean, invstd, var_u
+
+
+def bn_prelu_backward(x, gamma, beta, alpha, mean, invstd, d_y, training):
+    lib = _lib.load()
+    x, (C, H, W) = _chw(x, "x")
+    d_y = _f32c(d_y, "d_y")
+    dx = torch.empty_like(x)
+    dg, db, da = (torch.empty(C, device=x.device) for _ in range(3))
+    _lib.check(lib.crnerf_bn_prelu_backward_f32(_lib.dev_ptr(x), _lib.dev_ptr(_f32c(gamma, "bn.weight")), _lib.dev_ptr(_f32c(beta, "bn.bias")),
+                                                _lib.dev_ptr(_f32c(alpha, "act.weight")), _lib.dev_ptr(mean), _lib.dev_ptr(invstd), _lib.dev_ptr(d_y),
+                                                _lib.dev_ptr(dx), _lib.dev_ptr(dg), _lib.dev_ptr(db), _lib.dev_ptr(da), C, H * W, int(bool(training)),
+                                                _lib.stream_ptr()), "crnerf_bn_prelu_backward_f32")
+    return dx, dg, db, da
+
+
+def avgpool3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=1)."""
+    lib = _lib.load()
+    x, (C, H, W) = _chw(x, "x")
+    y = torch.empty(1, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device)
+    _lib.check(lib.crnerf_avgpool3s2_f32(_lib.dev_ptr(x), _lib.dev_ptr(y), C, H, W, 0, _lib.stream_ptr()), "crnerf_avgpool3s2_f32")
+    return y
+
+
+def avgpool3s2_backward(d_y, in_shape):
+    lib = _lib.load()
+    d_y = _f32c(d_y, "d_y")
+    C, H, W = in_shape
+    dx = torch.empty(1, C, H, W, device=d_y.device)
+    _lib.check(lib.crnerf_avgpool3s2_f32(_lib.dev_ptr(d_y), _lib.dev_ptr(dx), C, H, W, 1, _lib.stream_ptr()), "crnerf_avgpool3s2_f32")
+    return dx
+
+
+def fglo(x, w1, b1, w2, b2):
+    """FGlo: x * sigmoid(fc2(relu(fc1(mean_hw(x))))).  Returns (y, stats) -- stats is what the backward needs."""
+    lib = _lib.load()
+    x, (C, H, W) = _chw(x, "x")
+    R = w1.shape[0]
+    y, stats = torch.empty_like(x), torch.empty(2 * C + R, device=x.device)
+    _lib.check(lib.crnerf_fglo_f32(_lib.dev_ptr(x), _lib.dev_ptr(_f32c(w1, "fc.0.weight")), _lib.dev_ptr(_f32c(b1, "fc.0.bias")),
+                                   _lib.dev_ptr(_f32c(w2, "fc.2.weight")), _lib.dev_ptr(_f32c(b2, "fc.2.bias")), _lib.dev_ptr(stats), _lib.dev_ptr(y),
+                                   C, R, H * W, _lib.stream_ptr()), "crnerf_fglo_f32")
+    return y, stats
+
+
+def fglo_backward(x, w1, w2, stats, d_y):
+    lib = _lib.load()
+    x, (C, H, W) = _chw(x, "x")
+    d_y = _f32c(d_y, "d_y")
+    R = w1.shape[0]
+    dev = x.device
+    dx, dw1, db1, dw2, db2 = torch.empty_like(x), torch.empty(R, C, device=dev), torch.empty(R, device=dev), torch.empty(C, R, device=dev), \
+        torch.empty(C, device=dev)
+    scratch = torch.empty(2 * C, device=dev)
+    _lib.check(lib.crnerf_fglo_backward_f32(_lib.dev_ptr(x), _lib.dev_ptr(_f32c(w1, "fc.0.weight")), _lib.dev_ptr(_f32c(w2, "fc.2.weight")),
+                                            _lib.dev_ptr(stats), _lib.dev_ptr(d_y), _lib.dev_ptr(scratch), _lib.dev_ptr(dx), _lib.dev_ptr(dw1),
+                                            _lib.dev_ptr(db1), _lib.dev_ptr(dw2), _lib.dev_ptr(db2), C, R, H * W, _lib.stream_ptr()),
+               "crnerf_fglo_backward_f32")
+    return dx, dw1, db1, dw2, db2
+
+
+def bilinear_gather(x, size, idx=None, sigmoid=False):
+    """F.interpolate(x[1,1,h,w], size, mode='bilinear', align_corners=False) (then sigmoid), at pixels idx (None: all, as [1,1,Ho,Wo])."""
+    lib = _lib.load()
+    x, (C, h, w) = _chw(x, "x")
+    if C != 1:
+        raise ValueError("crnerf_amd: bilinear_gather: one channel expected (the mask), got %d" % C)
+    Ho, Wo = int(size[0]), int(size[1])
+    if idx is None:
+        out, n = torch.empty(1, 1, Ho, Wo, device=x.device), Ho * Wo
+    else:
+        idx = idx.contiguous()
+        out, n = torch.empty(idx.numel(), device=x.device), idx.numel()
+    _lib.check(lib.crnerf_bilinear_gather_f32(_lib.dev_ptr(x), h, w, Ho, Wo, _lib.dev_ptr(idx, "idx", torch.int64), n, int(bool(sigmoid)),
+                                              _lib.dev_ptr(out), _lib.stream_ptr()), "crnerf_bilinear_gather_f32")
+    return out
+
+
+def bilinear_gather_backward(out, d_out, in_hw, size, idx=None, sigmoid=False):
+    lib = _lib.load()
+    h, w = in_hw
+    Ho, Wo = int(size[0]), int(size[1])
+    d_out = _f32c(d_out, "d_out")
+    n = d_out.numel()
+    d_in = torch.empty(1, 1, h, w, device=d_out.device)
+    _lib.check(lib.crnerf_bilinear_gather_backward_f32(_lib.dev_ptr(out) if sigmoid else None, _lib.dev_ptr(d_out), h, w, Ho, Wo,
+                                                       _lib.dev_ptr(idx.contiguous(), "idx", torch.int64) if idx is not None else None, n,
+                                                       int(bool(sigmoid)), _lib.dev_ptr(d_in), _lib.stream_ptr()), "crnerf_bilinear_gather_backward_f32")
+    return d_in

@@ -7,7 +7,7 @@ reference's drivers can be re-created without Lightning / imageio / torchvision:
     decode_image(...)             eval.py:288-295 (feature -> [1,64,H,W] view -> decoder -> [H*W,3])
     render_frame(...)             one video frame: rays generated on the device, style from the appearance encoder
     TrainingSystem                NeRFSystem.decode / forward / training_step, train_mask_grid_sample.py:127-226, :268-290
-                                  (encode_a / encode_random / encode_c configuration; use_mask needs the CGNet mask network, not built)
+                                  (command/train.sh's configuration: encode_a, encode_random, encode_c, use_mask)
 """
 from collections import defaultdict
 
@@ -95,8 +95,6 @@ class TrainingSystem:
 
     def __init__(self, hparams_, models=None, embeddings=None, enc_a=None, device="cuda"):
         from .losses import loss_dict
-        if getattr(hparams_, "use_mask", False):
-            raise NotImplementedError("crnerf_amd: use_mask needs the CGNet mask network (models/lightweight_seg.py), which is not built")
         self.hparams_ = hparams_
         self.loss = loss_dict['crnerf'](hparams_, coef=1)                                   # :74
         self.models = models or get_model(hparams_, device)
@@ -105,6 +103,11 @@ class TrainingSystem:
         self.enc_cont = encoder_sameoutputsize(out_channel=hparams_.nerf_out_dim).to(device) if getattr(hparams_, "encode_c", False) else None   # :84
         self.embedding_a_list = [None] * getattr(hparams_, "N_vocab", 1500)                 # :98
         self.models_to_train = list(self.models.values()) + [self.enc_a] + ([self.enc_cont] if self.enc_cont is not None else [])   # :84-97
+        self.implicit_mask = None
+        if getattr(hparams_, "use_mask", False):                                            # :113-115
+            from .models.lightweight_seg import Context_Guided_Network
+            self.implicit_mask = Context_Guided_Network(classes=1, M=2, N=2, input_channel=3).to(device)
+            self.models_to_train += [self.implicit_mask]
         self.global_step = 0
 
     def parameters(self):
@@ -127,7 +130,7 @@ class TrainingSystem:
         results['rgb_' + type] = rgbs_pred
         return results
 
-    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None):                             # :151-226
+    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None, hw_whole=None):              # :151-226
         import random
         hp = self.hparams_
         results = defaultdict(list)
@@ -137,6 +140,13 @@ class TrainingSystem:
         if hp.encode_random:
             idexlist = [k for k, v in enumerate(self.embedding_a_list) if v is not None]
             kwargs['a_embedded_random'] = kwargs['a_embedded_from_img'] if len(idexlist) == 0 else self.embedding_a_list[random.choice(idexlist)]
+        if self.implicit_mask is not None:                                                  # :170-176
+            from .models.lightweight_seg import mask_at_pixels
+            if rgb_idx is None or hw_whole is None:
+                raise ValueError("crnerf_amd: use_mask needs the batch's rgb_idx and the full-resolution image size (hw_whole)")
+            pred_mask = self.implicit_mask(whole_img)
+            # interpolate(pred_mask, hw_whole) -> '(h w) n' -> [rgb_idx], evaluated only at the batch's pixels
+            kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, rgb_idx.reshape(-1))
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
         ray_chunk = max(int(hp.chunk), 1 << 16)   # the reference's 8,192-ray chunks (:185-197) only bound its memory; rays are independent
@@ -152,6 +162,8 @@ class TrainingSystem:
             results = self.decode(results, "fine", **kwargs)
         if getattr(hp, "encode_c", False):
             results = self.decode(results, "content", **kwargs)                             # :207-208
+        if self.implicit_mask is not None:
+            results['out_mask'] = kwargs['mask_embedded_from_img']                          # :210-211
         results['a_embedded'] = kwargs['a_embedded_from_img']
         results['whole_img'] = whole_img
         if hp.encode_random:
@@ -168,7 +180,11 @@ class TrainingSystem:
     def training_step(self, batch):                                                         # :268-290
         rays, ts, rgbs = batch['rays'], batch['ts'], batch['rgbs']
         side = int(round(rays.shape[0] ** 0.5))
-        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'))
+        hw_whole = None
+        if batch.get('img_wh') is not None:
+            w_whole, h_whole = (int(v) for v in batch['img_wh'])                            # :272
+            hw_whole = (h_whole, w_whole)
+        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'), hw_whole)
         loss_d, annealing = self.loss(results, rgbs, self.hparams_, self.global_step)
         loss = sum(l for l in loss_d.values())
         self.global_step += 1

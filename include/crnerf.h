@@ -258,6 +258,44 @@ typedef struct crnerf_batch_args {
 } crnerf_batch_args;
 int crnerf_grid_sample_batch_f32(const crnerf_batch_args* args, void* stream);
 
+/* Operators of the transient-mask network: Context_Guided_Network(classes=1, M=2, N=2, input_channel=3),
+ * models/lightweight_seg.py:274-368, applied once per step to the 1/8-scale photo (train_mask_grid_sample.py:170-176).
+ * All tensors NCHW fp32, batch 1, contiguous; every backward OVERWRITES its gradient outputs. */
+typedef struct crnerf_conv_geom {           /* nn.Conv2d(cin, cout, k, stride, padding=pad, dilation=dil, bias=False); */
+  int32_t cin, cout, H, W;                  /* groups = 1, or groups = cin = cout when depthwise != 0                   */
+  int32_t k, stride, pad, dil, depthwise;   /* (Conv / ChannelWiseConv / ChannelWiseDilatedConv, lightweight_seg.py:12-140) */
+} crnerf_conv_geom;
+/* x[cin,H,W], w[cout, cin or 1, k, k] -> y[cout,Ho,Wo], Ho = (H + 2 pad - dil (k-1) - 1) / stride + 1 */
+int crnerf_conv2d_f32(const crnerf_conv_geom* geom, const float* x, const float* w, float* y, void* stream);
+/* d_x may be NULL (first layer) */
+int crnerf_conv2d_backward_f32(const crnerf_conv_geom* geom, const float* x, const float* w, const float* d_y, float* d_x, float* d_w,
+                               void* stream);
+/* BatchNorm2d(C, eps) followed by PReLU(C) (ConvBNPReLU / BNPReLU, lightweight_seg.py:12-52).  training != 0: batch
+ * statistics -- mean[C], invstd[C] (biased variance) and var_unbiased[C] are WRITTEN (the host applies the momentum
+ * update of running_mean / running_var with them); training == 0: mean / invstd are READ (running statistics). */
+int crnerf_bn_prelu_f32(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd,
+                        float* var_unbiased, float* y, int C, int64_t HW, float eps, int training, void* stream);
+int crnerf_bn_prelu_backward_f32(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean,
+                                 const float* invstd, const float* d_y, float* d_x, float* d_gamma, float* d_beta, float* d_alpha, int C,
+                                 int64_t HW, int training, void* stream);
+/* nn.AvgPool2d(3, stride=2, padding=1) (InputInjection, lightweight_seg.py:258-270): x[C,H,W] -> y[C,(H-1)/2+1,(W-1)/2+1];
+ * backward != 0: `in` is d_y and `out` d_x[C,H,W] (H, W always the un-pooled size). */
+int crnerf_avgpool3s2_f32(const float* in, float* out, int C, int H, int W, int backward, void* stream);
+/* FGlo (lightweight_seg.py:143-162): y = x * sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2), W1[R,C], W2[C,R], C <= 256, R <= 64.
+ * stats[2C+R] (means, hidden, gates) is written by the forward and read by the backward; scratch: 2C floats. */
+int crnerf_fglo_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R,
+                    int64_t HW, void* stream);
+int crnerf_fglo_backward_f32(const float* x, const float* w1, const float* w2, const float* stats, const float* d_y, float* scratch,
+                             float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, int C, int R, int64_t HW, void* stream);
+/* F.interpolate(in[1,1,h,w], size=(Ho,Wo), mode='bilinear', align_corners=False) evaluated at the n output pixels idx[]
+ * (row-major index into Ho x Wo; NULL = all pixels in order, n = Ho*Wo), optionally followed by sigmoid:
+ * the network's final upsample + sigmoid (lightweight_seg.py:366-367) and the full-resolution mask read at the batch's
+ * pixels, interpolate(...)[rgb_idx] (train_mask_grid_sample.py:172-175).  The backward zeroes d_in[h,w] first. */
+int crnerf_bilinear_gather_f32(const float* in, int h, int w, int Ho, int Wo, const int64_t* idx, int64_t n, int sigmoid, float* out,
+                               void* stream);
+int crnerf_bilinear_gather_backward_f32(const float* out, const float* d_out, int h, int w, int Ho, int Wo, const int64_t* idx, int64_t n,
+                                        int sigmoid, float* d_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,7 +99,8 @@ def test_grid_sample_batcher_vs_reference(golden, tag):
         assert s[k].dtype == (torch.int64 if k in ("ts", "rgb_idx") else torch.float32)
 
 
-def test_training_system_mirrors_nerfsystem_step():
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_training_system_mirrors_nerfsystem_step(use_mask):
     """NeRFSystem.forward / training_step (train_mask_grid_sample.py:151-226, :268-290) on the drop-in modules: result keys,
     loss keys, gradients reaching every trained module, the fused loss agreeing with the oracle on the same results, and a
     few optimiser steps reducing the loss."""
@@ -110,8 +111,9 @@ def test_training_system_mirrors_nerfsystem_step():
     class HPT(HP):
         nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
         img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [16, 16], 32, 32, 1.0, 1.0, 128, 8
-        use_mask, encode_c = False, True          # command/train.sh:24 trains with --encode_c
+        encode_c = True                            # command/train.sh:24 trains with --encode_c --use_mask
     hp = HPT()
+    hp.use_mask = use_mask
     torch.manual_seed(0)
     sys_ = pipeline.TrainingSystem(hp, device=DEV)
     sys_.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
@@ -121,14 +123,17 @@ def test_training_system_mirrors_nerfsystem_step():
     sys_.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
     R = 256
     batch = {"rays": torch.from_numpy(synth.rays(R, H=16, W=16)).to(DEV), "ts": torch.full((R,), 3, dtype=torch.int64, device=DEV),
-             "rgbs": torch.rand(R, 3, device=DEV), "whole_img": torch.rand(1, 3, 64, 80, device=DEV) * 2 - 1}
+             "rgbs": torch.rand(R, 3, device=DEV), "whole_img": torch.rand(1, 3, 64, 80, device=DEV) * 2 - 1,
+             "rgb_idx": torch.randint(0, 512 * 640, (R,), device=DEV), "img_wh": torch.tensor([640, 512])}
     opt = torch.optim.Adam(sys_.parameters(), lr=5e-4)
     losses = []
     for it in range(4):
         opt.zero_grad(set_to_none=True)
         loss, loss_d, results = sys_.training_step(batch)
         if it == 0:
-            assert list(loss_d.keys()) == ["kl_a", "rec_a_random", "c_l", "content_constraint", "f_l"]
+            assert list(loss_d.keys()) == ["kl_a", "rec_a_random", "c_l", "content_constraint"] + (["r_ms", "r_md"] if use_mask else []) + ["f_l"]
+            if use_mask:
+                assert results["out_mask"].shape == (R, 1) and 0 < float(results["out_mask"].min()) and float(results["out_mask"].max()) < 1
             for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "feature_fine_random", "depth_fine",
                       "rgb_coarse", "rgb_fine_img", "rgb_fine", "a_embedded", "whole_img", "a_embedded_random", "rgb_fine_random",
                       "a_embedded_random_rec", "rgb_content_img", "content_with_a_embed", "content_wo_a_embed"):
@@ -141,7 +146,7 @@ def test_training_system_mirrors_nerfsystem_step():
         loss.backward()
         if it == 0:
             for name, mod in (("coarse", sys_.models["coarse"]), ("fine", sys_.models["fine"]), ("decoder", sys_.models["decoder"]), ("enc_a", sys_.enc_a),
-                              ("enc_cont", sys_.enc_cont)):
+                              ("enc_cont", sys_.enc_cont)) + ((("implicit_mask", sys_.implicit_mask),) if use_mask else ()):
                 got = [p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0 for p in mod.parameters()]
                 assert all(got), (name, got)
         opt.step()

@@ -166,3 +166,41 @@ def test_video_camera_path_matches_reference(golden):
         np.testing.assert_allclose(got, g[key], rtol=0, atol=1e-14)
     for wh in ((320, 240), (800, 800)):
         np.testing.assert_allclose(video.define_camera(wh), g["K_%dx%d" % wh], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cgnet_oracle_matches_reference(golden, tag):
+    """oracle/cgnet_ref.py (numpy) against the imported reference's Context_Guided_Network: training-mode mask, running
+    statistics, mask read at full-resolution pixels, eval-mode mask (golden g13)."""
+    from _cgnet_fixture import seeded_state
+    from crnerf_amd.models.lightweight_seg import Context_Guided_Network
+    from oracle import cgnet_ref as C
+    g = golden("g13_cgnet")
+    net = Context_Guided_Network(classes=1, M=2, N=2, input_channel=3)
+    p = {k: v.numpy().astype(np.float64) for k, v in seeded_state(net, int(g[tag + "_seed"])).items()}
+    img, stats = g[tag + "_img"][0].astype(np.float64), {}
+    mask = C.cgnet_forward(img, p, True, stats_out=stats)
+    np.testing.assert_allclose(mask, g[tag + "_mask_train"][0, 0], atol=3e-6, rtol=0)
+    assert len(stats) == 2 * sum(1 for k in p if k.endswith("running_mean"))
+    for k, v in stats.items():
+        np.testing.assert_allclose(v, g[tag + "_stat/" + k], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(C.mask_at_pixels(mask, g[tag + "_hw_whole"], g[tag + "_idx"]), g[tag + "_picked"], atol=3e-6, rtol=0)
+    p.update(stats)
+    np.testing.assert_allclose(C.cgnet_forward(img, p, False), g[tag + "_mask_eval"][0, 0], atol=3e-6, rtol=0)
+
+
+def test_cgnet_mirror_has_the_reference_state_dict(golden):
+    """The mirror's parameter / buffer names and shapes are the reference's (118 entries, 257,714 parameters), so
+    `implicit_mask.*` checkpoint entries load unchanged; it refuses CPU tensors instead of falling back."""
+    from crnerf_amd.models.lightweight_seg import Context_Guided_Network
+    g = golden("g13_cgnet")
+    net = Context_Guided_Network(classes=1, M=2, N=2, input_channel=3)
+    sd = net.state_dict()
+    assert len(sd) == 118 and sum(p.numel() for p in net.parameters()) == 257714
+    stat_keys = {k[len("a_stat/"):] for k in g if k.startswith("a_stat/")}
+    grad_keys = {k[len("a_gnorm/"):] for k in g if k.startswith("a_gnorm/")}
+    assert stat_keys == {k for k in sd if "running" in k or "num_batches" in k}
+    assert grad_keys == {k for k, _ in net.named_parameters()}
+    assert sd["level3_0.conv1x1.conv.weight"].shape == (128, 131, 3, 3) and sd["level2_0.F_sur.conv.weight"].shape == (64, 1, 3, 3)
+    with pytest.raises(RuntimeError, match="HIP operators only"):
+        net(torch.zeros(1, 3, 16, 16))

@@ -22,7 +22,7 @@ class HP:
     weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
     nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
     img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [side, side], NC, NI, 1.0, 1.0, 8 * 1024, 1500
-    use_mask, encode_c = False, True       # command/train.sh:24 (--encode_c; --use_mask needs the CGNet mask network)
+    use_mask, encode_c = True, True        # command/train.sh:24 (--encode_c --use_mask)
 
 
 hp = HP()
