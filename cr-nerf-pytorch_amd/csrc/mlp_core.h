@@ -38,15 +38,16 @@ constexpr int LDS_SCRATCH = LDS_RING + RING_SLOTS * STAGE_BYTES;  // 120,832
 
 // Phase timer for tuning builds (-DCRNERF_TIMING): wave 0 of block 0 accumulates shader-clock cycles
 // per phase into crnerf_timing[]; compiled out otherwise.
-enum { T_PROLOGUE = 0, T_MMA, T_EPILOGUE, T_SIGMA, T_COMPOSITE, T_RAYLEVEL, T_TOTAL, T_X0, T_X1, T_X2, T_X3, T_X4, T_X5, T_X6, T_X7, T_COUNT };
+enum { T_PROLOGUE = 0, T_MMA, T_EPILOGUE, T_SIGMA, T_COMPOSITE, T_RAYLEVEL, T_TOTAL, T_X0, T_X1, T_X2, T_X3, T_X4, T_X5, T_X6, T_X7, T_REAL, T_COUNT };   // T_REAL: 100 MHz ticks from start() to flush()
 #ifdef CRNERF_TIMING
 static __device__ unsigned long long crnerf_timing[T_COUNT];   // one copy per translation unit
 struct PhaseTimer {
-  unsigned long long last, acc[T_COUNT];
+  unsigned long long last, acc[T_COUNT], real0;
   bool on;
   __device__ __forceinline__ void start(bool on_) {
     on = on_;
     for (int i = 0; i < T_COUNT; ++i) acc[i] = 0;
+    real0 = __builtin_amdgcn_s_memrealtime();
     last = __builtin_readcyclecounter();
   }
   __device__ __forceinline__ void tick(int phase) {
@@ -58,6 +59,7 @@ struct PhaseTimer {
     last = t;
   }
   __device__ __forceinline__ void flush() {
+    acc[T_REAL] = __builtin_amdgcn_s_memrealtime() - real0;
     if (on)
       for (int i = 0; i < T_COUNT; ++i) crnerf_timing[i] = acc[i];
   }

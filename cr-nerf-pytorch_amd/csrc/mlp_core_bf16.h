@@ -18,8 +18,9 @@
 //     2 x 128 VGPRs (ping-pong) instead of 512 as fp32.
 //   * every A fragment (1 KiB, one ds_read_b128 per lane) feeds TWO MFMAs (the two point groups): 4 waves x 1 KiB
 //     per 64 MFMA cycles = 64 B/clk/CU, half the LDS bandwidth.  Fragments are read B_AHEAD ahead of use.
-//   * weights stream L2 -> LDS through the same 6-slot x 16 KiB ring and barrier protocol as the fp32 core
-//     (mlp_core.h WeightPipe): one s_barrier per 16 fragments = 32 MFMAs = 1024 MFMA cycles.
+//   * weights stream L2 -> LDS through a 4-slot x 16 KiB ring with the barrier protocol of the fp32 core (mlp_core.h
+//     WeightPipe): one s_barrier per 16 fragments = 32 MFMAs = 1024 MFMA cycles; all ring arithmetic is compile-time
+//     (WeightPipeB below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "layout.h"
@@ -81,88 +82,87 @@ constexpr bool b_schedule_ok() {
 }
 static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protocol");
 
-// Weight ring for 4 waves x 4 pieces per stage; protocol documented at mlp_core.h WeightPipe.  Everything except
-// lane16 / rd_addr / nx_addr is wave-uniform (SGPRs): the stream pointers are scalar and the lane offset rides in the
-// instruction's VGPR-offset operand.
+// Weight ring of the bf16 core: B_RING = 4 slots x 16 KiB, and because a pass is 76 = 19 x 4 stages the ring is in the SAME
+// phase at the start of every tile -- so, with the tile code fully unrolled, every ring quantity is a compile-time
+// constant: stage c of a tile lives in slot c % 4, fragment reads are `ds_read_b128 v, rd_base offset:<slot, fragment>`
+// (4 x 16 KiB = the 16-bit offset range), the LDS-DMA destination of stage c + 3 is one of four precomputed M0 values.
+// What is left per stage is ONE VALU add (the fetch offset, riding in the LDS-DMA instruction's VGPR operand) and the
+// M0 write.  Scalar bookkeeping is NOT free beside the MFMA stream (tools/ubench: ~4 cycles per SALU instruction
+// wherever it is placed; the dynamic 6-slot ring's 11 instructions per stage cost 2.4 cycles per MFMA).
+// Protocol (as mlp_core.h WeightPipe, with distances for 4 slots): while stage c is multiplied, stage c + 3 is fetched
+// into the slot stage c - 1 has left (its last fragment read was issued before the barrier that opened stage c); the
+// barrier in stage c's k-step 14 waits vmcnt(8) -- stages c + 2 and c + 3 may be in flight, stage c + 1 has landed --
+// and opens stage c + 1 for the look-ahead reads.  Stages 76, 77, 78 are the NEXT tile's first three: they are fetched
+// from `nxt`, the stream of the model the next tile runs (begin_tile).
+constexpr int B_RING = 4;
+static_assert(STAGESB_PER_PASS % B_RING == 0, "the static ring needs a whole number of ring turns per pass");
+static_assert(B_RING * STAGE_BYTES <= 65536 && B_RING <= RING_SLOTS, "ds_read offsets are 16 bits; the LDS ring area is shared with the fp32 core");
+
 struct WeightPipeB {
-  // Scalar instructions are NOT free beside the MFMA stream (tools/ubench: ~3.5 cycles each wherever they are placed,
-  // i.e. the first version's ~27 SALU of ring bookkeeping per stage cost 2.4 cycles per MFMA), so the state is kept in
-  // the form that needs the fewest of them: LDS byte addresses that are bumped and wrapped instead of slot indices that
-  // are scaled, per-lane read addresses updated with VALU instructions (free up to four per MFMA gap), M0 written once
-  // per stage, and the once-per-pass stream switch behind a (uniform, almost never taken) branch.
-  const char* base[2];   // packed streams + this wave's 4 KiB column
-  const char* pf_ptr;    // stage being fetched
-  int pf_left, pf_pass, passes0, passes;
-  uint32_t pf_dst;       // LDS byte address the stage being fetched goes to (+ this wave's 4 KiB column)
-  uint32_t ring_lo, ring_hi;   // pf_dst range
-  uint32_t rd_addr, nx_addr;   // per-lane LDS byte address of fragment 0 of stage c / c+1
+  const char* base[2];   // packed streams + this wave's 4 KiB column (scalar)
+  const char* cur;       // stream of the tile being multiplied
+  const char* nxt;       // stream of the next tile
+  uint32_t m0s[B_RING];  // scalar: LDS byte address of slot k + this wave's 4 KiB column
+  uint32_t voff;         // per-lane: lane16 + STAGE_BYTES * (stage being fetched, tile-relative)
+  uint32_t rd_base;      // per-lane: LDS_RING + lane16
   uint32_t lane16;
   lds_char* lds;
 
-  __device__ __forceinline__ void issue_piece(int i) {
-#ifndef CRNERF_EXP_NOGLDS
-    // piece 0 writes M0 (= LDS base of the stage); pieces 1..3 reuse it with their instruction offset.  Nothing else in
-    // these kernels touches M0 (tests/test_host.py checks the ISA).
+  // piece `i` (0..3) of tile-relative stage F (76..78 = the next tile's 0..2).  Piece 0 writes M0; pieces 1..3 reuse it
+  // with their instruction offset (which applies to both sides).  Nothing else in these kernels touches M0
+  // (tests/test_host.py checks the ISA).
+  __device__ __forceinline__ void issue_piece(int i, int F) {   // both constant after unrolling
+    const char* src = F < STAGESB_PER_PASS ? cur : nxt;
     switch (i) {   // the instruction offset must be an immediate
-      case 0: glds16(pf_dst, pf_ptr, lane16, 0); break;
-      case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(1 * FRAG_BYTES) : "memory"); break;
-      case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(2 * FRAG_BYTES) : "memory"); break;
-      default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(3 * FRAG_BYTES) : "memory"); break;
+      case 0: glds16(m0s[F % B_RING], src, voff, 0); break;
+      case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(src), "n"(1 * FRAG_BYTES) : "memory"); break;
+      case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(src), "n"(2 * FRAG_BYTES) : "memory"); break;
+      default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(src), "n"(3 * FRAG_BYTES) : "memory"); break;
     }
-#endif
   }
-  // after the 4th piece of a stage: move the fetch cursor to the next stage
-  __device__ __forceinline__ void cursor_update() {
-    pf_dst = (pf_dst + STAGE_BYTES == ring_hi) ? ring_lo : pf_dst + STAGE_BYTES;
-    pf_ptr += STAGE_BYTES;
-    if (__builtin_expect(--pf_left == 0, 0)) {   // end of a pass: switch stream (once per 76 stages)
-      pf_left = STAGESB_PER_PASS;
-      pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
-      pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
-    }
-    asm volatile("" : "+s"(pf_ptr));   // opaque: else a single-pass kernel gets 302 precomputed addresses
+  // after the 4th piece of stage F: one VALU instruction
+  __device__ __forceinline__ void cursor_update(int F) {
+    voff = (F + 1 == STAGESB_PER_PASS) ? lane16 : voff + STAGE_BYTES;
+    asm volatile("" : "+v"(voff));   // keep it ONE register (else hipcc keeps a handful of pre-added offsets alive)
   }
-  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_, int lane,
-                                        int wave) {
+  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int first_model, int lane, int wave) {
     lds = lds_;
     lane16 = (uint32_t)lane * 16u;
-    ring_lo = (uint32_t)(uintptr_t)lds_ + LDS_RING + (uint32_t)wave * 4096u;
-    ring_hi = ring_lo + RING_SLOTS * STAGE_BYTES;
-    pf_dst = ring_lo;
+    rd_base = LDS_RING + lane16;
+#pragma unroll
+    for (int k = 0; k < B_RING; ++k) m0s[k] = (uint32_t)(uintptr_t)lds_ + LDS_RING + k * STAGE_BYTES + (uint32_t)wave * 4096u;
     base[0] = stream0 + wave * 4096;
     base[1] = stream1 + wave * 4096;
-    passes0 = passes0_;
-    passes = passes_;
-    pf_pass = 0;
-    pf_left = STAGESB_PER_PASS;
-    pf_ptr = (passes0 > 0) ? base[0] : base[1];
-    rd_addr = LDS_RING + lane16;
-    nx_addr = LDS_RING + STAGE_BYTES + lane16;
+    cur = nxt = base[first_model];
+    voff = lane16;
 #pragma unroll
-    for (int s = 0; s < RING_SLOTS - 1; ++s) {
+    for (int F = 0; F < B_RING - 1; ++F) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) issue_piece(i);
-      cursor_update();
+      for (int i = 0; i < 4; ++i) issue_piece(i, F);
+      cursor_update(F);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
+  // once per tile, before its first k-step: `next_model` = the model of the tile after this one (any valid model for
+  // the very last tile: its three stages are fetched and never read)
+  __device__ __forceinline__ void begin_tile(int next_model) {
+    cur = nxt;
+    nxt = next_model ? base[1] : base[0];
+    asm volatile("" : "+s"(cur), "+s"(nxt));
   }
   __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory");
-#ifndef CRNERF_EXP_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#endif
-    rd_addr = nx_addr;                                           // per-lane, VALU only
-    const uint32_t n = nx_addr + STAGE_BYTES;
-    nx_addr = n >= LDS_RING + RING_SLOTS * STAGE_BYTES + lane16 ? n - RING_SLOTS * STAGE_BYTES : n;
   }
-  // fragment `slot` of stage c (next == false) or c+1
-  __device__ __forceinline__ u32x4 read(bool next, int slot) const {
-    return *(const __attribute__((address_space(3))) u32x4*)(lds + (next ? nx_addr : rd_addr) + slot * FRAG_BYTES);
+  // fragment at padded stream position `pos` (tile-relative; 1216.. = the next tile's stage 0)
+  __device__ __forceinline__ u32x4 read(int pos) const {
+    return *(const __attribute__((address_space(3))) u32x4*)(lds + rd_base + ((pos / STAGE_FRAGS) % B_RING) * STAGE_BYTES +
+                                                              (pos % STAGE_FRAGS) * FRAG_BYTES);
   }
   __device__ __forceinline__ void prime(u32x4 (&q)[B_AHEAD]) const {
 #pragma unroll
-    for (int j = 0; j < B_AHEAD; ++j) q[j] = read(false, j);
+    for (int j = 0; j < B_AHEAD; ++j) q[j] = read(j);
   }
 };
 
@@ -199,6 +199,7 @@ struct EpiTemps {
 };
 
 struct NoEpi {
+  static constexpr bool EARLY = true;
   __device__ __forceinline__ void prefetch(int) {}
   __device__ __forceinline__ void load(int, int, int, const f32x16&) {}
   __device__ __forceinline__ void finish(int, int, int) {}
@@ -223,6 +224,7 @@ __device__ __forceinline__ uint32_t pack_pair(float v0, float v1) {
 // (hipcc's inline-asm hazard rule), i.e. two more issue slots per quarter in a gap that has none to spare.
 template <bool RELU>
 struct PackEpi : EpiTemps {
+  static constexpr bool EARLY = true;
   u32x4 (&dst)[KS_HID][2];
   __device__ __forceinline__ explicit PackEpi(u32x4 (&d)[KS_HID][2]) : dst(d) {}
   __device__ __forceinline__ void prefetch(int) {}
@@ -244,6 +246,7 @@ struct PackEpi : EpiTemps {
 
 // xyz_encoding_8: as PackEpi<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
 struct SigmaEpi : EpiTemps {
+  static constexpr bool EARLY = false;   // prefetch() in k-step 0 loads what finish() multiplies by
   u32x4 (&dst)[KS_HID][2];
   float (&sg)[2];
   const lds_float* wsig;
@@ -276,6 +279,7 @@ __device__ __forceinline__ float softplus_fast(float x) {
 }
 
 struct RgbEpi : EpiTemps {   // static_rgb: sigmoid, fp32 out
+  static constexpr bool EARLY = true;
   f32x16 (&feat)[2][2];
   __device__ __forceinline__ explicit RgbEpi(f32x16 (&f)[2][2]) : feat(f) {}
   __device__ __forceinline__ void prefetch(int) {}
@@ -296,6 +300,44 @@ __device__ __forceinline__ void load_bias_half(f32x16& bv, const lds_float* bias
     for (int j = 0; j < 4; ++j) bv[4 * c + j] = b[j];
   }
 }
+
+// Which of the previous tile's 16 epilogue quarters ride behind k-step s of the current tile.  Quarter 0 reads point
+// group 0's accumulator, whose last MFMA issued two gaps before k-step 0's second gap, so an epilogue without LDS
+// operands may start at once (EARLY); the sigma head's weights are fetched in k-step 0, so it starts in k-step 1.
+//   inside a 16+-k-step layer (the result is not needed before the next layer): one quarter per k-step up to k-step 15;
+//   first tile of such a layer (its k-step 14 reads what quarters 0-7 produce, k-step 15 the rest): done after k-step 14;
+//   where the k-steps are fewer than the quarters, the doubles are spread evenly;
+//   short layers (6 or 8 k-steps; the rgb layer's k-step 6 reads the result): one, then three per k-step in 1..5.
+struct EpiSlot { int first, count; };
+constexpr EpiSlot epi_slot(bool long_layer, bool first_tile, bool early, int s) {
+  if (!long_layer) return s == 0 ? EpiSlot{0, 1} : (s <= 5 ? EpiSlot{1 + 3 * (s - 1), 3} : EpiSlot{16, 0});
+  const int start = early ? 0 : 1, last = first_tile ? 14 : 15, m = last - start + 1, extra = 16 - m;
+  int done = 0;
+  for (int k = 0; k < m; ++k) {
+    int c = 1;
+    for (int j = 1; j <= extra; ++j) c += (k == j * m / (extra + 1)) ? 1 : 0;
+    if (start + k == s) return EpiSlot{done, c};
+    done += c;
+  }
+  return EpiSlot{16, 0};
+}
+constexpr bool epi_schedule_ok() {
+  for (int v = 0; v < 5; ++v) {   // short, long x {inner, first} x {early, late}
+    const bool lng = v > 0, ft = v == 2 || v == 4, early = v < 3;
+    int done = 0;
+    for (int s = 0; s < 16; ++s) {
+      const EpiSlot e = epi_slot(lng, ft, early, s);
+      if (e.count && e.first != done) return false;
+      if (e.count > 4 || (!early && s == 0 && e.count)) return false;
+      done += e.count;
+      if (lng && ft && ((s == 13 && done < 8) || (s == 14 && done < 16))) return false;
+      if (!lng && s == 5 && done < 16) return false;
+    }
+    if (done != 16) return false;
+  }
+  return true;
+}
+static_assert(epi_schedule_ok(), "epilogue quarters must cover 0..15 in order and meet the next layer's first reads");
 
 // One layer.  NT output tiles; per tile NSA k-steps with B operands srcA[s][g] then NSB from srcB (g = point group).
 // FBASE: pass-relative index of the layer's first fragment; G0: index of its first tile in the pass (tile G
@@ -319,11 +361,9 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int i = FBASE + T * NS + s;
-      // quarters of the previous tile's epilogue carried by this k-step.  Long layers: one per k-step from k-step 1,
-      // a second one every fourth k-step, done after k-step 13 (k-step 14 of a layer's first tile reads the result);
-      // the short layers (K = 96, 128) take four per k-step in k-steps 1..4.
-      const int first = LONG ? (s - 1) + (s - 1) / 4 : 4 * (s - 1);
-      const int count = s < 1 ? 0 : (LONG ? (s <= 13 ? (s % 4 == 0 ? 2 : 1) : 0) : (s <= 4 ? 4 : 0));
+      // quarters of the previous tile's epilogue carried by this k-step (epi_first / epi_count above)
+      const EpiSlot es = T == 0 ? epi_slot(LONG, true, PREV::EARLY, s) : epi_slot(LONG, false, EPI::EARLY, s);
+      const int first = es.first, count = es.count;
       const f32x16& pa0 = accs[cur ^ 1][0];
       const f32x16& pa1 = accs[cur ^ 1][1];
 
@@ -341,15 +381,14 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
         if (T == 0) prev.load(u, PT, qc, (qc & 1) ? pa1 : pa0);
         else epi.load(u, T - 1, qc, (qc & 1) ? pa1 : pa0);
       }
-      if (b_piece_at(i) >= 0) p.issue_piece(b_piece_at(i));
+      if (b_piece_at(i) >= 0) p.issue_piece(b_piece_at(i), i / STAGE_FRAGS + B_RING - 1);
       __builtin_amdgcn_sched_barrier(0);   // pin the hand-made pipeline (hipcc would bunch the fillers)
       // ---- gap 2
       accs[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b1), s == 0 ? biasv : accs[cur][1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // the LDS read goes FIRST behind the MFMA (tools/ubench: 32.5 cycles/MFMA; with the VALU pair first and the read last
       // the s_nop hipcc puts before the next k-step's MFMA becomes visible: 34.5)
-      const int pos = b_pos(i + B_AHEAD);
-      q[i % B_AHEAD] = p.read(pos / STAGE_FRAGS - b_cur_stage(i) != 0, pos % STAGE_FRAGS);
+      q[i % B_AHEAD] = p.read(b_pos(i + B_AHEAD));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < count; ++u) {
@@ -367,7 +406,7 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
         load_bias_half(biasv, nb, (T + 1 < NT) ? T + 1 : 0, h, s - (NS - 4));
       }
       if (b_advance_at(i)) p.advance();
-      if (b_cursor_at(i)) p.cursor_update();
+      if (b_cursor_at(i)) p.cursor_update(i / STAGE_FRAGS + B_RING - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -376,10 +415,11 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
 // One 64-point tile through one model.  pe[s][g] / dv[s][g]: the embeddings as B operands (posenc_b below);
 // q carries the look-ahead fragments between layers, tiles and passes.  Returns feat[g][t][r] = rgb feature
 // 32t + 8(r>>2) + 4h + (r&3) of point 32g + p, and sigma[g] (valid in both lane halves).
-__device__ __forceinline__ void mlp_tile_b(WeightPipeB& p, int model, const u32x4 (&pe)[KS_XYZ][2], const u32x4 (&dv)[KS_DIR][2],
+__device__ __forceinline__ void mlp_tile_b(WeightPipeB& p, int model, int next_model, const u32x4 (&pe)[KS_XYZ][2], const u32x4 (&dv)[KS_DIR][2],
                                            f32x16 (&feat)[2][2], float (&sigma)[2], int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm) {
   // the consts block is loop-invariant LDS: launder its address once per tile, or LICM hoists all ~1,300 bias /
   // sigma-weight reads out of the caller's tile loop and spills them to scratch
+  p.begin_tile(next_model);
   uint32_t c_off = model ? LDS_CONST1 : LDS_CONST0;
   asm volatile("" : "+s"(c_off));
   const lds_float* C = (const lds_float*)(p.lds + c_off);

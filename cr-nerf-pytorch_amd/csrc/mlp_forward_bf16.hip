@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char* __
 
   load_consts(lds, packed, packed);
   WeightPipeB pipe;
-  pipe.start(lds, packed + CONST_BYTES, packed + CONST_BYTES, 1, 1, lane, wave);
+  pipe.start(lds, packed + CONST_BYTES, packed + CONST_BYTES, 0, lane, wave);
   u32x4 q[B_AHEAD];
   pipe.prime(q);
   PhaseTimer tm;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_bf16_kernel(const char* __
     }
     f32x16 feat[2][2];
     float sigma[2];
-    mlp_tile_b(pipe, 0, pe, dv, feat, sigma, h, q, tm);
+    mlp_tile_b(pipe, 0, 0, pe, dv, feat, sigma, h, q, tm);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const long n = tile * 64 + 32 * g + p;

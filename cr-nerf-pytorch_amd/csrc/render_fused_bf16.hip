@@ -46,18 +46,17 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
   const int p = lane & 31, h = lane >> 5;
   const int Nc = a.Nc, Ni = a.Ni, Nf = Nc + Ni;
 
+  PhaseTimer tm;
+  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
   load_consts(lds, a.packed0, a.packed1);
   RayScratch scr;
   scr.bind(lds + LDS_SCRATCH + wave * SCRATCH_BYTES);
 
-  const int tiles_c = (Nc + 63) >> 6, tiles_f = Ni > 0 ? (Nf + 63) >> 6 : 0;
   WeightPipeB pipe;
-  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, tiles_c, tiles_c + tiles_f,
-             lane, wave);
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, 0, lane, wave);
   u32x4 q[B_AHEAD];
   pipe.prime(q);
-  PhaseTimer tm;
-  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
+  tm.tick(T_RAYLEVEL);   // kernel prologue: constants into LDS, first three weight stages in flight, first fragments read
 
 #pragma unroll 1
   for (int it = 0; it < a.iters; ++it) {
@@ -111,7 +110,9 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
         }
         f32x16 feat[2][2];
         float sigma[2];
-        mlp_tile_b(pipe, pass, pe, dv, feat, sigma, h, q, tm);
+        // the model of the tile after this one: same pass, the fine pass, or the next ray's coarse pass
+        const int next_model = tile + 1 < tiles ? pass : (pass + 1 < npass ? 1 : 0);
+        mlp_tile_b(pipe, pass, next_model, pe, dv, feat, sigma, h, q, tm);
         float noise[2];
         bool is_last[2], valid[2];
 #pragma unroll

@@ -18,15 +18,17 @@ for _ in range(3):
     ops.render_rays(pc, pf, rays, 64, 128, precision=PREC)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = (ctypes.c_ulonglong * 15)()
+buf = (ctypes.c_ulonglong * 16)()
 fn = (lib.crnerf_debug_read_timing_bf16 if PREC == "bf16" else
       lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16)
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
-names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"] + ["x%d" % i for i in range(8)]
+names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"] + ["x%d" % i for i in range(8)] + ["real (100 MHz)"]
 tot = buf[6]
 for n, v in zip(names, buf):
     print("%-18s %12d cycles  %6.2f %%" % (n, v, 100.0 * v / tot))
+if buf[15]:
+    print("wave lifetime %.1f us -> shader clock %.3f GHz" % (buf[15] / 100.0, tot / (buf[15] * 10.0)))
 if PREC == "bf16":
     print("ideal matrix-pipe cycles per wave: %d (4 tiles x 2416 MFMA x 32 cycles)" % (4 * 2416 * 32))
 else:

@@ -1,6 +1,8 @@
 """Generates + builds a micro-benchmark of the bf16 core's k-step shape (one wave per SIMD, 4 waves per workgroup):
   per k-step: 1 ds_read_b128 (A fragment, read 4 k-steps ahead) + 2 x v_mfma_f32_32x32x16_bf16 (two accumulators)
   + F filler instructions of a chosen kind.  Prints shader cycles per MFMA for each variant.
+Operands are bf16-looking random data (zeros would flatter the power draw); next to the cycles the tool prints the
+shader clock the governor settled on (shader cycles / 100 MHz real-time ticks) and the wall time of the loop.
 Usage (GPU box): python tools/ubench/gen_mfma_stream.py
 """
 import os, subprocess, sys
@@ -114,6 +116,7 @@ VARIANTS = [
 ]
 
 clob = '"s40", "s41", "s42", "s43", "s44", "s45", "s46", "scc", ' + ", ".join('"v%d"' % i for i in range(0, 96)) + ", " + ", ".join('"v%d"' % i for i in range(100, 196)) + ", " + ", ".join('"a%d"' % i for i in range(0, 88))
+INIT = "\\n\\t".join("v_xor_b32 v%d, 0x%x, %%0" % (r, (r * 0x01230123) & 0x007f007f) for r in list(range(0, 96)))
 src = ['#include <hip/hip_runtime.h>', '#include <stdio.h>', 'typedef __attribute__((address_space(3))) char lds_char;']
 for k, (name, kw) in enumerate(VARIANTS):
     src.append('''__global__ __launch_bounds__(256, 1) void k%d(unsigned long long* out, int iters, const char* gsrc0) {
@@ -123,25 +126,31 @@ for k, (name, kw) in enumerate(VARIANTS):
   const char* gsrc = gsrc0 + wv * 4096;
   unsigned ldsdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem) + 32768 + wv * 4096;
   unsigned voff = (threadIdx.x & 63) * 16;
-  for (int i = threadIdx.x; i < 4096; i += 256) ((float*)smem)[i] = 0.f;
+  // bf16-looking operands (sign, exponent near 1.0, random mantissa): the matrix pipe's power draw -- and with it the
+  // clock the governor settles on -- depends on the data toggling, zeros would flatter it
+  for (int i = threadIdx.x; i < 16384; i += 256) { unsigned x = (i * 2654435761u) ^ (i >> 3); ((unsigned*)smem)[i] = (x & 0x807f807fu) | 0x3f003f00u | ((x >> 9) & 0x00800080u); }
+  unsigned pat = ((threadIdx.x * 40503u) & 0x807f807fu) | 0x3f003f00u;
+  asm volatile("%s" ::"v"(pat) : %s);
   __syncthreads();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     asm volatile("%s" ::"v"(addr), "s"(gsrc), "s"(ldsdst), "v"(voff) : %s, "memory");
   }
   asm volatile("s_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15" ::: "memory");
   unsigned long long t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
-}''' % (k, body(**kw), clob))
-src.append('int main() { unsigned long long* d; hipMalloc(&d, 8); char* g; hipMalloc(&g, 1 << 20); hipMemset(g, 0, 1 << 20); unsigned long long h; const int iters = 200;')
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}''' % (k, INIT, clob, body(**kw), clob))
+src.append('int main() { unsigned long long* d; hipMalloc(&d, 16); char* g; hipMalloc(&g, 1 << 20); hipMemset(g, 0, 1 << 20); unsigned long long h[2]; const int iters = 4000;')
 for k, (name, kw) in enumerate(VARIANTS):
     src.append('  hipFuncSetAttribute((const void*)k%d, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);' % k)
     src.append('  for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(k%d, dim3(256), dim3(256), 65536, 0, d, iters, g); hipDeviceSynchronize(); }' % k)
-    src.append('  hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); printf("%%-46s %%6.2f cycles/MFMA\\n", "%s", (double)h / (iters * %d.0));' % (name, 2 * KSTEPS))
+    src.append('  hipMemcpy(h, d, 16, hipMemcpyDeviceToHost); printf("%%-46s %%6.2f cycles/MFMA   %%.3f GHz  %%.0f us\\n", "%s", (double)h[0] / (iters * %d.0), (double)h[0] / ((double)h[1] * 10.0), (double)h[1] / 100.0);' % (name, 2 * KSTEPS))
 src.append('  return 0; }')
 path = os.path.join(HERE, "mfma_stream_gen.hip")
 open(path, "w").write("\n".join(src))
 exe = os.path.join(HERE, "mfma_stream")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", exe, path])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", "-o", exe, path])
 if "--build-only" not in sys.argv:
     subprocess.check_call([exe])
