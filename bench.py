@@ -102,6 +102,11 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % a.gpus)
         a.gpus = world
     import torch.distributed as dist
+    # test hook: CRNERF_BENCH_TEST_BACKEND=gloo runs all ranks on cuda:0 over gloo, to exercise the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    test_backend = os.environ.get("CRNERF_BENCH_TEST_BACKEND")
+    if test_backend:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ      # launched by torch.distributed.run (also with --nproc-per-node 1)
@@ -109,7 +114,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if test_backend:
+            dist.init_process_group(test_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crnerf_amd.synth as synth
     from crnerf_amd import ops

@@ -153,3 +153,49 @@ def test_allreduce_gradients_averages_over_ranks():
         assert p.exitcode == 0
     want = [0.0 if i == 3 else 1.5 * (i + 1) for i in range(24)]
     assert got[0] == want and got[1] == want
+
+
+# ---------------------------------------------------------------- the same protocol on the HIP kernels (GPU box)
+def _gpu_worker(rank, world, port, n_pixels, out_q):
+    """Two ranks share cuda:0 and exchange over gloo (RCCL refuses two ranks on one device): what runs on each rank is
+    exactly what runs per GPU -- crnerf_crossray_decode_sharded_f32's three phases around the two all-reduces."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crnerf_amd.models.linearStyleTransfer import style_net
+        from crnerf_amd.parallel import decode_sharded, shard_bounds
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(0)
+        feat = torch.from_numpy(rng.uniform(0, 1, (n_pixels, 64)).astype(np.float32)).to(dev)
+        style = torch.from_numpy(rng.uniform(0, 1, (1, 64, 32, 32)).astype(np.float32)).to(dev)
+        net = style_net(Args()).to(dev)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(4).items()})
+        lo, hi = shard_bounds(n_pixels, world, rank)
+        with torch.no_grad():
+            rgb = decode_sharded(net, feat[lo:hi].contiguous(), style)
+            if n_pixels % world == 0:
+                assert torch.equal(decode_sharded(net, feat[lo:hi].contiguous(), style, equal_shards=True), rgb)
+        out_q.put((rank, rgb.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pixels", [35 * 29, 32 * 32, 1])
+def test_decode_sharded_on_hip_kernels_two_ranks(n_pixels):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, n_pixels, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    feat = torch.from_numpy(rng.uniform(0, 1, (n_pixels, 64)).astype(np.float32))
+    style = torch.from_numpy(rng.uniform(0, 1, (1, 64, 32, 32)).astype(np.float32))
+    ref = O.crossray_decode(O.to_torch(synth.decoder_state(4)), O.feature_to_grid(feat, 1, n_pixels), style).reshape(3, n_pixels)
+    assert np.array_equal(got[0], got[1])
+    torch.testing.assert_close(torch.from_numpy(got[0]), ref, atol=2e-6, rtol=0)
