@@ -102,3 +102,49 @@ def allreduce_gradients(modules, group=None, average=True):
         else:
             p.grad.copy_(g)
         off += n
+
+
+class GatherRays(torch.autograd.Function):
+    """Ray-parallel training of ONE batch (BASELINE configs[3]: a 65,536-ray grid sharded over the GPUs of a node): the
+    renderer runs on this rank's contiguous block of rays; the rows it produces ([n_local, C] features) are all-gathered
+    so that every rank decodes the whole grid and evaluates the same full-batch loss (the decoder's statistics are
+    cross-ray, and it is ~1 % of the step).  Backward: the local block of the incoming gradient -- every rank holds
+    dL/d(full grid) already, so the adjoint of the gather needs NO communication; what does need a sum afterwards are
+    the gradients of the sharded part's parameters (the two MLPs), see sync_ray_parallel_gradients."""
+
+    @staticmethod
+    def forward(ctx, x, n_total, group):
+        ws, rk = dist.get_world_size(group), dist.get_rank(group)
+        lo, hi = shard_bounds(n_total, ws, rk)
+        if x.shape[0] != hi - lo:
+            raise ValueError("crnerf_amd: GatherRays: this rank holds %d rows, its block of %d is [%d, %d)" % (x.shape[0], n_total, lo, hi))
+        ctx.block = (lo, hi)
+        biggest = shard_bounds(n_total, ws, 0)[1]
+        mine = x.contiguous()
+        if mine.shape[0] < biggest:                       # uneven split: pad to the largest block
+            mine = torch.cat([mine, mine.new_zeros((biggest - mine.shape[0],) + tuple(mine.shape[1:]))])
+        parts = [torch.empty_like(mine) for _ in range(ws)]
+        dist.all_gather(parts, mine, group=group)
+        return torch.cat([p[:shard_bounds(n_total, ws, r)[1] - shard_bounds(n_total, ws, r)[0]] for r, p in enumerate(parts)])
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, hi = ctx.block
+        return g[lo:hi], None, None
+
+
+def gather_rays(x, n_total, group=None):
+    return GatherRays.apply(x, n_total, group)
+
+
+def sync_ray_parallel_gradients(sharded_modules, replicated_modules, group=None):
+    """After loss.backward() of a ray-parallel step: parameters of the sharded part (the MLPs) hold partial sums over this
+    rank's rays -> SUM over ranks; parameters of the replicated part (decoder, encoders, mask network) hold the full
+    gradient on every rank -> averaged, which only removes rank-to-rank rounding differences (float atomics) so the
+    replicas cannot drift.  One flat all-reduce."""
+    ws = dist.get_world_size(group)
+    for m in replicated_modules:
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad /= ws
+    allreduce_gradients(list(sharded_modules) + list(replicated_modules), group=group, average=False)

@@ -93,8 +93,12 @@ class TrainingSystem:
     """The training-side orchestration of the reference's NeRFSystem without Lightning: same dict keys, same order of
     operations, autograd through the HIP twins (models/rendering.py grad path, autograd.py) and the fused loss."""
 
-    def __init__(self, hparams_, models=None, embeddings=None, enc_a=None, device="cuda"):
+    def __init__(self, hparams_, models=None, embeddings=None, enc_a=None, device="cuda", ray_parallel_group=False):
+        """ray_parallel_group: False = every process trains on its own batches (the reference's DDP; all-reduce the
+        gradients with parallel.allreduce_gradients); a torch.distributed group (None = the default group) = the ranks of
+        the group split EVERY batch's rays between them (parallel.GatherRays) and sync_gradients() must follow backward."""
         from .losses import loss_dict
+        self.ray_group = ray_parallel_group
         self.hparams_ = hparams_
         self.loss = loss_dict['crnerf'](hparams_, coef=1)                                   # :74
         self.models = models or get_model(hparams_, device)
@@ -112,6 +116,12 @@ class TrainingSystem:
 
     def parameters(self):
         return [p for m in self.models_to_train for p in m.parameters()]
+
+    def sync_gradients(self):
+        """Ray-parallel mode, after loss.backward(): MLP gradients summed over the ranks, replicated modules averaged."""
+        from .parallel import sync_ray_parallel_gradients
+        sharded = [m for k, m in self.models.items() if k in ("coarse", "fine")]
+        sync_ray_parallel_gradients(sharded, [m for m in self.models_to_train if m not in sharded], self.ray_group)
 
     def decode(self, results, type, **kwargs):                                              # :127-149
         feature = results['feature_' + type] if type != 'content' else results['feature_fine']
@@ -149,14 +159,25 @@ class TrainingSystem:
             kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, rgb_idx.reshape(-1))
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
+        image_id = int(ts[0])
+        if self.ray_group is not False:                                                     # this rank's block of the batch
+            from .parallel import gather_rays, shard_rays
+            rays, (lo, hi) = shard_rays(rays, self.ray_group)
+            ts = ts[lo:hi]
         ray_chunk = max(int(hp.chunk), 1 << 16)   # the reference's 8,192-ray chunks (:185-197) only bound its memory; rays are independent
-        for i in range(0, B, ray_chunk):
+        for i in range(0, rays.shape[0], ray_chunk):
             part = render_rays_cross_ray(self.models, self.embeddings, rays[i:i + ray_chunk], ts[i:i + ray_chunk], hp.N_samples, hp.use_disp,
                                          hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, False, **kwargs)
             for k, v in part.items():
                 results[k] += [v]
         for k, v in results.items():
             results[k] = torch.cat(v, 0)
+        if self.ray_group is not False:      # the decoder is cross-ray: every rank gets the whole feature grid (weights_* / depth_* stay local)
+            for k in ("feature_coarse", "feature_fine"):
+                if k in results:
+                    results[k] = gather_rays(results[k], B, self.ray_group)
+            if "feature_fine_random" in results:
+                results["feature_fine_random"] = results["feature_fine"]
         results = self.decode(results, "coarse", **kwargs)
         if hp.N_importance > 0:
             results = self.decode(results, "fine", **kwargs)
@@ -171,7 +192,7 @@ class TrainingSystem:
             results = self.decode(results, "fine_random", **kwargs)
             results['a_embedded_random_rec'] = self.enc_a(results['rgb_fine_random'])       # :219
             results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
-            self.embedding_a_list[int(ts[0])] = kwargs['a_embedded_from_img'].clone().detach()
+            self.embedding_a_list[image_id] = kwargs['a_embedded_from_img'].clone().detach()
         if getattr(hp, "encode_c", False):                                                  # :222-224
             results['content_with_a_embed'] = self.enc_cont(results['rgb_fine_img'])
             results['content_wo_a_embed'] = self.enc_cont(results['rgb_content_img'])

@@ -199,3 +199,110 @@ def test_decode_sharded_on_hip_kernels_two_ranks(n_pixels):
     ref = O.crossray_decode(O.to_torch(synth.decoder_state(4)), O.feature_to_grid(feat, 1, n_pixels), style).reshape(3, n_pixels)
     assert np.array_equal(got[0], got[1])
     torch.testing.assert_close(torch.from_numpy(got[0]), ref, atol=2e-6, rtol=0)
+
+
+# ---------------------------------------------------------------- ray-parallel training (BASELINE configs[3])
+def _gather_worker(rank, world, port, n, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crnerf_amd.parallel import gather_rays, shard_bounds
+        full = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+        lo, hi = shard_bounds(n, world, rank)
+        x = full[lo:hi].clone().requires_grad_(True)
+        y = gather_rays(x, n)
+        assert torch.equal(y.detach(), full)
+        cot = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) * 0.5 + 1.0
+        (y * cot).sum().backward()
+        out_q.put((rank, bool(torch.equal(x.grad, cot[lo:hi]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7, 1])
+def test_gather_rays_forward_and_adjoint(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}
+
+
+class _HPT:
+    maskrs_max, maskrs_min, maskrs_k, maskrd = 5e-2, 6e-3, 1e-3, 1e-3
+    weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
+    nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+    img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [16, 16], 32, 32, 0.0, 0.0, 128, 8   # deterministic render
+    use_mask, encode_c = True, True
+
+
+def _train_step(ray_group):
+    from crnerf_amd import pipeline
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    sys_ = pipeline.TrainingSystem(_HPT(), device=dev, ray_parallel_group=ray_group)
+    sys_.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
+    sys_.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
+    sys_.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
+    sys_.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    sys_.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+    g = torch.Generator().manual_seed(7)
+    R = 256
+    batch = {"rays": torch.from_numpy(synth.rays(R, H=16, W=16)).to(dev), "ts": torch.full((R,), 3, dtype=torch.int64, device=dev),
+             "rgbs": torch.rand(R, 3, generator=g).to(dev), "whole_img": (torch.rand(1, 3, 64, 80, generator=g) * 2 - 1).to(dev),
+             "rgb_idx": torch.randint(0, 512 * 640, (R,), generator=g).to(dev), "img_wh": torch.tensor([640, 512])}
+    loss, loss_d, _ = sys_.training_step(batch)
+    loss.backward()
+    if ray_group is not False:
+        sys_.sync_gradients()
+    names = ["coarse", "fine", "decoder"]
+    mods = [sys_.models[k] for k in names] + [sys_.enc_a, sys_.enc_cont, sys_.implicit_mask]
+    grads = {"%s.%s" % (n, k): p.grad.detach().cpu().numpy() for n, m in zip(names + ["enc_a", "enc_cont", "implicit_mask"], mods)
+             for k, p in m.named_parameters()}
+    return float(loss.detach()), {k: float(v.detach()) for k, v in loss_d.items()}, grads
+
+
+def _train_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out_q.put((rank,) + _train_step(None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ray_parallel_training_step_matches_single_process():
+    """One batch, its rays split over two ranks (sharing cuda:0, gloo): after sync_gradients() both ranks hold the loss
+    and the gradients a single process computes for the whole batch -- renderer sharded, features all-gathered,
+    decoder / encoders / mask network / loss replicated, MLP gradients summed."""
+    ref_loss, ref_terms, ref_grads = _train_step(False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        r, loss, terms, grads = q.get(timeout=600)
+        got[r] = (loss, terms, grads)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        loss, terms, grads = got[r]
+        assert abs(loss - ref_loss) <= 2e-6 * abs(ref_loss), (loss, ref_loss)
+        assert terms.keys() == ref_terms.keys()
+        assert grads.keys() == ref_grads.keys()
+        for k, gref in ref_grads.items():
+            scale = float(np.abs(gref).max()) + 1e-30
+            assert float(np.abs(grads[k] - gref).max()) <= 2e-4 * scale, (r, k, float(np.abs(grads[k] - gref).max()), scale)
+    for k in got[0][2]:
+        assert np.array_equal(got[0][2][k], got[1][2][k]), k      # replicas stay bit-identical after the sync

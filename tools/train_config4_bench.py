@@ -27,7 +27,15 @@ class HP:
 
 hp = HP()
 torch.manual_seed(0)
-sysm = pipeline.TrainingSystem(hp, device=dev)
+# under torch.distributed.run (one process per GPU) the batch's rays are split over the ranks (BASELINE configs[3])
+import os
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    import torch.distributed as dist
+    dev = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=torch.device(dev))
+sysm = pipeline.TrainingSystem(hp, device=dev, ray_parallel_group=None if world > 1 else False)
 sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
 sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
 sysm.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
@@ -49,6 +57,8 @@ def step(i):
     opt.zero_grad(set_to_none=True)
     loss, loss_d, _ = sysm.training_step(batch)
     loss.backward()
+    if world > 1:
+        sysm.sync_gradients()
     opt.step()
     return loss
 
@@ -64,5 +74,7 @@ for i in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 pts = R * (NC + NC + NI)
+if world > 1 and dist.get_rank() != 0:
+    raise SystemExit(0)
 print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.1f ms -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
       % (R, side, side, NC, NI, dt * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
