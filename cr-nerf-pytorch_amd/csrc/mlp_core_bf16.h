@@ -199,7 +199,6 @@ struct EpiTemps {
 };
 
 struct NoEpi {
-  static constexpr bool EARLY = true;
   __device__ __forceinline__ void prefetch(int) {}
   __device__ __forceinline__ void load(int, int, int, const f32x16&) {}
   __device__ __forceinline__ void finish(int, int, int) {}
@@ -224,7 +223,6 @@ __device__ __forceinline__ uint32_t pack_pair(float v0, float v1) {
 // (hipcc's inline-asm hazard rule), i.e. two more issue slots per quarter in a gap that has none to spare.
 template <bool RELU>
 struct PackEpi : EpiTemps {
-  static constexpr bool EARLY = true;
   u32x4 (&dst)[KS_HID][2];
   __device__ __forceinline__ explicit PackEpi(u32x4 (&d)[KS_HID][2]) : dst(d) {}
   __device__ __forceinline__ void prefetch(int) {}
@@ -246,7 +244,6 @@ struct PackEpi : EpiTemps {
 
 // xyz_encoding_8: as PackEpi<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
 struct SigmaEpi : EpiTemps {
-  static constexpr bool EARLY = false;   // prefetch() in k-step 0 loads what finish() multiplies by
   u32x4 (&dst)[KS_HID][2];
   float (&sg)[2];
   const lds_float* wsig;
@@ -279,7 +276,6 @@ __device__ __forceinline__ float softplus_fast(float x) {
 }
 
 struct RgbEpi : EpiTemps {   // static_rgb: sigmoid, fp32 out
-  static constexpr bool EARLY = true;
   f32x16 (&feat)[2][2];
   __device__ __forceinline__ explicit RgbEpi(f32x16 (&f)[2][2]) : feat(f) {}
   __device__ __forceinline__ void prefetch(int) {}
@@ -300,44 +296,6 @@ __device__ __forceinline__ void load_bias_half(f32x16& bv, const lds_float* bias
     for (int j = 0; j < 4; ++j) bv[4 * c + j] = b[j];
   }
 }
-
-// Which of the previous tile's 16 epilogue quarters ride behind k-step s of the current tile.  Quarter 0 reads point
-// group 0's accumulator, whose last MFMA issued two gaps before k-step 0's second gap, so an epilogue without LDS
-// operands may start at once (EARLY); the sigma head's weights are fetched in k-step 0, so it starts in k-step 1.
-//   inside a 16+-k-step layer (the result is not needed before the next layer): one quarter per k-step up to k-step 15;
-//   first tile of such a layer (its k-step 14 reads what quarters 0-7 produce, k-step 15 the rest): done after k-step 14;
-//   where the k-steps are fewer than the quarters, the doubles are spread evenly;
-//   short layers (6 or 8 k-steps; the rgb layer's k-step 6 reads the result): one, then three per k-step in 1..5.
-struct EpiSlot { int first, count; };
-constexpr EpiSlot epi_slot(bool long_layer, bool first_tile, bool early, int s) {
-  if (!long_layer) return s == 0 ? EpiSlot{0, 1} : (s <= 5 ? EpiSlot{1 + 3 * (s - 1), 3} : EpiSlot{16, 0});
-  const int start = early ? 0 : 1, last = first_tile ? 14 : 15, m = last - start + 1, extra = 16 - m;
-  int done = 0;
-  for (int k = 0; k < m; ++k) {
-    int c = 1;
-    for (int j = 1; j <= extra; ++j) c += (k == j * m / (extra + 1)) ? 1 : 0;
-    if (start + k == s) return EpiSlot{done, c};
-    done += c;
-  }
-  return EpiSlot{16, 0};
-}
-constexpr bool epi_schedule_ok() {
-  for (int v = 0; v < 5; ++v) {   // short, long x {inner, first} x {early, late}
-    const bool lng = v > 0, ft = v == 2 || v == 4, early = v < 3;
-    int done = 0;
-    for (int s = 0; s < 16; ++s) {
-      const EpiSlot e = epi_slot(lng, ft, early, s);
-      if (e.count && e.first != done) return false;
-      if (e.count > 4 || (!early && s == 0 && e.count)) return false;
-      done += e.count;
-      if (lng && ft && ((s == 13 && done < 8) || (s == 14 && done < 16))) return false;
-      if (!lng && s == 5 && done < 16) return false;
-    }
-    if (done != 16) return false;
-  }
-  return true;
-}
-static_assert(epi_schedule_ok(), "epilogue quarters must cover 0..15 in order and meet the next layer's first reads");
 
 // One layer.  NT output tiles; per tile NSA k-steps with B operands srcA[s][g] then NSB from srcB (g = point group).
 // FBASE: pass-relative index of the layer's first fragment; G0: index of its first tile in the pass (tile G
@@ -361,9 +319,12 @@ __device__ __forceinline__ void mma_layer_b(WeightPipeB& p, const u32x4 (&srcA)[
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int i = FBASE + T * NS + s;
-      // quarters of the previous tile's epilogue carried by this k-step (epi_first / epi_count above)
-      const EpiSlot es = T == 0 ? epi_slot(LONG, true, PREV::EARLY, s) : epi_slot(LONG, false, EPI::EARLY, s);
-      const int first = es.first, count = es.count;
+      // quarters of the previous tile's epilogue carried by this k-step.  Long layers: one per k-step from k-step 1,
+      // a second one every fourth k-step, done after k-step 13 (k-step 14 of a layer's first tile reads the result);
+      // the short layers (K = 96, 128) take four per k-step in k-steps 1..4.  (Spreading them over k-steps 0..15 with
+      // a single double in a layer's first tile measured the same cycles and cost 17 more spilled registers.)
+      const int first = LONG ? (s - 1) + (s - 1) / 4 : 4 * (s - 1);
+      const int count = s < 1 ? 0 : (LONG ? (s <= 13 ? (s % 4 == 0 ? 2 : 1) : 0) : (s <= 4 ? 4 : 0));
       const f32x16& pa0 = accs[cur ^ 1][0];
       const f32x16& pa1 = accs[cur ^ 1][1];
 
