@@ -4,8 +4,8 @@
 //   reflpad, conv6 3x3 128->128, lrelu | AdaptiveAvgPool2d(32) | conv7 1x1 128->64, lrelu
 // It runs once per image on the 1/8-scale photo (a few thousand pixels, ~0.6 GFLOP) and produces the
 // style operand of the cross-ray decoder, written pixel-major [1024,64] (= what crossray.hip consumes).
-// Direct convolutions, activations pixel-major (HWC) so one wave = one pixel x 64 output channels:
-// the input value is a wave-uniform broadcast, the weight row a coalesced 256-B read of the
+// Direct convolutions, activations pixel-major (HWC) so one wave = 8 pixels of a row x 64 output channels:
+// the input values are wave-uniform scalar loads, the weight row a coalesced 256-B read of the
 // [cin][tap][cout] re-layout made on the fly into the workspace.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
@@ -31,29 +31,59 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restric
   out[idx] = in[c * HW + px];
 }
 
-// out[px][o] = act(b[o] + sum_{c,tap} in[reflect(px+tap)][c] * wt[c][tap][o]);  TAPS = 9 (3x3, reflection pad 1) or 1
+// out[px][o] = act(b[o] + sum_{c,tap} in[reflect(px+tap)][c] * wt[c][tap][o]);  TAPS = 9 (3x3, reflection pad 1) or 1.
+// One wave = PX horizontally adjacent pixels x 64 output channels: the weight row is ONE coalesced 256-B read per
+// (tap, c) feeding PX FMAs, the PX input values are wave-uniform -> scalar loads (s_load) and SGPR FMA operands.  (The
+// first version did one pixel per wave: two vector loads per FMA, 2.9 TFLOP/s on the 128x128 training images.)  The
+// summation order per output (tap-major, then c) is that of the one-pixel version: results are bit-identical.
+constexpr int CONV_PX = 8;
 template <int TAPS, bool ACT>
 __global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ b,
                                                    float* __restrict__ out, int H, int W, int cin, int cout) {
   const int o = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int px = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (px >= H * W || o >= cout) return;
-  const int y = px / W, x = px % W;
-  float acc = b[o];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int groups_per_row = (W + CONV_PX - 1) / CONV_PX;
+  const int g = blockIdx.x * 4 + wave;
+  const int y = g / groups_per_row, x0 = (g % groups_per_row) * CONV_PX;
+  if (y >= H) return;
+  const int oc = o < cout ? o : cout - 1;
+  float acc[CONV_PX];
+#pragma unroll
+  for (int j = 0; j < CONV_PX; ++j) acc[j] = b[oc];
   if (TAPS == 9) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky) {
+      const long row = (long)reflect(y + ky - 1, H) * W;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const float* ip = in + ((long)reflect(y + ky - 1, H) * W + reflect(x + kx - 1, W)) * cin;
-        const float* wp = wt + (ky * 3 + kx) * cout + o;
-        for (int c = 0; c < cin; ++c) acc = fmaf(ip[c], wp[(long)c * 9 * cout], acc);
+        const float* ip[CONV_PX];
+#pragma unroll
+        for (int j = 0; j < CONV_PX; ++j) ip[j] = in + (row + reflect((x0 + j < W ? x0 + j : W - 1) + kx - 1, W)) * cin;
+        const float* wp = wt + (ky * 3 + kx) * cout + oc;
+#pragma unroll 4
+        for (int c = 0; c < cin; ++c) {
+          const float wv = wp[(long)c * 9 * cout];
+#pragma unroll
+          for (int j = 0; j < CONV_PX; ++j) acc[j] = fmaf(ip[j][c], wv, acc[j]);
+        }
       }
+    }
   } else {
-    const float* ip = in + (long)px * cin;
-    for (int c = 0; c < cin; ++c) acc = fmaf(ip[c], wt[(long)c * cout + o], acc);
+    const float* ip[CONV_PX];
+#pragma unroll
+    for (int j = 0; j < CONV_PX; ++j) ip[j] = in + ((long)y * W + (x0 + j < W ? x0 + j : W - 1)) * cin;
+#pragma unroll 4
+    for (int c = 0; c < cin; ++c) {
+      const float wv = wt[(long)c * cout + oc];
+#pragma unroll
+      for (int j = 0; j < CONV_PX; ++j) acc[j] = fmaf(ip[j][c], wv, acc[j]);
+    }
   }
-  out[(long)px * cout + o] = ACT ? lrelu(acc) : acc;
+  if (o < cout) {
+#pragma unroll
+    for (int j = 0; j < CONV_PX; ++j)
+      if (x0 + j < W) out[((long)y * W + x0 + j) * cout + o] = ACT ? lrelu(acc[j]) : acc[j];
+  }
 }
 
 // MaxPool2d(2,2), floor mode
@@ -112,7 +142,8 @@ size_t encoder_workspace_bytes(int H, int W) {
 
 template <int TAPS, bool ACT>
 static void conv(const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st) {
-  hipLaunchKernelGGL((conv_kernel<TAPS, ACT>), dim3((H * W + 3) / 4, (cout + 63) / 64), dim3(256), 0, st, in, wt, b, out, H, W, cin, cout);
+  const int groups = H * ((W + CONV_PX - 1) / CONV_PX);   // waves: one per group of CONV_PX pixels of a row
+  hipLaunchKernelGGL((conv_kernel<TAPS, ACT>), dim3((groups + 3) / 4, (cout + 63) / 64), dim3(256), 0, st, in, wt, b, out, H, W, cin, cout);
 }
 
 // img[3,H,W] (NCHW), weights = conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias -> out[1024,64] pixel-major

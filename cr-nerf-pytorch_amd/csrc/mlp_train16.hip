@@ -222,7 +222,8 @@ struct WgradJob {
 template <int MT, int NT>
 __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
                                                     bool bias_wave) {
-  constexpr int KS = 4;                       // k-steps (2 points each) per iteration
+  // k-steps (2 points each) per iteration = prefetch depth: the small blocks are bandwidth-bound, keep more rows in flight
+  constexpr int KS = MT * NT >= 8 ? 4 : (MT * NT >= 4 ? 8 : 16);
   int dcol[MT], acol[NT];
   float dmask[MT], amask[NT];
 #pragma unroll
@@ -298,17 +299,32 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
-  // wave tiles: 2 (M) x 2 (N) of 128 x 128 -- or, for the narrow heads (M <= 128: dir_encoding, static_rgb, static_sigma),
-  // 1 x 4 of 128 x 64, so that all four waves have columns to work on instead of two (or one) of them
-  const bool nsplit = j.M <= 128;
-  const int m0 = blockIdx.y * 256 + (nsplit ? 0 : (wave & 1) * 128);
-  const int n0 = blockIdx.z * 256 + (nsplit ? wave * 64 : (wave >> 1) * 128);
-  const int ncap = nsplit ? 2 : 4;
+  // The workgroup's 256 x 256 block holds tm x tn live 32 x 32 MFMA tiles (<= 8 x 8).  Its four waves are laid out 2 x 2,
+  // 1 x 4 or 4 x 1 over them -- whichever keeps the most waves busy and, among those, gives the busiest wave the fewest
+  // tiles: 256 x 256 layers -> 2 x 2 of 4 x 4 tiles; 256 x 93 (embedding blocks) -> 4 x 1 of 2 x 3; 128 x 256 -> 1 x 4 of
+  // 4 x 2; 128 x 27 -> 4 x 1 of 1 x 1; 64 x 128 and 1 x 256 -> 1 x 4.  (With a fixed 2 x 2 layout the narrow blocks ran
+  // on two or one of the four SIMDs.)
+  const int tm = (j.M - (int)blockIdx.y * 256 + 31) / 32 < 8 ? (j.M - (int)blockIdx.y * 256 + 31) / 32 : 8;
+  const int tn = (j.N - (int)blockIdx.z * 256 + 31) / 32 < 8 ? (j.N - (int)blockIdx.z * 256 + 31) / 32 : 8;
+  int wm = 2, wn = 2, best = -1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int cm = c == 0 ? 1 : (c == 1 ? 2 : 4), cn = 4 / cm;   // ties go to 1 x 4 (measured: 128 x 256 runs 669 us as 1 x 4, 809 us as 2 x 2)
+    const int pm = (tm + cm - 1) / cm, pn = (tn + cn - 1) / cn;          // tiles per wave
+    if (pm > 4 || pn > 4) continue;
+    const int active = ((tm + pm - 1) / pm) * ((tn + pn - 1) / pn);
+    const int score = active * 64 - pm * pn;
+    if (score > best) { best = score; wm = cm; wn = cn; }
+  }
+  const int wmi = wm == 2 ? (wave & 1) : (wm == 4 ? wave : 0), wni = wm == 2 ? (wave >> 1) : (wn == 4 ? wave : 0);
+  const int pm = (tm + wm - 1) / wm, pn = (tn + wn - 1) / wn;
+  const int m0 = blockIdx.y * 256 + wmi * pm * 32;
+  const int n0 = blockIdx.z * 256 + wni * pn * 32;
   const long p0 = (long)blockIdx.x * j.chunk;
   const long p1 = p0 + j.chunk < j.P ? p0 + j.chunk : j.P;
-  const int mt = (j.M - m0 + 31) / 32 < 4 ? (j.M - m0 + 31) / 32 : 4;   // live 32-row tiles of this wave (<= 0: none)
-  const int nt = (j.N - n0 + 31) / 32 < ncap ? (j.N - n0 + 31) / 32 : ncap;
-  const bool bias_wave = nsplit ? wave == 0 : (wave >> 1) == 0;          // one wave per M block sums the bias gradient
+  const int mt = tm - wmi * pm < pm ? tm - wmi * pm : pm;                 // live 32-row tiles of this wave (<= 0: none)
+  const int nt = tn - wni * pn < pn ? tn - wni * pn : pn;
+  const bool bias_wave = wni == 0;                                        // one wave per row block sums the bias gradient
   if (mt <= 0 || nt <= 0) return;
   f32x16 acc[4][4];
 #pragma unroll
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  if (!nsplit && mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
+  if (mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
     // ---- full 128x128 wave tile (every 256-wide layer): branch-free stream.  Column mapping: MFMA tile t, lane i <->
     // column 4i + t, so a lane's four operands of a point are ONE 16-byte load (512 contiguous bytes per half-wave) and
     // the whole k-step is 2 x global_load_dwordx4 + 16 MFMAs.  (The guarded generic loop below puts a branch around

@@ -21,4 +21,9 @@ tot = sum(v[0] for v in agg.values())
 print("last step: %.2f ms in kernels over %.2f ms wall (rocprofv3 --kernel-trace)" % (tot / 1e6, (e - s) / 1e6))
 for k, v in sorted(agg.items(), key=lambda x: -x[1][0])[:24]:
     print("%-64s n=%4d %9.3f ms %5.1f %%" % (k, v[1], v[0] / 1e6, 100 * v[0] / tot))
+import os
+if os.environ.get("DETAIL"):      # per-launch list of one kernel in the last step, e.g. DETAIL=wgrad_kernel
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= s and os.environ["DETAIL"] in r["Kernel_Name"]:
+            print("%9.1f us  grid %s x %s x %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", "")))
 PY
