@@ -16,6 +16,8 @@ FLOPs per launch (1,233,152 FLOP/point x 256 points/ray x rays) / its
 measured live with HIP events on the launch stream.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X guide).
 cpu_baseline: the CPU oracle (plain-PyTorch restatement of the reference, oracle/cpu_ref.py) timed on
 this box's host cores on a bounded sample of the same workload; rank 0, N == 1 only.
+parity (with cpu_baseline): BASELINE's "PSNR vs ref" -- the decoded image of the timed batch against the oracle's image of the
+same rays and weights: max |d rgb|, PSNR, and the PSNR difference against a common noisy target (bar: 0.05 dB).
 """
 import argparse
 import json
@@ -46,7 +48,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(rays_np, st_c, st_f, dst, grid_hw):
+def cpu_baseline(rays_np, st_c, st_f, dst, grid_hw, style_nchw=None, gpu_rgb=None):
     """Oracle (kind 'port') on the host cores: same rays/weights/sample counts, bounded to ~10-30 s.
     The thread count is calibrated first (torch's intra-op pool collapses when every SMT thread of a
     big host is used on 256-wide layers): the fastest of a few candidates on a 128-ray probe is used."""
@@ -54,7 +56,7 @@ def cpu_baseline(rays_np, st_c, st_f, dst, grid_hw):
     ncpu = os.cpu_count() or 1
     wc, wf, d = O.to_torch(st_c), O.to_torch(st_f), O.to_torch(dst)
     rays = torch.from_numpy(rays_np)
-    style = torch.rand(1, 64, 32, 32, generator=torch.Generator().manual_seed(0))
+    style = style_nchw if style_nchw is not None else torch.rand(1, 64, 32, 32, generator=torch.Generator().manual_seed(0))
 
     def step(r):
         with torch.no_grad():
@@ -75,7 +77,15 @@ def cpu_baseline(rays_np, st_c, st_f, dst, grid_hw):
         if t > 20.0:
             break
     torch.set_num_threads(best_n)
-    step(rays)  # warm-up
+    ref_rgb = step(rays)  # warm-up; also the checker for the "parity" object
+    parity = None
+    if gpu_rgb is not None:
+        ref, got = ref_rgb.reshape(3, -1).double(), gpu_rgb.reshape(3, -1).double()
+        target = (ref + 0.05 * torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64))
+        psnr = lambda a, b: float(-10.0 * torch.log10(((a - b) ** 2).mean()))  # noqa: E731  (metrics.py:12-13)
+        parity = {"max_abs_rgb_vs_oracle": float((ref - got).abs().max()), "psnr_vs_oracle_db": psnr(got, ref),
+                  "delta_psnr_db": psnr(got, target) - psnr(ref, target),
+                  "note": "decoded 32x32 image of the timed batch vs the CPU oracle on the same rays/weights; delta_psnr against a target = oracle image + N(0, 0.05^2)"}
     times = []
     t_all = time.perf_counter()
     while len(times) < 3 or (time.perf_counter() - t_all < 10.0 and len(times) < 20):
@@ -86,7 +96,7 @@ def cpu_baseline(rays_np, st_c, st_f, dst, grid_hw):
             break
     times.sort()
     med = times[len(times) // 2]
-    return {"value": rays.shape[0] / med, "unit": "rays/s", "cores": best_n, "kind": "port",
+    return parity, {"value": rays.shape[0] / med, "unit": "rays/s", "cores": best_n, "kind": "port",
             "sample": "%d reps (median) of the full step on %d rays x (%d+%d) samples + %dx%d cross-ray decode, fp32, torch %s CPU, "
                       "no_grad, %d threads (fastest of a 128-ray probe over 8..128 threads; host has %d logical CPUs)"
                       % (len(times), rays.shape[0], NC, NI, grid_hw[0], grid_hw[1], torch.__version__, best_n, ncpu)}
@@ -164,11 +174,11 @@ def main():
             torch.cuda.synchronize()
 
         for _ in range(a.warmup):
-            step()
+            last_rgb = step()
         fence()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            step(i)
+            last_rgb = step(i)
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
@@ -203,7 +213,9 @@ def main():
                          "flops_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(rays_np, st_c, st_f, dst, grid_hw)
+            parity, line["cpu_baseline"] = cpu_baseline(rays_np, st_c, st_f, dst, grid_hw, style.cpu().contiguous(), last_rgb.float().cpu())
+            if parity:
+                line["parity"] = parity
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
