@@ -1,0 +1,44 @@
+"""Tuning tool (GPU box): times the training twins of the MLP in isolation at P points (default 2^20):
+plain forward (inference kernel), forward-with-save, backward (dgrad + wgrad).  CRNERF_EXTRA_FLAGS rebuilds with
+experiment macros first.  Measured: 9.1 / 10.2 / 20.5 ms = 142 / 127 / 126 TFLOP/s; ablations of the forward's activation
+stores: none 9.24 ms, same instructions with a quarter of the bytes 9.81 ms, non-temporal stores 10.2 ms (no effect)."""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+flags = os.environ.get("CRNERF_EXTRA_FLAGS")
+if flags:
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
+import torch
+import crnerf_amd.synth as synth
+from crnerf_amd import ops
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+dev = "cuda:0"
+st = {k: torch.from_numpy(v).to(dev) for k, v in synth.mlp_state(1, 2.0, 0.5).items()}
+packed, packed_t = ops.pack_mlp_weights(st), ops.pack_mlp_weights_t(st)
+x = torch.rand(P, 120, device=dev) * 2 - 1
+d_out = torch.randn(P, 65, device=dev)
+
+
+def timed(fn, n=3):
+    keep = [fn(), fn()]          # two live results: the caching allocator then holds both blocks the loop alternates between
+    del keep
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, r
+
+
+flop = P * 1.233152e6
+t_f, _ = timed(lambda: ops.mlp_forward(packed, x))
+t_s, (out, acts) = timed(lambda: ops.mlp_forward_train(packed, x))
+t_b, _ = timed(lambda: ops.mlp_backward(packed_t, x, out, d_out, acts))
+print("flags: %s   P = %d" % (flags, P))
+print("forward (inference kernel)  %7.2f ms  %6.1f TFLOP/s" % (t_f * 1e3, flop / t_f / 1e12))
+print("forward with saved acts     %7.2f ms  %6.1f TFLOP/s" % (t_s * 1e3, flop / t_s / 1e12))
+print("backward (dgrad + wgrad)    %7.2f ms  %6.1f TFLOP/s" % (t_b * 1e3, 2 * flop / t_b / 1e12))
+if flags and not os.environ.get("CRNERF_KEEP_BUILD"):
+    env = {k: v for k, v in os.environ.items() if k != "CRNERF_EXTRA_FLAGS"}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL, env=env)
