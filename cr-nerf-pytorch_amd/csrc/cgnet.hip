@@ -36,6 +36,44 @@ __global__ void cg_conv_fwd_kernel(ConvGeom g, const float* __restrict__ x, cons
   y[idx] = acc;
 }
 
+// Dense convolutions with many input channels (35 ... 256 x 9 taps): one WAVE per output element, lanes stride over the
+// (ci, ky, kx) products (weights read coalesced) and a butterfly adds them up -- the maps are tiny, so what costs is the
+// length of one thread's serial loop (1,179 dependent FMAs for level3_0), not arithmetic.
+__global__ __launch_bounds__(256) void cg_conv_fwd_wave_kernel(ConvGeom g, const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y) {
+  const int out = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (out >= g.cout * g.Ho * g.Wo) return;
+  const int ox = out % g.Wo, oy = (out / g.Wo) % g.Ho, co = out / (g.Wo * g.Ho);
+  const int kk = g.k * g.k, n = g.cin * kk;
+  float acc = 0.0f;
+  for (int idx = lane; idx < n; idx += 64) {
+    const int ci = idx / kk, t = idx % kk;
+    const int iy = oy * g.stride + (t / g.k) * g.dil - g.pad, ix = ox * g.stride + (t % g.k) * g.dil - g.pad;
+    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) acc = fmaf(w[(long)co * n + idx], x[(ci * g.H + iy) * g.W + ix], acc);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) y[out] = acc;
+}
+
+// dx[ci][iy][ix]: lanes stride over (co, ky, kx)
+__global__ __launch_bounds__(256) void cg_conv_dgrad_wave_kernel(ConvGeom g, const float* __restrict__ w, const float* __restrict__ dy, float* __restrict__ dx) {
+  const int in = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (in >= g.cin * g.H * g.W) return;
+  const int ix = in % g.W, iy = (in / g.W) % g.H, ci = in / (g.W * g.H);
+  const int kk = g.k * g.k, n = g.cout * kk;
+  float acc = 0.0f;
+  for (int idx = lane; idx < n; idx += 64) {
+    const int co = idx / kk, t = idx % kk;
+    const int ty = iy + g.pad - (t / g.k) * g.dil, tx = ix + g.pad - (t % g.k) * g.dil;
+    if (ty < 0 || tx < 0 || ty % g.stride || tx % g.stride) continue;
+    const int oy = ty / g.stride, ox = tx / g.stride;
+    if (oy < g.Ho && ox < g.Wo) acc = fmaf(w[((long)co * g.cin + ci) * kk + t], dy[(co * g.Ho + oy) * g.Wo + ox], acc);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) dx[in] = acc;
+}
+
 __global__ void cg_conv_dgrad_kernel(ConvGeom g, const float* __restrict__ w, const float* __restrict__ dy, float* __restrict__ dx) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= g.cin * g.H * g.W) return;
@@ -80,13 +118,15 @@ __global__ __launch_bounds__(64) void cg_conv_wgrad_kernel(ConvGeom g, const flo
 
 int launch_cg_conv_forward(const ConvGeom& g, const float* x, const float* w, float* y, hipStream_t st) {
   const int n = g.cout * g.Ho * g.Wo;
-  hipLaunchKernelGGL(cg_conv_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, x, w, y);
+  if (!g.depthwise && g.cin * g.k * g.k >= 128) hipLaunchKernelGGL(cg_conv_fwd_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, st, g, x, w, y);
+  else hipLaunchKernelGGL(cg_conv_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, x, w, y);
   return check_launch("cg_conv_forward");
 }
 int launch_cg_conv_backward(const ConvGeom& g, const float* x, const float* w, const float* dy, float* dx, float* dw, hipStream_t st) {
   if (dx) {
     const int n = g.cin * g.H * g.W;
-    hipLaunchKernelGGL(cg_conv_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, w, dy, dx);
+    if (!g.depthwise && g.cout * g.k * g.k >= 128) hipLaunchKernelGGL(cg_conv_dgrad_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, st, g, w, dy, dx);
+    else hipLaunchKernelGGL(cg_conv_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, w, dy, dx);
   }
   const int nw = g.cout * (g.depthwise ? 1 : g.cin) * g.k * g.k;
   hipLaunchKernelGGL(cg_conv_wgrad_kernel, dim3(nw), dim3(64), 0, st, g, x, dy, dw);

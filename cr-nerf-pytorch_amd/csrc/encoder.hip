@@ -4,9 +4,9 @@
 //   reflpad, conv6 3x3 128->128, lrelu | AdaptiveAvgPool2d(32) | conv7 1x1 128->64, lrelu
 // It runs once per image on the 1/8-scale photo (a few thousand pixels, ~0.6 GFLOP) and produces the
 // style operand of the cross-ray decoder, written pixel-major [1024,64] (= what crossray.hip consumes).
-// Direct convolutions, activations pixel-major (HWC) so one wave = 8 pixels of a row x 64 output channels:
-// the input values are wave-uniform scalar loads, the weight row a coalesced 256-B read of the
-// [cin][tap][cout] re-layout made on the fly into the workspace.
+// Direct convolutions, activations pixel-major (HWC): one workgroup = 8 pixels of a row x 64 output channels, input
+// channels split over its four waves; the input values are wave-uniform scalar loads, the weight row a coalesced 256-B
+// read of the [cin][tap][cout] re-layout made on the fly into the workspace.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
@@ -32,24 +32,28 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restric
 }
 
 // out[px][o] = act(b[o] + sum_{c,tap} in[reflect(px+tap)][c] * wt[c][tap][o]);  TAPS = 9 (3x3, reflection pad 1) or 1.
-// One wave = PX horizontally adjacent pixels x 64 output channels: the weight row is ONE coalesced 256-B read per
-// (tap, c) feeding PX FMAs, the PX input values are wave-uniform -> scalar loads (s_load) and SGPR FMA operands.  (The
-// first version did one pixel per wave: two vector loads per FMA, 2.9 TFLOP/s on the 128x128 training images.)  The
-// summation order per output (tap-major, then c) is that of the one-pixel version: results are bit-identical.
+// One workgroup = PX horizontally adjacent pixels x 64 output channels; its four waves split the input channels (a
+// quarter each when cin % 16 == 0) and their partial sums are added in wave order through LDS.  Per wave the weight row is
+// ONE coalesced 256-B read per (tap, c) feeding PX FMAs, the PX input values are wave-uniform -> scalar loads (s_load)
+// and SGPR FMA operands.  The images here are small (32x32 ... 256x256), so what bounds this kernel is the length of one
+// wave's dependent load -> FMA chain, not arithmetic: one pixel per wave (two vector loads per FMA) ran 3.6 ms on the
+// training step's 128x128 images, eight pixels per wave 1.4 ms, the channel split cuts the chain four times again.
 constexpr int CONV_PX = 8;
 template <int TAPS, bool ACT>
 __global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ b,
                                                    float* __restrict__ out, int H, int W, int cin, int cout) {
-  const int o = blockIdx.y * 64 + (threadIdx.x & 63);
+  __shared__ float red[3][CONV_PX][64];
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.y * 64 + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int groups_per_row = (W + CONV_PX - 1) / CONV_PX;
-  const int g = blockIdx.x * 4 + wave;
-  const int y = g / groups_per_row, x0 = (g % groups_per_row) * CONV_PX;
-  if (y >= H) return;
+  const int y = blockIdx.x / groups_per_row, x0 = (blockIdx.x % groups_per_row) * CONV_PX;
+  const bool split = (cin & 15) == 0;
+  const int c0 = split ? wave * (cin >> 2) : 0, c1 = split ? c0 + (cin >> 2) : (wave == 0 ? cin : 0);
   const int oc = o < cout ? o : cout - 1;
   float acc[CONV_PX];
 #pragma unroll
-  for (int j = 0; j < CONV_PX; ++j) acc[j] = b[oc];
+  for (int j = 0; j < CONV_PX; ++j) acc[j] = 0.0f;
   if (TAPS == 9) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in,
         for (int j = 0; j < CONV_PX; ++j) ip[j] = in + (row + reflect((x0 + j < W ? x0 + j : W - 1) + kx - 1, W)) * cin;
         const float* wp = wt + (ky * 3 + kx) * cout + oc;
 #pragma unroll 4
-        for (int c = 0; c < cin; ++c) {
+        for (int c = c0; c < c1; ++c) {
           const float wv = wp[(long)c * 9 * cout];
 #pragma unroll
           for (int j = 0; j < CONV_PX; ++j) acc[j] = fmaf(ip[j][c], wv, acc[j]);
@@ -73,16 +77,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in,
 #pragma unroll
     for (int j = 0; j < CONV_PX; ++j) ip[j] = in + ((long)y * W + (x0 + j < W ? x0 + j : W - 1)) * cin;
 #pragma unroll 4
-    for (int c = 0; c < cin; ++c) {
+    for (int c = c0; c < c1; ++c) {
       const float wv = wt[(long)c * cout + oc];
 #pragma unroll
       for (int j = 0; j < CONV_PX; ++j) acc[j] = fmaf(ip[j][c], wv, acc[j]);
     }
   }
-  if (o < cout) {
+  if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < CONV_PX; ++j)
-      if (x0 + j < W) out[((long)y * W + x0 + j) * cout + o] = ACT ? lrelu(acc[j]) : acc[j];
+    for (int j = 0; j < CONV_PX; ++j) red[wave - 1][j][lane] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && o < cout) {
+    const float bias = b[o];
+#pragma unroll
+    for (int j = 0; j < CONV_PX; ++j) {
+      const float v = bias + (((acc[j] + red[0][j][lane]) + red[1][j][lane]) + red[2][j][lane]);   // fixed order: deterministic
+      if (x0 + j < W) out[((long)y * W + x0 + j) * cout + o] = ACT ? lrelu(v) : v;
+    }
   }
 }
 
@@ -142,8 +154,8 @@ size_t encoder_workspace_bytes(int H, int W) {
 
 template <int TAPS, bool ACT>
 static void conv(const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st) {
-  const int groups = H * ((W + CONV_PX - 1) / CONV_PX);   // waves: one per group of CONV_PX pixels of a row
-  hipLaunchKernelGGL((conv_kernel<TAPS, ACT>), dim3((groups + 3) / 4, (cout + 63) / 64), dim3(256), 0, st, in, wt, b, out, H, W, cin, cout);
+  const int groups = H * ((W + CONV_PX - 1) / CONV_PX);   // workgroups: one per group of CONV_PX pixels of a row
+  hipLaunchKernelGGL((conv_kernel<TAPS, ACT>), dim3(groups, (cout + 63) / 64), dim3(256), 0, st, in, wt, b, out, H, W, cin, cout);
 }
 
 // img[3,H,W] (NCHW), weights = conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias -> out[1024,64] pixel-major
