@@ -116,7 +116,7 @@ template <int TAPS>
 __global__ __launch_bounds__(256) void enc_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ wd,
                                                         float* __restrict__ d_in, int H, int W, int cin, int cout) {
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int px = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int px = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: g[q][o] becomes a scalar load
   if (px >= H * W) return;
   const int py = px / W, pxx = px % W;
   float acc = 0.0f;

@@ -399,19 +399,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
 #undef CRNERF_WG
 }
 
-// dst[m*ldc + n] = sum_c partial[c][m][n]   (fixed summation tree: deterministic; 8 loads in flight per thread)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * N) return;
-  const long stride = (long)M * N;
+// dst[m*ldc + n] = sum_c partial[c][m][n]   (fixed summation tree: deterministic; 8 loads in flight per thread), and in the
+// same launch db[m] = sum_c bias_partial[c][m] (threads M*N .. M*N + M - 1) when db != null
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc,
+                                                           const float* __restrict__ bias_partial, float* __restrict__ db) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* src = partial;
+  long stride = (long)M * N;
+  float* out;
+  if (idx < M * N) out = dst + (long)(idx / N) * ldc + idx % N;
+  else {
+    idx -= M * N;
+    if (!db || idx >= M) return;
+    src = bias_partial; stride = M; out = db + idx;
+  }
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int c = 0;
   for (; c + 8 <= nchunk; c += 8) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += partial[(c + u) * stride + idx];
+    for (int u = 0; u < 8; ++u) a[u] += src[(c + u) * stride + idx];
   }
-  for (; c < nchunk; ++c) a[0] += partial[c * stride + idx];
-  dst[(long)(idx / N) * ldc + idx % N] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  for (; c < nchunk; ++c) a[0] += src[c * stride + idx];
+  *out = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // points per wgrad workgroup: small enough to fill the chip at 1024-ray batches, large enough that the
@@ -436,8 +445,7 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
   float* bws = ws + (size_t)nchunk * M * N;
   WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk};
   hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc);
-  if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, bws, nchunk, 1, M, db, M);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);
   return 0;
 }
 
