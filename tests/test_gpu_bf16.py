@@ -178,4 +178,4 @@ def test_reference_signature_with_precision_keyword_and_decoded_image_psnr():
     target = imgs["f32"] + 0.05 * torch.randn(imgs["f32"].shape, generator=g)
     psnr = {k: float(O.psnr(v, target)) for k, v in imgs.items()}
     assert abs(psnr["bf16"] - psnr["f32"]) <= 0.05, psnr
-    assert float((imgs["bf16"] - imgs["f32"]).abs().max()) < 4e-2   # pixels; mean is ~1e-3 (printed by tools/bf16_check.py)
+    assert float((imgs["bf16"] - imgs["f32"]).abs().max()) < 4e-2   # pixels; mean is ~1e-3
