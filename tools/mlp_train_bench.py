@@ -1,7 +1,7 @@
 """Tuning tool (GPU box): times the training twins of the MLP in isolation at P points (default 2^20):
 plain forward (inference kernel), forward-with-save, backward (dgrad + wgrad).  CRNERF_EXTRA_FLAGS rebuilds with
 experiment macros first.  Measured: 9.1 / 10.2 / 20.5 ms = 142 / 127 / 126 TFLOP/s; ablations of the forward's activation
-stores: none 9.24 ms, same instructions with a quarter of the bytes 9.81 ms, non-temporal stores 10.2 ms (no effect)."""
+stores: none 9.24 ms, same instructions with a quarter of the bytes 9.81 ms, non-temporal stores 10.2 ms (no effect), stores spread one per MFMA group over the next layer 10.14 ms (no effect)."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
