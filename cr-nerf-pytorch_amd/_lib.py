@@ -185,6 +185,12 @@ def dev_ptr(t, name="tensor", dtype=torch.float32):
         return None
     if not t.is_cuda:
         raise RuntimeError("crnerf_amd: %s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream (stream_ptr): a tensor of another GPU would be reached through peer
+        # access, unordered with its producers -- one process drives one GPU (torch.cuda.set_device(LOCAL_RANK) first)
+        raise RuntimeError("crnerf_amd: %s lives on cuda:%d but the current device is cuda:%d; call torch.cuda.set_device(%d) "
+                           "(or wrap the call in torch.cuda.device) before using the HIP path"
+                           % (name, t.device.index, torch.cuda.current_device(), t.device.index))
     if t.dtype != dtype:
         raise TypeError("crnerf_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():

@@ -18,6 +18,8 @@ from . import ops
 class MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *params):
+        if module is not None and hasattr(module, "invalidate_packed"):
+            module.invalidate_packed()       # an optimiser step follows; optimisers that write p.data do not bump p._version
         state = dict(zip(ops.MLP_TENSOR_NAMES, params))
         packed = ops.pack_mlp_weights(state)
         out, acts = ops.mlp_forward_train(packed, x)

@@ -1,5 +1,6 @@
 // extern "C" surface of libcrnerf_hip.so -- see include/crnerf.h for the contract of every symbol.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,6 +23,40 @@ int check_launch(const char* what) {
   if (e == hipSuccess) return 0;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return CRNERF_ERR_HIP;
+}
+
+int num_cus() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
+  struct Slot { const void* fn; int dev; size_t bytes; };
+  static Slot slots[128];
+  static int n_slots = 0;
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  Slot* s = nullptr;
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i].fn == fn && slots[i].dev == dev) { s = &slots[i]; break; }
+  if (s && s->bytes >= bytes) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "hipFuncSetAttribute(%s, %zu bytes of LDS) failed", what, bytes);
+    return set_error(-10, msg);
+  }
+  if (!s && n_slots < 128) s = &slots[n_slots++];
+  if (s) { s->fn = fn; s->dev = dev; s->bytes = bytes; }
+  return 0;
 }
 
 }  // namespace crnerf

@@ -248,8 +248,7 @@ static int gram_blocks(long HW) {
 
 static int launch_gram(const GramJob& a, const GramJob& b, hipStream_t stream) {
   const size_t shmem = (size_t)GF_FLOATS * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(gram_mfma_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)gram_mfma_kernel, shmem, "gram_mfma_kernel")) return rc;
   hipLaunchKernelGGL(gram_mfma_kernel, dim3(a.nblk + b.nblk), dim3(256), shmem, stream, a, b);
   return 0;
 }
@@ -847,8 +846,7 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   ChainJob jc{d.content, HW, st + ST_CMEAN, d.cnet, S_c, xc[0], h1[0], h2[0], d1[0], d2[0], d3[0], dxc[0], nb_c};
   ChainJob js{d.style, HWs, st + ST_SMEAN, d.snet, S_s, xc[1], h1[1], h2[1], d1[1], d2[1], d3[1], dxc[1], nb_s};
   const size_t shmem = (size_t)CH_FLOATS * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)dec_bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(dec_bwd_chain_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)dec_bwd_chain_kernel, shmem, "dec_bwd_chain_kernel")) return rc;
   hipLaunchKernelGGL(dec_bwd_chain_kernel, dim3(nb_c + nb_s), dim3(64), shmem, stream, jc, js);
   // 6. conv weight / bias gradients: snet = grads[0..5], cnet = grads[8..13]
   for (int net = 0; net < 2; ++net) {

@@ -8,6 +8,11 @@ namespace crnerf {
 // thread-local last-error slot behind crnerf_last_error(); returns code
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached per device): the persistent kernels launch
+// one workgroup per CU
+int num_cus();
+// raises `fn`'s dynamic-LDS limit to `bytes` once per (function, device) instead of on every launch; returns 0 or an error code
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 
 struct MlpTensors {  // device pointers to the 24 tensors of one NeRF_sigma (models/nerf.py:137-154)
   const float* w[8];   // xyz_encoding_{1..8}.0.weight

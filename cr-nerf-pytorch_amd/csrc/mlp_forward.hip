@@ -78,11 +78,11 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(const char* __restr
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream) {
   if (P <= 0) return 0;
   const long groups = (P + 127) / 128;  // 128 points per workgroup-iteration
-  const int grid = (int)(groups < 256 ? groups : 256);
+  const int cus = num_cus();
+  const int grid = (int)(groups < cus ? groups : cus);
   const int iters = (int)((groups + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH;
-  hipError_t e = hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(mlp_forward_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)mlp_forward_kernel, shmem, "mlp_forward_kernel")) return rc;
   hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(256), shmem, stream, (const char*)packed, x, out, sigma_only, P,
                      iters);
   return check_launch("mlp_forward_kernel");

@@ -457,14 +457,14 @@ size_t mlp_train_scratch_bytes(long P) {
 }
 
 static int launch_core(const void* fn, int grid, size_t shmem) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  return e == hipSuccess ? 0 : set_error(-10, "hipFuncSetAttribute(train kernel) failed");
+  return ensure_dynamic_lds(fn, shmem, "train kernel");
 }
 
 int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream) {
   if (P <= 0) return 0;
   const long groups = (P + 127) / 128;
-  const int grid = (int)(groups < 256 ? groups : 256), iters = (int)((groups + grid - 1) / grid);
+  const int cus = num_cus();
+  const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (int rc = launch_core((const void*)mlp_forward_train16_kernel, grid, LDS_SCRATCH)) return rc;
   hipLaunchKernelGGL(mlp_forward_train16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packed, x, out, acts, P, iters);
   return check_launch("mlp_forward_train16_kernel");
@@ -479,7 +479,8 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
   float* ws = d_sig + P;
   const long groups = (P + 127) / 128;
-  const int grid = (int)(groups < 256 ? groups : 256), iters = (int)((groups + grid - 1) / grid);
+  const int cus = num_cus();
+  const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (int rc = launch_core((const void*)mlp_backward16_kernel, grid, LDS_SCRATCH)) return rc;
   hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
   if (int rc = check_launch("mlp_backward16_kernel")) return rc;

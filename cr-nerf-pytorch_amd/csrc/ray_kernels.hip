@@ -105,8 +105,7 @@ int launch_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, 
   if (Nc < 3 || Ni < 1) return set_error(-2, "sample_pdf_merge: need N_samples >= 3 and N_importance >= 1");
   const size_t shmem = (size_t)(3 * ((Nc + 3) & ~3) + 2 * ((Ni + 3) & ~3)) * 4;
   if (shmem > 160 * 1024) return set_error(-2, "sample_pdf_merge: 3*N_samples + 2*N_importance exceeds LDS");
-  hipError_t e = hipFuncSetAttribute((const void*)sample_pdf_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(sample_pdf_merge_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)sample_pdf_merge_kernel, shmem, "sample_pdf_merge_kernel")) return rc;
   const int grid = (int)(R < 8192 ? R : 8192);
   hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), shmem, stream, z_coarse, weights_coarse, u, u_stride, z_fine_sorted,
                      z_samples, R, Nc, Ni);
@@ -231,8 +230,7 @@ int launch_composite_backward(const float* raw, const float* z, const float* noi
   if (N < 1) return set_error(-2, "composite_backward: N must be >= 1");
   const size_t shmem = (size_t)4 * 3 * N * sizeof(float);
   if (shmem > 160 * 1024) return set_error(-2, "composite_backward: N too large for LDS");
-  hipError_t e = hipFuncSetAttribute((const void*)composite_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(composite_backward_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)composite_backward_kernel, shmem, "composite_backward_kernel")) return rc;
   const long blocks = (R + 3) / 4;
   const int grid = (int)(blocks < 4096 ? blocks : 4096);
   hipLaunchKernelGGL(composite_backward_kernel, dim3(grid), dim3(256), shmem, stream, raw, z, noise, noise_std, d_feature, d_depth,

@@ -264,11 +264,11 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
   const long quads = (a.R + 3) / 4;
-  const int grid = (int)(quads < 256 ? quads : 256);
+  const int cus = num_cus();
+  const int grid = (int)(quads < cus ? quads : cus);
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)render_rays16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(render_rays16_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)render_rays16_kernel, shmem, "render_rays16_kernel")) return rc;
   hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
   return check_launch("render_rays16_kernel");
 }

@@ -168,11 +168,11 @@ int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream) {
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
   const long quads = (a.R + 3) / 4;
-  const int grid = (int)(quads < 256 ? quads : 256);   // one workgroup per CU, persistent over ray quads
+  const int cus = num_cus();
+  const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES;
-  hipError_t e = hipFuncSetAttribute((const void*)render_rays_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e != hipSuccess) return set_error(-10, "hipFuncSetAttribute(render_rays_bf16_kernel) failed");
+  if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16_kernel, shmem, "render_rays_bf16_kernel")) return rc;
   hipLaunchKernelGGL(render_rays_bf16_kernel, dim3(grid), dim3(256), shmem, stream, k);
   return check_launch("render_rays_bf16_kernel");
 }

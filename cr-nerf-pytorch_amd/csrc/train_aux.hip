@@ -103,11 +103,11 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a, LossScal
       const float d = a.a_rand[i] - a.a_rec[i];
       g.d_a_rec[i] = a.mse_a ? -u[1] * 2.0f * d : -u[1] * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
     }
-  if (a.c_wo && g.d_c_wo)
+  if (a.c_wo && (g.d_c_wo || g.d_c_with))          // either side of the content pair may be the only one that needs a gradient
     for (long i = tid; i < a.n_c; i += nthr) {
       const float d = u[3] * 2.0f * (a.c_wo[i] - a.c_with[i]);
-      g.d_c_wo[i] = d;
-      g.d_c_with[i] = -d;
+      if (g.d_c_wo) g.d_c_wo[i] = d;
+      if (g.d_c_with) g.d_c_with[i] = -d;
     }
 }
 

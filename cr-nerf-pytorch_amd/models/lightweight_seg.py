@@ -6,6 +6,10 @@ Mirror of models/lightweight_seg.py:12-368: the same module tree, so the same pa
 unchanged; each module's forward is one fused HIP call (conv, BatchNorm+PReLU, FGlo, pooling, upsample+sigmoid), with
 the backward in HIP too.  torch supplies only the parameter containers, the channel concatenations and the residual
 add.  One image per call (batch 1) -- that is the only way the reference uses it.
+
+Attribution: the architecture (module tree, layer hyper-parameters and therefore the attribute names a checkpoint's
+state_dict fixes) is CGNet by Tianyi Wu et al. (wutianyi@ict.ac.cn, (c) 2018), as vendored in the reference's
+models/lightweight_seg.py; only that schema is shared -- every forward here dispatches to this repo's HIP operators.
 """
 import torch
 from torch import nn
@@ -39,8 +43,8 @@ class ConvBNPReLU(nn.Module):
         self.bn = nn.BatchNorm2d(nOut, eps=1e-03)
         self.act = nn.PReLU(nOut)
 
-    def forward(self, input):
-        return _bn_prelu(self.conv(input), self.bn, self.act)
+    def forward(self, x):
+        return _bn_prelu(self.conv(x), self.bn, self.act)
 
 
 class BNPReLU(nn.Module):
@@ -49,8 +53,8 @@ class BNPReLU(nn.Module):
         self.bn = nn.BatchNorm2d(nOut, eps=1e-03)
         self.act = nn.PReLU(nOut)
 
-    def forward(self, input):
-        return _bn_prelu(input, self.bn, self.act)
+    def forward(self, x):
+        return _bn_prelu(x, self.bn, self.act)
 
 
 class Conv(nn.Module):
@@ -58,8 +62,8 @@ class Conv(nn.Module):
         super().__init__()
         self.conv = _ConvParam(nIn, nOut, kSize, stride)
 
-    def forward(self, input):
-        return self.conv(input)
+    def forward(self, x):
+        return self.conv(x)
 
 
 class ChannelWiseConv(nn.Module):
@@ -67,8 +71,8 @@ class ChannelWiseConv(nn.Module):
         super().__init__()
         self.conv = _ConvParam(nIn, nOut, kSize, stride, groups=nIn)
 
-    def forward(self, input):
-        return self.conv(input)
+    def forward(self, x):
+        return self.conv(x)
 
 
 class ChannelWiseDilatedConv(nn.Module):
@@ -76,8 +80,8 @@ class ChannelWiseDilatedConv(nn.Module):
         super().__init__()
         self.conv = _ConvParam(nIn, nOut, kSize, stride, dilation=d, groups=nIn)
 
-    def forward(self, input):
-        return self.conv(input)
+    def forward(self, x):
+        return self.conv(x)
 
 
 class FGlo(nn.Module):
@@ -101,11 +105,10 @@ class ContextGuidedBlock_Down(nn.Module):
         self.reduce = Conv(2 * nOut, nOut, 1, 1)
         self.F_glo = FGlo(nOut, reduction)
 
-    def forward(self, input):
-        output = self.conv1x1(input)
-        joi_feat = torch.cat([self.F_loc(output), self.F_sur(output)], 1)
-        joi_feat = self.reduce(_bn_prelu(joi_feat, self.bn, self.act))
-        return self.F_glo(joi_feat)
+    def forward(self, x):
+        y = self.conv1x1(x)
+        local_and_surround = torch.cat([self.F_loc(y), self.F_sur(y)], 1)
+        return self.F_glo(self.reduce(_bn_prelu(local_and_surround, self.bn, self.act)))
 
 
 class ContextGuidedBlock(nn.Module):
@@ -119,11 +122,10 @@ class ContextGuidedBlock(nn.Module):
         self.add = add
         self.F_glo = FGlo(nOut, reduction)
 
-    def forward(self, input):
-        output = self.conv1x1(input)
-        joi_feat = self.bn_prelu(torch.cat([self.F_loc(output), self.F_sur(output)], 1))
-        output = self.F_glo(joi_feat)
-        return input + output if self.add else output
+    def forward(self, x):
+        y = self.conv1x1(x)
+        y = self.F_glo(self.bn_prelu(torch.cat([self.F_loc(y), self.F_sur(y)], 1)))
+        return x + y if self.add else y
 
 
 class InputInjection(nn.Module):
@@ -131,10 +133,10 @@ class InputInjection(nn.Module):
         super().__init__()
         self.ratio = downsamplingRatio
 
-    def forward(self, input):
+    def forward(self, x):
         for _ in range(self.ratio):
-            input = AvgPool3s2Fn.apply(input)
-        return input
+            x = AvgPool3s2Fn.apply(x)
+        return x
 
 
 class Context_Guided_Network(nn.Module):
@@ -160,22 +162,21 @@ class Context_Guided_Network(nn.Module):
         self.bn_prelu_3 = BNPReLU(256)
         self.classifier = nn.Sequential(Conv(256, classes, 1, 1))
 
-    def forward(self, input):
-        if not input.is_cuda:
-            raise RuntimeError("crnerf_amd: Context_Guided_Network runs on the HIP operators only; input is on %s" % input.device)
-        output0 = self.level1_2(self.level1_1(self.level1_0(input)))
-        inp1 = self.sample1(input)
-        inp2 = self.sample2(input)
-        output1_0 = self.level2_0(self.b1(torch.cat([output0, inp1], 1)))
-        output1 = output1_0
-        for layer in self.level2:
-            output1 = layer(output1)
-        output2_0 = self.level3_0(self.bn_prelu_2(torch.cat([output1, output1_0, inp2], 1)))
-        output2 = output2_0
-        for layer in self.level3:
-            output2 = layer(output2)
-        classifier = self.classifier(self.bn_prelu_3(torch.cat([output2_0, output2], 1)))
-        return BilinearGatherFn.apply(classifier, tuple(input.shape[2:]), None, True)
+    def forward(self, image):
+        if not image.is_cuda:
+            raise RuntimeError("crnerf_amd: Context_Guided_Network runs on the HIP operators only; input is on %s" % image.device)
+        stage1 = self.level1_2(self.level1_1(self.level1_0(image)))                     # 1/2 scale, 32 channels
+        half, quarter = self.sample1(image), self.sample2(image)                        # the image itself, re-injected at 1/2 and 1/4
+        stage2_in = self.level2_0(self.b1(torch.cat([stage1, half], 1)))                # 1/4 scale, 64 channels
+        stage2 = stage2_in
+        for block in self.level2:
+            stage2 = block(stage2)
+        stage3_in = self.level3_0(self.bn_prelu_2(torch.cat([stage2, stage2_in, quarter], 1)))   # 1/8 scale, 128 channels
+        stage3 = stage3_in
+        for block in self.level3:
+            stage3 = block(stage3)
+        logits = self.classifier(self.bn_prelu_3(torch.cat([stage3_in, stage3], 1)))
+        return BilinearGatherFn.apply(logits, tuple(image.shape[2:]), None, True)       # x8 bilinear upsample + sigmoid
 
 
 def mask_at_pixels(pred_mask, hw_whole, rgb_idx):

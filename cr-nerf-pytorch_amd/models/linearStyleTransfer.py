@@ -140,7 +140,7 @@ class style_net(nn.Module):
         xp, (H, W) = _pixel_major(content_feature)
         sp, _ = _pixel_major(style_feature)
         if train:
-            from ..autograd import DecoderFn   # HIP forward; backward is interim (see autograd.py)
+            from ..autograd import DecoderFn   # HIP forward + HIP backward (crnerf_crossray_decode_backward_f32)
             return DecoderFn.apply(xp, sp, *self.decoder_tensors()).view(1, 3, H, W)
         return ops.crossray_decode(xp, sp, self.decoder_tensors()).view(1, 3, H, W)
 

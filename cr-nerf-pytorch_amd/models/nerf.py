@@ -61,6 +61,22 @@ class NeRF_sigma(nn.Module):
         self._packed_key = None
 
     # ---- packed weights (kernel layout), rebuilt whenever a parameter changes
+    def invalidate_packed(self):
+        """Drop the cached kernel-layout copies of the weights.  Called automatically by train(), load_state_dict() and every
+        grad-mode forward (a training step is about to change the parameters); call it by hand after updating parameters
+        through `p.data` outside of those (p.data.* does not bump p._version, which is what the cache key watches --
+        torch_optimizer's radam/ranger update that way)."""
+        self._packed = None
+        self._packed_key = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def packed_weights(self, precision="f32"):
         """Packed buffer for the crnerf_*_f32 (default) or crnerf_*_bf16 entry points; re-packed when a parameter changes."""
         bf16 = ops._is_bf16(precision)

@@ -38,7 +38,10 @@ def get_embeddings(hparams_):
 
 
 def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=()):
-    ckpt = torch.load(ckpt_path, map_location="cpu")
+    # the reference's checkpoints are Lightning files: callback / optimizer / scheduler state with non-tensor objects next to
+    # 'state_dict', which torch >= 2.6's weights_only=True default refuses; they are the user's own trusted files, as for the
+    # reference (utils/__init__.py:68 torch.load without restrictions)
+    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
     ckpt = ckpt.get("state_dict", ckpt)                      # Lightning checkpoint or a bare state_dict
     out = {}
     for key, value in ckpt.items():
@@ -79,10 +82,13 @@ def decode_image(models, results, H, W, a_embedded_from_img, key=None):
 
 
 @torch.no_grad()
-def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, near=0.0, far=5.0, chunk=32768, precision=None):
+def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, near=0.0, far=5.0, chunk=32768, precision=None, a_emb=None):
     """One frame of the appearance-hallucination video path (appearance_modification_video.py:224-262):
-    style image -> appearance embedding, camera -> rays on the device, render, decode.  Returns [H,W,3] in [0,1]."""
-    a_emb = enc_a(style_img)
+    style image -> appearance embedding, camera -> rays on the device, render, decode.  Returns [H,W,3] in [0,1].
+    a_emb: a precomputed enc_a(style_img) -- the reference encodes the style image ONCE per video (:216-222), so frame loops
+    pass it in instead of re-running the encoder per frame."""
+    if a_emb is None:
+        a_emb = enc_a(style_img)
     rays = generate_rays(H, W, K, c2w, near, far, device=style_img.device)
     res = batched_inference(models, embeddings, rays, None, hparams_.N_samples, hparams_.N_importance, hparams_.use_disp,
                             chunk, False, args=hparams_, a_embedded_from_img=a_emb, precision=precision)
@@ -113,9 +119,29 @@ class TrainingSystem:
             self.implicit_mask = Context_Guided_Network(classes=1, M=2, N=2, input_channel=3).to(device)
             self.models_to_train += [self.implicit_mask]
         self.global_step = 0
+        self.training = True
 
     def parameters(self):
         return [p for m in self.models_to_train for p in m.parameters()]
+
+    def train(self, mode=True):
+        """LightningModule.train()/eval() over every trained module (BatchNorm of the mask network, packed-weight caches)."""
+        for m in self.models_to_train:
+            m.train(mode)
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _draw(self, seen):
+        """random.choice(seen) of train_mask_grid_sample.py:165-167.  In ray-parallel mode every rank must decode 'fine_random'
+        with the SAME style (all ranks evaluate one full-batch loss, parallel.GatherRays), so the draw comes from a generator
+        seeded by the step counter instead of the process-local `random` state."""
+        import random
+        if self.ray_group is False:
+            return random.choice(seen)
+        return random.Random(0x5EED + self.global_step).choice(seen)
 
     def sync_gradients(self):
         """Ray-parallel mode, after loss.backward(): MLP gradients summed over the ranks, replicated modules averaged."""
@@ -140,23 +166,25 @@ class TrainingSystem:
         results['rgb_' + type] = rgbs_pred
         return results
 
-    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None, hw_whole=None):              # :151-226
-        import random
+    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None, hw_whole=None, val_mode=False):   # :151-226
+        """val_mode=True (validation_step, :362): the transient mask is the whole interpolated image (no rgb_idx gather, :174-175)
+        and the reference switches to 2,048-ray chunks (:181-182) -- a memory bound only: rays are independent, so the chunk
+        size never changes the result and the renderer's own chunking is kept."""
         hp = self.hparams_
         results = defaultdict(list)
         kwargs = {'args': hp}
         whole_img = (whole_img + 1) / 2                                                     # [-1,1] -> [0,1]  :156
         kwargs['a_embedded_from_img'] = self.enc_a(whole_img)
         if hp.encode_random:
-            idexlist = [k for k, v in enumerate(self.embedding_a_list) if v is not None]
-            kwargs['a_embedded_random'] = kwargs['a_embedded_from_img'] if len(idexlist) == 0 else self.embedding_a_list[random.choice(idexlist)]
+            seen = [k for k, v in enumerate(self.embedding_a_list) if v is not None]
+            kwargs['a_embedded_random'] = kwargs['a_embedded_from_img'] if len(seen) == 0 else self.embedding_a_list[self._draw(seen)]
         if self.implicit_mask is not None:                                                  # :170-176
             from .models.lightweight_seg import mask_at_pixels
-            if rgb_idx is None or hw_whole is None:
+            if hw_whole is None or (rgb_idx is None and not val_mode):
                 raise ValueError("crnerf_amd: use_mask needs the batch's rgb_idx and the full-resolution image size (hw_whole)")
             pred_mask = self.implicit_mask(whole_img)
-            # interpolate(pred_mask, hw_whole) -> '(h w) n' -> [rgb_idx], evaluated only at the batch's pixels
-            kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, rgb_idx.reshape(-1))
+            # interpolate(pred_mask, hw_whole) -> '(h w) n' -> [rgb_idx], evaluated only at the batch's pixels (all of them in val_mode)
+            kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, None if val_mode else rgb_idx.reshape(-1))
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
         image_id = int(ts[0])
@@ -210,6 +238,28 @@ class TrainingSystem:
         loss = sum(l for l in loss_d.values())
         self.global_step += 1
         return loss, loss_d, results
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_nb=0):                                           # :339-402
+        """One whole validation image (PhototourismDataset split='val' hands over every ray of the image, `img_wh` = its size):
+        forward in val_mode, the training loss terms, PSNR of the finest decode (metrics.py:12-13).  Returns the reference's log
+        dict -- 'val_loss', the loss terms, 'val_psnr' -- plus 'results' for callers that want the images (the reference sends
+        img_gt / prediction / random-appearance prediction / mask to wandb here, :371-391; its 'val_ssim' is kornia's, out of scope)."""
+        rays, ts, rgbs = batch['rays'].squeeze(), batch['ts'].squeeze(), batch['rgbs'].squeeze()
+        W, H = (int(v) for v in torch.as_tensor(batch['img_wh']).reshape(-1)[:2])          # :346-347
+        was_training = self.training
+        self.eval()                                                                         # Lightning runs validation in eval mode
+        try:
+            results = self.forward(rays, ts, batch['whole_img'], W, H, batch.get('rgb_idx'), hw_whole=(H, W), val_mode=True)
+        finally:
+            self.train(was_training)
+        loss_d, _ = self.loss(results, rgbs, self.hparams_, self.global_step)
+        log = {'val_loss': sum(l for l in loss_d.values())}
+        log.update(loss_d)
+        typ = 'fine' if 'rgb_fine' in results else 'coarse'
+        log['val_psnr'] = -10.0 * torch.log10(((results['rgb_%s' % typ] - rgbs) ** 2).mean())
+        log['results'] = results
+        return log
 
 
 __all__ = ["get_model", "get_embeddings", "load_ckpt", "extract_model_state_dict", "batched_inference", "decode_image", "render_frame",

@@ -31,19 +31,35 @@ def _uniform_linear(rng, shape, fan_in, gain):
     return rng.uniform(-bound, bound, size=shape).astype(np.float32)
 
 
-def mlp_state(seed, gain=1.0, sigma_bias=0.0):
+def mlp_state(seed, gain=1.0, sigma_bias=0.0, band_limit=None):
     """24 tensors of one NeRF_sigma, nn.Linear-style U(-g/sqrt(fan_in), g/sqrt(fan_in)).
-    gain=3 gives the "peaky" variant (sigma spans 0..50, features saturate) of SURVEY 8c."""
+    gain=3 gives the "peaky" variant (sigma spans 0..50, features saturate) of SURVEY 8c.
+    band_limit=k0: the "smooth-density" variant -- the columns of the two layers that read the xyz embedding
+    (xyz_encoding_1, and the first 93 columns of the skip layer xyz_encoding_5; nerf.py:137-141) that belong to frequency
+    2^k are scaled by 2^-(k-k0) for k > k0, so the network is a smooth function of position (|d out/d x| = O(2^k0))
+    instead of amplifying a 1-ulp depth change by 2^14.  On such a net the reference itself is well-conditioned
+    (tests/golden/make_golden.py::smooth_goldens records its own 1-ulp sensitivity), so end-to-end parity can be held
+    to SURVEY 8d's stated tolerances."""
     rng = np.random.default_rng(seed)
     out = {}
     for name, shape in zip(MLP_TENSOR_NAMES, MLP_TENSOR_SHAPES):
         fan_in = shape[1] if len(shape) == 2 else MLP_TENSOR_SHAPES[MLP_TENSOR_NAMES.index(name.replace("bias", "weight"))][1]
         out[name] = _uniform_linear(rng, shape, fan_in, gain)
     out["static_sigma.0.bias"] = out["static_sigma.0.bias"] + np.float32(sigma_bias)
+    if band_limit is not None:
+        for name in ("xyz_encoding_1.0.weight", "xyz_encoding_5.0.weight"):
+            for k in range(15):                               # embedding columns [x | sin 2^0 x, cos 2^0 x | sin 2^1 x, ...], 3 wide each
+                out[name][:, 3 + 6 * k:9 + 6 * k] *= np.float32(2.0 ** (-max(k - band_limit, 0)))
     return out
 
 
-def decoder_state(seed, gain=1.0):
+def decoder_state(seed, gain=1.0, contrast=1.0):
+    """22 tensors of style_net (+ the unused blur kernel), nn.Conv2d / nn.Linear-style uniform init.
+    contrast != 1: the "high-gain" decoder of the parity instruments -- with default-scale weights the pixel-specific part
+    of the decode (unzip(T @ compress(x - mean)), linearStyleTransfer.py:86-88) is ~1e-2 of the style-mean part, so the image
+    spans rgb in [0.55, 0.66] and a feature error is damped ~500x.  `contrast` multiplies multi_net.unzip.weight and centres
+    the rgb bias for a 0.5-mean style; contrast=4000 makes the image span ~[0.14, 0.78] and a 1e-3 feature error move
+    pixels by ~7e-3, so PSNR / max|d rgb| respond to feature-level errors."""
     rng = np.random.default_rng(seed)
     out = {}
     for name, shape in DECODER_SHAPES.items():
@@ -52,6 +68,10 @@ def decoder_state(seed, gain=1.0):
             continue
         wshape = DECODER_SHAPES[name.replace("bias", "weight")]
         out[name] = _uniform_linear(rng, shape, wshape[1], gain)
+    if contrast != 1.0:
+        out["multi_net.unzip.weight"] = out["multi_net.unzip.weight"] * np.float32(contrast)
+        w = out["decoder.feat_2_rgb_list.0.weight"].reshape(3, 64)
+        out["decoder.feat_2_rgb_list.0.bias"] = (-0.5 * w.sum(1)).astype(np.float32)
     return out
 
 

@@ -82,8 +82,9 @@ def render_video(models, embeddings, enc_a, style_img, hparams_, scene="brandenb
     w, h = hparams_.img_wh
     K, poses = define_camera(hparams_.img_wh), define_poses(scene, n_frames)
     frames = {}
+    a_emb = enc_a(style_img)            # once per style image, as the reference (appearance_modification_video.py:239)
     for i in range(rank, n_frames, world_size):
         img = pipeline.render_frame(models, embeddings, enc_a, style_img, h, w, K, poses[i].astype(np.float32), hparams_, near=near, far=far,
-                                    chunk=chunk, precision=precision)
+                                    chunk=chunk, precision=precision, a_emb=a_emb)
         frames[i] = (img.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
     return frames

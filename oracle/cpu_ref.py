@@ -36,12 +36,12 @@ def mlp_forward(w, x, sigma_only=False):
     for layer in range(1, 9):
         if layer == 5:  # skip connection, input first (:168-169)
             h = torch.cat((xyz, h), dim=1)
-        h = F.relu(F.linear(h, w["xyz_encoding_%d.0.weight" % layer], w["xyz_encoding_%d.0.bias" % layer]))
+        h = F.relu_(F.linear(h, w["xyz_encoding_%d.0.weight" % layer], w["xyz_encoding_%d.0.bias" % layer]))  # nn.ReLU(True), :142
     sigma = F.softplus(F.linear(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))  # :172, beta=1 thr=20
     if sigma_only:
         return sigma
     final = F.linear(h, w["xyz_encoding_final.weight"], w["xyz_encoding_final.bias"])       # :176
-    g = F.relu(F.linear(torch.cat((final, x[:, 93:]), dim=1), w["dir_encoding.0.weight"], w["dir_encoding.0.bias"]))
+    g = F.relu_(F.linear(torch.cat((final, x[:, 93:]), dim=1), w["dir_encoding.0.weight"], w["dir_encoding.0.bias"]))  # :153
     feat = torch.sigmoid(F.linear(g, w["static_rgb.0.weight"], w["static_rgb.0.bias"]))      # :180
     return torch.cat((feat, sigma), dim=-1)                                                  # :181
 

