@@ -181,5 +181,7 @@ class Context_Guided_Network(nn.Module):
 
 def mask_at_pixels(pred_mask, hw_whole, rgb_idx):
     """interpolate(pred_mask, size=hw_whole)[rgb_idx] without forming the full-resolution mask
-    (train_mask_grid_sample.py:172-175: interpolate -> rearrange('b c h w -> (b h w) c') -> [rgb_idx]).  -> [n,1]"""
-    return BilinearGatherFn.apply(pred_mask, (int(hw_whole[0]), int(hw_whole[1])), rgb_idx, False).unsqueeze(1)
+    (train_mask_grid_sample.py:172-175: interpolate -> rearrange('b c h w -> (b h w) c') -> [rgb_idx]).  -> [n,1]
+    rgb_idx=None: every pixel, row-major (NeRFSystem.forward's val_mode, :174-175 without the gather)."""
+    out = BilinearGatherFn.apply(pred_mask, (int(hw_whole[0]), int(hw_whole[1])), rgb_idx, False)
+    return out.reshape(-1, 1)
