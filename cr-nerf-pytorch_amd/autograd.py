@@ -42,6 +42,122 @@ def mlp_forward_with_grad(module, x):
     return MlpFn.apply(x, module, *params)
 
 
+_RECOMPUTE = [False]
+
+
+def set_training_recompute(flag=True):
+    """Memory-bounded training (activation checkpointing per ray chunk): the grad-mode forward of render_rays_cross_ray runs the
+    INFERENCE renderer and keeps only rays / depths / noise; backward re-runs the fused training forward of the chunk (one more
+    MLP forward = +1/3 of the MLP work) and then the backward twins.  Saved state drops from ~10.5 KB per sample point to < 1 KB."""
+    _RECOMPUTE[0] = bool(flag)
+
+
+def get_training_recompute():
+    import os
+    return _RECOMPUTE[0] or os.environ.get("CRNERF_TRAIN_RECOMPUTE", "") not in ("", "0")
+
+
+def _embed_points(rays, z, view_dir):
+    """x[P,120] = cat(PosEmbedding_xyz(o + d z), PosEmbedding_dir(d)) for the wgrad of the layers that read it (rendering.py:108-114);
+    rebuilt in backward instead of being stored between forward and backward."""
+    R, N = z.shape
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+    demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
+    return torch.cat([ops.posenc(pts, 15), demb[:, None, :].expand(R, N, 27).reshape(R * N, 27)], 1)
+
+
+class FusedRenderFn(torch.autograd.Function):
+    """render_rays_cross_ray's arithmetic (rendering.py:100-194) for one chunk of rays as ONE differentiable node:
+    fwd crnerf_render_rays_train_f32 (posenc + both MLPs + activation save + compositing + sample_pdf/merge in one launch),
+    bwd per pass crnerf_composite_backward_f32 -> crnerf_mlp_backward_f32.  weights_coarse -> sample_pdf carries no gradient
+    (.detach() at rendering.py:184); rays, depths and noise are inputs, not differentiated."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, *params):
+        ctx.set_materialize_grads(False)     # an unused pass (e.g. coarse when only feature_fine feeds the loss) gets None, not zeros
+        Nc, Ni = cfg["Nc"], cfg["Ni"]
+        n_models = 2 if Ni > 0 else 1
+        states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(n_models)]
+        for mod in cfg["modules"]:
+            if mod is not None and hasattr(mod, "invalidate_packed"):
+                mod.invalidate_packed()      # an optimiser step follows (see MlpFn)
+        packed = [ops.pack_mlp_weights(st) for st in states]
+        recompute = get_training_recompute()
+        out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
+                              z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
+                              noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute)
+        ctx.cfg, ctx.recompute, ctx.n_models = cfg, recompute, n_models
+        keep = [rays, out["z_fine"] if Ni > 0 else rays.new_empty(0)]
+        if not recompute:
+            keep += [out["acts_coarse"], out["raw_coarse"]] + ([out["acts_fine"], out["raw_fine"]] if Ni > 0 else [])
+        ctx.n_keep = len(keep)
+        ctx.save_for_backward(*keep, *params)
+        res = (out["weights_coarse"], out["feature_coarse"], out["depth_coarse"])
+        if Ni > 0:
+            res += (out["weights_fine"], out["feature_fine"], out["depth_fine"])
+        return res
+
+    @staticmethod
+    def backward(ctx, *g):
+        cfg = ctx.cfg
+        Nc, Ni = cfg["Nc"], cfg["Ni"]
+        saved = ctx.saved_tensors
+        keep, params = saved[:ctx.n_keep], saved[ctx.n_keep:]
+        rays, z_fine = keep[0], keep[1]
+        states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(ctx.n_models)]
+        if ctx.recompute:
+            packed = [ops.pack_mlp_weights(st) for st in states]
+            out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
+                                  z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
+                                  noise_std=cfg["noise_std"], train=True)
+            per_pass = [(out["acts_coarse"], out["raw_coarse"])] + ([(out["acts_fine"], out["raw_fine"])] if Ni > 0 else [])
+            z_fine = out["z_fine"] if Ni > 0 else z_fine
+            del out
+        else:
+            per_pass = [(keep[2], keep[3])] + ([(keep[4], keep[5])] if Ni > 0 else [])
+        grads = []
+        for m, (acts, raw) in enumerate(per_pass):
+            d_w, d_f, d_d = g[3 * m], g[3 * m + 1], g[3 * m + 2]
+            z = z_fine if m == 1 else cfg["z_coarse"]
+            noise = cfg["noise_f"] if m == 1 else cfg["noise_c"]
+            if d_w is None and d_f is None and d_d is None:
+                grads += [None] * 24
+                continue
+            if d_f is None:
+                d_f = torch.zeros(raw.shape[0], 64, device=raw.device)
+            d_raw = ops.composite_backward(raw, z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
+                                           None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
+            x = _embed_points(rays, z, cfg["view_dir"])
+            grads += ops.mlp_backward(ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65), d_raw.view(-1, 65), acts)
+            del x, d_raw
+        return (None, None) + tuple(grads)
+
+
+def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std):
+    """Grad-mode render of `rays` in ray chunks of ~2^20 fine sample points (rays are independent; the chunk bounds the
+    backward's scratch -- 10 KB of layer deltas per point -- and, in recompute mode, the live activations)."""
+    from .models.rendering import _linspace_tables
+    R = rays.shape[0]
+    z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
+    if z_coarse is None:                      # rendering.py:160-167, the reference's own un-fused arithmetic
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+        z_coarse = z_coarse.expand(R, Nc).contiguous()
+    names = ops.MLP_TENSOR_NAMES
+    params = [dict(coarse.named_parameters())[n] for n in names] + ([dict(fine.named_parameters())[n] for n in names] if Ni > 0 else [])
+    step = max(4, ((1 << 20) // (Nc + Ni)) // 4 * 4)
+    parts = []
+    for lo in range(0, R, step):
+        hi = min(R, lo + step)
+        sl = lambda t: None if t is None else t[lo:hi].contiguous()  # noqa: E731
+        cfg = {"Nc": Nc, "Ni": Ni, "use_disp": use_disp, "view_dir": sl(view_dir), "z_coarse": sl(z_coarse),
+               "u": (u_steps if u is None else sl(u)) if Ni > 0 else None, "noise_c": sl(noise_c), "noise_f": sl(noise_f),
+               "noise_std": float(noise_std), "modules": (coarse, fine)}
+        parts.append(FusedRenderFn.apply(cfg, rays[lo:hi].contiguous(), *params))
+    keys = ["weights_coarse", "feature_coarse", "depth_coarse"] + (["weights_fine", "feature_fine", "depth_fine"] if Ni > 0 else [])
+    return {k: (parts[0][i] if len(parts) == 1 else torch.cat([p[i] for p in parts], 0)) for i, k in enumerate(keys)}
+
+
 class CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, z, noise, noise_std):

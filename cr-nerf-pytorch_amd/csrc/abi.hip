@@ -174,7 +174,8 @@ int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coar
   return launch_sample_pdf_merge(z_coarse, weights_coarse, u, (long)u_stride, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
 }
 
-static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16) {
+static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16, void* acts_c = nullptr, void* acts_f = nullptr,
+                              float* raw_c = nullptr, float* raw_f = nullptr) {
   REQUIRE(a, "args");
   if (a->n_rays == 0) return 0;
   if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays: negative n_rays");
@@ -190,12 +191,23 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
+  r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
   if (bf16) return launch_render_rays_bf16(r, (hipStream_t)stream);
+  if (acts_c) return launch_render_rays16(r, (hipStream_t)stream);       // the training twin exists on the 16x16x4 core only
   return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
 }
 
 int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false); }
 int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
+
+int crnerf_render_rays_train_f32(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
+                                 void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
+  if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
+  return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine);
+}
 
 size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }
 

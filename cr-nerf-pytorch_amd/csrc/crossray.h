@@ -4,7 +4,7 @@
 
 namespace crnerf {
 
-constexpr int CROSSRAY_SUM_BLOCKS = 256;   // partial rows of the channel-sum reduction (one workgroup per CU)
+constexpr int CROSSRAY_SUM_BLOCKS = 256;   // partial rows of the channel-sum reduction (one 1024-thread workgroup per CU)
 constexpr int CROSSRAY_GRAM_BLOCKS = 256;  // partial Grams (one workgroup per CU)
 // two jobs x (sum partials + Gram partials) + stats; see WS_* in crossray.hip
 constexpr size_t CROSSRAY_WORKSPACE_BYTES = (size_t)2560 * 1024;

@@ -37,28 +37,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------- channel sums (two jobs)
 struct SumJob { const float* x; long HW; float* partial; int nblk; };
 
-__global__ __launch_bounds__(256) void chansum_partial_kernel(SumJob j0, SumJob j1) {
-  // thread = (pixel slot, channel quad); 16 channel quads x 16 pixel slots per block
-  __shared__ f32x4 red[256];
+constexpr int SUM_THREADS = 1024;   // 16 channel quads x 64 pixel slots
+__global__ __launch_bounds__(SUM_THREADS) void chansum_partial_kernel(SumJob j0, SumJob j1) {
+  // thread = (pixel slot, channel quad); 16 channel quads x 64 pixel slots per block, one block per CU
+  __shared__ f32x4 red[SUM_THREADS];
   const bool second = (int)blockIdx.x >= j0.nblk;
   const SumJob j = second ? j1 : j0;
   const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
   const int cq = threadIdx.x & 15, ps = threadIdx.x >> 4;
-  // four independent row streams per thread: 64 B in flight per lane (a single dependent add chain reached 12 % of HBM)
-  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const long step = (long)j.nblk * 16;
-  long px = (long)blk * 16 + ps;
-  for (; px + 3 * step < j.HW; px += 4 * step) {
-    a0 += *(const f32x4*)(j.x + px * 64 + cq * 4);
-    a1 += *(const f32x4*)(j.x + (px + step) * 64 + cq * 4);
-    a2 += *(const f32x4*)(j.x + (px + 2 * step) * 64 + cq * 4);
-    a3 += *(const f32x4*)(j.x + (px + 3 * step) * 64 + cq * 4);
+  // eight independent row streams per thread x 16 waves per CU: 128 B in flight per lane, ~32 MB on the chip (HBM needs ~16 MB
+  // by Little's law; one dependent add chain on 4 waves/CU reached 12 % of HBM, four streams 37 %).  The partial-row count
+  // stays <= CROSSRAY_SUM_BLOCKS = 256 because the Gram kernel's prologue re-reads every partial row.
+  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+  // the block owns a contiguous pixel range (whole 64-pixel rounds); the eight streams are rounds k, k+1, ..., k+7 -- the
+  // tail is handled by clamping the row and zeroing its weight, never by a serial one-stream loop
+  const long rounds = (j.HW + 63) / 64, per = (rounds + j.nblk - 1) / j.nblk;
+  const long r0 = (long)blk * per, r1 = r0 + per < rounds ? r0 + per : rounds;
+  const float* base = j.x + cq * 4;
+  const long last = j.HW - 1;
+  for (long rd = r0; rd < r1; rd += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long px = (rd + u) * 64 + ps;
+      const bool ok = rd + u < r1 && px <= last;
+      v[u] = *(const f32x4*)(base + (ok ? px : last) * 64);
+      if (!ok) v[u] = f32x4{0, 0, 0, 0};
+    }
+    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; a4 += v[4]; a5 += v[5]; a6 += v[6]; a7 += v[7];
   }
-  for (; px < j.HW; px += step) a0 += *(const f32x4*)(j.x + px * 64 + cq * 4);
-  const f32x4 acc = (a0 + a1) + (a2 + a3);
+  const f32x4 acc = ((a0 + a4) + (a1 + a5)) + ((a2 + a6) + (a3 + a7));
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 8; s >= 1; s >>= 1) {
+  for (int s = 32; s >= 1; s >>= 1) {
     if (ps < s) red[threadIdx.x] += red[threadIdx.x + s * 16];
     __syncthreads();
   }
@@ -66,27 +77,48 @@ __global__ __launch_bounds__(256) void chansum_partial_kernel(SumJob j0, SumJob 
 }
 
 struct RedJob { const float* partial; int rows; float* out; };
-// out[c] = sum_r partial[r][c], cols columns per job, fixed order (deterministic)
-__global__ void reduce_rows_kernel(RedJob j0, RedJob j1, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[c] = sum_r partial[r][c], cols columns per job, fixed summation tree (deterministic).  One 1024-thread block per 64
+// columns: 16 row slices x 64 columns, four independent accumulators per thread, slices combined through LDS in a fixed order.
+// (The first version walked the rows serially from one thread per column: 256 dependent L2 round trips = 60 us per call at an
+// 800x800 grid, more than the 25 us channel-sum pass it finishes.)
+constexpr int RED_THREADS = 1024;
+__global__ __launch_bounds__(RED_THREADS) void reduce_rows_kernel(RedJob j0, RedJob j1, int cols) {
+  __shared__ float red[RED_THREADS];
   const RedJob j = blockIdx.y ? j1 : j0;
-  if (c >= cols || !j.out) return;
-  float s = 0.0f;
-  for (int r = 0; r < j.rows; ++r) s += j.partial[(long)r * cols + c];
-  j.out[c] = s;
+  if (!j.out) return;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (c < cols) {
+    int r = sl;
+    for (; r + 48 < j.rows; r += 64) {
+      a0 += j.partial[(long)r * cols + c];
+      a1 += j.partial[(long)(r + 16) * cols + c];
+      a2 += j.partial[(long)(r + 32) * cols + c];
+      a3 += j.partial[(long)(r + 48) * cols + c];
+    }
+    for (; r < j.rows; r += 16) a0 += j.partial[(long)r * cols + c];
+  }
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (int s = 8; s >= 1; s >>= 1) {
+    if (sl < s) red[threadIdx.x] += red[threadIdx.x + s * 64];
+    __syncthreads();
+  }
+  if (sl == 0 && c < cols) j.out[c] = red[cl];
 }
 
 static int chansum_blocks(long HW) {
-  const long b = (HW + 15) / 16;
+  const long b = (HW + 63) / 64;
   return (int)(b < CROSSRAY_SUM_BLOCKS ? (b < 1 ? 1 : b) : CROSSRAY_SUM_BLOCKS);
 }
 
 int launch_crossray_chansum(const float* x, long HW, float* sum_out, float* workspace, hipStream_t stream) {
   if (HW <= 0) return set_error(-2, "crossray_chansum: empty grid");
   SumJob j{x, HW, workspace, chansum_blocks(HW)}, none{nullptr, 0, nullptr, 0};
-  hipLaunchKernelGGL(chansum_partial_kernel, dim3(j.nblk), dim3(256), 0, stream, j, none);
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(j.nblk), dim3(SUM_THREADS), 0, stream, j, none);
   RedJob r{workspace, j.nblk, sum_out}, rn{nullptr, 0, nullptr};
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(64), 0, stream, r, rn, 64);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(RED_THREADS), 0, stream, r, rn, 64);
   return check_launch("crossray_chansum");
 }
 
@@ -261,7 +293,7 @@ int launch_crossray_gram(const float* x, long HW, const float* mean, const CnnTe
   none.nblk = 0;
   if (int rc = launch_gram(a, none, stream)) return rc;
   RedJob r{workspace, a.nblk, gram_sum}, rn{nullptr, 0, nullptr};
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 1), dim3(256), 0, stream, r, rn, 1024);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(16, 1), dim3(RED_THREADS), 0, stream, r, rn, 1024);
   return check_launch("crossray_gram");
 }
 
@@ -432,12 +464,12 @@ int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
   }
   if (d.HWs <= 0) return set_error(-2, "crossray_decode: empty style grid");
   SumJob s0{d.content, d.HW, ws + WS_SUMP0, chansum_blocks(d.HW)}, s1{d.style, d.HWs, ws + WS_SUMP1, chansum_blocks(d.HWs)};
-  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(SUM_THREADS), 0, stream, s0, s1);
   GramJob g0{d.content, d.HW, nullptr, ws + WS_SUMP0, s0.nblk, (float)(1.0 / (double)d.HW), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, gram_blocks(d.HW)};
   GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
   if (int rc = launch_gram(g0, g1, stream)) return rc;
   RedJob r0{ws + WS_GRAMP0, g0.nblk, st + ST_CGRAM}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 2), dim3(256), 0, stream, r0, r1, 1024);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(16, 2), dim3(RED_THREADS), 0, stream, r0, r1, 1024);
   FcJob f0{st + ST_CGRAM, (float)(1.0 / (double)d.HW), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
   FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
   hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
@@ -460,10 +492,10 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
   const bool have = d.HW > 0;                         // a rank may hold no pixels
   SumJob s0{d.content, d.HW, ws + WS_SUMP0, have ? chansum_blocks(d.HW) : 0}, s1{d.style, d.HWs, ws + WS_SUMP1, chansum_blocks(d.HWs)};
   if (phase == 0) {
-    hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+    hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(SUM_THREADS), 0, stream, s0, s1);
     if (have) {
       RedJob r0{ws + WS_SUMP0, s0.nblk, xchg}, rn{nullptr, 0, nullptr};
-      hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(64), 0, stream, r0, rn, 64);
+      hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 1), dim3(RED_THREADS), 0, stream, r0, rn, 64);
     } else if (hipMemsetAsync(xchg, 0, 64 * sizeof(float), stream) != hipSuccess) return set_error(-10, "hipMemsetAsync failed");
     return check_launch("crossray_decode_sharded phase 0");
   }
@@ -472,7 +504,7 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
     GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
     if (int rc = launch_gram(g0, g1, stream)) return rc;
     RedJob r0{ws + WS_GRAMP0, g0.nblk, have ? xchg + 64 : nullptr}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(4, 2), dim3(256), 0, stream, r0, r1, 1024);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(16, 2), dim3(RED_THREADS), 0, stream, r0, r1, 1024);
     if (!have) {
       if (hipMemsetAsync(xchg + 64, 0, 1024 * sizeof(float), stream) != hipSuccess) return set_error(-10, "hipMemsetAsync failed");
       // the mean is needed by fold on every rank
@@ -858,9 +890,9 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   }
   // 7. centering terms
   SumJob s0{dxc[0], HW, sum_ws, chansum_blocks(HW)}, s1{dxc[1], HWs, sum_ws + 64 * CROSSRAY_SUM_BLOCKS, chansum_blocks(HWs)};
-  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(256), 0, stream, s0, s1);
+  hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(SUM_THREADS), 0, stream, s0, s1);
   RedJob r0{s0.partial, s0.nblk, cs_c}, r1{s1.partial, s1.nblk, cs_s};
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 2), dim3(64), 0, stream, r0, r1, 64);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 2), dim3(RED_THREADS), 0, stream, r0, r1, 64);
   hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HW * 64 + 255) / 256)), dim3(256), 0, stream, d_content, dxc[0], dmean_c, cs_c, HW, 1);
   hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HWs * 64 + 255) / 256)), dim3(256), 0, stream, d_style, dxc[1], dmean_s, cs_s, HWs, 0);
   return check_launch("crossray_decode_backward");

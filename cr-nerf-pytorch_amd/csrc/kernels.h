@@ -70,6 +70,11 @@ struct RenderArgs {
   float* feature_fine;         // [R,64]
   float* depth_fine;           // [R]
   float* z_fine;               // [R,Nc+Ni] optional (null to skip)
+  // training twin (crnerf_render_rays_train_f32; all null for inference): saved activations + raw MLP outputs per pass
+  void* train_acts_coarse = nullptr;   // crnerf_mlp_train_acts_bytes(R*Nc)
+  void* train_acts_fine = nullptr;     // crnerf_mlp_train_acts_bytes(R*(Nc+Ni))
+  float* train_raw_coarse = nullptr;   // [R*Nc,65]
+  float* train_raw_fine = nullptr;     // [R*(Nc+Ni),65]
 };
 int launch_render_rays(const RenderArgs& a, hipStream_t stream);
 int launch_render_rays16(const RenderArgs& a, hipStream_t stream);

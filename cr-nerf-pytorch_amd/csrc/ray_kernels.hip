@@ -4,6 +4,7 @@
 // coalesced 260-B sample rows, wave-prefix transmittance.
 // Reference: models/rendering.py:116-143 (compositing), :7-46 + :183-187 (sample_pdf, merge).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "ray_ops.h"
 
@@ -129,26 +130,65 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
                                                                  const float* __restrict__ noise, float noise_std,
                                                                  const float* __restrict__ d_feature, const float* __restrict__ d_depth,
                                                                  const float* __restrict__ d_weights, float* __restrict__ d_raw,
-                                                                 long R, int N) {
+                                                                 long R, int N, int dbg) {
+  // One ray per wavefront.  raw is read ONCE (phase A; a separate strided pass over the sigma column is evicted from L2 before
+  // the row pass re-reads the same lines: measured 2x the fetch bytes) and d_raw is written ONCE as a flat stream (phase D).
   extern __shared__ __attribute__((aligned(16))) float smb[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* al = smb + (size_t)wave * 3 * N;   // alpha
+  float* al = smb + (size_t)wave * (5 * N + 64);   // alpha
   float* Tt = al + N;                       // transmittance
   float* gg = Tt + N;                       // g_n
+  float* dsg = gg + N;                      // dL/dsigma_n
+  float* sig = dsg + N;                     // raw sigma_n (+ noise)
+  float* gfs = sig + N;                     // dL/dfeature of the ray, by channel
   for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
     const float* rr = raw + r * (long)N * OUT_DIM;
     const float* zr = z + r * (long)N;
     float* dr = d_raw + r * (long)N * OUT_DIM;
-    // phase 1: alpha, T (same arithmetic as the forward kernel)
+    // phase A: lane = channel.  32 sample rows in flight per wave; their 32 dot products g_f . f_n are reduced TOGETHER by a
+    // transpose-reduce: at the step for lane bit B each lane keeps half of its values and receives the partner's other half, so
+    // a batch costs 16+8+4+2+1+1 = 32 cross-lane moves (one per sample) instead of a 6-step butterfly per sample (192).  After
+    // the five halving steps lane l holds the sum for sample u = (l >> 1) & 31.  The row's 65th float (sigma) rides along.
+    const float gf = d_feature[r * FEAT_DIM + lane];
+    const float gd = d_depth ? d_depth[r] : 0.0f;
+    gfs[lane] = gf;
+    const bool even = !(lane & 1);
+    if (dbg & 1)
+    for (int n = 0; n < N; n += 32) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {     // unconditional loads (clamped row): a branch around a load costs a vmcnt(0) at the join
+        const int nu = n + u < N ? n + u : N - 1;
+        const float x = rr[(long)nu * OUT_DIM + lane];
+        v[u] = (n + u < N) ? gf * x : 0.0f;
+      }
+      const int ms = n + (lane & 31);
+      if (lane < 32 && ms < N) sig[ms] = rr[(long)ms * OUT_DIM + FEAT_DIM] + (noise ? noise[r * (long)N + ms] * noise_std : 0.0f);
+#define CRNERF_FOLD(W, BIT)                                         \
+  {                                                                 \
+    const bool up = (lane & (BIT)) != 0;                            \
+    _Pragma("unroll") for (int u = 0; u < (W) / 2; ++u) {          \
+      const float lo = v[u], hi = v[u + (W) / 2];                   \
+      v[u] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, (BIT));      \
+    }                                                               \
+  }
+      CRNERF_FOLD(32, 32) CRNERF_FOLD(16, 16) CRNERF_FOLD(8, 8) CRNERF_FOLD(4, 4) CRNERF_FOLD(2, 2)
+#undef CRNERF_FOLD
+      const float dot = v[0] + __shfl_xor(v[0], 1);
+      const int m = n + ((lane >> 1) & 31);
+      if (even && m < N) gg[m] = dot + gd * zr[m] + (d_weights ? d_weights[r * (long)N + m] : 0.0f);
+    }
+    wave_lds_fence();
+    // phase B: lane = sample.  alpha, T (same arithmetic as the forward kernel), sigma from LDS
     double carry = 1.0;
+    if (dbg & 2)
     for (int base = 0; base < N; base += 64) {
       const int n = base + lane;
       const bool valid = n < N;
       const int nc = valid ? n : N - 1;
       const float zn = zr[nc], znext = zr[nc + 1 < N ? nc + 1 : N - 1];
-      const float s = rr[(long)nc * OUT_DIM + FEAT_DIM] + ((noise && valid) ? noise[r * (long)N + n] * noise_std : 0.0f);
       const float delta = (n == N - 1) ? 1e2f : znext - zn;
-      const float alpha = valid ? 1.0f - expf(-delta * fmaxf(s, 0.0f)) : 0.0f;
+      const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sig[nc], 0.0f)) : 0.0f;
       double incl = (double)(1.0f - alpha);
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -161,36 +201,10 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
       carry *= shfl_f64(incl, 63, 64);
     }
     wave_lds_fence();
-    // phase 2: lane = channel.  g_n and dL/df_n
-    const float gf = d_feature[r * FEAT_DIM + lane];
-    const float gd = d_depth ? d_depth[r] : 0.0f;
-    int n = 0;
-    for (; n + 8 <= N; n += 8) {          // eight sample rows in flight, their eight cross-lane sums interleaved
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = gf * rr[(long)(n + u) * OUT_DIM + lane];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] += __shfl_xor(v[u], d);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        dr[(long)(n + u) * OUT_DIM + lane] = (al[n + u] * Tt[n + u]) * gf;
-        if (lane == 0) gg[n + u] = v[u] + gd * zr[n + u] + (d_weights ? d_weights[r * (long)N + n + u] : 0.0f);
-      }
-    }
-    for (; n < N; ++n) {
-      float v = gf * rr[(long)n * OUT_DIM + lane];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-      const float w = al[n] * Tt[n];
-      dr[(long)n * OUT_DIM + lane] = w * gf;
-      if (lane == 0) gg[n] = v + gd * zr[n] + (d_weights ? d_weights[r * (long)N + n] : 0.0f);
-    }
-    wave_lds_fence();
-    // phase 3: reverse affine scan, lane = sample (lane 0 = LAST sample of the chunk)
-    float ucarry = 0.0f;   // U of the first (lowest-index) sample of the previously processed (later) chunk... see below
+    // phase C: reverse affine scan, lane = sample (lane 0 = LAST sample of the chunk)
+    float ucarry = 0.0f;                 // U of the lowest sample of the chunk processed before (the later samples)
     float a_next = 1.0f, b_next = 0.0f;  // (1-alpha, g*alpha) of the sample right after the current chunk
+    if (dbg & 4)
     for (int top = N; top > 0; top -= 64) {
       const int n = top - 1 - lane;                 // descending
       const bool valid = n >= 0;
@@ -199,9 +213,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
       const float a_self = valid ? 1.0f - al[nc] : 1.0f, b_self = valid ? gg[nc] * al[nc] : 0.0f;
       float a = __shfl_up(a_self, 1, 64), b = __shfl_up(b_self, 1, 64);
       if (lane == 0) { a = a_next; b = b_next; }
-      // inclusive scan of affine maps along increasing lane: F_lane = f_lane o F_{lane-1}?  U_n = b + a * U_{n+1},
-      // U_{n+1} belongs to lane-1: compose so that (A,B) maps the chunk's incoming U (ucarry) to U_n
-      float A = a, B = b;
+      float A = a, B = b;                            // inclusive scan of the affine maps: (A,B) takes the chunk's incoming U to U_n
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const float Ap = __shfl_up(A, d, 64), Bp = __shfl_up(B, d, 64);
@@ -210,15 +222,31 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
       const float U = fmaf(A, ucarry, B);
       if (valid) {
         const float zn = zr[nc], znext = zr[nc + 1 < N ? nc + 1 : N - 1];
-        const float s = rr[(long)nc * OUT_DIM + FEAT_DIM] + (noise ? noise[r * (long)N + nc] * noise_std : 0.0f);
         const float delta = (nc == N - 1) ? 1e2f : znext - zn;
         const float dalpha = Tt[nc] * (gg[nc] - U);
-        dr[(long)nc * OUT_DIM + FEAT_DIM] = (s > 0.0f) ? dalpha * delta * (1.0f - al[nc]) : 0.0f;
+        dsg[nc] = (sig[nc] > 0.0f) ? dalpha * delta * (1.0f - al[nc]) : 0.0f;
       }
-      // hand over to the next (earlier) chunk: its lane 0 needs (a,b) of this chunk's lowest sample and U of it
       ucarry = __shfl(U, 63, 64);
       a_next = __shfl(a_self, 63, 64);
       b_next = __shfl(b_self, 63, 64);
+    }
+    wave_lds_fence();
+    // phase D: the ray's d_raw block [N][65] as ONE flat contiguous stream (element e = 65 n + c: w_n gf_c for c < 64,
+    // dL/dsigma_n for c = 64), 16 bytes per lane when the block is 16-byte aligned (N % 4 == 0).  Writing channels 0..63 and the
+    // sigma column in separate passes leaves every 260-B row as partial lines that leave L2 before they are completed.
+    const int total = N * OUT_DIM;
+    auto elem = [&](int e) {
+      const int nn = e / OUT_DIM, c = e - nn * OUT_DIM;
+      return c < FEAT_DIM ? (al[nn] * Tt[nn]) * gfs[c] : dsg[nn];
+    };
+    if (!(dbg & 8)) {
+    } else if ((N & 3) == 0) {
+      for (int e = 4 * lane; e < total; e += 256) {
+        const float4 o = make_float4(elem(e), elem(e + 1), elem(e + 2), elem(e + 3));
+        *(float4*)(dr + e) = o;
+      }
+    } else {
+      for (int e = lane; e < total; e += 64) dr[e] = elem(e);
     }
     wave_lds_fence();
   }
@@ -228,13 +256,14 @@ int launch_composite_backward(const float* raw, const float* z, const float* noi
                               const float* d_depth, const float* d_weights, float* d_raw, long R, int N, hipStream_t stream) {
   if (R <= 0) return 0;
   if (N < 1) return set_error(-2, "composite_backward: N must be >= 1");
-  const size_t shmem = (size_t)4 * 3 * N * sizeof(float);
+  const size_t shmem = (size_t)4 * (5 * N + 64) * sizeof(float);
   if (shmem > 160 * 1024) return set_error(-2, "composite_backward: N too large for LDS");
   if (int rc = ensure_dynamic_lds((const void*)composite_backward_kernel, shmem, "composite_backward_kernel")) return rc;
   const long blocks = (R + 3) / 4;
   const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  static const int dbg = getenv("CRNERF_CB_PHASES") ? atoi(getenv("CRNERF_CB_PHASES")) : 15;   // timing experiments only
   hipLaunchKernelGGL(composite_backward_kernel, dim3(grid), dim3(256), shmem, stream, raw, z, noise, noise_std, d_feature, d_depth,
-                     d_weights, d_raw, R, N);
+                     d_weights, d_raw, R, N, dbg);
   return check_launch("composite_backward_kernel");
 }
 

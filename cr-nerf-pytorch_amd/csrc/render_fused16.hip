@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "mlp_core16.h"
+#include "mlp_train16.h"
 #include "ray_ops.h"
 
 namespace crnerf {
@@ -108,7 +109,32 @@ __device__ __forceinline__ void merge_sort_pair(PairScratch& s, int Nc, int Ni, 
   }
 }
 
-__global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a) {
+// What the training twin adds to the renderer (crnerf_render_rays_train_f32): every tile's layer activations + relu bits
+// (ActSaver, mlp_train16.h) and its raw MLP output row, per pass.  The inference kernel instantiates the no-op hook.
+struct NoHook {
+  __device__ __forceinline__ NoSave saver(int, long, int, int, bool, int) const { return NoSave(); }
+  __device__ __forceinline__ void raw(int, long, int, int, bool, int, const f32x4 (&)[4], float) const {}
+};
+struct TrainHook {
+  float* acts[2];   // [10][R*N][256] + masks, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
+  float* rawo[2];   // [R*N][65]
+  long R;
+  __device__ __forceinline__ ActSaver saver(int pass, long r, int N, int n, bool ok, int g) const {
+    return ActSaver{acts[pass], R * N, r * N + n, ok, g};
+  }
+  __device__ __forceinline__ void raw(int pass, long r, int N, int n, bool ok, int g, const f32x4 (&feat)[4], float sigma) const {
+    if (!ok) return;
+    float* o = rawo[pass] + (r * N + n) * OUT_DIM;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[16 * T + 4 * g + q] = feat[T][q];
+    if (g == 0) o[FEAT_DIM] = sigma;
+  }
+};
+
+template <class HOOK>
+__device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, const HOOK& hook) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
   const int lane = threadIdx.x & 63;
@@ -177,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
         f32x4 pe[6], feat[4];
         posenc_regs16<XYZ_FREQS, 6>(x, y, z, g, pe);
         float sigma;
-        mlp_tile16(pipe, pass, pe, dirsrc, feat, sigma, g, q, tm);
+        mlp_tile16(pipe, pass, pe, dirsrc, feat, sigma, g, q, tm, hook.saver(pass, r, N, n, valid && ray_ok, g));
+        hook.raw(pass, r, N, n, valid && ray_ok, g, feat, sigma);
         // ---- compositing, rendering.py:121-143
         const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
         const float delta = (n == N - 1) ? 1e2f : znext - zn;
@@ -249,6 +276,12 @@ __global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+__global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a) { render_rays16_impl(a, NoHook{}); }
+
+// Fused TRAINING forward: the same launch (posenc -> MLP -> compositing, coarse -> sample_pdf -> fine) that also keeps what
+// the backward twins need -- no [P,93] / [P,120] embeddings and no separate compositing pass ever exist in HBM.
+__global__ __launch_bounds__(512, 2) void render_rays_train16_kernel(RenderParams16 a, TrainHook h) { render_rays16_impl(a, h); }
+
 int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
   if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays: N_samples must be in [2, 256] for the fused kernel");
@@ -268,6 +301,14 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   const int grid = (int)(quads < cus ? quads : cus);
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float);
+  if (a.train_acts_coarse) {
+    if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train: fine buffers are NULL");
+    if (!a.train_raw_coarse) return set_error(-1, "render_rays_train: raw_coarse is NULL");
+    TrainHook h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
+    if (int rc = ensure_dynamic_lds((const void*)render_rays_train16_kernel, shmem, "render_rays_train16_kernel")) return rc;
+    hipLaunchKernelGGL(render_rays_train16_kernel, dim3(grid), dim3(512), shmem, stream, k, h);
+    return check_launch("render_rays_train16_kernel");
+  }
   if (int rc = ensure_dynamic_lds((const void*)render_rays16_kernel, shmem, "render_rays16_kernel")) return rc;
   hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
   return check_launch("render_rays16_kernel");

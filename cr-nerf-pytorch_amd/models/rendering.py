@@ -118,7 +118,13 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    if train or N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
+    if train and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX and (N_importance == 0 or N_samples >= 3):
+        # training: the fused renderer's training twin (one launch per ray chunk: posenc + MLPs + activation save + compositing +
+        # sample_pdf/merge) as one autograd node whose backward runs the HIP backward twins (autograd.FusedRenderFn)
+        from ..autograd import fused_render_with_grad
+        out = fused_render_with_grad(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
+                                     float(noise_std))
+    elif train or N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
         # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
         # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)
         out = _render_unfused(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,

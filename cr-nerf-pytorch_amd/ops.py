@@ -175,10 +175,15 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
 
 
 def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
-                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32"):
-    """Fused renderer.  Returns a dict of freshly allocated tensors."""
+                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False):
+    """Fused renderer.  Returns a dict of freshly allocated tensors.  train=True (fp32 only): the training twin
+    crnerf_render_rays_train_f32 -- the dict additionally holds what the backward needs: z_coarse (as used), z_fine,
+    acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65]."""
     lib = _lib.load()
     bf16 = _is_bf16(precision)
+    if train and bf16:
+        raise ValueError("crnerf_amd: the fused training forward is fp32 (precision='f32')")
+    want_z_fine = want_z_fine or train
     _check_packed(packed_coarse, bf16)
     _check_packed(packed_fine, bf16)
     rays = _f32c(rays, "rays")
@@ -208,6 +213,17 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine"):
         setattr(a, k, out[k].data_ptr() if k in out else None)
+    if train:
+        Nf = Nc + Ni
+        out["acts_coarse"] = torch.empty(lib.crnerf_mlp_train_acts_bytes(R * Nc), dtype=torch.uint8, device=dev)
+        out["raw_coarse"] = new(R, Nc, 65)
+        if Ni > 0:
+            out["acts_fine"] = torch.empty(lib.crnerf_mlp_train_acts_bytes(R * Nf), dtype=torch.uint8, device=dev)
+            out["raw_fine"] = new(R, Nf, 65)
+        vp = lambda k: ctypes.c_void_p(out[k].data_ptr()) if k in out else None  # noqa: E731
+        _lib.check(lib.crnerf_render_rays_train_f32(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"),
+                                                    _lib.stream_ptr()), "crnerf_render_rays_train_f32")
+        return out
     fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
     return out

@@ -120,6 +120,16 @@ typedef struct crnerf_render_args {
 } crnerf_render_args;
 int crnerf_render_rays_f32(const crnerf_render_args* args, void* stream);
 
+/* Training twin of the call above (the reference trains THROUGH render_rays_cross_ray under autograd, rendering.py:100-143):
+ * the same fused launch -- positional encoding, both NeRF_sigma passes, compositing, sample_pdf + merge -- that additionally
+ * keeps what the backward twins need: per pass the layer activations in the crnerf_mlp_forward_train_f32 layout
+ * (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes, point index = ray*N + sample) and the raw MLP outputs raw_*[R*N,65].
+ * args->z_fine is REQUIRED when n_importance > 0 (the backward composites at those depths).  Backward = per pass
+ * crnerf_composite_backward_f32 (raw, z, noise -> d_raw) then crnerf_mlp_backward_f32 (x = the embedded points, which the
+ * caller rebuilds from rays and z with crnerf_posenc_f32 -- they are never stored between forward and backward). */
+int crnerf_render_rays_train_f32(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse,
+                                 float* raw_fine, void* stream);
+
 /* ---- bf16 matrix-core variants (BASELINE config 3: "1x MI355X bf16"; SURVEY 8b minimum export set
  * crnerf_mlp_forward_{f32,bf16} / crnerf_render_rays_{f32,bf16}).  Same reference functions, mixed precision:
  * the operands of every nn.Linear of NeRF_sigma except static_sigma -- weights and input activations, including the

@@ -1,0 +1,125 @@
+"""The fused TRAINING renderer (crnerf_render_rays_train_f32 + autograd.FusedRenderFn): one launch does what the reference does
+under autograd in render_rays_cross_ray (rendering.py:100-194) and keeps the activations the backward twins need.  Checked
+against the inference renderer (same outputs, bit for bit), the stand-alone training twins (same saved activations), the
+un-fused grad path, and -- through tests/test_gpu_parity.py::test_training_step_gradients_vs_autograd_oracle, which now runs
+this path -- torch autograd through the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import crnerf_amd.synth as synth
+from crnerf_amd import autograd as AG
+from crnerf_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def C(a):
+    return T(np.ascontiguousarray(a)).to(DEV)
+
+
+class _Args:
+    nerf_out_dim, img_wh, pertubeCord = 64, [8, 8], False
+
+
+def _inputs(R, Nc, Ni, seed=0):
+    rng = np.random.default_rng(seed)
+    rays = synth.rays(R, seed=seed)
+    z = np.sort(rng.uniform(rays[:, 6:7], rays[:, 7:8], (R, Nc)).astype(np.float32), -1)
+    u = rng.uniform(0, 1, (R, max(Ni, 1))).astype(np.float32)
+    return C(rays), C(z), C(u), C(rng.normal(size=(R, Nc)).astype(np.float32)), C(rng.normal(size=(R, Nc + Ni)).astype(np.float32))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("R,Nc,Ni", [(37, 64, 64), (5, 33, 20), (16, 64, 0), (9, 256, 256)])
+def test_train_forward_equals_inference_and_standalone_twins(R, Nc, Ni):
+    st_c, st_f = {k: C(v) for k, v in synth.mlp_state(5, 2.0, 0.5).items()}, {k: C(v) for k, v in synth.mlp_state(6, 2.0, 0.5).items()}
+    pc, pf = ops.pack_mlp_weights(st_c), ops.pack_mlp_weights(st_f)
+    rays, z, u, nc, nf = _inputs(R, Nc, Ni)
+    kw = dict(z_coarse=z, u=u if Ni else None, noise_coarse=nc, noise_fine=nf if Ni else None, noise_std=0.7)
+    inf = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, want_z_fine=True, **kw)
+    trn = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, train=True, **kw)
+    for k in inf:
+        assert torch.equal(inf[k], trn[k]), k                        # the hooks do not touch the arithmetic
+    # what was saved == what the stand-alone training forward saves for the same points
+    for tag, pk, zz, N in (("coarse", pc, z, Nc),) + ((("fine", pf, trn["z_fine"], Nc + Ni),) if Ni else ()):
+        x = AG._embed_points(rays, zz, None)
+        out, acts = ops.mlp_forward_train(pk, x)
+        raw = trn["raw_" + tag].view(-1, 65)
+        # embeddings: in-register sincosf vs the posenc kernel's -- same routine, same arguments
+        assert float((raw - out).abs().max()) <= 2e-6, tag
+        a_f, a_s = trn["acts_" + tag], acts
+        n_act = 10 * R * N * 256
+        fa, fs = a_f[:4 * n_act].view(torch.float32).view(10, R * N, 256), a_s[:4 * n_act].view(torch.float32).view(10, R * N, 256)
+        assert float((fa[:9] - fs[:9]).abs().max()) <= 2e-5 * float(fs[:9].abs().max()) and float((fa[9, :, :128] - fs[9, :, :128]).abs().max()) <= 2e-5
+        # relu bits are consistent with the saved activations of the same buffer
+        bits = a_f[4 * n_act:].view(torch.int64).view(10, R * N, 4)
+        g = 2
+        k = torch.arange(64, device=DEV)
+        feat = 16 * (k // 4) + 4 * g + (k % 4)
+        on = ((bits[3, :, g, None] >> k) & 1).bool()
+        assert torch.equal(on, fa[3][:, feat] > 0)
+
+
+def _modules(seed_c=41, seed_f=42):
+    from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
+    args = _Args()
+    models = {"coarse": NeRF_sigma("coarse", args, in_channels_xyz=93, in_channels_dir=27).to(DEV),
+              "fine": NeRF_sigma("fine", args, in_channels_xyz=93, in_channels_dir=27, encode_random=True).to(DEV)}
+    models["coarse"].load_state_dict({k: T(v) for k, v in synth.mlp_state(seed_c, 2.0, 0.5).items()})
+    models["fine"].load_state_dict({k: T(v) for k, v in synth.mlp_state(seed_f, 2.0, 0.5).items()})
+    return models, {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}, args
+
+
+def _grads(models, fn):
+    for m in models.values():
+        m.zero_grad(set_to_none=True)
+    fn().backward()
+    return {"%s.%s" % (t, n): p.grad.clone() for t, m in models.items() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("R", [64, 8200])     # 8200 rays x 128 samples: two ray chunks of the fused path
+def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R):
+    from crnerf_amd.models import rendering
+    models, emb, args = _modules()
+    rays, z, u, nc, nf = _inputs(R, 64, 64, seed=3)
+    gw = torch.randn(R, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gd = torch.randn(R, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def loss_of(out):
+        return ((out["feature_fine"] * gw).sum() + 0.5 * (out["feature_coarse"] * gw).sum() + (out["depth_fine"] * gd).sum()
+                + 0.1 * (out["weights_fine"] ** 2).sum())
+
+    def fused():
+        return loss_of(AG.fused_render_with_grad(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0))
+
+    def unfused():
+        return loss_of(rendering._render_unfused(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0, False, 1 << 20,
+                                                 train=True))
+    g_f = _grads(models, fused)
+    g_u = _grads(models, unfused)
+    for k in g_u:
+        scale = float(g_u[k].abs().max()) + 1e-12
+        assert float((g_f[k] - g_u[k]).abs().max()) <= 3e-4 * scale, (k, float((g_f[k] - g_u[k]).abs().max()), scale)
+    AG.set_training_recompute(True)
+    try:
+        g_r = _grads(models, fused)
+    finally:
+        AG.set_training_recompute(False)
+    for k in g_f:
+        assert torch.equal(g_r[k], g_f[k]), k       # recompute re-runs the identical forward: identical gradients
+
+
+def test_reference_signature_grad_mode_uses_fused_training_renderer():
+    from crnerf_amd.models.rendering import render_rays_cross_ray
+    models, emb, args = _modules()
+    rays = C(synth.rays(32, seed=1, H=4, W=8))
+    torch.manual_seed(0)
+    res = render_rays_cross_ray(models, emb, rays, None, 64, False, 1.0, 1.0, 64, 4096, False, args=args)
+    assert res["feature_fine"].requires_grad and res["feature_fine"].grad_fn.__class__.__name__ == "FusedRenderFnBackward"
+    assert res["feature_fine_random"] is res["feature_fine"]
+    res["feature_fine"].sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in models["fine"].parameters())
+    assert all(p.grad is None for p in models["coarse"].parameters())          # weights_coarse -> sample_pdf is detached (rendering.py:184)
