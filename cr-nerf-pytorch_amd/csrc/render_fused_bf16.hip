@@ -38,7 +38,13 @@ struct RenderParamsB {
   float* z_fine;
 };
 
+#ifdef CRNERF_TIMING
+static __device__ unsigned long long crnerf_wg_times[2 * 1024];   // per workgroup: s_memrealtime at kernel entry / exit (100 MHz), tools/wg_times.py
+#endif
 __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB a) {
+#ifdef CRNERF_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
   const int lane = threadIdx.x & 63;
@@ -151,6 +157,9 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
   }
   tm.flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CRNERF_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream) {
@@ -178,6 +187,9 @@ int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream) {
 }
 
 #ifdef CRNERF_TIMING
+extern "C" int crnerf_debug_read_wgtimes_bf16(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_wg_times), sizeof(unsigned long long) * 2 * 1024);
+}
 extern "C" int crnerf_debug_read_timing_bf16(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_timing), sizeof(unsigned long long) * T_COUNT);
 }
