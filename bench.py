@@ -194,14 +194,16 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
     with torch.no_grad():
         pcb, pfb = ops.pack_mlp_weights(to_dev(st_c), precision="bf16"), ops.pack_mlp_weights(to_dev(st_f), precision="bf16")
         n = max(a.steps, 50)
+        # n launches back to back between ONE pair of events, nothing but the C call on the host side between them: a per-launch
+        # event pair (and ~100 us of Python per ops.render_rays call) would be charged to a 0.24 ms kernel; the fp32 kernel's
+        # 2.26 ms hides both.  This average is what rocprofv3 --kernel-trace reports as the kernel's duration.
+        launch, _ = ops.render_rays(pcb, pfb, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="bf16", launcher=True)
         for _ in range(5):
-            ops.render_rays(pcb, pfb, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="bf16")
-        # n launches back to back between ONE pair of events: a per-launch event pair adds ~15-25 us of event / submission latency to a
-        # 0.24 ms kernel (the fp32 kernel's 2.26 ms hides it); this average is what rocprofv3 --kernel-trace reports as the kernel's duration
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
-            ops.render_rays(pcb, pfb, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="bf16")
+            launch()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n

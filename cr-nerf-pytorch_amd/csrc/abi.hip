@@ -37,6 +37,16 @@ int num_cus() {
   return cached[dev];
 }
 
+unsigned int* sched_slot(const void* symbol) {
+  static std::mutex mu;
+  static int cursor = 0;
+  void* base = nullptr;
+  if (hipGetSymbolAddress(&base, symbol) != hipSuccess || !base) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  const int k = cursor++ % SCHED_SLOTS;
+  return (unsigned int*)base + 2 * k;
+}
+
 int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
   struct Slot { const void* fn; int dev; size_t bytes; };
   static Slot slots[128];

@@ -11,6 +11,13 @@ int check_launch(const char* what);
 // compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached per device): the persistent kernels launch
 // one workgroup per CU
 int num_cus();
+// Dynamic work distribution of the persistent renderers (launches with more ray quads than workgroups): a slot of two device
+// counters {next quad, finished workgroups}, zero between launches (the last workgroup to finish resets its slot).  Slots rotate
+// so that launches in flight on different streams do not share one.  Why: the eight XCDs do not run at the same clock under
+// MFMA load (tools/wg_times.py: workgroup lifetimes differ by up to 10 % between XCDs), so a static quad -> workgroup map makes
+// every launch as slow as its slowest XCD.
+constexpr int SCHED_SLOTS = 64;
+unsigned int* sched_slot(const void* symbol);   // symbol: the translation unit's `__device__ unsigned int [SCHED_SLOTS][2]` array
 // raises `fn`'s dynamic-LDS limit to `bytes` once per (function, device) instead of on every launch; returns 0 or an error code
 int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
 

@@ -21,8 +21,11 @@ struct RenderParams16 {
   const float* rays; const float* view_dir; const float* z_coarse; const float* z_steps; const float* u; long u_stride;
   const float* noise_c; const float* noise_f; float noise_std; int use_disp;
   long R; int Nc, Ni, iters;
+  unsigned int* sched;   // null: static quad -> workgroup map (iters passes); else {next-quad counter, finished-workgroup counter}
   float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
 };
+
+static __device__ unsigned int crnerf_sched16[SCHED_SLOTS][2];   // kernels.h "Dynamic work distribution"
 
 constexpr int PAIR_FLOATS = 4 * MAX_NC + (MAX_NC + MAX_NI) + 128;   // zc, wc, cdf, zf(<=MAX_NI==MAX_NC), zs, exchange
 constexpr int PAIR_BYTES = PAIR_FLOATS * 4;
@@ -157,9 +160,17 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
   PhaseTimer tm;
   tm.start(blockIdx.x == 0 && threadIdx.x == 0);
 
+  // ray quads: statically strided over the grid, or (a.sched) pulled from a device counter -- the index for the NEXT pass is
+  // requested at the top of a pass and picked up at its end, so the atomic's round trip is never waited for
+  __attribute__((address_space(3))) unsigned int* qslot =
+      (__attribute__((address_space(3))) unsigned int*)(lds + LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float));
+  const long quads = (a.R + 3) / 4;
+  long quad = blockIdx.x;
 #pragma unroll 1
-  for (int it = 0; it < a.iters; ++it) {
-    const long rr = ((long)it * gridDim.x + blockIdx.x) * 4 + pair;
+  for (int it = 0; a.sched ? quad < quads : it < a.iters; ++it) {
+    unsigned int nxt = 0;
+    if (a.sched && threadIdx.x == 0) nxt = gridDim.x + atomicAdd(a.sched, 1u);
+    const long rr = quad * 4 + pair;
     const bool ray_ok = rr < a.R;
     const long r = ray_ok ? rr : a.R - 1;
     const float* ray = a.rays + r * 8;
@@ -270,7 +281,13 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
       }
       tm.tick(T_RAYLEVEL);
     }
+    if (a.sched && threadIdx.x == 0) *qslot = nxt;
     wg_barrier();   // scratch is rewritten by the next ray
+    quad = a.sched ? (long)__builtin_amdgcn_readfirstlane((int)*qslot) : quad + gridDim.x;   // slot rewritten a whole pass later
+  }
+  if (a.sched && threadIdx.x == 0 && atomicAdd(a.sched + 1, 1u) == gridDim.x - 1) {   // last workgroup out: leave the slot zeroed
+    atomicExch(a.sched, 0u);       // device-scope, like the increments: the per-XCD L2s are not coherent for plain stores
+    atomicExch(a.sched + 1, 0u);
   }
   tm.flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,7 +317,8 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   const int cus = num_cus();
   const int grid = (int)(quads < cus ? quads : cus);
   k.iters = (int)((quads + grid - 1) / grid);
-  const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float);
+  k.sched = k.iters > 1 ? sched_slot((const void*)crnerf_sched16) : nullptr;
+  const size_t shmem = LDS_SCRATCH + 4 * PAIR_BYTES + V16_WAVES * 32 * sizeof(float) + 16;
   if (a.train_acts_coarse) {
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train: raw_coarse is NULL");

@@ -29,6 +29,7 @@ struct RenderParamsB {
   long R;
   int Nc, Ni;
   int iters;
+  unsigned int* sched;   // null: static quad -> workgroup map (iters passes); else {next-quad counter, finished-workgroup counter}
   float* weights_c;
   float* feature_c;
   float* depth_c;
@@ -38,6 +39,7 @@ struct RenderParamsB {
   float* z_fine;
 };
 
+static __device__ unsigned int crnerf_sched_bf16[SCHED_SLOTS][2];   // kernels.h "Dynamic work distribution"
 #ifdef CRNERF_TIMING
 static __device__ unsigned long long crnerf_wg_times[2 * 1024];   // per workgroup: s_memrealtime at kernel entry / exit (100 MHz), tools/wg_times.py
 #endif
@@ -64,9 +66,16 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
   pipe.prime(q);
   tm.tick(T_RAYLEVEL);   // kernel prologue: constants into LDS, first three weight stages in flight, first fragments read
 
+  // ray quads: statically strided over the grid, or (a.sched) pulled from a device counter -- the index for the NEXT pass is
+  // requested at the top of a pass and picked up at its end, so the atomic's round trip is never waited for
+  __attribute__((address_space(3))) unsigned int* qslot = (__attribute__((address_space(3))) unsigned int*)(lds + LDS_SCRATCH + 4 * SCRATCH_BYTES);
+  const long quads = (a.R + 3) / 4;
+  long quad = blockIdx.x;
 #pragma unroll 1
-  for (int it = 0; it < a.iters; ++it) {
-    const long rr = ((long)it * gridDim.x + blockIdx.x) * 4 + wave;
+  for (int it = 0; a.sched ? quad < quads : it < a.iters; ++it) {
+    unsigned int nxt = 0;
+    if (a.sched && threadIdx.x == 0) nxt = gridDim.x + atomicAdd(a.sched, 1u);
+    const long rr = quad * 4 + wave;
     const bool ray_ok = rr < a.R;
     const long r = ray_ok ? rr : a.R - 1;
     const float* ray = a.rays + r * 8;
@@ -154,6 +163,18 @@ __global__ __launch_bounds__(256, 1) void render_rays_bf16_kernel(RenderParamsB 
       }
       tm.tick(T_RAYLEVEL);
     }
+    if (a.sched) {
+      if (threadIdx.x == 0) *qslot = nxt;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      quad = (long)__builtin_amdgcn_readfirstlane((int)*qslot);   // rewritten only at the end of the next pass, many barriers later
+    } else {
+      quad += gridDim.x;
+    }
+  }
+  if (a.sched && threadIdx.x == 0 && atomicAdd(a.sched + 1, 1u) == gridDim.x - 1) {   // last workgroup out: leave the slot zeroed
+    atomicExch(a.sched, 0u);       // device-scope, like the increments: the per-XCD L2s are not coherent for plain stores
+    atomicExch(a.sched + 1, 0u);
   }
   tm.flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,7 +201,8 @@ int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream) {
   const int cus = num_cus();
   const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
   k.iters = (int)((quads + grid - 1) / grid);
-  const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES;
+  k.sched = k.iters > 1 ? sched_slot((const void*)crnerf_sched_bf16) : nullptr;
+  const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES + 16;
   if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16_kernel, shmem, "render_rays_bf16_kernel")) return rc;
   hipLaunchKernelGGL(render_rays_bf16_kernel, dim3(grid), dim3(256), shmem, stream, k);
   return check_launch("render_rays_bf16_kernel");

@@ -175,7 +175,7 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
 
 
 def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
-                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False):
+                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False, launcher=False):
     """Fused renderer.  Returns a dict of freshly allocated tensors.  train=True (fp32 only): the training twin
     crnerf_render_rays_train_f32 -- the dict additionally holds what the backward needs: z_coarse (as used), z_fine,
     acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65]."""
@@ -213,6 +213,16 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine"):
         setattr(a, k, out[k].data_ptr() if k in out else None)
+    if launcher:      # measurement helper: re-launch the same call on the same buffers with nothing but the C call on the host side
+        if train:
+            raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
+        fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
+        name = "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"
+        held = (keep, rays, packed_coarse, packed_fine)      # the argument struct holds raw pointers: keep their tensors alive
+
+        def launch(_held=held):
+            _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), name)
+        return launch, out
     if train:
         Nf = Nc + Ni
         out["acts_coarse"] = torch.empty(lib.crnerf_mlp_train_acts_bytes(R * Nc), dtype=torch.uint8, device=dev)

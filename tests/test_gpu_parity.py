@@ -255,6 +255,24 @@ def test_render_full_size_properties():
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_render_dynamic_quad_scheduling_is_invisible(precision):
+    """Launches with more ray quads than workgroups pull quads from a device counter (kernels.h "Dynamic work distribution");
+    launches that fit one pass use the static map.  Rays are independent, so both must give the same bits, launch after launch
+    (the counter slot is left zeroed by the last workgroup), for a ragged ray count too."""
+    pk = lambda st: ops.pack_mlp_weights({k: C(v) for k, v in st.items()}, precision=precision)  # noqa: E731
+    pc, pf = pk(synth.mlp_state(1, 3.0, 1.0)), pk(synth.mlp_state(2, 3.0, 1.0))
+    rays = C(synth.rays(5003, seed=2))
+    kw = dict(z_steps=torch.linspace(0, 1, 64, device=DEV), u=torch.linspace(0, 1, 32, device=DEV), precision=precision)
+    big = [ops.render_rays(pc, pf, rays, 64, 32, **kw) for _ in range(3)]          # 1251 quads > 256 workgroups: dynamic
+    parts = [ops.render_rays(pc, pf, rays[lo:lo + 1000].contiguous(), 64, 32, **kw) for lo in range(0, 5003, 1000)]   # <= 250 quads: static
+    for k in big[0]:
+        ref = torch.cat([q[k] for q in parts], 0)
+        for b in big:
+            assert torch.equal(b[k], ref), k
+
+
+@torch.no_grad()
 @pytest.mark.parametrize("nc,ni", [(64, 64), (48, 40), (256, 256), (33, 1), (3, 5)])
 def test_render_other_sample_counts_vs_oracle(nc, ni):
     st_c, st_f = synth.mlp_state(5, 3.0, 1.0), synth.mlp_state(6, 3.0, 1.0)
