@@ -373,8 +373,15 @@ def main():
                          "flops_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(rays_np, st_c, st_f, dst, grid_hw, style.cpu().contiguous())
-            line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
+            # untimed legs; the headline line above must be printed whatever happens in them
+            try:
+                line["cpu_baseline"] = cpu_baseline(rays_np, st_c, st_f, dst, grid_hw, style.cpu().contiguous())
+            except Exception as e:   # noqa: BLE001
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
+            except Exception as e:   # noqa: BLE001
+                line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rgb_sums is not None:
             line["test_rgb_checksum_per_rank"] = rgb_sums
         print(json.dumps(line), flush=True)

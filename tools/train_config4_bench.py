@@ -56,7 +56,7 @@ rgbs = torch.rand(n_img * iw * ih, 3, device=dev)
 imgs = [torch.rand(1, 3, ih // 8, iw // 8, device=dev) * 2 - 1 for _ in range(n_img)]     # 1/8-scale appearance images, in [-1, 1]
 wh = np.array([[iw, ih]] * n_img)
 batcher = GridSampleBatcher(rays, rgbs, wh, batch_size=R, all_imgs=imgs)
-opt = torch.optim.Adam(sysm.parameters(), lr=5e-4)
+opt = torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True)   # the reference: Adam(lr, eps=1e-8) (utils/__init__.py get_optimizer); fused = one multi-tensor launch
 
 
 def step(i):
