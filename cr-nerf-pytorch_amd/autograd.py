@@ -30,7 +30,7 @@ class MlpFn(torch.autograd.Function):
     def backward(ctx, d_out):
         x, out, acts, *params = ctx.saved_tensors
         packed_t = ops.pack_mlp_weights_t(dict(zip(ops.MLP_TENSOR_NAMES, params)))
-        grads = ops.mlp_backward(packed_t, x, out, d_out.contiguous(), acts)
+        grads = ops.mlp_backward(packed_t, x, out, d_out.contiguous(), acts, wgrad_bf16=get_wgrad_bf16())
         return (None, None) + tuple(grads)
 
 
@@ -43,6 +43,20 @@ def mlp_forward_with_grad(module, x):
 
 
 _RECOMPUTE = [False]
+_WGRAD_BF16 = [False]
+
+
+def set_wgrad_precision(precision="f32"):
+    """"f32" (default): every gradient in exact fp32, as the reference's autograd.  "bf16": opt-in mixed precision for the weight
+    gradients of the 256x256 layers only (CRNERF_BWD_WGRAD_BF16, include/crnerf.h): same fp32 operands, rounded to bf16 in
+    registers, bf16 MFMA with fp32 accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
+    Forward, loss, data gradients, biases and all other tensors are unchanged."""
+    _WGRAD_BF16[0] = ops._is_bf16(precision)
+
+
+def get_wgrad_bf16():
+    import os
+    return _WGRAD_BF16[0] or os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0")
 
 
 def set_training_recompute(flag=True):
@@ -128,7 +142,8 @@ class FusedRenderFn(torch.autograd.Function):
             d_raw = ops.composite_backward(raw, z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
                                            None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
             x = _embed_points(rays, z, cfg["view_dir"])
-            grads += ops.mlp_backward(ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65), d_raw.view(-1, 65), acts)
+            grads += ops.mlp_backward(ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65), d_raw.view(-1, 65), acts,
+                                      wgrad_bf16=get_wgrad_bf16())
             del x, d_raw
         return (None, None) + tuple(grads)
 

@@ -134,12 +134,18 @@ int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out,
 
 int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                             float* const* grads, int64_t n, void* stream) {
+  return crnerf_mlp_backward_ex_f32(packed_t, x, out, d_out, acts, scratch, grads, n, 0, stream);
+}
+
+int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
+                               float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
+  if (flags & ~CRNERF_BWD_WGRAD_BF16) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: unknown flag bits");
   REQUIRE(packed_t, "packed_t"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
   REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward: a gradient pointer is NULL");
-  return launch_mlp_backward(packed_t, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream);
+  return launch_mlp_backward(packed_t, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags);
 }
 
 int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream) {

@@ -35,8 +35,9 @@ int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream);
 size_t mlp_train_acts_bytes(long P);
 size_t mlp_train_scratch_bytes(long P);
 int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream);
+// flags: bit 0 = weight gradients of the 256 x 256 layers from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
-                        float* const* grads, long P, hipStream_t stream);
+                        float* const* grads, long P, hipStream_t stream, int flags = 0);
 int launch_ray_directions(float fx, float fy, float cx, float cy, int H, int W, float* dirs, hipStream_t stream);
 int launch_rays_from_directions(const float* dirs, const float* c2w_host, long n, float* rays_o, float* rays_d, hipStream_t stream);
 int launch_generate_rays(const float* intr4_host, const float* c2w_host, int H, int W, float near, float far, float* rays, hipStream_t stream);
@@ -44,8 +45,9 @@ size_t encoder_workspace_bytes(int H, int W);
 int launch_encoder_forward(const float* img, int H, int W, const float* const* w, void* workspace, float* out, hipStream_t st);
 // dst[m*ldc + n] = sum_p D[p][m] * A[p][n] (and db[m] = sum_p D[p][m] when db != null); ws: wgrad_workspace_floats()
 size_t wgrad_workspace_floats(long P, int M, int N);
+// bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st);
+          hipStream_t st, int bf16 = 0);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,

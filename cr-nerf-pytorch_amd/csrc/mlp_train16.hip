@@ -182,6 +182,7 @@ struct WgradJob {
   float* partial;                      // [nchunk][M][N]
   float* bias_partial;                 // [nchunk][M] column sums of D (bias gradient) or null
   long P; int chunk;
+  int bf16;                            // != 0: the full 256 x 256 tiles multiply bf16-rounded operands (fp32 accumulate), see wgrad_kernel
 };
 
 template <int MT, int NT>
@@ -303,10 +304,72 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     // column 4i + t, so a lane's four operands of a point are ONE 16-byte load (512 contiguous bytes per half-wave) and
     // the whole k-step is 2 x global_load_dwordx4 + 16 MFMAs.  (The guarded generic loop below puts a branch around
     // every load and MFMA; hipcc then waits vmcnt(0) at each join, i.e. for the prefetch it has just issued.)
-    constexpr int KF = 4;
     const float* dbase = j.D + m0 + 4 * i;
     const float* abase = j.A + n0 + 4 * i;
     const long plast = p1 - 1;
+    if (j.bf16) {
+      // ---- opt-in mixed precision (crnerf_mlp_backward_ex_f32, CRNERF_BWD_WGRAD_BF16): the SAME fp32 operands from HBM, rounded to
+      // bf16 (RNE) in registers and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  k-step = 16 points; lane
+      // (i, kk) supplies points 8kk..8kk+7 of the step for its four columns 4i..4i+3 (one 16-byte load per point and operand,
+      // exactly the bytes of the fp32 path).  The matrix work shrinks 16x, so the kernel runs at the HBM rate of its operand
+      // reads (2 KB per point and layer).  The bias gradient is summed from the un-rounded deltas.
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      f32x4 dcur[8], acur[8], dnxt[8], anxt[8];
+      auto fetch16 = [&](long pb, f32x4 (&d)[8], f32x4 (&a)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const long pt = pb + 8 * kk + e;
+          const long pc = pt < plast ? pt : plast;
+          const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
+          const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
+          const float keep = pt < p1 ? 1.0f : 0.0f;
+          d[e] = dv * keep;
+          a[e] = av;
+        }
+      };
+      auto frag = [&](const f32x4 (&v)[8], int t) {
+        union { bf16x2_t h[4]; bf16x8_t v8; } u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.h[q] = bf16x2_t{(__bf16)v[2 * q][t], (__bf16)v[2 * q + 1][t]};   // v_cvt_pk_bf16_f32
+        return u.v8;
+      };
+      const bool do_bias16 = j.bias_partial && blockIdx.z == 0 && bias_wave;
+      f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
+      fetch16(p0, dcur, acur);
+      for (long pb = p0; pb < p1; pb += 16) {
+        fetch16(pb + 16, dnxt, anxt);
+        if (do_bias16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += dcur[e];
+        }
+        bf16x8_t df[4], af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { df[t] = frag(dcur, t); af[t] = frag(acur, t); }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a], af[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+      }
+      if (do_bias16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bsum[t] += __shfl_xor(bsum[t], 32);
+        if (kk == 0) *(f32x4*)(j.bias_partial + (long)blockIdx.x * j.M + m0 + 4 * i) = bsum;
+      }
+      float* outp16 = j.partial + (long)blockIdx.x * j.M * j.N;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
+          const f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+          *(f32x4*)(outp16 + (long)m * j.N + n0 + 4 * i) = v;
+        }
+      return;
+    }
+    constexpr int KF = 4;
     f32x4 dc[KF], ac[KF], dnx[KF], anx[KF];
     auto fetch4 = [&](long pb, f32x4 (&d)[KF], f32x4 (&a)[KF]) {
 #pragma unroll
@@ -404,11 +467,11 @@ size_t wgrad_workspace_floats(long P, int M, int N) {
 }
 
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st) {
+          hipStream_t st, int bf16) {
   const int chunk = wg_chunk(P);
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
-  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk};
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16};
   hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);
   return 0;
@@ -437,7 +500,8 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
 
 // grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
-                        float* const* grads, long P, hipStream_t stream) {
+                        float* const* grads, long P, hipStream_t stream, int flags) {
+  const int wb = flags & 1;
   if (P <= 0) return 0;
   float* deltas = (float*)scratch;
   float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
@@ -456,12 +520,12 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
       wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream);
-      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream);
+      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb);
     } else {
-      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream);
+      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb);
     }
   }
-  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream);            // xyz_encoding_final
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb);            // xyz_encoding_final
   wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
   wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream);  // dir_encoding: cat([final, dir])
   wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream);

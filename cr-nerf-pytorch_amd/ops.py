@@ -84,16 +84,18 @@ def mlp_forward_train(packed, x):
     return out, acts
 
 
-def mlp_backward(packed_t, x, out, d_out, acts):
-    """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order."""
+def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
+    """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: CRNERF_BWD_WGRAD_BF16
+    (include/crnerf.h) -- the 256x256 layers' weight gradients from bf16-rounded operands, everything else exact fp32."""
     lib = _lib.load()
     x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
     n = x.shape[0]
     grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
     scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
-    _lib.check(lib.crnerf_mlp_backward_f32(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
-                                           ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
-                                           _lib.ptr_array(grads, "grad"), n, _lib.stream_ptr()), "crnerf_mlp_backward_f32")
+    _lib.check(lib.crnerf_mlp_backward_ex_f32(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
+                                              ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
+                                              _lib.ptr_array(grads, "grad"), n, 1 if wgrad_bf16 else 0, _lib.stream_ptr()),
+               "crnerf_mlp_backward_ex_f32")
     return grads
 
 
