@@ -242,3 +242,49 @@ def test_content_decoder_backward_vs_autograd():
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-4)
     torch.testing.assert_close(net.decoder.feat_2_rgb_list[0].weight.grad.cpu().reshape(3, 64), w.grad, atol=1e-5, rtol=1e-4)
     torch.testing.assert_close(net.decoder.feat_2_rgb_list[0].bias.grad.cpu(), b.grad, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("which", ["content_wo_a_embed", "content_with_a_embed"])
+def test_loss_backward_when_only_one_side_of_the_content_pair_needs_grad(which):
+    """Round-1 advisor finding: the content-constraint gradient was guarded by d_c_wo alone -- a NULL write when only
+    content_wo_a_embed required grad, an unwritten torch.empty when only content_with_a_embed did."""
+    gen = torch.Generator().manual_seed(3)
+    R = 300
+    rc = torch.rand(R, 3, generator=gen).to(DEV)
+    tg = torch.rand(R, 3, generator=gen).to(DEV)
+    a = torch.rand(1, 64, 32, 32, generator=gen).to(DEV)
+    c = {"content_wo_a_embed": torch.rand(1, 64, 32, 32, generator=gen).to(DEV), "content_with_a_embed": torch.rand(1, 64, 32, 32, generator=gen).to(DEV)}
+    c[which].requires_grad_(True)
+    hp = HP()
+    ret, _ = CRNeRFLoss(hp)({"rgb_coarse": rc, "a_embedded": a, **c}, tg, hp, 0)
+    ret["content_constraint"].backward()
+    d = c["content_wo_a_embed"].detach() - c["content_with_a_embed"].detach()
+    want = (2.0 * d / d.numel()) * hp.weightcontent * (1.0 if which == "content_wo_a_embed" else -1.0)
+    torch.testing.assert_close(c[which].grad, want, rtol=1e-5, atol=1e-12)
+    other = "content_with_a_embed" if which == "content_wo_a_embed" else "content_wo_a_embed"
+    assert c[other].grad is None
+
+
+@torch.no_grad()
+def test_packed_weight_cache_follows_p_data_updates_through_train_and_invalidate():
+    """Round-1 advisor finding: optimisers that write p.data (torch_optimizer radam / ranger) do not bump p._version, the packed
+    cache's key.  train(), load_state_dict(), a grad-mode forward and invalidate_packed() drop the cache."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd.models.nerf import NeRF_sigma
+
+    class A:
+        nerf_out_dim = 64
+    m = NeRF_sigma("coarse", A(), in_channels_xyz=93, in_channels_dir=27).to(DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(3, 2.0).items()})
+    x = torch.rand(64, 120, generator=torch.Generator().manual_seed(0)).to(DEV)
+    y0 = m(x).clone()
+    m.static_rgb[0].bias.data.add_(0.5)                 # the update path that leaves _version alone
+    m.invalidate_packed()
+    y1 = m(x).clone()
+    assert float((y1[:, :64] - y0[:, :64]).abs().max()) > 1e-3
+    m.static_rgb[0].bias.data.add_(0.5)
+    m.train()                                            # Lightning calls this after every validation loop
+    y2 = m(x).clone()
+    assert float((y2[:, :64] - y1[:, :64]).abs().max()) > 1e-3
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(3, 2.0).items()})
+    assert torch.equal(m(x), y0)
