@@ -25,6 +25,7 @@
 // activations stay in registers, the 72 KiB of weights sit in LDS as A-operand fragments, and the
 // 32x32 Gram update itself is 16 more MFMAs per tile (H H^T through a 4 KiB LDS transpose).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "crossray.h"
 
@@ -812,6 +813,128 @@ __global__ __launch_bounds__(64) void dec_bwd_chain_kernel(ChainJob j0, ChainJob
   }
 }
 
+// ---- the same chain on the fp32 MFMA (round 2).  One thread per pixel (kernel above) is 40 k broadcast-LDS FMAs in a row:
+// 0.3 ms per launch whatever the grid size, 0.9 ms of a 14.8 ms training step at the reference's 1,024-ray batch.  Here a wavefront
+// owns 32 pixels, swapped-operand like the Gram kernel: D[feature][pixel] = M[feature][k] . src[k][pixel], activations and deltas
+// stay in registers through the three forward and four backward products, the seven matrices (W1, W2, W3, S, W3^T, W2^T, W1^T)
+// sit in LDS as A-operand fragments.  frag(v, t)[lane = 32 kk + i][j] = M[32 t + i][8 v + 4 kk + j].
+constexpr int CF_L1 = 0;                    // W1   [128 x  64]: 8 k-groups x 4 tiles = 32 fragments
+constexpr int CF_L2 = CF_L1 + 32 * 256;     // W2   [ 64 x 128]: 16 x 2 = 32
+constexpr int CF_L3 = CF_L2 + 32 * 256;     // W3   [ 32 x  64]: 8 x 1 = 8
+constexpr int CF_S = CF_L3 + 8 * 256;       // S    [ 32 x  32]: 4 x 1 = 4
+constexpr int CF_T3 = CF_S + 4 * 256;       // W3^T [ 64 x  32]: 4 x 2 = 8
+constexpr int CF_T2 = CF_T3 + 8 * 256;      // W2^T [128 x  64]: 8 x 4 = 32
+constexpr int CF_T1 = CF_T2 + 32 * 256;     // W1^T [ 64 x 128]: 16 x 2 = 32
+constexpr int CF_FRAGS = 148;
+constexpr int CF_B1 = CF_T1 + 32 * 256, CF_B2 = CF_B1 + 128, CF_B3 = CF_B2 + 64, CF_MEAN = CF_B3 + 32, CF_FLOATS = CF_MEAN + 64;
+static_assert(CF_B1 == CF_FRAGS * 256 && CF_FLOATS * 4 <= 160 * 1024, "chain fragments must fit the 160 KiB LDS");
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&a)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[t][r] = 0.0f;
+}
+// rows of a pixel-major [P][ld] buffer from the D[feature][pixel] register layout: lane (p, h) holds features 32t + 8q + 4h + 0..3
+template <int NT>
+__device__ __forceinline__ void store_tiles(float* base, long px, int ld, const f32x16 (&a)[NT], int h, bool valid) {
+  if (!valid) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = {a[t][4 * q + 0], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]};
+      *(f32x4*)(base + px * ld + 32 * t + 8 * q + 4 * h) = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void dec_bwd_chain_mfma_kernel(ChainJob j0, ChainJob j1) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const bool second = (int)blockIdx.x >= j0.nblk;
+  const ChainJob J = second ? j1 : j0;
+  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  // stage the 148 fragments: element (frag, lane-slot l = 32 kk + i) = 4 consecutive columns of row 32 t + i of the matrix
+  for (int idx = tid; idx < CF_FRAGS * 64; idx += 256) {
+    const int frag = idx >> 6, l = idx & 63, i = l & 31, kk = l >> 5;
+    const float* M; int ld, nt, f; bool tr;
+    if (frag < 32) { M = J.w.w1; ld = 64; nt = 4; f = frag; tr = false; }
+    else if (frag < 64) { M = J.w.w2; ld = 128; nt = 2; f = frag - 32; tr = false; }
+    else if (frag < 72) { M = J.w.w3; ld = 64; nt = 1; f = frag - 64; tr = false; }
+    else if (frag < 76) { M = J.S; ld = 32; nt = 1; f = frag - 72; tr = false; }
+    else if (frag < 84) { M = J.w.w3; ld = 64; nt = 2; f = frag - 76; tr = true; }
+    else if (frag < 116) { M = J.w.w2; ld = 128; nt = 4; f = frag - 84; tr = true; }
+    else { M = J.w.w1; ld = 64; nt = 2; f = frag - 116; tr = true; }
+    const int v = f / nt, t = f - v * nt;
+    const int row = 32 * t + i, col = 8 * v + 4 * kk;
+    f32x4 val;
+    if (!tr) val = *(const f32x4*)(M + row * ld + col);
+    else val = f32x4{M[(col + 0) * ld + row], M[(col + 1) * ld + row], M[(col + 2) * ld + row], M[(col + 3) * ld + row]};   // M^T[row][col + j]
+    *(f32x4*)(sm + 4 * idx) = val;
+  }
+  if (tid < 128) sm[CF_B1 + tid] = J.w.b1[tid];
+  if (tid < 64) { sm[CF_B2 + tid] = J.w.b2[tid]; sm[CF_MEAN + tid] = J.mean[tid]; }
+  if (tid < 32) sm[CF_B3 + tid] = J.w.b3[tid];
+  __syncthreads();
+
+  const long tiles = (J.P + 31) / 32;
+  for (long tile = (long)wave * J.nblk + blk; tile < tiles; tile += (long)J.nblk * 4) {   // tiles spread over workgroups first
+    const long px = tile * 32 + p;
+    const bool valid = px < J.P;
+    const float* row = J.x + (valid ? px : 0) * 64;
+    f32x16 xin[2];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const f32x4 xv = *(const f32x4*)(row + 8 * v + 4 * h);
+      const f32x4 mv = *(const f32x4*)(sm + CF_MEAN + 8 * v + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xin[v >> 2][(v & 3) * 4 + j] = xv[j] - mv[j];
+    }
+    store_tiles<2>(J.xc, px, 64, xin, h, valid);
+    f32x16 a1[4], a2[2], a3[1];
+    bias_init<4>(a1, sm + CF_B1, h);
+    conv_mfma<4, 8>(sm + CF_L1, lane, xin, a1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[t][r] = lrelu02(a1[t][r]);
+    store_tiles<4>(J.h1, px, 128, a1, h, valid);
+    bias_init<2>(a2, sm + CF_B2, h);
+    conv_mfma<2, 16>(sm + CF_L2, lane, a1, a2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[t][r] = lrelu02(a2[t][r]);
+    store_tiles<2>(J.h2, px, 64, a2, h, valid);
+    bias_init<1>(a3, sm + CF_B3, h);
+    conv_mfma<1, 8>(sm + CF_L3, lane, a2, a3);
+    // backward: dh3 = S h3;  d2 = (W3^T dh3) . lrelu'(h2);  d1 = (W2^T d2) . lrelu'(h1);  dxc = W1^T d1
+    f32x16 d3[1], d2[2], d1[4], dx[2];
+    zero_tiles<1>(d3);
+    conv_mfma<1, 4>(sm + CF_S, lane, a3, d3);
+    store_tiles<1>(J.d3, px, 32, d3, h, valid);
+    zero_tiles<2>(d2);
+    conv_mfma<2, 4>(sm + CF_T3, lane, d3, d2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[t][r] *= dlrelu(a2[t][r]);
+    store_tiles<2>(J.d2, px, 64, d2, h, valid);
+    zero_tiles<4>(d1);
+    conv_mfma<4, 8>(sm + CF_T2, lane, d2, d1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[t][r] *= dlrelu(a1[t][r]);
+    store_tiles<4>(J.d1, px, 128, d1, h, valid);
+    zero_tiles<2>(dx);
+    conv_mfma<2, 16>(sm + CF_T1, lane, d1, dx);
+    store_tiles<2>(J.dxc, px, 64, dx, h, valid);
+  }
+}
+
 // dst[px][c] (+)= dxc[px][c] + (dmean[c] - colsum[c]) / P
 __global__ void dec_bwd_finish_kernel(float* __restrict__ dst, const float* __restrict__ dxc, const float* __restrict__ dmean,
                                       const float* __restrict__ colsum, long P, int accumulate) {
@@ -877,9 +1000,19 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   const int nb_c = (int)((HW + 63) / 64 < 1024 ? (HW + 63) / 64 : 1024), nb_s = (int)((HWs + 63) / 64 < 1024 ? (HWs + 63) / 64 : 1024);
   ChainJob jc{d.content, HW, st + ST_CMEAN, d.cnet, S_c, xc[0], h1[0], h2[0], d1[0], d2[0], d3[0], dxc[0], nb_c};
   ChainJob js{d.style, HWs, st + ST_SMEAN, d.snet, S_s, xc[1], h1[1], h2[1], d1[1], d2[1], d3[1], dxc[1], nb_s};
-  const size_t shmem = (size_t)CH_FLOATS * 4;
-  if (int rc = ensure_dynamic_lds((const void*)dec_bwd_chain_kernel, shmem, "dec_bwd_chain_kernel")) return rc;
-  hipLaunchKernelGGL(dec_bwd_chain_kernel, dim3(nb_c + nb_s), dim3(64), shmem, stream, jc, js);
+  static const bool scalar_chain = getenv("CRNERF_CHAIN_SCALAR") != nullptr;     // A/B switch for the round-1 one-thread-per-pixel kernel
+  if (scalar_chain) {
+    const size_t shmem = (size_t)CH_FLOATS * 4;
+    if (int rc = ensure_dynamic_lds((const void*)dec_bwd_chain_kernel, shmem, "dec_bwd_chain_kernel")) return rc;
+    hipLaunchKernelGGL(dec_bwd_chain_kernel, dim3(nb_c + nb_s), dim3(64), shmem, stream, jc, js);
+  } else {
+    const long tc = (HW + 31) / 32, ts = (HWs + 31) / 32;
+    jc.nblk = (int)(tc < 256 ? tc : 256);
+    js.nblk = (int)(ts < 256 ? ts : 256);
+    const size_t shmem = (size_t)CF_FLOATS * 4;
+    if (int rc = ensure_dynamic_lds((const void*)dec_bwd_chain_mfma_kernel, shmem, "dec_bwd_chain_mfma_kernel")) return rc;
+    hipLaunchKernelGGL(dec_bwd_chain_mfma_kernel, dim3(jc.nblk + js.nblk), dim3(256), shmem, stream, jc, js);
+  }
   // 6. conv weight / bias gradients: snet = grads[0..5], cnet = grads[8..13]
   for (int net = 0; net < 2; ++net) {
     const long P = net ? HWs : HW;
