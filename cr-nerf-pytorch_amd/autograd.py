@@ -35,7 +35,7 @@ class MlpFn(torch.autograd.Function):
 
 
 def mlp_forward_with_grad(module, x):
-    params = [dict(module.named_parameters())[n] for n in ops.MLP_TENSOR_NAMES]
+    params = list(ops.mlp_params(module))
     if x.requires_grad:
         raise NotImplementedError("crnerf_amd: gradients w.r.t. the embedded input of NeRF_sigma are not implemented "
                                   "(the rendering path never needs them: embeddings are functions of fixed ray geometry)")
@@ -159,7 +159,7 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
         z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
         z_coarse = z_coarse.expand(R, Nc).contiguous()
     names = ops.MLP_TENSOR_NAMES
-    params = [dict(coarse.named_parameters())[n] for n in names] + ([dict(fine.named_parameters())[n] for n in names] if Ni > 0 else [])
+    params = list(ops.mlp_params(coarse)) + (list(ops.mlp_params(fine)) if Ni > 0 else [])
     step = max(4, ((1 << 20) // (Nc + Ni)) // 4 * 4)
     parts = []
     for lo in range(0, R, step):

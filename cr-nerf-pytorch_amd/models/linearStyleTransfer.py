@@ -99,7 +99,7 @@ class encoder_sameoutputsize(nn.Module):
         if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3:
             raise ValueError("encoder_sameoutputsize expects [1,3,H,W], got %s" % (tuple(x.shape),))
         convs = (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or ops.any_requires_grad(self)):
             from ..autograd import EncoderFn   # training: HIP forward-with-save + HIP backward (csrc/encoder_train.hip)
             grid = EncoderFn.apply(x.to(torch.float32).contiguous(), *[t for c in convs for t in (c.weight, c.bias)])
             return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)
@@ -129,7 +129,7 @@ class style_net(nn.Module):
         return k.crossray_fold(s_matrix, c_matrix, c_mean, s_mean, mn.lin_tensors() + list(self.decoder.rgb_tensors()))
 
     def forward(self, content_feature, style_feature, type=None):
-        train = torch.is_grad_enabled() and (content_feature.requires_grad or any(p.requires_grad for p in self.parameters()))
+        train = torch.is_grad_enabled() and (content_feature.requires_grad or ops.any_requires_grad(self))
         if style_feature is None and type == "content":
             if train:   # decoder only: sigmoid(1x1 conv), nerf_decoder_stylenerf.py:279-291 (n_blocks == 0)
                 from ..autograd import ContentDecoderFn

@@ -80,8 +80,8 @@ class NeRF_sigma(nn.Module):
     def packed_weights(self, precision="f32"):
         """Packed buffer for the crnerf_*_f32 (default) or crnerf_*_bf16 entry points; re-packed when a parameter changes."""
         bf16 = ops._is_bf16(precision)
-        params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        params = dict(zip(ops.MLP_TENSOR_NAMES, ops.mlp_params(self)))
+        key = tuple((p.data_ptr(), p._version, p.device) for p in params.values())
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key
@@ -91,7 +91,7 @@ class NeRF_sigma(nn.Module):
 
     def forward(self, x, sigma_only=False, output_random=True, precision=None):
         """precision: None -> crnerf_amd.get_precision(); an extension of the reference signature (nerf.py:157)."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or ops.any_requires_grad(self)):
             if sigma_only:
                 raise NotImplementedError("crnerf_amd: sigma_only has no backward twin (no reference caller uses it)")
             from ..autograd import mlp_forward_with_grad   # training: HIP forward-with-save + HIP backward

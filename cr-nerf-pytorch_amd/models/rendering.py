@@ -98,7 +98,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     for m in (coarse, fine):
         if m is not None and not isinstance(m, NeRF_sigma):
             raise NotImplementedError("crnerf_amd: models must be crnerf_amd NeRF_sigma instances")
-    train = torch.is_grad_enabled() and any(p.requires_grad for m in (coarse, fine) if m is not None for p in m.parameters())
+    train = torch.is_grad_enabled() and any(ops.any_requires_grad(m) for m in (coarse, fine) if m is not None)
     precision = kwargs.get('precision', None)
     if precision is None:
         from .. import get_precision

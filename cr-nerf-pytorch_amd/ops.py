@@ -15,6 +15,35 @@ MLP_TENSOR_SHAPES = (
     + [(256, 256), (256,), (1, 256), (1,), (128, 283), (128,), (64, 128), (64,)])
 
 
+def cached_params(module):
+    """tuple(module.parameters()) looked up once: nn.Module.parameters() walks the module tree on every call, and the grad-mode
+    checks of the shim modules ran it ~6,000 generator steps per training step (1-2 ms of host time at the reference's 1,024-ray
+    batch, where the step is host-bound).  The shim modules create all their parameters in __init__, and nn.Module.to() /
+    load_state_dict() keep the Parameter objects, so the tuple stays valid."""
+    c = module.__dict__.get("_crnerf_pcache")
+    if c is None:
+        c = tuple(module.parameters())
+        module.__dict__["_crnerf_pcache"] = c
+    return c
+
+
+def any_requires_grad(module):
+    for q in cached_params(module):
+        if q.requires_grad:
+            return True
+    return False
+
+
+def mlp_params(module):
+    """The 24 NeRF_sigma parameters in MLP_TENSOR_NAMES order, looked up once per module."""
+    c = module.__dict__.get("_crnerf_mlp_params")
+    if c is None:
+        named = dict(module.named_parameters())
+        c = tuple(named[n] for n in MLP_TENSOR_NAMES)
+        module.__dict__["_crnerf_mlp_params"] = c
+    return c
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.to(torch.float32).contiguous()
