@@ -75,9 +75,16 @@ for i in range(n_warm):
     step(i)
 torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
+prof = None
+if os.environ.get("CRNERF_TRAIN_BENCH_PROFILE"):      # host-side profile of the timed steps (cProfile, top entries by internal time)
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
 t0 = time.perf_counter()
 for i in range(n):
     l = step(n_warm + i)
+if prof is not None:
+    prof.disable()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 pts = R * (NC + NC + NI)
@@ -94,5 +101,10 @@ if world > 1:
     print("ranks %d: loss and parameter checksums identical on every rank: %s" % (world, same), flush=True)
     if not same:
         raise SystemExit("replicas diverged: %s" % [c.tolist() for c in allc])
+if prof is not None:
+    import io, pstats
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+    print(buf.getvalue())
 print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.1f ms -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
       % (R, side, side, NC, NI, dt * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
