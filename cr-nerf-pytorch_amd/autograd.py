@@ -21,14 +21,22 @@ class MlpFn(torch.autograd.Function):
         if module is not None and hasattr(module, "invalidate_packed"):
             module.invalidate_packed()       # an optimiser step follows; optimisers that write p.data do not bump p._version
         state = dict(zip(ops.MLP_TENSOR_NAMES, params))
-        packed = ops.pack_mlp_weights(state)
-        out, acts = ops.mlp_forward_train(packed, x)
+        ctx.mixed = None
+        if get_training_bf16():
+            packed, tensors = ops.pack_mlp_weights_mixed(state)
+            out, acts = ops.mlp_forward_train_mixed(packed, tensors, x)
+            ctx.mixed = packed          # forward and transposed fragment streams: the backward needs no second pack
+        else:
+            out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(state), x)
         ctx.save_for_backward(x, out, acts, *params)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         x, out, acts, *params = ctx.saved_tensors
+        if ctx.mixed is not None:
+            tensors = [p.detach() for p in params]
+            return (None, None) + tuple(ops.mlp_backward_mixed(ctx.mixed, tensors, x, out, d_out.contiguous(), acts))
         packed_t = ops.pack_mlp_weights_t(dict(zip(ops.MLP_TENSOR_NAMES, params)))
         grads = ops.mlp_backward(packed_t, x, out, d_out.contiguous(), acts, wgrad_bf16=get_wgrad_bf16())
         return (None, None) + tuple(grads)
@@ -52,6 +60,22 @@ def set_wgrad_precision(precision="f32"):
     registers, bf16 MFMA with fp32 accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
     Forward, loss, data gradients, biases and all other tensors are unchanged."""
     _WGRAD_BF16[0] = ops._is_bf16(precision)
+
+
+_TRAIN_BF16 = [False]
+
+
+def set_training_precision(precision="f32"):
+    """"f32" (default): training through the fp32 twins -- the reference's arithmetic.  "bf16": opt-in mixed precision for NeRF_sigma
+    in grad mode (crnerf_mlp_*_mixed_f32, include/crnerf.h): forward in the arithmetic of the bf16 inference kernels, data and weight
+    gradients from bf16-rounded operands, fp32 accumulation and fp32 storage everywhere.  The renderer then runs un-fused (posenc ->
+    per-layer GEMMs -> compositing): with the matrix work 16x cheaper the MLP passes are bound by their activation traffic."""
+    _TRAIN_BF16[0] = ops._is_bf16(precision)
+
+
+def get_training_bf16():
+    import os
+    return _TRAIN_BF16[0] or os.environ.get("CRNERF_TRAIN_BF16", "") not in ("", "0")
 
 
 def get_wgrad_bf16():
@@ -148,6 +172,60 @@ class FusedRenderFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class MixedRecomputeRenderFn(torch.autograd.Function):
+    """set_training_precision("bf16") + set_training_recompute(True), one chunk of rays: the forward IS the fused bf16 inference
+    renderer (crnerf_render_rays_bf16: ~0.22 ms per 1,024 rays, nothing kept but rays / depths / noise); backward rebuilds each
+    pass from the embedded points with the mixed-precision training twins (crnerf_mlp_forward_train_mixed_f32 -> composite backward
+    -> crnerf_mlp_backward_mixed_f32) at the forward's own depths.  The two forwards implement the same arithmetic (bf16-rounded
+    operands, fp32 accumulation) with different summation orders and sin/cos routines, so the gradient is taken at outputs that
+    differ from the ones the loss saw by the bf16 kernels' mutual tolerance (mean 3e-5, tests/test_gpu_bf16.py)."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, *params):
+        ctx.set_materialize_grads(False)
+        Nc, Ni = cfg["Nc"], cfg["Ni"]
+        n_models = 2 if Ni > 0 else 1
+        states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(n_models)]
+        for mod in cfg["modules"]:
+            if mod is not None and hasattr(mod, "invalidate_packed"):
+                mod.invalidate_packed()
+        packed = [ops.pack_mlp_weights(st, precision="bf16") for st in states]
+        out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
+                              z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
+                              noise_std=cfg["noise_std"], want_z_fine=True, precision="bf16")
+        ctx.cfg, ctx.n_models = cfg, n_models
+        ctx.save_for_backward(rays, out["z_fine"] if Ni > 0 else rays.new_empty(0), *params)
+        res = (out["weights_coarse"], out["feature_coarse"], out["depth_coarse"])
+        if Ni > 0:
+            res += (out["weights_fine"], out["feature_fine"], out["depth_fine"])
+        return res
+
+    @staticmethod
+    def backward(ctx, *g):
+        cfg = ctx.cfg
+        rays, z_fine, *params = ctx.saved_tensors
+        grads = []
+        for m in range(ctx.n_models):
+            d_w, d_f, d_d = g[3 * m], g[3 * m + 1], g[3 * m + 2]
+            if d_w is None and d_f is None and d_d is None:
+                grads += [None] * 24
+                continue
+            z = z_fine if m == 1 else cfg["z_coarse"]
+            noise = cfg["noise_f"] if m == 1 else cfg["noise_c"]
+            state = dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24]))
+            packed, tensors = ops.pack_mlp_weights_mixed(state)
+            x = _embed_points(rays, z, cfg["view_dir"])
+            raw, acts = ops.mlp_forward_train_mixed(packed, tensors, x)
+            R, N = z.shape
+            if d_f is None:
+                d_f = torch.zeros(R, 64, device=raw.device)
+            d_raw = ops.composite_backward(raw.view(R, N, 65), z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
+                                           None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
+            grads += ops.mlp_backward_mixed(packed, tensors, x, raw, d_raw.view(-1, 65), acts)
+            del x, raw, acts, d_raw
+        return (None, None) + tuple(grads)
+
+
 def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std):
     """Grad-mode render of `rays` in ray chunks of ~2^20 fine sample points (rays are independent; the chunk bounds the
     backward's scratch -- 10 KB of layer deltas per point -- and, in recompute mode, the live activations)."""
@@ -168,7 +246,8 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
         cfg = {"Nc": Nc, "Ni": Ni, "use_disp": use_disp, "view_dir": sl(view_dir), "z_coarse": sl(z_coarse),
                "u": (u_steps if u is None else sl(u)) if Ni > 0 else None, "noise_c": sl(noise_c), "noise_f": sl(noise_f),
                "noise_std": float(noise_std), "modules": (coarse, fine)}
-        parts.append(FusedRenderFn.apply(cfg, rays[lo:hi].contiguous(), *params))
+        fn = MixedRecomputeRenderFn if (get_training_bf16() and get_training_recompute()) else FusedRenderFn
+        parts.append(fn.apply(cfg, rays[lo:hi].contiguous(), *params))
     keys = ["weights_coarse", "feature_coarse", "depth_coarse"] + (["weights_fine", "feature_fine", "depth_fine"] if Ni > 0 else [])
     return {k: (parts[0][i] if len(parts) == 1 else torch.cat([p[i] for p in parts], 0)) for i, k in enumerate(keys)}
 

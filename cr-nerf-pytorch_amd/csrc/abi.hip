@@ -216,6 +216,35 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
 int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false); }
 int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
 
+size_t crnerf_packed_mlp_mixed_bytes(void) { return gemm_packed_bytes(); }
+
+int crnerf_pack_mlp_weights_mixed(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_mixed: a tensor pointer is NULL");
+  return launch_pack_mlp_gemm(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_train_mixed_f32(const float* const* tensors, const void* packed, const float* x, float* out, void* acts, int64_t n,
+                                       void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(acts, "acts");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_train_mixed: negative n");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "mlp_forward_train_mixed: a tensor pointer is NULL");
+  return launch_mlp_forward_train_mixed(to_tensors(tensors), packed, x, out, (float*)acts, (long)n, (hipStream_t)stream);
+}
+
+int crnerf_mlp_backward_mixed_f32(const float* const* tensors, const void* packed, const float* x, const float* out, const float* d_out,
+                                  const void* acts, void* scratch, float* const* grads, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
+  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_mixed: a tensor / gradient pointer is NULL");
+  return launch_mlp_backward_mixed(to_tensors(tensors), packed, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream);
+}
+
 int crnerf_render_rays_train_f32(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
                                  void* stream) {
   REQUIRE(a, "args");

@@ -38,6 +38,14 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
 // flags: bit 0 = weight gradients of the 256 x 256 layers from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags = 0);
+int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
+                      long P, hipStream_t stream, int wb);
+// mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs on the fp32 buffers of the fp32 twins
+size_t gemm_packed_bytes();
+int launch_pack_mlp_gemm(const MlpTensors& t, void* packed, hipStream_t st);
+int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, float* acts, long P, hipStream_t st);
+int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const float* acts,
+                              void* scratch, float* const* grads, long P, hipStream_t st);
 int launch_ray_directions(float fx, float fy, float cx, float cy, int H, int W, float* dirs, hipStream_t stream);
 int launch_rays_from_directions(const float* dirs, const float* c2w_host, long n, float* rays_o, float* rays_d, hipStream_t stream);
 int launch_generate_rays(const float* intr4_host, const float* c2w_host, int H, int W, float near, float far, float* rays, hipStream_t stream);

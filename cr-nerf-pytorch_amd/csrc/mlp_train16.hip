@@ -498,21 +498,10 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
   return check_launch("mlp_forward_train16_kernel");
 }
 
-// grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
-int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
-                        float* const* grads, long P, hipStream_t stream, int flags) {
-  const int wb = flags & 1;
-  if (P <= 0) return 0;
-  float* deltas = (float*)scratch;
-  float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
-  float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
-  float* ws = d_sig + P;
-  const long groups = (P + 127) / 128;
-  const int cus = num_cus();
-  const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
-  if (int rc = launch_core((const void*)mlp_backward16_kernel, grid, LDS_SCRATCH)) return rc;
-  hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
-  if (int rc = check_launch("mlp_backward16_kernel")) return rc;
+// The weight / bias gradients of all eleven nn.Linear from the saved activations and the stored deltas (shared by the fp32 twins and
+// the mixed-precision twins of mlp_gemm_bf16.hip).  wb != 0: bf16-operand path for the 256 x 256 layers.
+int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
+                      long P, hipStream_t stream, int wb) {
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
   // xyz_encoding_1: input x[:, :93]
@@ -531,6 +520,24 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream);
   wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream);   // static_rgb
   return check_launch("mlp_backward wgrad");
+}
+
+// grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
+int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
+                        float* const* grads, long P, hipStream_t stream, int flags) {
+  const int wb = flags & 1;
+  if (P <= 0) return 0;
+  float* deltas = (float*)scratch;
+  float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
+  float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
+  float* ws = d_sig + P;
+  const long groups = (P + 127) / 128;
+  const int cus = num_cus();
+  const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
+  if (int rc = launch_core((const void*)mlp_backward16_kernel, grid, LDS_SCRATCH)) return rc;
+  hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
+  if (int rc = check_launch("mlp_backward16_kernel")) return rc;
+  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb);
 }
 
 }  // namespace crnerf

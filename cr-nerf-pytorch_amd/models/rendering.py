@@ -118,7 +118,9 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    if train and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX and (N_importance == 0 or N_samples >= 3):
+    from ..autograd import get_training_bf16, get_training_recompute
+    if (train and (not get_training_bf16() or get_training_recompute()) and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
+            and (N_importance == 0 or N_samples >= 3)):
         # training: the fused renderer's training twin (one launch per ray chunk: posenc + MLPs + activation save + compositing +
         # sample_pdf/merge) as one autograd node whose backward runs the HIP backward twins (autograd.FusedRenderFn)
         from ..autograd import fused_render_with_grad

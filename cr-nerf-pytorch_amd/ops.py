@@ -128,6 +128,44 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
     return grads
 
 
+def pack_mlp_weights_mixed(state):
+    """bf16 B-operand fragment streams of every nn.Linear (forward and transposed) for the mixed-precision training twins
+    (crnerf_mlp_*_mixed_f32, include/crnerf.h).  Returns (packed, tensors): the twins also read the fp32 biases / sigma head."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_mixed_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_mixed(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_mixed")
+    return out, tensors
+
+
+def mlp_forward_train_mixed(packed_mixed, tensors, x):
+    """Mixed-precision forward that keeps the layer activations (fp32 storage, bf16 MFMA operands).  Returns (out[n,65], acts)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    n = x.shape[0]
+    out = torch.empty(n, 65, dtype=torch.float32, device=x.device)
+    acts = torch.empty(lib.crnerf_mlp_train_acts_bytes(n), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_mlp_forward_train_mixed_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(x),
+                                                      _lib.dev_ptr(out), ctypes.c_void_p(acts.data_ptr()), n, _lib.stream_ptr()),
+               "crnerf_mlp_forward_train_mixed_f32")
+    return out, acts
+
+
+def mlp_backward_mixed(packed_mixed, tensors, x, out, d_out, acts):
+    """Gradients of sum(out * d_out) w.r.t. the 24 tensors through the mixed-precision twins (MLP_TENSOR_NAMES order)."""
+    lib = _lib.load()
+    x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
+    n = x.shape[0]
+    grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
+    scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.crnerf_mlp_backward_mixed_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(x),
+                                                 _lib.dev_ptr(out), _lib.dev_ptr(d_out), ctypes.c_void_p(acts.data_ptr()),
+                                                 ctypes.c_void_p(scratch.data_ptr()), _lib.ptr_array(grads, "grad"), n, _lib.stream_ptr()),
+               "crnerf_mlp_backward_mixed_f32")
+    return grads
+
+
 def posenc(x, n_freqs):
     lib = _lib.load()
     x = _f32c(x, "x")

@@ -74,6 +74,39 @@ def mlp_forward_bf16(w, x, sigma_only=False):
     return torch.cat((feat, sigma), dim=-1)
 
 
+class _LinearBf16(torch.autograd.Function):
+    """nn.Linear in the arithmetic of the mixed-precision training twins (crnerf_mlp_*_mixed_f32): both operands of each of the
+    three products -- forward, data gradient, weight gradient -- rounded to bf16, fp32 accumulation; the bias gradient is the
+    un-rounded column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(bf16_round(x), bf16_round(w), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gq = bf16_round(g)
+        return gq @ bf16_round(w), gq.t() @ bf16_round(x), g.sum(0)
+
+
+def mlp_forward_bf16_train(w, x):
+    """mlp_forward_bf16 with a backward: same forward values, gradients as the mixed-precision twins define them."""
+    lin = lambda h, name: _LinearBf16.apply(h, w[name + ".weight"], w[name + ".bias"])  # noqa: E731
+    xyz = x[:, :93]
+    h = xyz
+    for layer in range(1, 9):
+        if layer == 5:
+            h = torch.cat((xyz, h), dim=1)
+        h = F.relu(lin(h, "xyz_encoding_%d.0" % layer))
+    sigma = F.softplus(F.linear(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))
+    final = lin(h, "xyz_encoding_final")
+    g = F.relu(lin(torch.cat((final, x[:, 93:]), dim=1), "dir_encoding.0"))
+    feat = torch.sigmoid(lin(g, "static_rgb.0"))
+    return torch.cat((feat, sigma), dim=-1)
+
+
 # ------------------------------------------------------------------ models/rendering.py
 def composite(raw, z, noise=None, noise_std=0.0):
     """Compositing half of inference(), models/rendering.py:116-143.
