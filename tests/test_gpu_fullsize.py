@@ -123,8 +123,22 @@ def test_config2_full_image_bf16_800x800():
 
 
 # ------------------------------------------------------------------ configs[3]: one 65,536-ray training step, grid-sample masking
-def test_config3_training_step_65536_rays_use_mask():
+@pytest.mark.parametrize("mode", ["f32", "bf16+recompute"])
+def test_config3_training_step_65536_rays_use_mask(mode):
+    """mode f32: the exact fp32 twins (the reference's arithmetic).  bf16+recompute: the opt-in mixed-precision twins with the fused
+    bf16 renderer as forward: the same checks, and the step must fit 60 GB."""
+    from crnerf_amd import autograd as AG
     from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
+    AG.set_training_precision("bf16" if mode != "f32" else "f32")
+    AG.set_training_recompute(mode != "f32")
+    try:
+        _config3_step(mode, GridSampleBatcher)
+    finally:
+        AG.set_training_precision("f32")
+        AG.set_training_recompute(False)
+
+
+def _config3_step(mode, GridSampleBatcher):
 
     class HP(HPBase):
         img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [256, 256], 64, 64, 1.0, 1.0, 8 * 1024, 1500
@@ -167,8 +181,8 @@ def test_config3_training_step_65536_rays_use_mask():
             first = float(loss.detach())
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     assert np.isfinite(first) and float(loss.detach()) < first * 1.5
-    record("configs3_train_step_65536", {"ms_step": min(times) * 1e3, "rays_per_s": R / min(times), "peak_mem_GiB": peak, "loss": float(loss.detach())})
-    assert peak < 200.0                                              # fits one 288 GB MI355X with margin
+    record("configs3_train_step_65536_%s" % mode, {"ms_step": min(times) * 1e3, "rays_per_s": R / min(times), "peak_mem_GiB": peak, "loss": float(loss.detach())})
+    assert peak < (200.0 if mode == "f32" else 60.0)                 # fp32: fits one 288 GB MI355X with margin; mixed + recompute: < 60 GB
 
 
 # ------------------------------------------------------------------ configs[4]: appearance-hallucination video frames, 320x240, 256+256
