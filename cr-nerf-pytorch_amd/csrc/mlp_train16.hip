@@ -197,6 +197,84 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
   for (int t = 0; t < NT; ++t) { const int c = n0 + 32 * t + i; acol[t] = c < j.N ? c : j.N - 1; amask[t] = c < j.N ? 1.0f : 0.0f; }
   const long plast = p1 - 1;
+  if (j.bf16) {
+    // opt-in mixed precision (CRNERF_BWD_WGRAD_BF16), narrow blocks: the same dword-per-lane operand loads, eight points per lane
+    // and k-step of 16 points, rounded to bf16 in registers and multiplied on v_mfma_f32_32x32x16_bf16 (see the full-tile path in
+    // wgrad_kernel); bias sums from the un-rounded deltas
+    typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 pbf16x2 __attribute__((ext_vector_type(2)));
+    float dcu[8][MT], acu[8][NT], dnx[8][MT], anx[8][NT];
+    auto fetch16 = [&](long pb, float (&d)[8][MT], float (&a)[8][NT]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const long pt = pb + 8 * kk + e;
+        const long pc = pt < plast ? pt : plast;
+        const float keep = pt < p1 ? 1.0f : 0.0f;
+        const float* dr = j.D + pc * j.ldd;
+        const float* ar = j.A + pc * j.lda;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) d[e][t] = dr[dcol[t]] * (dmask[t] * keep);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[e][t] = ar[acol[t]] * amask[t];
+      }
+    };
+    const bool do_bias16 = j.bias_partial && blockIdx.z == 0 && bias_wave;
+    float bs16[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) bs16[t] = 0.0f;
+    fetch16(p0, dcu, acu);
+    for (long pb = p0; pb < p1; pb += 16) {
+      fetch16(pb + 16, dnx, anx);
+      pbf16x8 df[MT], af[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        union { pbf16x2 h[4]; pbf16x8 v8; } u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.h[q] = pbf16x2{(__bf16)dcu[2 * q][t], (__bf16)dcu[2 * q + 1][t]};
+        df[t] = u.v8;
+        if (do_bias16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bs16[t] += dcu[e][t];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        union { pbf16x2 h[4]; pbf16x8 v8; } u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.h[q] = pbf16x2{(__bf16)acu[2 * q][t], (__bf16)acu[2 * q + 1][t]};
+        af[t] = u.v8;
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a], af[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) dcu[e][t] = dnx[e][t];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acu[e][t] = anx[e][t];
+      }
+    }
+    if (do_bias16) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        bs16[t] += __shfl_xor(bs16[t], 32);
+        if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs16[t];
+      }
+    }
+    float* out16 = j.partial + (long)blockIdx.x * j.M * j.N;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk, nn = n0 + 32 * b + i;
+          if (m < j.M && nn < j.N) out16[(long)m * j.N + nn] = acc[a][b][r];
+        }
+    return;
+  }
   float dc[KS][MT], ac[KS][NT], dn[KS][MT], an[KS][NT];
   auto fetch = [&](long pb, float (&d)[KS][MT], float (&a)[KS][NT]) {
 #pragma unroll
@@ -505,10 +583,10 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
   // xyz_encoding_1: input x[:, :93]
-  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream);
+  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb);
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
-      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream);
+      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb);
       wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb);
     } else {
       wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb);
@@ -516,9 +594,9 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
   }
   wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb);            // xyz_encoding_final
   wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
-  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream);  // dir_encoding: cat([final, dir])
-  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream);
-  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream);   // static_rgb
+  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb);  // dir_encoding: cat([final, dir])
+  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb);
+  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb);   // static_rgb
   return check_launch("mlp_backward wgrad");
 }
 

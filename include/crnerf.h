@@ -74,9 +74,8 @@ size_t crnerf_mlp_train_scratch_bytes(int64_t n);
 int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out, void* acts, int64_t n, void* stream);
 int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                             float* const* grads, int64_t n, void* stream);
-/* Same with option flags (0 = the call above).  CRNERF_BWD_WGRAD_BF16: the weight gradients of the 256x256 layers (xyz_encoding_2..8
- * incl. the hidden block of the skip layer, xyz_encoding_final: 86 % of the wgrad FLOPs) are computed from the SAME fp32 deltas and
- * activations rounded to bf16 (RNE) in registers, on the bf16 MFMA with fp32 accumulation over the points -- an opt-in mixed
+/* Same with option flags (0 = the call above).  CRNERF_BWD_WGRAD_BF16: the weight gradients of every nn.Linear except static_sigma
+ * are computed from the SAME fp32 deltas and activations / embeddings rounded to bf16 (RNE) in registers, on the bf16 MFMA with fp32 accumulation over the points -- an opt-in mixed
  * precision with no counterpart in the reference (its autograd is fp32): data gradients, biases, every other tensor and the loss
  * stay exact fp32; each affected dW entry carries an unbiased rounding noise of ~2^-8 / sqrt(points) relative to its terms. */
 #define CRNERF_BWD_WGRAD_BF16 1
