@@ -199,7 +199,37 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
   const float* eb = (const float*)(gsm + (size_t)NT * ks * 1024);
   const long tiles = (j.P + GEMM_TILE - 1) / GEMM_TILE;
   const int chunks = (ks + GEMM_PF - 1) / GEMM_PF;
-  for (long tile = (long)blockIdx.x * GEMM_WAVES + wave; tile < tiles; tile += (long)gridDim.x * GEMM_WAVES) {
+  const long tstride = (long)gridDim.x * GEMM_WAVES;
+  // operand staging lives ACROSS tiles: the first chunk of the next tile is requested in the last k-chunk of the current one, so loads
+  // are in flight during the epilogue's store phase too
+  float nxt[GEMM_PF][GEMM_MT][8];
+#pragma unroll
+  for (int u = 0; u < GEMM_PF; ++u)
+#pragma unroll
+    for (int m = 0; m < GEMM_MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nxt[u][m][e] = 1.0f;
+  auto rows_of = [&](long tile, long (&rw)[GEMM_MT]) {
+#pragma unroll
+    for (int m = 0; m < GEMM_MT; ++m) { const long rr = tile * GEMM_TILE + 32 * m + i; rw[m] = rr < j.P ? rr : j.P - 1; }
+  };
+  // k-step s reads columns 16 s + 8 hh .. +7 of the segmented input row; steps past the end re-read the last step (unused)
+  auto fetch = [&](int c, const long (&rw)[GEMM_MT], float (&buf)[GEMM_PF][GEMM_MT][8]) {
+#pragma unroll
+    for (int u = 0; u < GEMM_PF; ++u) {
+      const int s = c * GEMM_PF + u < ks ? c * GEMM_PF + u : ks - 1;
+      const bool first = A1KIND == SEG_NONE || s < ks0;            // segment by selects: one load path, no branch
+      gemm_load_a(first ? j.a0.p : j.a1.p, first ? j.a0.ld : j.a1.ld, first ? j.a0.lo : j.a1.lo, first ? j.a0.hi : j.a1.hi, rw,
+                  16 * (first ? s : s - ks0) + 8 * hh, buf[u]);
+    }
+  };
+  {
+    const long t0 = (long)blockIdx.x * GEMM_WAVES + wave;
+    long rw0[GEMM_MT];
+    rows_of(t0 < tiles ? t0 : 0, rw0);
+    if (!(j.dbg & 2)) fetch(0, rw0, nxt);
+  }
+  for (long tile = (long)blockIdx.x * GEMM_WAVES + wave; tile < tiles; tile += tstride) {
     const long row0 = tile * GEMM_TILE;
     gb_f32x16 acc[GEMM_MT][NT];
 #pragma unroll
@@ -208,9 +238,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
-    long rws[GEMM_MT];   // rows of this lane's two point tiles (clamped: always readable)
-#pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m) { const long rr = row0 + 32 * m + i; rws[m] = rr < j.P ? rr : j.P - 1; }
+    long rws[GEMM_MT];   // rows of this lane's point tiles (clamped: always readable)
+    rows_of(tile, rws);
     uint4 bin[GEMM_MT];
 #pragma unroll
     for (int m = 0; m < GEMM_MT; ++m) bin[m] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -218,24 +247,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
 #pragma unroll
       for (int m = 0; m < GEMM_MT; ++m) bin[m] = *(const uint4*)(j.bits_in + (rws[m] * 2 + hh) * 4);
     }
-    // k-step s reads columns 16 s + 8 hh .. +7 of the segmented input row; steps past the end re-read the last step (unused)
-    auto fetch = [&](int c, float (&buf)[GEMM_PF][GEMM_MT][8]) {
-#pragma unroll
-      for (int u = 0; u < GEMM_PF; ++u) {
-        const int s = c * GEMM_PF + u < ks ? c * GEMM_PF + u : ks - 1;
-        const bool first = A1KIND == SEG_NONE || s < ks0;            // segment by selects: one load path, no branch
-        gemm_load_a(first ? j.a0.p : j.a1.p, first ? j.a0.ld : j.a1.ld, first ? j.a0.lo : j.a1.lo, first ? j.a0.hi : j.a1.hi, rws,
-                    16 * (first ? s : s - ks0) + 8 * hh, buf[u]);
-      }
-    };
-    float nxt[GEMM_PF][GEMM_MT][8];
-#pragma unroll
-    for (int u = 0; u < GEMM_PF; ++u)
-#pragma unroll
-      for (int m = 0; m < GEMM_MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) nxt[u][m][e] = 1.0f;
-    if (!(j.dbg & 2)) fetch(0, nxt);
+    long rws_next[GEMM_MT];                                // the next tile of this wave (clamped to a valid tile when there is none)
+    rows_of(tile + tstride < tiles ? tile + tstride : tile, rws_next);
 #pragma unroll 1
     for (int c = 0; c < chunks; ++c) {
       gb_bf16x8 curb[GEMM_PF][GEMM_MT];                    // this chunk's operands, rounded (v_cvt_pk_bf16_f32); frees the fp32 staging
@@ -248,7 +261,13 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
           for (int q = 0; q < 4; ++q) cv.h[q] = gb_bf16x2{(__bf16)nxt[u][m][2 * q], (__bf16)nxt[u][m][2 * q + 1]};
           curb[u][m] = cv.v8;
         }
-      if (!(j.dbg & 2)) fetch(c + 1 < chunks ? c + 1 : c, nxt);       // the next chunk's operands fly while this one's MFMAs run
+      if (!(j.dbg & 2)) {                                  // the next chunk's operands fly while this one's MFMAs run; after the last chunk,
+        const bool last = c + 1 == chunks;                   // the NEXT TILE's first chunk (rows by select: one load path, no branch)
+        long rsel[GEMM_MT];
+#pragma unroll
+        for (int m = 0; m < GEMM_MT; ++m) rsel[m] = last ? rws_next[m] : rws[m];
+        fetch(last ? 0 : c + 1, rsel, nxt);
+      }
 #pragma unroll
       for (int u = 0; u < GEMM_PF; ++u) {
         const int s = c * GEMM_PF + u;
