@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]")
+    ap.add_argument("--peer-exchange", action="store_true",
+                    help="N > 1: carry the decoder's two reductions through HIP-IPC peer windows (parallel.PeerExchange) instead of RCCL")
     return ap.parse_args()
 
 
@@ -304,7 +306,8 @@ def main():
     import crnerf_amd.synth as synth
     from crnerf_amd import ops
     from crnerf_amd.models.linearStyleTransfer import style_net
-    from crnerf_amd.parallel import decode_sharded
+    from crnerf_amd.parallel import PeerExchange, decode_sharded
+    exchange = PeerExchange() if (use_dist and world > 1 and a.peer_exchange) else None
 
     R = a.rays
     W = int(R ** 0.5)
@@ -337,7 +340,7 @@ def main():
                 ev[i][1].record()
             feat = out["feature_fine"]
             if use_dist:
-                return decode_sharded(net, feat, style, gather=True, equal_shards=True)
+                return decode_sharded(net, feat, style, gather=True, equal_shards=True, exchange=exchange)
             return net(feat.t().reshape(1, 64, *grid_hw), style)
 
         def fence():
@@ -358,6 +361,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+        if exchange is not None:
+            exchange.check()
         rgb_sums = None
         if use_dist and test_backend:      # test hook only: every rank must hold the same gathered image
             mine = torch.tensor([float(last_rgb.double().sum()), float(last_rgb.shape[-1])], dtype=torch.float64, device=dev)
@@ -385,7 +390,8 @@ def main():
                                    % (2 if bf16 else 1, " arithmetic (bf16 MFMA operands, fp32 accumulate) on the configs[1] ray batch" if bf16 else "",
                                       R, NC, NI, grid_hw[0], grid_hw[1]),
                        "rays_per_gpu": R, "n_samples": NC, "n_importance": NI,
-                       "parallelism": "rays sharded %d-way, weights replicated" % world},
+                       "parallelism": "rays sharded %d-way, weights replicated" % world,
+                       "reductions": "none" if world == 1 else ("peer windows (HIP IPC)" if exchange is not None else "RCCL all-reduce")},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "kernel_ms": kern_ms,
                          "flops_per_launch": flops},
@@ -403,6 +409,8 @@ def main():
         if rgb_sums is not None:
             line["test_rgb_checksum_per_rank"] = rgb_sums
         print(json.dumps(line), flush=True)
+    if exchange is not None:
+        exchange.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -30,6 +30,8 @@ EXPORTS = [
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
     "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
     "crnerf_fglo_f32", "crnerf_fglo_backward_f32", "crnerf_bilinear_gather_f32", "crnerf_bilinear_gather_backward_f32",
+    "crnerf_peer_window_bytes", "crnerf_peer_window_create", "crnerf_peer_window_open", "crnerf_peer_window_close", "crnerf_peer_window_destroy",
+    "crnerf_peer_window_status", "crnerf_peer_allreduce_f32",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -167,6 +169,13 @@ def load():
             "crnerf_fglo_backward_f32": (ctypes.c_int, [vp] * 11 + [i32, i32, i64, vp]),
             "crnerf_bilinear_gather_f32": (ctypes.c_int, [vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
             "crnerf_bilinear_gather_backward_f32": (ctypes.c_int, [vp, vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
+            "crnerf_peer_window_bytes": (ctypes.c_size_t, []),
+            "crnerf_peer_window_create": (ctypes.c_int, [pp, ctypes.c_char_p]),
+            "crnerf_peer_window_open": (ctypes.c_int, [ctypes.c_char_p, pp]),
+            "crnerf_peer_window_close": (ctypes.c_int, [vp]),
+            "crnerf_peer_window_destroy": (ctypes.c_int, [vp]),
+            "crnerf_peer_window_status": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
+            "crnerf_peer_allreduce_f32": (ctypes.c_int, [vp, i32, pp, i32, i32, ctypes.c_uint32, i64, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
 SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "render_fused_bf16.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip",
-           "crossray.hip"]
+           "crossray.hip", "peer_xchg.hip"]
 HEADERS = ["layout.h", "mlp_core.h", "mlp_core16.h", "mlp_train16.h", "mlp_core_bf16.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
 # the kernels call fmaf() explicitly wherever a fused multiply-add is wanted.

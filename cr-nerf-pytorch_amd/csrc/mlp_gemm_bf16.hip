@@ -435,7 +435,6 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
   float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
   float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
   float* ws = d_sig + P;
-  auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
   hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((P * OUT_DIM + 255) / 256)), dim3(256), 0, st, out, d_out, d_rgb, d_sig, P);
   const GemmSeg none{nullptr, 0, 0, 0, 0};

@@ -8,7 +8,14 @@ all-gather of RGB (12 B/pixel) assembles the image on every rank.
 
 `kernels` is the compute backend (default: the HIP ops); tests inject a CPU stand-in to exercise the
 exchange protocol under gloo.
+
+The two reductions travel by RCCL all-reduce by default.  `PeerExchange` is the opt-in alternative for them (ranks of ONE
+node): a HIP-IPC window per rank and one single-workgroup push / flag / sum kernel per reduction (csrc/peer_xchg.hip) --
+pass it as `decode_sharded(..., exchange=...)`.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,13 +33,89 @@ def shard_rays(rays, group=None):
     return rays[lo:hi].contiguous(), (lo, hi)
 
 
+class PeerExchange:
+    """All-reduce of <= 1024 floats through HIP-IPC peer windows (crnerf_peer_* in include/crnerf.h) instead of RCCL.
+
+    Collective constructor: every rank of `group` (one process per GPU, all on one node, at most 8) creates its window and
+    the 64-byte IPC handles are exchanged through the group itself (all_gather_object).  `all_reduce(t)` then sums a
+    contiguous float32 device tensor in place on the CURRENT stream with one kernel launch and no host synchronisation;
+    every rank must issue the same sequence of calls.  Sums are formed in rank order on every rank (bit-identical
+    replicas).  A peer that does not arrive within `timeout_s` turns the result into NaN; `check()` (synchronising) raises
+    and names it -- after that the exchange is out of step and must be rebuilt.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on
+    hosts whose driver only supports dmabuf IPC."""
+
+    def __init__(self, group=None, timeout_s=5.0):
+        from . import _lib
+        self._lib_mod = _lib
+        lib = _lib.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise ValueError("crnerf_amd: PeerExchange serves the GPUs of one node (world_size <= 8), got %d" % self.world)
+        self.timeout_us = int(timeout_s * 1e6)
+        self.device = torch.cuda.current_device()
+        own = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(lib.crnerf_peer_window_create(ctypes.byref(own), handle), "crnerf_peer_window_create")
+        self._own = own
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (bytes(handle.raw), os.uname().nodename), group=group)
+        if len({h[1] for h in handles}) != 1:
+            lib.crnerf_peer_window_destroy(own)
+            raise RuntimeError("crnerf_amd: PeerExchange: ranks on different hosts (%s); IPC windows are node-local" % sorted({h[1] for h in handles}))
+        self._windows = (ctypes.c_void_p * self.world)()
+        self._opened = []
+        for r, (h, _) in enumerate(handles):
+            if r == self.rank:
+                self._windows[r] = own.value
+                continue
+            w = ctypes.c_void_p()
+            _lib.check(lib.crnerf_peer_window_open(h, ctypes.byref(w)), "crnerf_peer_window_open")
+            self._windows[r] = w.value
+            self._opened.append(w)
+        self.epoch = 0
+        dist.barrier(group=group)   # every window is open everywhere before the first push
+
+    def all_reduce(self, t):
+        if self._own is None:
+            raise RuntimeError("crnerf_amd: PeerExchange is closed")
+        if t.numel() > 1024:
+            raise ValueError("crnerf_amd: PeerExchange.all_reduce carries at most 1024 floats, got %d" % t.numel())
+        self.epoch = self.epoch + 1 if self.epoch < 0xFFFFFFFE else 1
+        lib = self._lib_mod.load()
+        self._lib_mod.check(lib.crnerf_peer_allreduce_f32(self._lib_mod.dev_ptr(t, "all_reduce tensor"), t.numel(), self._windows, self.rank, self.world,
+                                                          self.epoch, self.timeout_us, self._lib_mod.stream_ptr()), "crnerf_peer_allreduce_f32")
+        return t
+
+    def check(self):
+        """Synchronises the device; raises if any reduction so far gave up waiting for a peer."""
+        st = ctypes.c_int(0)
+        self._lib_mod.check(self._lib_mod.load().crnerf_peer_window_status(self._own, ctypes.byref(st)), "crnerf_peer_window_status")
+        if st.value:
+            raise RuntimeError("crnerf_amd: PeerExchange: rank %d did not arrive within %.1f s at rank %d; results since then are NaN and the "
+                               "exchange must be rebuilt" % (st.value - 1, self.timeout_us / 1e6, self.rank))
+
+    def close(self):
+        """Collective: no rank may free its window while a peer can still push into it."""
+        if self._own is None:
+            return
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        lib = self._lib_mod.load()
+        for w in self._opened:
+            lib.crnerf_peer_window_close(w)
+        dist.barrier(group=self.group)
+        lib.crnerf_peer_window_destroy(self._own)
+        self._own, self._opened = None, []
+
+
 class _HipKernels:
     def __getattr__(self, name):
         from . import ops
         return getattr(ops, name)
 
 
-def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False):
+def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False, exchange=None):
     """Cross-ray decode of a ray-sharded feature grid.
 
     net: style_net; feature_local: this rank's [R_local,64] block of feature_fine (pixel-major, rank
@@ -43,7 +126,8 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
 
     Three kernel phases around two all-reduces (crnerf_crossray_decode_sharded_f32): channel sums ->
     all-reduce(64 floats) -> Gram of the centred conv chain -> all-reduce(1024 floats) -> fc / fold /
-    apply on the local pixels -> all-gather of RGB."""
+    apply on the local pixels -> all-gather of RGB.  exchange: a PeerExchange built on the same group carries the two
+    reductions instead of RCCL (default None = RCCL)."""
     k = kernels or _HipKernels()
     dev = feature_local.device
     n_local = feature_local.shape[0]
@@ -58,9 +142,10 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     weights = net.decoder_tensors()
     xchg = torch.zeros(64 + 1024, dtype=torch.float32, device=dev)
     k.crossray_decode_sharded(feature_local, sp, weights, 0, xchg, count)
-    dist.all_reduce(xchg[:64], group=group)           # reduction 1: channel sums -> global mean  (linearStyleTransfer.py:59-65)
+    reduce = exchange.all_reduce if exchange is not None else (lambda t: dist.all_reduce(t, group=group))
+    reduce(xchg[:64])                                 # reduction 1: channel sums -> global mean  (linearStyleTransfer.py:59-65)
     k.crossray_decode_sharded(feature_local, sp, weights, 1, xchg, count)
-    dist.all_reduce(xchg[64:], group=group)           # reduction 2: Gram of the centred conv chain (linearStyleTransfer.py:29-34)
+    reduce(xchg[64:])                                 # reduction 2: Gram of the centred conv chain (linearStyleTransfer.py:29-34)
     rgb_local = k.crossray_decode_sharded(feature_local, sp, weights, 2, xchg, count)
     if rgb_local is None:
         rgb_local = torch.zeros(3, 0, device=dev)

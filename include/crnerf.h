@@ -216,6 +216,24 @@ int crnerf_crossray_decode_f32(const float* content, int64_t HW, const float* st
 int crnerf_crossray_decode_sharded_f32(const float* content, int64_t HW_local, const float* style, int64_t HWs, const float* const* weights,
                                        int phase, float* xchg, double count_global, void* workspace, float* rgb, int64_t plane_stride,
                                        void* stream);
+/* Peer-window all-reduce: an alternative carrier for the two reductions above (the reference has no counterpart: it is
+ * single-GPU at inference, train_mask_grid_sample.py:441-450 uses Lightning DDP only for gradients).  Every rank creates one
+ * window in its own HBM, hands the 64-byte HIP IPC handle to the other processes of the node (any host channel), opens theirs,
+ * and then reduces n <= 1024 floats IN PLACE with one single-workgroup kernel per rank: push to every window, flag, bounded
+ * wait, sum in rank order (bit-identical on all ranks).  `windows` = HOST array of world_size device pointers, windows[rank] = own.
+ * `epoch` = 1, 2, 3, ... the same on all ranks for the same reduction, +1 per call.  A peer that does not arrive within
+ * timeout_us leaves NaN in `data` and 1 + its rank in the window's status word (crnerf_peer_window_status; synchronises). */
+#define CRNERF_PEER_MAX_RANKS 8
+#define CRNERF_PEER_MAX_FLOATS 1024
+#define CRNERF_PEER_HANDLE_BYTES 64
+size_t crnerf_peer_window_bytes(void);
+int crnerf_peer_window_create(void** window, void* handle_out64);
+int crnerf_peer_window_open(const void* handle64, void** window);
+int crnerf_peer_window_close(void* opened_window);
+int crnerf_peer_window_destroy(void* own_window);
+int crnerf_peer_window_status(void* own_window, int* status);
+int crnerf_peer_allreduce_f32(float* data, int n, void* const* windows, int rank, int world_size, uint32_t epoch, int64_t timeout_us,
+                              void* stream);
 /* Backward of crnerf_crossray_decode_f32 (in the reference: autograd through style_net.forward): d_rgb[c*d_plane_stride + px]
  * -> d_content[HW,64], d_style[HWs,64] and grads[22] (same order as `weights`, each OVERWRITTEN).
  * workspace: crnerf_crossray_backward_workspace_bytes(HW, HWs). */

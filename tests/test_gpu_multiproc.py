@@ -50,3 +50,25 @@ def test_train_config3_two_ranks_ray_parallel_replicas_agree():
     out = _launch(["tools/train_config4_bench.py", "4096", "32", "32"], extra_env={"CRNERF_TRAIN_BENCH_STEPS": "1,2"})
     assert "identical on every rank: True" in out, out
     assert "config-4 training step, 4096 rays" in out, out
+
+
+def test_bench_two_ranks_peer_exchange_matches_the_collective_path():
+    """--peer-exchange: the decoder's two reductions through HIP-IPC windows; with two ranks a + b is the same sum in either
+    carrier, so the gathered image must be the same one, on both ranks."""
+    base = json.loads([ln for ln in _launch(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"]).splitlines() if ln.startswith("{")][0])
+    for env in ({}, {"CRNERF_PEER_WINDOW_COARSE": "1"}):
+        out = _launch(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--peer-exchange"], extra_env=env)
+        j = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+        assert j["config"]["reductions"] == "peer windows (HIP IPC)"
+        sums = j["test_rgb_checksum_per_rank"]
+        assert sums[0] == sums[1] == base["test_rgb_checksum_per_rank"][0], (sums, base["test_rgb_checksum_per_rank"])
+
+
+def test_peer_exchange_sums_are_exact_and_identical_on_three_ranks():
+    out = _launch(["tests/_peer_worker.py", "sums"], nproc=3, timeout=300)
+    assert out.count("peer sums exact: True") == 3, out
+
+
+def test_peer_exchange_missing_rank_gives_nan_and_a_name_not_a_hang():
+    out = _launch(["tests/_peer_worker.py", "timeout"], nproc=2, timeout=120)
+    assert "rank 0 timeout detected: nan=True msg=True" in out, out
