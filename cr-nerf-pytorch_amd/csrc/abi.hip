@@ -217,6 +217,8 @@ int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return r
 int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
 
 size_t crnerf_packed_mlp_mixed_bytes(void) { return gemm_packed_bytes(); }
+size_t crnerf_mlp_train_mixed_acts_bytes(int64_t n) { return mlp_train_mixed_acts_bytes((long)n); }
+size_t crnerf_mlp_train_mixed_scratch_bytes(int64_t n) { return mlp_train_mixed_scratch_bytes((long)n); }
 
 int crnerf_pack_mlp_weights_mixed(const float* const* tensors, void* packed, void* stream) {
   REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
@@ -232,7 +234,7 @@ int crnerf_mlp_forward_train_mixed_f32(const float* const* tensors, const void* 
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_train_mixed: negative n");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "mlp_forward_train_mixed: a tensor pointer is NULL");
-  return launch_mlp_forward_train_mixed(to_tensors(tensors), packed, x, out, (float*)acts, (long)n, (hipStream_t)stream);
+  return launch_mlp_forward_train_mixed(to_tensors(tensors), packed, x, out, acts, (long)n, (hipStream_t)stream);
 }
 
 int crnerf_mlp_backward_mixed_f32(const float* const* tensors, const void* packed, const float* x, const float* out, const float* d_out,
@@ -242,7 +244,7 @@ int crnerf_mlp_backward_mixed_f32(const float* const* tensors, const void* packe
   REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!tensors[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_mixed: a tensor / gradient pointer is NULL");
-  return launch_mlp_backward_mixed(to_tensors(tensors), packed, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream);
+  return launch_mlp_backward_mixed(to_tensors(tensors), packed, x, out, d_out, acts, scratch, grads, (long)n, (hipStream_t)stream);
 }
 
 int crnerf_render_rays_train_f32(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,

@@ -40,12 +40,16 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
                         float* const* grads, long P, hipStream_t stream, int flags = 0);
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
                       long P, hipStream_t stream, int wb);
-// mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs on the fp32 buffers of the fp32 twins
+// mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs; activations, deltas and the embedded input travel as bf16
 size_t gemm_packed_bytes();
+size_t mlp_train_mixed_acts_bytes(long P);
+size_t mlp_train_mixed_scratch_bytes(long P);
 int launch_pack_mlp_gemm(const MlpTensors& t, void* packed, hipStream_t st);
-int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, float* acts, long P, hipStream_t st);
-int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const float* acts,
+int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, void* acts, long P, hipStream_t st);
+int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const void* acts,
                               void* scratch, float* const* grads, long P, hipStream_t st);
+// dst[m * ldc + n] = sum_c partial[c][m][n] (+ db[m] = sum_c bias_partial[c][m]): the deterministic partial-sum reduction of the wgrad kernels
+int launch_wgrad_reduce(const float* partial, int nchunk, int M, int N, float* dst, int ldc, const float* bias_partial, float* db, hipStream_t st);
 int launch_ray_directions(float fx, float fy, float cx, float cy, int H, int W, float* dirs, hipStream_t stream);
 int launch_rays_from_directions(const float* dirs, const float* c2w_host, long n, float* rays_o, float* rays_d, hipStream_t stream);
 int launch_generate_rays(const float* intr4_host, const float* c2w_host, int H, int W, float near, float far, float* rays, hipStream_t stream);

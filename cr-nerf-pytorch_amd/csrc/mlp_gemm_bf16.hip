@@ -1,15 +1,23 @@
 // Opt-in mixed-precision TRAINING twins of NeRF_sigma.forward (models/nerf.py:157-182): every nn.Linear except static_sigma as one
-// points x features GEMM on the bf16 MFMA -- operands (fp32 in HBM, exactly the buffers of the fp32 twins) are rounded to bf16
-// (RNE) in registers, products accumulate in fp32, biases / activations / the sigma head / all storage stay fp32.  The forward has
-// the semantics of the bf16 inference entry points (include/crnerf.h "bf16 variants"; oracle mlp_forward_bf16); the data gradient
-// is the same GEMM on the transposed matrices with the relu mask in the epilogue; the weight gradients are wgrad_kernel's bf16 path.
+// points x features GEMM on the bf16 MFMA.  Operands are bf16 (RNE), products accumulate in fp32, biases / activations / the sigma
+// head are evaluated in fp32 on the accumulators -- and what travels through HBM between the layers is bf16: the saved
+// activations, the layer deltas of the backward, the embedded input.  (Rounding at the store instead of at the next load changes
+// nothing for the GEMMs -- the operand was rounded anyway -- and halves the traffic these passes are bound by; round 2's first
+// version kept fp32 buffers and rounded in registers: 1 KiB in + 1 KiB out per point and layer.)
+// The forward has the semantics of the bf16 inference entry points (include/crnerf.h "bf16 variants"; oracle mlp_forward_bf16);
+// the data gradient is the same GEMM on the transposed matrices with the relu mask in the epilogue; the weight gradients multiply
+// the stored bf16 deltas and activations (wgrad_b_kernel below).  oracle/cpu_ref.py mlp_forward_bf16_train restates all three.
 //
-// Why un-fused: with the matrix work 16x cheaper these passes are bound by their activation traffic (1 KiB per point and layer in,
-// 1 KiB out), not by the MFMA; a persistent workgroup keeps the layer's weight matrix in LDS as B-operand fragments and streams
-// 256-point tiles (64 per wave) through it.
+// Why un-fused: with the matrix work 16x cheaper these passes are bound by their activation traffic, not by the MFMA; a persistent
+// workgroup keeps the layer's weight matrix in LDS as MFMA operand fragments and streams 32-point tiles (one per wave) through it.
 //   C[P x N] = act(A[P x K] . W[N x K]^T + bias)         A = up to two column segments (the skip / dir concatenations)
-//   v_mfma_f32_32x32x16_bf16: a-operand lane (i, hh) = A[point i][k = 8 hh + e], b-operand lane (j, hh) = W[feature j][k = 8 hh + e];
-//   accumulator register r of lane (j, hh) = C[point (r&3) + 8 (r>>2) + 4 hh][feature j].
+//   v_mfma_f32_32x32x16_bf16, swapped operands: a-operand lane (j, hh) = W[feature j][k = 8 hh + e], b-operand lane (i, hh) =
+//   A[point i][k = 8 hh + e]; accumulator register r of lane (i, hh) = C[point i][feature (r&3) + 8 (r>>2) + 4 hh].
+//
+// Storage order of an activation / delta row (256 bf16 = 512 B): within every group of 32 features, feature 8 q + 4 hh + e sits at
+// position 16 hh + 4 q + e -- the 16 values lane (i, hh) holds of a 32-feature tile are then 32 contiguous bytes (two 16-byte
+// stores; in reference order they are four 8-byte pieces 16 bytes apart).  Consumers never see the permutation: the packed weight
+// fragments carry it in their k index, the weight-gradient kernel un-permutes when it writes dW.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -21,6 +29,23 @@ namespace crnerf {
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
+typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;   // raw storage
+
+__host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 2) & 1) << 4) | (((f >> 3) & 3) << 2) | (f & 3); }      // feature -> position
+__host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 2) & 3) << 3) | (((c >> 4) & 1) << 2) | (c & 3); }    // position -> feature
+static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(8 * 2 + 4 * 1 + 3) == 16 + 4 * 2 + 3, "storage permutation");
+
+constexpr int XB_W = 128;        // embedded input as bf16: [0, 93) xyz embedding, [93, 96) zero, [96, 123) direction embedding, [123, 128) zero
+constexpr int XB_DIR = 96;
+constexpr int DRGB_W = 64;
+
+__device__ __forceinline__ uint32_t gb_pk(float a, float b) {
+  const gb_bf16x2 v = {(__bf16)a, (__bf16)b};   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float gb_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float gb_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // ---- packed weights: per matrix a stream of 1 KiB fragments, frag(t, s)[lane = 32 hh + j][e] = bf16(M[32 t + j][16 s + 8 hh + e]),
 // tile-major (t = feature tile of 32, s = k-step of 16); rows / columns beyond the matrix are zero.  The LDS image is the global image.
@@ -31,7 +56,6 @@ enum {
   GM_COUNT
 };
 
-constexpr int DIR_SEG_LO = 5;   // the direction embedding x[:, 93:120] is addressed as the 16-byte-aligned x[:, 88:120], first 5 columns masked
 __host__ __device__ constexpr int gm_frags(int N, int K) { return ((N + 31) / 32) * (K / 16); }
 
 struct GemmLayout {
@@ -59,15 +83,15 @@ static GemmLayout make_layout() {
 }
 static const GemmLayout& layout() { static const GemmLayout L = make_layout(); return L; }
 
-size_t gemm_packed_bytes() { return (size_t)layout().total_frags * 1024 + 4096; }   // + fp32 consts: biases are read from the tensors
+size_t gemm_packed_bytes() { return (size_t)layout().total_frags * 1024 + 4096; }
 
 struct PackJob {
   const float* W; int ld;        // source matrix, row-major
-  int rows, cols;                // valid extent of M (after the optional transpose)
-  int col0;                      // first source column (forward) / first source column of the block being transposed
-  int transpose;                 // M[r][c] = W[c][col0 + r]   (else M[r][c] = W[r][seg(c)])
-  int seg0_cols, seg0_pad;       // forward with two segments: columns [0, seg0_cols) come first, padded to seg0_pad
-  int seg1_lo;                   // ... and the second segment starts seg1_lo columns into its padded range (see GemmSeg::lo)
+  int rows, cols;                // forward: output features / source columns; transpose: rows of M / rows of the source block
+  int col0;                      // transpose: first source column of the block
+  int transpose;                 // M[r][c] = W[k(c)][col0 + r]   (else M[r][c] = W[r][src(c)])
+  int seg0_cols, seg0_pad;       // forward: source columns [0, seg0_cols) occupy the padded range [0, seg0_pad), the rest follows
+  int perm0, perm1;              // the k range of segment 0 / 1 indexes a row in storage order (an activation or delta slot), not reference order
   int N, K, off_frag;
 };
 
@@ -78,7 +102,6 @@ __global__ __launch_bounds__(256) void gemm_pack_kernel(PackJob j, uint4* __rest
     const int frag = idx >> 6, lane = idx & 63, jn = lane & 31, hh = lane >> 5;
     const int t = frag / ks, s = frag - t * ks;
     const int r = 32 * t + jn;
-    union { gb_bf16x2 h[4]; uint4 u; } v;
     float e[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -86,254 +109,239 @@ __global__ __launch_bounds__(256) void gemm_pack_kernel(PackJob j, uint4* __rest
       float val = 0.0f;
       if (r < j.rows) {
         if (j.transpose) {
-          if (c < j.cols) val = j.W[(long)c * j.ld + j.col0 + r];
+          const int cc = j.perm0 ? unperm32(c) : c;
+          if (cc < j.cols) val = j.W[(long)cc * j.ld + j.col0 + r];
         } else {
-          // padded column c -> source column: segment 0 occupies [0, seg0_pad) (valid < seg0_cols), the rest follows
           int src = -1;
-          if (c < j.seg0_pad) { if (c < j.seg0_cols) src = c; }
-          else { const int c1 = c - j.seg0_pad - j.seg1_lo; if (c1 >= 0 && c1 + j.seg0_cols < j.cols) src = c1 + j.seg0_cols; }
+          if (c < j.seg0_pad) { const int cc = j.perm0 ? unperm32(c) : c; if (cc < j.seg0_cols) src = cc; }
+          else { const int c1 = c - j.seg0_pad, cc = j.perm1 ? unperm32(c1) : c1; if (cc + j.seg0_cols < j.cols) src = cc + j.seg0_cols; }
           if (src >= 0) val = j.W[(long)r * j.ld + src];
         }
       }
       e[q] = val;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v.h[q] = gb_bf16x2{(__bf16)e[2 * q], (__bf16)e[2 * q + 1]};
-    packed[(long)(j.off_frag + frag) * 64 + lane] = v.u;
+    packed[(long)(j.off_frag + frag) * 64 + lane] = make_uint4(gb_pk(e[0], e[1]), gb_pk(e[2], e[3]), gb_pk(e[4], e[5]), gb_pk(e[6], e[7]));
   }
 }
 
 int launch_pack_mlp_gemm(const MlpTensors& t, void* packed, hipStream_t st) {
   const GemmLayout& L = layout();
-  auto fwd = [&](int id, const float* W, int ld, int rows, int cols, int seg0_cols, int seg0_pad, int seg1_lo = 0) {
-    PackJob j{W, ld, rows, cols, 0, 0, seg0_cols, seg0_pad, seg1_lo, L.m[id].N, L.m[id].K, L.m[id].off_frag};
+  auto fwd = [&](int id, const float* W, int ld, int rows, int cols, int seg0_cols, int seg0_pad, int perm0, int perm1) {
+    PackJob j{W, ld, rows, cols, 0, 0, seg0_cols, seg0_pad, perm0, perm1, L.m[id].N, L.m[id].K, L.m[id].off_frag};
     hipLaunchKernelGGL(gemm_pack_kernel, dim3(64), dim3(256), 0, st, j, (uint4*)packed);
   };
-  auto tr = [&](int id, const float* W, int ld, int rows, int cols, int col0) {   // M = (W[:, col0 : col0 + rows])^T, M is rows x cols
-    PackJob j{W, ld, rows, cols, col0, 1, 0, 0, 0, L.m[id].N, L.m[id].K, L.m[id].off_frag};
+  auto tr = [&](int id, const float* W, int ld, int rows, int cols, int col0, int permk) {   // M = (W[:, col0 : col0 + rows])^T, M is rows x cols
+    PackJob j{W, ld, rows, cols, col0, 1, 0, 0, permk, 0, L.m[id].N, L.m[id].K, L.m[id].off_frag};
     hipLaunchKernelGGL(gemm_pack_kernel, dim3(64), dim3(256), 0, st, j, (uint4*)packed);
   };
-  fwd(GM_L1, t.w[0], 93, 256, 93, 93, 96);
+  fwd(GM_L1, t.w[0], 93, 256, 93, 93, 96, 0, 0);
   for (int l = 1; l < 8; ++l) {
-    if (l == 4) fwd(GM_L5, t.w[4], 349, 256, 349, 93, 96);
-    else fwd(GM_L1 + l, t.w[l], 256, 256, 256, 256, 256);
+    if (l == 4) fwd(GM_L5, t.w[4], 349, 256, 349, 93, 96, 0, 1);          // [embedding | h4 (storage order)]
+    else fwd(GM_L1 + l, t.w[l], 256, 256, 256, 256, 256, 1, 0);
   }
-  fwd(GM_FINAL, t.w_final, 256, 256, 256, 256, 256);
-  fwd(GM_DIR, t.w_dir, 283, 128, 283, 256, 256, DIR_SEG_LO);
-  fwd(GM_RGB, t.w_rgb, 128, 64, 128, 128, 128);
-  tr(GM_T_RGB, t.w_rgb, 128, 128, 64, 0);
-  tr(GM_T_DIR, t.w_dir, 283, 256, 128, 0);
-  tr(GM_T_FINAL, t.w_final, 256, 256, 256, 0);
-  for (int l = 7; l >= 1; --l) tr(GM_T8 + (7 - l), t.w[l], l == 4 ? 349 : 256, 256, 256, l == 4 ? 93 : 0);
+  fwd(GM_FINAL, t.w_final, 256, 256, 256, 256, 256, 1, 0);
+  fwd(GM_DIR, t.w_dir, 283, 128, 283, 256, 256, 1, 0);                    // [final (storage order) | direction embedding]
+  fwd(GM_RGB, t.w_rgb, 128, 64, 128, 128, 128, 1, 0);
+  tr(GM_T_RGB, t.w_rgb, 128, 128, 64, 0, 0);                              // k = d_rgb, reference order
+  tr(GM_T_DIR, t.w_dir, 283, 256, 128, 0, 1);
+  tr(GM_T_FINAL, t.w_final, 256, 256, 256, 0, 1);
+  for (int l = 7; l >= 1; --l) tr(GM_T8 + (7 - l), t.w[l], l == 4 ? 349 : 256, 256, 256, l == 4 ? 93 : 0, 1);
   return check_launch("gemm_pack_kernel");
 }
 
+// ---- embedded input x[P,120] fp32 -> xb[P,128] bf16 (16-byte units; both embeddings start on a 16-byte boundary and are zero-padded)
+__global__ __launch_bounds__(256) void embed_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb, long P) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P * (XB_W / 8)) return;
+  const long p = idx >> 4;
+  const int u = (int)(idx & 15);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * u + e;
+    const int src = c < XYZ_DIM ? c : (c >= XB_DIR && c < XB_DIR + DIR_DIM ? c - (XB_DIR - XYZ_DIM) : -1);
+    v[e] = src >= 0 ? x[p * IN_DIM + src] : 0.0f;
+  }
+  *(uint4*)(xb + p * XB_W + 8 * u) = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
+}
+
 // ---- the GEMM
-// A column segment: `pad` (multiple of 16) padded columns of rows p + row * ld, of which [lo, hi) are real and the rest read as zero.
-// p + row * ld is 16-byte aligned and all `pad` columns lie inside the row's allocation (every load is an unconditional float4).
-// The direction embedding x[:, 93:120] is not 16-byte aligned: it is addressed as x[:, 88:120] with lo = 5 (DIR_SEG_LO).
-struct GemmSeg { const float* p; int ld; int lo; int hi; int pad; };
-static_assert((XYZ_DIM - DIR_SEG_LO) % 4 == 0 && XYZ_DIM - DIR_SEG_LO + 32 == IN_DIM, "dir segment = the last 32 columns of the [P,120] input row");
+// A column segment: `pad` (multiple of 16) bf16 columns of rows p + row * ld, all physically present (padding columns hold zeros,
+// or meet zero weight columns), 16-byte aligned.
+struct GemmSeg { const bf16_t* p; int ld; int pad; };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
-enum { SEG_NONE = 0, SEG_VEC = 1 };                              // second A segment: absent / present
 struct GemmJob {
-  GemmSeg a0, a1;                 // a0: 16-byte aligned rows, ld % 4 == 0 (vector loads; the tail of its last k-step may read up to 7 floats
-                                  // past `cols` inside the row's allocation and zeroes them)
+  GemmSeg a0, a1;
   const uint4* frags;             // fragment stream of the feature tiles of this pass
   int N, K;                       // features of this pass (<= 32 NT), K = a0.pad + a1.pad
-  int col_off;                    // first output column / bias index of this pass
+  int col_off;                    // first output feature / bias index of this pass (multiple of 32)
   const float* bias;              // indexed by col_off + feature, or null
   int act;
-  const uint32_t* bits_in;                    // epilogue: C *= relu' from the activity bits the forward wrote (below), or null
-  uint32_t* bits_out;                         // ACT_RELU forward: activity bits of the output, or null.  Layout per point: 32 bytes =
-                                              // [hh = 0,1][tile t = 0..7] u16, bit 4 q + e <-> feature 32 t + 8 q + 4 hh + e: exactly what
-                                              // lane (point, hh) produces / consumes, so 16 bytes per lane and tile of 64 points
-                                              // (the activation itself would be another 1 KiB per point and layer of HBM reads)
-  const float* r1_row; const float* r1_col;   // epilogue: C += r1_row[row] * r1_col[col]   (the sigma head's branch into d(h8)) or null
-  float* out; int ldo;
+  const uint32_t* bits_in;        // epilogue: C *= relu' from the activity bits the forward wrote (below), or null
+  uint32_t* bits_out;             // ACT_RELU forward: activity bits of the output, or null.  Layout per point: 32 bytes =
+                                  // [hh = 0,1][tile t = 0..7] u16, bit 4 q + e <-> feature 32 t + 8 q + 4 hh + e: exactly what
+                                  // lane (point, hh) produces / consumes, so 16 bytes per lane and tile of 32 points
+  const float* r1_row;            // epilogue: C += r1_row[row] * colvec[feature]   (the sigma head's branch into d(h8)) or null
+  const float* colvec;            // [features]: the rank-1 column vector, or (SIG) static_sigma.weight
+  const float* sig_b; float* sig_out;   // SIG: sig_out[row * 65 + 64] = softplus(colvec . relu(C[row]) + sig_b[0]) on the fp32 accumulators
+  bf16_t* out; int ldo;           // bf16 output rows in storage order (ACT_NONE / ACT_RELU)
+  float* out_f; int ldo_f;        // fp32 output rows in reference order (ACT_SIGMOID: the [P,65] result)
   long P;
   int dbg;                        // timing experiments only (CRNERF_GEMM_DBG): 1 = no epilogue, 2 = no operand loads, 4 = no MFMAs
 };
 
-constexpr int GEMM_LDS_BYTES = 128 * 1024 + 2048;   // fragments + bias / rank-1 column vector
-constexpr int GEMM_MT = 1;        // 32-point tiles per wave: 1 keeps the kernel under 256 registers -> two waves per SIMD, so one wave's
-                                  // store phase overlaps another's load phase (MT = 2 at one wave per SIMD: 8.4 ms per 2^20-point forward)
-constexpr int GEMM_WAVES = 8;
-constexpr int GEMM_TILE = 32 * GEMM_MT;
-constexpr int GEMM_PF = 4;        // k-steps per prefetch chunk: 4 x 4 KiB per wave in flight (~16 MB on the chip)
+constexpr int GEMM_LDS_BYTES = 128 * 1024 + 2048;   // fragments + bias / column vector
+constexpr int GEMM_WAVES = 8;     // two per SIMD (< 256 registers): one wave's store phase overlaps another's load phase
+constexpr int GEMM_TILE = 32;     // points per wave tile
+constexpr int GEMM_PF = 8;        // k-steps per prefetch chunk: 8 x 16 B per lane = 8 KiB per wave in flight (~16 MB on the chip); 4 in the
+                                  // sigma-head variant, which otherwise spills
 
-__device__ __forceinline__ void gemm_load_a(const float* p, int ld, int lo, int hi, const long (&rws)[GEMM_MT], int cl, float (&v)[GEMM_MT][8]) {
-  // UNCONDITIONAL loads (a branch around a load costs a vmcnt(0) at the join and serialises the prefetch); padding columns are read
-  // from inside the row and zeroed by a select
-#pragma unroll
-  for (int m = 0; m < GEMM_MT; ++m) {
-    const float* rp = p + rws[m] * ld;
-    const float4 x0 = *(const float4*)(rp + cl), x1 = *(const float4*)(rp + cl + 4);
-    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[m][e] = (cl + e >= lo && cl + e < hi) ? x[e] : 0.0f;
-  }
-}
-
-// NT feature tiles of 32 per pass: 8 (N = 256), 4 (N = 128), 2 (N = 64).  ACT / MASK (relu' bits in) / R1 (rank-1 term) are compile-time:
-// as run-time switches they became ~1,400 branches and 200 spilled registers in the epilogue, and every store sat behind a spill
-// reload's s_waitcnt vmcnt(0) -- i.e. behind the previous store's completion.
-template <int NT, int A1KIND, int ACT, bool MASK, bool R1>
+// NT feature tiles of 32 per pass: 8 (N = 256), 4 (N = 128), 2 (N = 64).  SEG2 / ACT / MASK (relu' bits in) / R1 (rank-1 term) / SIG
+// (fused sigma head) are compile-time: as run-time switches they became ~1,400 branches and 200 spilled registers in the epilogue,
+// and every store sat behind a spill reload's s_waitcnt vmcnt(0) -- i.e. behind the previous store's completion.
+template <int NT, bool SEG2, int ACT, bool MASK, bool R1, bool SIG>
 __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_kernel(GemmJob j) {
   extern __shared__ __attribute__((aligned(16))) char gsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hh = lane >> 5;
   const int ks = j.K / 16, ks0 = j.a0.pad / 16;
+  constexpr int PF = SIG ? GEMM_PF / 2 : GEMM_PF;
   {   // stage the weight fragments: the LDS image is the global image
     const int n16 = NT * ks * 64;
     uint4* dst = (uint4*)gsm;
     for (int idx = tid; idx < n16; idx += 64 * GEMM_WAVES) dst[idx] = j.frags[idx];
-    float* eb = (float*)(gsm + (size_t)NT * ks * 1024);   // behind the fragments: [0, 256) bias of this pass' features, [256, 512) rank-1 column vector
+    float* eb = (float*)(gsm + (size_t)NT * ks * 1024);   // behind the fragments: [0, 256) bias of this pass' features, [256, 512) column vector
     if (tid < 32 * NT) {
       const bool ok = tid < j.N;
       eb[tid] = (j.bias && ok) ? j.bias[j.col_off + tid] : 0.0f;
-      eb[256 + tid] = (j.r1_col && ok) ? j.r1_col[j.col_off + tid] : 0.0f;
+      eb[256 + tid] = (j.colvec && ok) ? j.colvec[j.col_off + tid] : 0.0f;
     }
   }
   __syncthreads();
   const float* eb = (const float*)(gsm + (size_t)NT * ks * 1024);
   const long tiles = (j.P + GEMM_TILE - 1) / GEMM_TILE;
-  const int chunks = (ks + GEMM_PF - 1) / GEMM_PF;
+  const int chunks = (ks + PF - 1) / PF;
   const long tstride = (long)gridDim.x * GEMM_WAVES;
   // operand staging lives ACROSS tiles: the first chunk of the next tile is requested in the last k-chunk of the current one, so loads
-  // are in flight during the epilogue's store phase too
-  float nxt[GEMM_PF][GEMM_MT][8];
+  // are in flight during the epilogue's store phase too.  Loads are UNCONDITIONAL (a branch around a load costs a vmcnt(0) at the
+  // join and serialises the prefetch): rows are clamped, k-steps past the end re-read the last one, segments are chosen by selects.
+  uint4 nxt[PF];
 #pragma unroll
-  for (int u = 0; u < GEMM_PF; ++u)
+  for (int u = 0; u < PF; ++u) nxt[u] = make_uint4(0u, 0u, 0u, 0u);
+  auto row_of = [&](long tile) { const long rr = tile * GEMM_TILE + i; return rr < j.P ? rr : j.P - 1; };
+  auto fetch = [&](int c, long rw, uint4 (&buf)[PF]) {
 #pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) nxt[u][m][e] = 1.0f;
-  auto rows_of = [&](long tile, long (&rw)[GEMM_MT]) {
-#pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m) { const long rr = tile * GEMM_TILE + 32 * m + i; rw[m] = rr < j.P ? rr : j.P - 1; }
-  };
-  // k-step s reads columns 16 s + 8 hh .. +7 of the segmented input row; steps past the end re-read the last step (unused)
-  auto fetch = [&](int c, const long (&rw)[GEMM_MT], float (&buf)[GEMM_PF][GEMM_MT][8]) {
-#pragma unroll
-    for (int u = 0; u < GEMM_PF; ++u) {
-      const int s = c * GEMM_PF + u < ks ? c * GEMM_PF + u : ks - 1;
-      const bool first = A1KIND == SEG_NONE || s < ks0;            // segment by selects: one load path, no branch
-      gemm_load_a(first ? j.a0.p : j.a1.p, first ? j.a0.ld : j.a1.ld, first ? j.a0.lo : j.a1.lo, first ? j.a0.hi : j.a1.hi, rw,
-                  16 * (first ? s : s - ks0) + 8 * hh, buf[u]);
+    for (int u = 0; u < PF; ++u) {
+      const int s = c * PF + u < ks ? c * PF + u : ks - 1;
+      const bool first = !SEG2 || s < ks0;
+      const bf16_t* p = first ? j.a0.p : j.a1.p;
+      const int ld = first ? j.a0.ld : j.a1.ld;
+      buf[u] = *(const uint4*)(p + rw * ld + 16 * (first ? s : s - ks0) + 8 * hh);
     }
   };
   {
     const long t0 = (long)blockIdx.x * GEMM_WAVES + wave;
-    long rw0[GEMM_MT];
-    rows_of(t0 < tiles ? t0 : 0, rw0);
-    if (!(j.dbg & 2)) fetch(0, rw0, nxt);
+    if (!(j.dbg & 2)) fetch(0, row_of(t0 < tiles ? t0 : 0), nxt);
   }
   for (long tile = (long)blockIdx.x * GEMM_WAVES + wave; tile < tiles; tile += tstride) {
-    const long row0 = tile * GEMM_TILE;
-    gb_f32x16 acc[GEMM_MT][NT];
+    gb_f32x16 acc[NT];
 #pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
-    long rws[GEMM_MT];   // rows of this lane's point tiles (clamped: always readable)
-    rows_of(tile, rws);
-    uint4 bin[GEMM_MT];
-#pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m) bin[m] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (MASK) {
-#pragma unroll
-      for (int m = 0; m < GEMM_MT; ++m) bin[m] = *(const uint4*)(j.bits_in + (rws[m] * 2 + hh) * 4);
-    }
-    long rws_next[GEMM_MT];                                // the next tile of this wave (clamped to a valid tile when there is none)
-    rows_of(tile + tstride < tiles ? tile + tstride : tile, rws_next);
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const long row = tile * GEMM_TILE + i;
+    const bool row_ok = row < j.P;
+    const long rw = row_ok ? row : j.P - 1;                // clamped: always readable
+    uint4 bin = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (MASK) bin = *(const uint4*)(j.bits_in + (rw * 2 + hh) * 4);
+    const long rw_next = row_of(tile + tstride < tiles ? tile + tstride : tile);
 #pragma unroll 1
     for (int c = 0; c < chunks; ++c) {
-      gb_bf16x8 curb[GEMM_PF][GEMM_MT];                    // this chunk's operands, rounded (v_cvt_pk_bf16_f32); frees the fp32 staging
+      uint4 cur[PF];
 #pragma unroll
-      for (int u = 0; u < GEMM_PF; ++u)
-#pragma unroll
-        for (int m = 0; m < GEMM_MT; ++m) {
-          union { gb_bf16x2 h[4]; gb_bf16x8 v8; } cv;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) cv.h[q] = gb_bf16x2{(__bf16)nxt[u][m][2 * q], (__bf16)nxt[u][m][2 * q + 1]};
-          curb[u][m] = cv.v8;
-        }
+      for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
       if (!(j.dbg & 2)) {                                  // the next chunk's operands fly while this one's MFMAs run; after the last chunk,
-        const bool last = c + 1 == chunks;                   // the NEXT TILE's first chunk (rows by select: one load path, no branch)
-        long rsel[GEMM_MT];
-#pragma unroll
-        for (int m = 0; m < GEMM_MT; ++m) rsel[m] = last ? rws_next[m] : rws[m];
-        fetch(last ? 0 : c + 1, rsel, nxt);
+        const bool last = c + 1 == chunks;                 // the NEXT TILE's first chunk
+        fetch(last ? 0 : c + 1, last ? rw_next : rw, nxt);
       }
 #pragma unroll
-      for (int u = 0; u < GEMM_PF; ++u) {
-        const int s = c * GEMM_PF + u;
+      for (int u = 0; u < PF; ++u) {
+        const int s = c * PF + u;
         if (s < ks && !(j.dbg & 4)) {
+          const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, cur[u]);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const gb_bf16x8 bfr = *(const gb_bf16x8*)(gsm + ((size_t)(t * ks + s) * 64 + lane) * 16);
-#pragma unroll
-            for (int m = 0; m < GEMM_MT; ++m)
-              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, curb[u][m], acc[m][t], 0, 0, 0);   // swapped: D[feature][point]
+            const gb_bf16x8 wf = *(const gb_bf16x8*)(gsm + ((size_t)(t * ks + s) * 64 + lane) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, b, acc[t], 0, 0, 0);   // swapped: D[feature][point]
           }
         }
       }
     }
-    // epilogue.  Swapped operands leave lane (p, hh) with point row0 + 32 m + p and, in registers 4 q .. 4 q + 3 of tile t, the four
-    // consecutive features 32 t + 8 q + 4 hh + 0..3: one 16-byte store per quad (un-swapped, a lane holds ONE feature of 16 points:
-    // 256 dword stores per tile and wave).
+    // epilogue.  Swapped operands leave lane (i, hh) with point `row` and, in registers 4 q .. 4 q + 3 of tile t, the four consecutive
+    // features 32 t + 8 q + 4 hh + 0..3 -- positions 32 t + 16 hh + 4 q + 0..3 of the stored row.
     if (j.dbg & 1) continue;
-    const bool vec_out = (j.ldo & 3) == 0;
     const int t_off = j.col_off >> 5;
+    const float r1 = R1 ? j.r1_row[rw] : 0.0f;
+    const uint32_t bw_in[4] = {bin.x, bin.y, bin.z, bin.w};
+    uint32_t bw_out[4] = {0u, 0u, 0u, 0u};
+    float sg = 0.0f;
 #pragma unroll
-    for (int m = 0; m < GEMM_MT; ++m) {
-      const long row = row0 + 32 * m + i;
-      const bool row_ok = row < j.P;
-      float* orow = j.out + rws[m] * j.ldo + j.col_off + 4 * hh;
-      const float r1 = R1 ? j.r1_row[rws[m]] : 0.0f;
-      const uint32_t bw_in[4] = {bin[m].x, bin[m].y, bin[m].z, bin[m].w};
-      uint32_t bw_out[4] = {0u, 0u, 0u, 0u};
+    for (int t = 0; t < NT; ++t) {
+      const int tg = t_off + t;                                   // tile index within the point's 256 features
+      const uint32_t half_in = MASK ? bw_in[(tg >> 1) & 3] >> ((tg & 1) * 16) : 0xffffu;
+      uint32_t half_out = 0u;
+      float v[16];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int tg = t_off + t;                                 // tile index within the point's 256 features
-        const uint32_t half_in = MASK ? bw_in[(tg >> 1) & 3] >> ((tg & 1) * 16) : 0xffffu;
-        uint32_t half_out = 0u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int fcol = 32 * t + 8 * q + 4 * hh;               // < 32 NT; features beyond N (multiple of 32 here) do not exist
-          const float4 b = *(const float4*)(eb + fcol);
-          float v[4] = {acc[m][t][4 * q + 0] + b.x, acc[m][t][4 * q + 1] + b.y, acc[m][t][4 * q + 2] + b.z, acc[m][t][4 * q + 3] + b.w};
-          if (R1) {
-            const float4 rc = *(const float4*)(eb + 256 + fcol);
-            v[0] = fmaf(r1, rc.x, v[0]); v[1] = fmaf(r1, rc.y, v[1]); v[2] = fmaf(r1, rc.z, v[2]); v[3] = fmaf(r1, rc.w, v[3]);
-          }
+      for (int q = 0; q < 4; ++q) {
+        const int fcol = 32 * t + 8 * q + 4 * hh;                 // < 32 NT; features beyond N (multiple of 32 here) do not exist
+        const float4 b = *(const float4*)(eb + fcol);
+        v[4 * q + 0] = acc[t][4 * q + 0] + b.x; v[4 * q + 1] = acc[t][4 * q + 1] + b.y;
+        v[4 * q + 2] = acc[t][4 * q + 2] + b.z; v[4 * q + 3] = acc[t][4 * q + 3] + b.w;
+        if (R1 || SIG) {
+          const float4 cv = *(const float4*)(eb + 256 + fcol);
+          const float cvs[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (ACT == ACT_RELU) { v[e] = fmaxf(v[e], 0.0f); half_out |= (v[e] > 0.0f ? 1u : 0u) << (4 * q + e); }
-            else if (ACT == ACT_SIGMOID) v[e] = sigmoid_ref(v[e]);
-            if (MASK) v[e] = ((half_in >> (4 * q + e)) & 1u) ? v[e] : 0.0f;
-          }
-          if (row_ok) {
-            float* o = orow + 32 * t + 8 * q;
-            if (vec_out) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+            if (R1) v[4 * q + e] = fmaf(r1, cvs[e], v[4 * q + e]);
+            if (SIG) sg = fmaf(cvs[e], fmaxf(v[4 * q + e], 0.0f), sg);   // static_sigma on the un-rounded relu output (nerf.py:146,172)
           }
         }
-        bw_out[(tg >> 1) & 3] |= half_out << ((tg & 1) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float& x = v[4 * q + e];
+          if (ACT == ACT_RELU) { x = fmaxf(x, 0.0f); half_out |= (x > 0.0f ? 1u : 0u) << (4 * q + e); }
+          else if (ACT == ACT_SIGMOID) x = sigmoid_ref(x);
+          if (MASK) x = ((half_in >> (4 * q + e)) & 1u) ? x : 0.0f;
+        }
       }
-      if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the words this pass covers: 8 tiles = 16 bytes, 4 tiles = 8 bytes
-        uint32_t* bo = j.bits_out + (row * 2 + hh) * 4;
-        if (NT == 8) *(uint4*)bo = make_uint4(bw_out[0], bw_out[1], bw_out[2], bw_out[3]);
-        else if (NT == 4) { const int w0 = (t_off >> 1) & 3; *(uint2*)(bo + w0) = make_uint2(bw_out[w0], bw_out[w0 + 1]); }
+      bw_out[(tg >> 1) & 3] |= half_out << ((tg & 1) * 16);
+      if (row_ok) {
+        if (ACT == ACT_SIGMOID) {
+          float* o = j.out_f + row * j.ldo_f + j.col_off + 32 * t + 4 * hh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[8 * q + e] = v[4 * q + e];
+        } else {
+          bf16_t* o = j.out + row * j.ldo + j.col_off + 32 * t + 16 * hh;
+          *(uint4*)o = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
+          *(uint4*)(o + 8) = make_uint4(gb_pk(v[8], v[9]), gb_pk(v[10], v[11]), gb_pk(v[12], v[13]), gb_pk(v[14], v[15]));
+        }
       }
+    }
+    if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the words this pass covers: 8 tiles = 16 bytes, 4 tiles = 8 bytes
+      uint32_t* bo = j.bits_out + (row * 2 + hh) * 4;
+      if (NT == 8) *(uint4*)bo = make_uint4(bw_out[0], bw_out[1], bw_out[2], bw_out[3]);
+      else if (NT == 4) { const int w0 = (t_off >> 1) & 3; *(uint2*)(bo + w0) = make_uint2(bw_out[w0], bw_out[w0 + 1]); }
+    }
+    if (SIG) {
+      sg += __shfl_xor(sg, 32);
+      if (row_ok && hh == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
     }
   }
 }
 
-static int run_gemm(const GemmJob& j_in, int a1kind, hipStream_t st) {
+static int run_gemm(const GemmJob& j_in, hipStream_t st) {
   if (j_in.P <= 0) return 0;
   static const int dbg = getenv("CRNERF_GEMM_DBG") ? atoi(getenv("CRNERF_GEMM_DBG")) : 0;
   GemmJob j = j_in;
@@ -345,111 +353,319 @@ static int run_gemm(const GemmJob& j_in, int a1kind, hipStream_t st) {
   const int grid = (int)(wg < cus ? wg : cus);
   const size_t shmem = (size_t)nt * (j.K / 16) * 1024 + 2048;
   if (shmem > GEMM_LDS_BYTES) return set_error(-2, "linear_bf16: weight tile exceeds LDS");
-  const bool mask = j.bits_in != nullptr, r1 = j.r1_row != nullptr;
-  if (j.N != 32 * nt) return set_error(-2, "linear_bf16: feature count must be a multiple of 32");
-#define CRNERF_GEMM(NTV, KIND, ACTV, MASKV, R1V)                                                                                            \
-  if (nt == NTV && a1kind == KIND && j.act == ACTV && mask == MASKV && r1 == R1V) {                                                         \
-    if (int rc = ensure_dynamic_lds((const void*)linear_bf16_kernel<NTV, KIND, ACTV, MASKV, R1V>, GEMM_LDS_BYTES, "linear_bf16_kernel")) return rc; \
-    hipLaunchKernelGGL((linear_bf16_kernel<NTV, KIND, ACTV, MASKV, R1V>), dim3(grid), dim3(64 * GEMM_WAVES), shmem, st, j);                  \
-    return 0;                                                                                                                               \
+  const bool seg2 = j.a1.p != nullptr, mask = j.bits_in != nullptr, r1 = j.r1_row != nullptr, sig = j.sig_out != nullptr;
+  if (j.N != 32 * nt || (j.col_off & 31)) return set_error(-2, "linear_bf16: feature count and offset must be multiples of 32");
+#define CRNERF_GEMM(NTV, SEG2V, ACTV, MASKV, R1V, SIGV)                                                                                             \
+  if (nt == NTV && seg2 == SEG2V && j.act == ACTV && mask == MASKV && r1 == R1V && sig == SIGV) {                                                  \
+    if (int rc = ensure_dynamic_lds((const void*)linear_bf16_kernel<NTV, SEG2V, ACTV, MASKV, R1V, SIGV>, GEMM_LDS_BYTES, "linear_bf16_kernel")) \
+      return rc;                                                                                                                                    \
+    hipLaunchKernelGGL((linear_bf16_kernel<NTV, SEG2V, ACTV, MASKV, R1V, SIGV>), dim3(grid), dim3(64 * GEMM_WAVES), shmem, st, j);               \
+    return 0;                                                                                                                                       \
   }
-  CRNERF_GEMM(8, SEG_NONE, ACT_RELU, false, false)       // xyz_encoding_1..4, 6..8
-  CRNERF_GEMM(4, SEG_VEC, ACT_RELU, false, false)        // xyz_encoding_5 (two passes), dir_encoding
-  CRNERF_GEMM(8, SEG_NONE, ACT_NONE, false, false)       // xyz_encoding_final; d(final)
-  CRNERF_GEMM(2, SEG_NONE, ACT_SIGMOID, false, false)    // static_rgb
-  CRNERF_GEMM(4, SEG_NONE, ACT_NONE, true, false)        // d(dir act)
-  CRNERF_GEMM(8, SEG_NONE, ACT_NONE, true, true)         // d(h8): + the sigma head's branch
-  CRNERF_GEMM(8, SEG_NONE, ACT_NONE, true, false)        // d(h7..h1)
+  CRNERF_GEMM(8, false, ACT_RELU, false, false, false)      // xyz_encoding_1..4, 6, 7
+  CRNERF_GEMM(8, false, ACT_RELU, false, false, true)       // xyz_encoding_8 + static_sigma
+  CRNERF_GEMM(4, true, ACT_RELU, false, false, false)       // xyz_encoding_5 (two passes), dir_encoding
+  CRNERF_GEMM(8, false, ACT_NONE, false, false, false)      // xyz_encoding_final; d(final)
+  CRNERF_GEMM(2, false, ACT_SIGMOID, false, false, false)   // static_rgb
+  CRNERF_GEMM(4, false, ACT_NONE, true, false, false)       // d(dir act)
+  CRNERF_GEMM(8, false, ACT_NONE, true, true, false)        // d(h8): + the sigma head's branch
+  CRNERF_GEMM(8, false, ACT_NONE, true, false, false)       // d(h7..h1)
 #undef CRNERF_GEMM
   return set_error(-2, "linear_bf16: unsupported shape");
 }
 
-// sigma = softplus(w_sigma . h8 + b) on the un-rounded fp32 activations (models/nerf.py:146,172); one point per lane group of 16
-__global__ __launch_bounds__(256) void sigma_head_kernel(const float* __restrict__ h8, const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ out, long P) {
-  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
-  const long p = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp;
-  if (p >= P) return;
-  float s = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 x = *(const float4*)(h8 + p * ACT_W + 64 * q + 4 * sub), ww = *(const float4*)(w + 64 * q + 4 * sub);
-    s = fmaf(x.x, ww.x, s); s = fmaf(x.y, ww.y, s); s = fmaf(x.z, ww.z, s); s = fmaf(x.w, ww.w, s);
+// d_rgb_pre = d_out[:, :64] * f (1 - f) -> bf16;  d_sig_pre = d_out[:, 64] * (1 - exp(-sigma)) -> fp32    (sigmoid', softplus')
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ out, const float* __restrict__ d_out, bf16_t* __restrict__ d_rgb,
+                                                        float* __restrict__ d_sig, long P) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per point and pair of features (+ one for sigma)
+  if (idx >= P * 33) return;
+  const long p = idx / 33;
+  const int c = (int)(idx - p * 33);
+  const float* o = out + p * OUT_DIM;
+  const float* g = d_out + p * OUT_DIM;
+  if (c < 32) {
+    const float f0 = o[2 * c], f1 = o[2 * c + 1];
+    *(uint32_t*)(d_rgb + p * DRGB_W + 2 * c) = gb_pk(g[2 * c] * f0 * (1.0f - f0), g[2 * c + 1] * f1 * (1.0f - f1));
+  } else {
+    d_sig[p] = g[FEAT_DIM] * (1.0f - expf(-o[FEAT_DIM]));
   }
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 16);
-  if (sub == 0) out[p * OUT_DIM + FEAT_DIM] = softplus_ref(s + b[0]);
 }
 
-// d_rgb_pre = d_out[:, :64] * f (1 - f);  d_sig_pre = d_out[:, 64] * (1 - exp(-sigma))    (sigmoid', softplus')
-__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ out, const float* __restrict__ d_out, float* __restrict__ d_rgb,
-                                                        float* __restrict__ d_sig, long P) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P * OUT_DIM) return;
-  const long p = idx / OUT_DIM;
-  const int c = (int)(idx - p * OUT_DIM);
-  const float f = out[idx], g = d_out[idx];
-  if (c < FEAT_DIM) d_rgb[p * FEAT_DIM + c] = g * f * (1.0f - f);
-  else d_sig[p] = g * (1.0f - expf(-f));
+// ---- weight gradients from the stored bf16 rows: C[m][n] = sum_p D[p][m] * A[p][n] on v_mfma_f32_32x32x16_bf16 (k = 16 points).
+// Workgroup = a 256 x 256 block of C over a chunk of points; a wave owns a 128 x 128 sub-block (4 x 4 MFMA tiles) -- MFMA tile t,
+// lane i <-> column 4 i + t, so a lane's four columns of a point are ONE 8-byte load (256 contiguous bytes per half-wave) -- and
+// assembles the 8-point operand with v_perm_b32; lane (i, kk) supplies points 8 kk .. 8 kk + 7 of the k-step.  Blocks narrower than
+// 256 leave waves without a sub-block: those split the chunk's POINTS instead (wp sub-chunks, each with its own partial-sum slot),
+// and columns beyond M / N are loaded from a valid address and dropped at the output -- the matrix work is 16x cheaper than in
+// fp32, so a whole-tile MFMA on a 27-column block costs nothing next to the row traffic.  (A first version loaded the narrow blocks
+// column by column, 2 bytes per lane: 26.8 ms of wgrad in a 16,384-ray step against 15.1 ms for the fp32-storage kernel.)
+// Partial sums per (chunk, sub-chunk) are reduced by wgrad_reduce_kernel (mlp_train16.hip), deterministically.
+// permD / permA: the operand's columns are in storage order -- the output index is un-permuted when dW is written.
+struct WgradBJob {
+  const bf16_t* D; int ldd; int M; int Dw; int permD;    // Dw / Aw: readable columns (multiple of 4, >= M / N)
+  const bf16_t* A; int lda; int N; int Aw; int permA;
+  float* partial;                      // [nchunk * wp][M][N], reference order
+  float* bias_partial;                 // [nchunk * wp][M] column sums of D (bias gradient) or null
+  long P; int chunk;
+};
+
+__host__ __device__ inline int wgb_wp(int M, int N) { return 4 / (((M < 256 ? M : 256) + 127) / 128 * (((N < 256 ? N : 256) + 127) / 128)); }
+
+__global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int bm = j.M - (int)blockIdx.y * 256 < 256 ? j.M - (int)blockIdx.y * 256 : 256;   // live extent of this block
+  const int bn = j.N - (int)blockIdx.z * 256 < 256 ? j.N - (int)blockIdx.z * 256 : 256;
+  const int wm = (bm + 127) / 128, wn = (bn + 127) / 128, wp = 4 / (wm * wn);
+  const int wmi = wave % wm, wni = (wave / wm) % wn, wpi = wave / (wm * wn);
+  const int m0 = blockIdx.y * 256 + wmi * 128, n0 = blockIdx.z * 256 + wni * 128;
+  const long c0 = (long)blockIdx.x * j.chunk;
+  const long c1 = c0 + j.chunk < j.P ? c0 + j.chunk : j.P;
+  const long sub = ((j.chunk + wp - 1) / wp + 15) / 16 * 16;
+  const long p0 = c0 + wpi * sub < c1 ? c0 + wpi * sub : c1;
+  const long p1 = p0 + sub < c1 ? p0 + sub : c1;                                          // may be empty: the slot is still written (zeros)
+  const long slot = (long)blockIdx.x * wp + wpi;
+  gb_f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  const int mc = m0 + 4 * i, nc = n0 + 4 * i;                                             // this lane's first column of each operand
+  const bf16_t* dbase = j.D + (mc < j.Dw ? mc : 0);
+  const bf16_t* abase = j.A + (nc < j.Aw ? nc : 0);
+  const long plast = j.P - 1;
+  uint2 dcur[8], acur[8], dnxt[8], anxt[8];
+  auto fetch16 = [&](long pb, uint2 (&d)[8], uint2 (&a)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long pt = pb + 8 * kk + e;
+      const long pc = pt < plast ? pt : plast;                  // clamped: always a readable row
+      const uint2 dv = *(const uint2*)(dbase + pc * j.ldd);
+      const uint2 av = *(const uint2*)(abase + pc * j.lda);
+      const bool keep = pt < p1;                                // rows past the sub-chunk contribute nothing
+      d[e] = make_uint2(keep ? dv.x : 0u, keep ? dv.y : 0u);
+      a[e] = make_uint2(keep ? av.x : 0u, keep ? av.y : 0u);    // (also the other operand: 0 x garbage of a clamped row could be 0 x inf)
+    }
+  };
+  auto frag = [&](const uint2 (&v)[8], int t) {                 // column t of the lane's four, points 0..7 -> one MFMA operand
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = (t >> 1) ? v[2 * q].y : v[2 * q].x, hi = (t >> 1) ? v[2 * q + 1].y : v[2 * q + 1].x;
+      w[q] = __builtin_amdgcn_perm(hi, lo, (t & 1) ? 0x07060302u : 0x05040100u);
+    }
+    return __builtin_bit_cast(gb_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+  };
+  const bool do_bias = j.bias_partial && blockIdx.z == 0 && wni == 0;
+  gb_f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
+  fetch16(p0, dcur, acur);
+  for (long pb = p0; pb < p1; pb += 16) {
+    fetch16(pb + 16, dnxt, anxt);
+    if (do_bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bsum[0] += gb_lo(dcur[e].x); bsum[1] += gb_hi(dcur[e].x); bsum[2] += gb_lo(dcur[e].y); bsum[3] += gb_hi(dcur[e].y);
+      }
+    }
+    gb_bf16x8 df[4], af[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { df[t] = frag(dcur, t); af[t] = frag(acur, t); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a], af[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bsum[t] += __shfl_xor(bsum[t], 32);
+    if (kk == 0 && mc < j.M) *(gb_f32x4*)(j.bias_partial + slot * j.M + (j.permD ? unperm32(mc) : mc)) = bsum;   // M is a multiple of 4
+  }
+  float* outp = j.partial + slot * j.M * j.N;
+  const int fn = j.permA ? unperm32(nc) : nc;                   // the permutation keeps groups of four together
+  const bool vec = (j.N & 3) == 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
+      if (m >= j.M || nc >= j.N) continue;
+      float* o = outp + (long)(j.permD ? unperm32(m) : m) * j.N + fn;
+      if (vec) *(gb_f32x4*)o = gb_f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+      else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (nc + b < j.N) o[b] = acc[a][b][r];
+      }
+    }
+}
+
+// static_sigma: dW[n] = sum_p d_sig[p] * h8[p][n], db = sum_p d_sig[p] -- a weighted column sum over the stored h8 rows (512 B per
+// point).  Thread = (16-byte unit of the row, one of 8 row slots); four rows per thread in flight; partial[block][257] in storage order.
+constexpr int SIGW_BLOCKS = 256;
+__global__ __launch_bounds__(256) void sigma_wgrad_kernel(const bf16_t* __restrict__ h8, const float* __restrict__ d_sig, long P, long chunk,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[8][260];
+  const int u = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bs = 0.0f;
+  for (long p = p0 + rs; p < p1; p += 32) {
+    uint4 v[4];
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long pp = p + 8 * e;
+      const bool ok = pp < p1;
+      const long pc = ok ? pp : p1 - 1;
+      v[e] = *(const uint4*)(h8 + pc * ACT_W + 8 * u);
+      g[e] = ok ? d_sig[pc] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[0] = fmaf(g[e], gb_lo(v[e].x), a[0]); a[1] = fmaf(g[e], gb_hi(v[e].x), a[1]);
+      a[2] = fmaf(g[e], gb_lo(v[e].y), a[2]); a[3] = fmaf(g[e], gb_hi(v[e].y), a[3]);
+      a[4] = fmaf(g[e], gb_lo(v[e].z), a[4]); a[5] = fmaf(g[e], gb_hi(v[e].z), a[5]);
+      a[6] = fmaf(g[e], gb_lo(v[e].w), a[6]); a[7] = fmaf(g[e], gb_hi(v[e].w), a[7]);
+      bs += g[e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rs][8 * u + k] = a[k];
+  if (u == 0) red[rs][256] = bs;
+  __syncthreads();
+  for (int c = threadIdx.x; c < 257; c += 256) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][c];
+    partial[(long)blockIdx.x * 257 + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(320) void sigma_wgrad_finish_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db) {
+  const int f = threadIdx.x;
+  if (f < 256) dw[f] = sums[perm32(f)];
+  else if (f == 256) db[0] = sums[256];
+}
+
+static int wgb_chunk(long P) {   // points per workgroup (multiple of the 16-point k-step), as wg_chunk of mlp_train16.hip
+  long c = (P + 255) / 256;
+  c = (c + 15) / 16 * 16;
+  return (int)(c < 128 ? 128 : c);
+}
+
+static int wgrad_b(const bf16_t* D, int ldd, int M, int Dw, int permD, const bf16_t* A, int lda, int N, int Aw, int permA, float* dst, int ldc,
+                   float* db, long P, float* ws, hipStream_t st) {
+  const int chunk = wgb_chunk(P);
+  const int nchunk = (int)((P + chunk - 1) / chunk);
+  const int slots = nchunk * wgb_wp(M, N);
+  float* bws = ws + (size_t)slots * M * N;
+  WgradBJob j{D, ldd, M, Dw, permD, A, lda, N, Aw, permA, ws, db ? bws : nullptr, P, chunk};
+  hipLaunchKernelGGL(wgrad_b_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  return launch_wgrad_reduce(ws, slots, M, N, dst, ldc, bws, db, st);
+}
+
+// ---- buffers.  acts: [10][P][256] bf16 activations (storage order) | [10][P] x 32 B relu bits | xb [P][128] bf16.
+//      scratch: [10][P][256] bf16 deltas | d_rgb [P][64] bf16 | d_sig [P] fp32 | (16-byte aligned) weight-gradient workspace.
+static size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
+size_t mlp_train_mixed_acts_bytes(long P) { return (size_t)P * (ACT_SLOTS * ACT_W * 2 + ACT_SLOTS * 32 + XB_W * 2); }
+static size_t mixed_ws_offset(long P) { return align16((size_t)P * (ACT_SLOTS * ACT_W * 2 + DRGB_W * 2 + 4)); }
+size_t mlp_train_mixed_scratch_bytes(long P) {
+  const int chunk = wgb_chunk(P);
+  const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
+  return mixed_ws_offset(P) + (nchunk * (256 * 256 + 256) + (size_t)SIGW_BLOCKS * 257 + 512) * 4;
 }
 
 static const uint4* frag_ptr(const void* packed, int id) { return (const uint4*)packed + (size_t)layout().m[id].off_frag * 64; }
 
-int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, float* acts, long P, hipStream_t st) {
+int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, void* acts, long P, hipStream_t st) {
   if (P <= 0) return 0;
   const GemmLayout& L = layout();
-  auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
-  const GemmSeg none{nullptr, 0, 0, 0, 0};
+  bf16_t* abase = (bf16_t*)acts;
+  auto A = [&](int slot) { return abase + (size_t)slot * P * ACT_W; };
+  uint32_t* bits_base = (uint32_t*)(abase + (size_t)ACT_SLOTS * P * ACT_W);
+  auto bits = [&](int slot) { return bits_base + (size_t)slot * P * 8; };   // 32 bytes per point and slot
+  bf16_t* xb = (bf16_t*)(bits_base + (size_t)ACT_SLOTS * P * 8);
+  hipLaunchKernelGGL(embed_bf16_kernel, dim3((unsigned)((P * (XB_W / 8) + 255) / 256)), dim3(256), 0, st, x, xb, P);
+  const GemmSeg none{nullptr, 0, 0};
   // tiles [t0, t0 + nt) of matrix `id` as one pass (a 256 x 352 matrix does not fit the 128 KiB of LDS: the skip layer runs as two
   // 128-feature passes and reads its input twice)
-  auto bits = [&](int slot) { return (uint32_t*)(acts + (size_t)ACT_SLOTS * P * ACT_W) + (size_t)slot * P * 8; };   // 32 bytes per point and slot
-  auto gemm = [&](int id, int t0, int nt, GemmSeg a0, GemmSeg a1, int a1kind, const float* bias, int act, float* o, int ldo, uint32_t* bo) {
+  auto gemm = [&](int id, int t0, int nt, GemmSeg a0, GemmSeg a1, const float* bias, int act, bf16_t* o, uint32_t* bo, bool sig = false) {
     const int ks = L.m[id].K / 16;
     const int n = L.m[id].N - 32 * t0 < 32 * nt ? L.m[id].N - 32 * t0 : 32 * nt;
-    GemmJob j{a0, a1, frag_ptr(packed, id) + (size_t)t0 * ks * 64, n, L.m[id].K, 32 * t0, bias, act, nullptr, bo, nullptr, nullptr, o, ldo, P, 0};
-    return run_gemm(j, a1kind, st);
+    GemmJob j{a0, a1, frag_ptr(packed, id) + (size_t)t0 * ks * 64, n, L.m[id].K, 32 * t0, bias, act, nullptr, bo, nullptr,
+              sig ? t.w_sigma : nullptr, sig ? t.b_sigma : nullptr, sig ? out : nullptr, o, ACT_W, out, OUT_DIM, P, 0};
+    return run_gemm(j, st);
   };
-  const GemmSeg emb{x, IN_DIM, 0, XYZ_DIM, 96};
-  if (int rc = gemm(GM_L1, 0, 8, emb, none, SEG_NONE, t.b[0], ACT_RELU, A(0), ACT_W, bits(0))) return rc;
+  const GemmSeg emb{xb, XB_W, 96};
+  if (int rc = gemm(GM_L1, 0, 8, emb, none, t.b[0], ACT_RELU, A(0), bits(0))) return rc;
   for (int l = 1; l < 8; ++l) {
-    const GemmSeg h{A(l - 1), ACT_W, 0, 256, 256};
+    const GemmSeg h{A(l - 1), ACT_W, 256};
     if (l == 4) {
-      if (int rc = gemm(GM_L5, 0, 4, emb, h, SEG_VEC, t.b[4], ACT_RELU, A(4), ACT_W, bits(4))) return rc;
-      if (int rc = gemm(GM_L5, 4, 4, emb, h, SEG_VEC, t.b[4], ACT_RELU, A(4), ACT_W, bits(4))) return rc;
-    } else if (int rc = gemm(GM_L1 + l, 0, 8, h, none, SEG_NONE, t.b[l], ACT_RELU, A(l), ACT_W, bits(l))) return rc;
+      if (int rc = gemm(GM_L5, 0, 4, emb, h, t.b[4], ACT_RELU, A(4), bits(4))) return rc;
+      if (int rc = gemm(GM_L5, 4, 4, emb, h, t.b[4], ACT_RELU, A(4), bits(4))) return rc;
+    } else if (int rc = gemm(GM_L1 + l, 0, 8, h, none, t.b[l], ACT_RELU, A(l), bits(l), l == 7)) return rc;   // layer 8 carries static_sigma
   }
-  hipLaunchKernelGGL(sigma_head_kernel, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, st, A(7), t.w_sigma, t.b_sigma, out, P);
-  if (int rc = gemm(GM_FINAL, 0, 8, GemmSeg{A(7), ACT_W, 0, 256, 256}, none, SEG_NONE, t.b_final, ACT_NONE, A(8), ACT_W, nullptr)) return rc;
-  if (int rc = gemm(GM_DIR, 0, 4, GemmSeg{A(8), ACT_W, 0, 256, 256}, GemmSeg{x + XYZ_DIM - DIR_SEG_LO, IN_DIM, DIR_SEG_LO, 32, 32}, SEG_VEC, t.b_dir, ACT_RELU, A(9), ACT_W,
-                    bits(9)))
-    return rc;
-  if (int rc = gemm(GM_RGB, 0, 2, GemmSeg{A(9), ACT_W, 0, 128, 128}, none, SEG_NONE, t.b_rgb, ACT_SIGMOID, out, OUT_DIM, nullptr)) return rc;
+  if (int rc = gemm(GM_FINAL, 0, 8, GemmSeg{A(7), ACT_W, 256}, none, t.b_final, ACT_NONE, A(8), nullptr)) return rc;
+  if (int rc = gemm(GM_DIR, 0, 4, GemmSeg{A(8), ACT_W, 256}, GemmSeg{xb + XB_DIR, XB_W, 32}, t.b_dir, ACT_RELU, A(9), bits(9))) return rc;
+  if (int rc = gemm(GM_RGB, 0, 2, GemmSeg{A(9), ACT_W, 128}, none, t.b_rgb, ACT_SIGMOID, nullptr, nullptr)) return rc;
   return check_launch("mlp_forward_train_mixed");
 }
 
-int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const float* acts,
+int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const void* acts,
                               void* scratch, float* const* grads, long P, hipStream_t st) {
   if (P <= 0) return 0;
+  (void)x;                                   // the bf16 copy the forward left in `acts` is what the weight gradients read
   const GemmLayout& L = layout();
-  float* deltas = (float*)scratch;
-  float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
-  float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
-  float* ws = d_sig + P;
+  const bf16_t* abase = (const bf16_t*)acts;
+  auto A = [&](int slot) { return abase + (size_t)slot * P * ACT_W; };
+  const uint32_t* bits_base = (const uint32_t*)(abase + (size_t)ACT_SLOTS * P * ACT_W);
+  auto bits = [&](int slot) { return bits_base + (size_t)slot * P * 8; };
+  const bf16_t* xb = (const bf16_t*)(bits_base + (size_t)ACT_SLOTS * P * 8);
+  bf16_t* deltas = (bf16_t*)scratch;
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
-  hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((P * OUT_DIM + 255) / 256)), dim3(256), 0, st, out, d_out, d_rgb, d_sig, P);
-  const GemmSeg none{nullptr, 0, 0, 0, 0};
-  auto bits = [&](int slot) { return (const uint32_t*)(acts + (size_t)ACT_SLOTS * P * ACT_W) + (size_t)slot * P * 8; };
-  auto dg = [&](int id, GemmSeg a0, const uint32_t* mask, const float* r1r, const float* r1c, float* o) {
-    GemmJob j{a0, none, frag_ptr(packed, id), L.m[id].N, L.m[id].K, 0, nullptr, ACT_NONE, mask, nullptr, r1r, r1c, o, ACT_W, P, 0};
-    return run_gemm(j, SEG_NONE, st);
+  bf16_t* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
+  float* d_sig = (float*)(d_rgb + (size_t)P * DRGB_W);
+  float* ws = (float*)((char*)scratch + mixed_ws_offset(P));
+  hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((P * 33 + 255) / 256)), dim3(256), 0, st, out, d_out, d_rgb, d_sig, P);
+  const GemmSeg none{nullptr, 0, 0};
+  auto dg = [&](int id, GemmSeg a0, const uint32_t* mask, const float* r1r, const float* r1c, bf16_t* o) {
+    GemmJob j{a0, none, frag_ptr(packed, id), L.m[id].N, L.m[id].K, 0, nullptr, ACT_NONE, mask, nullptr, r1r, r1c, nullptr, nullptr, o, ACT_W,
+              nullptr, 0, P, 0};
+    return run_gemm(j, st);
   };
-  if (int rc = dg(GM_T_RGB, GemmSeg{d_rgb, FEAT_DIM, 0, 64, 64}, bits(9), nullptr, nullptr, D(9))) return rc;        // through static_rgb, relu' of dir act
-  if (int rc = dg(GM_T_DIR, GemmSeg{D(9), ACT_W, 0, 128, 128}, nullptr, nullptr, nullptr, D(8))) return rc;        // through dir_encoding[:, :256] (final is linear)
-  if (int rc = dg(GM_T_FINAL, GemmSeg{D(8), ACT_W, 0, 256, 256}, bits(7), d_sig, t.w_sigma, D(7))) return rc;          // through final + the sigma head, relu' of h8
-  for (int l = 7; l >= 1; --l)                                                                                    // through xyz_encoding_{l+1}, relu' of h_l
-    if (int rc = dg(GM_T8 + (7 - l), GemmSeg{D(l), ACT_W, 0, 256, 256}, bits(l - 1), nullptr, nullptr, D(l - 1))) return rc;
+  if (int rc = dg(GM_T_RGB, GemmSeg{d_rgb, DRGB_W, 64}, bits(9), nullptr, nullptr, D(9))) return rc;           // through static_rgb, relu' of dir act
+  if (int rc = dg(GM_T_DIR, GemmSeg{D(9), ACT_W, 128}, nullptr, nullptr, nullptr, D(8))) return rc;           // through dir_encoding[:, :256] (final is linear)
+  if (int rc = dg(GM_T_FINAL, GemmSeg{D(8), ACT_W, 256}, bits(7), d_sig, t.w_sigma, D(7))) return rc;         // through final + the sigma head, relu' of h8
+  for (int l = 7; l >= 1; --l)                                                                                // through xyz_encoding_{l+1}, relu' of h_l
+    if (int rc = dg(GM_T8 + (7 - l), GemmSeg{D(l), ACT_W, 256}, bits(l - 1), nullptr, nullptr, D(l - 1))) return rc;
   if (int rc = check_launch("mlp_backward_mixed")) return rc;
-  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, st, 1);
+  // weight / bias gradients of the eleven nn.Linear (grads in crnerf.h tensor order)
+  wgrad_b(D(0), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[0], XYZ_DIM, grads[1], P, ws, st);          // xyz_encoding_1
+  for (int l = 1; l < 8; ++l) {
+    if (l == 4) {                                                                                              // xyz_encoding_5: cat([xyz, h4])
+      wgrad_b(D(4), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[8], XYZ_DIM + 256, grads[9], P, ws, st);
+      wgrad_b(D(4), ACT_W, 256, 256, 1, A(3), ACT_W, 256, 256, 1, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, st);
+    } else {
+      wgrad_b(D(l), ACT_W, 256, 256, 1, A(l - 1), ACT_W, 256, 256, 1, grads[2 * l], 256, grads[2 * l + 1], P, ws, st);
+    }
+  }
+  wgrad_b(D(8), ACT_W, 256, 256, 1, A(7), ACT_W, 256, 256, 1, grads[16], 256, grads[17], P, ws, st);             // xyz_encoding_final
+  {                                                                                                            // static_sigma
+    const long chunk = (P + SIGW_BLOCKS - 1) / SIGW_BLOCKS;
+    const int nblk = (int)((P + chunk - 1) / chunk);
+    float* part = ws;
+    float* sums = ws + (size_t)SIGW_BLOCKS * 257;
+    hipLaunchKernelGGL(sigma_wgrad_kernel, dim3(nblk), dim3(256), 0, st, A(7), d_sig, P, chunk, part);
+    if (int rc = launch_wgrad_reduce(part, nblk, 1, 257, sums, 257, nullptr, nullptr, st)) return rc;
+    hipLaunchKernelGGL(sigma_wgrad_finish_kernel, dim3(1), dim3(320), 0, st, sums, grads[18], grads[19]);
+  }
+  wgrad_b(D(9), ACT_W, 128, 128, 1, A(8), ACT_W, 256, 256, 1, grads[20], 256 + DIR_DIM, grads[21], P, ws, st);   // dir_encoding: cat([final, dir])
+  wgrad_b(D(9), ACT_W, 128, 128, 1, xb + XB_DIR, XB_W, DIR_DIM, 32, 0, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, st);
+  wgrad_b(d_rgb, DRGB_W, FEAT_DIM, DRGB_W, 0, A(9), ACT_W, 128, 128, 1, grads[22], 128, grads[23], P, ws, st);   // static_rgb
+  return check_launch("mlp_backward_mixed wgrad");
 }
 
 }  // namespace crnerf

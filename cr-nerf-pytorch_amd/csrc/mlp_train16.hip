@@ -529,6 +529,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *out = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
+int launch_wgrad_reduce(const float* partial, int nchunk, int M, int N, float* dst, int ldc, const float* bias_partial, float* db, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, partial, nchunk, M, N, dst, ldc, bias_partial, db);
+  return 0;
+}
+
 // points per wgrad workgroup: small enough to fill the chip at 1024-ray batches, large enough that the
 // partial-sum workspace (nchunk x M x N) stays ~50 MB per layer at 65k-ray batches
 static int wg_chunk(long P) {

@@ -140,12 +140,12 @@ def pack_mlp_weights_mixed(state):
 
 
 def mlp_forward_train_mixed(packed_mixed, tensors, x):
-    """Mixed-precision forward that keeps the layer activations (fp32 storage, bf16 MFMA operands).  Returns (out[n,65], acts)."""
+    """Mixed-precision forward that keeps the layer activations (bf16 rows, kernel-internal order).  Returns (out[n,65], acts)."""
     lib = _lib.load()
     x = _f32c(x, "x")
     n = x.shape[0]
     out = torch.empty(n, 65, dtype=torch.float32, device=x.device)
-    acts = torch.empty(lib.crnerf_mlp_train_acts_bytes(n), dtype=torch.uint8, device=x.device)
+    acts = torch.empty(lib.crnerf_mlp_train_mixed_acts_bytes(n), dtype=torch.uint8, device=x.device)
     _lib.check(lib.crnerf_mlp_forward_train_mixed_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(x),
                                                       _lib.dev_ptr(out), ctypes.c_void_p(acts.data_ptr()), n, _lib.stream_ptr()),
                "crnerf_mlp_forward_train_mixed_f32")
@@ -158,7 +158,7 @@ def mlp_backward_mixed(packed_mixed, tensors, x, out, d_out, acts):
     x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
     n = x.shape[0]
     grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
-    scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+    scratch = torch.empty(lib.crnerf_mlp_train_mixed_scratch_bytes(n), dtype=torch.uint8, device=x.device)
     _lib.check(lib.crnerf_mlp_backward_mixed_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(x),
                                                  _lib.dev_ptr(out), _lib.dev_ptr(d_out), ctypes.c_void_p(acts.data_ptr()),
                                                  ctypes.c_void_p(scratch.data_ptr()), _lib.ptr_array(grads, "grad"), n, _lib.stream_ptr()),

@@ -82,13 +82,17 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream);
 
-/* ---- opt-in mixed-precision training twins (no counterpart in the reference, whose autograd is fp32): the same buffers
- * as the fp32 twins above -- x[n,120], out[n,65], acts (crnerf_mlp_train_acts_bytes; only the activation rows are used), scratch
- * (crnerf_mlp_train_scratch_bytes), grads -- but every nn.Linear except static_sigma runs as one points x features GEMM on the bf16
- * MFMA: fp32 operands from HBM rounded to bf16 (RNE) in registers, fp32 accumulation, fp32 biases / activations / sigma head / storage.
- * Forward = the arithmetic of crnerf_mlp_forward_bf16; backward = data gradients through the transposed matrices (operands rounded
- * the same way) + the weight gradients of crnerf_mlp_backward_ex_f32(CRNERF_BWD_WGRAD_BF16).  `tensors` = the 24 fp32 tensors
- * (biases and the sigma head are read from them), `packed_mixed` = crnerf_pack_mlp_weights_mixed of the same tensors. */
+/* ---- opt-in mixed-precision training twins (no counterpart in the reference, whose autograd is fp32).  Same interface
+ * as the fp32 twins above -- x[n,120], out[n,65], grads in fp32 -- but every nn.Linear except static_sigma runs as one points x
+ * features GEMM on the bf16 MFMA: operands rounded to bf16 (RNE), fp32 accumulation, fp32 biases / activations / sigma head; and
+ * what is kept between the passes is bf16: `acts` (crnerf_mlp_train_mixed_acts_bytes: the ten activation rows, relu bits, the
+ * embedded input) and the layer deltas in `scratch` (crnerf_mlp_train_mixed_scratch_bytes) -- 5.7 + 5.3 KB per point against
+ * 10.6 + 10.5 KB of the fp32 twins.  Forward = the arithmetic of crnerf_mlp_forward_bf16; backward = data gradients through the
+ * transposed matrices, weight gradients from the stored rows, bias gradients as column sums of the stored (rounded) deltas.
+ * `tensors` = the 24 fp32 tensors (biases and the sigma head are read from them), `packed_mixed` = crnerf_pack_mlp_weights_mixed
+ * of the same tensors.  Both buffers are opaque to the caller (rows are stored in a kernel-internal feature order). */
+size_t crnerf_mlp_train_mixed_acts_bytes(int64_t n);
+size_t crnerf_mlp_train_mixed_scratch_bytes(int64_t n);
 size_t crnerf_packed_mlp_mixed_bytes(void);
 int crnerf_pack_mlp_weights_mixed(const float* const* tensors, void* packed_mixed, void* stream);
 int crnerf_mlp_forward_train_mixed_f32(const float* const* tensors, const void* packed_mixed, const float* x, float* out, void* acts, int64_t n,

@@ -76,8 +76,8 @@ def mlp_forward_bf16(w, x, sigma_only=False):
 
 class _LinearBf16(torch.autograd.Function):
     """nn.Linear in the arithmetic of the mixed-precision training twins (crnerf_mlp_*_mixed_f32): both operands of each of the
-    three products -- forward, data gradient, weight gradient -- rounded to bf16, fp32 accumulation; the bias gradient is the
-    un-rounded column sum."""
+    three products -- forward, data gradient, weight gradient -- rounded to bf16, fp32 accumulation.  The twins STORE activations and
+    layer deltas as bf16, so the bias gradient is the column sum of the rounded delta."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -88,7 +88,22 @@ class _LinearBf16(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         gq = bf16_round(g)
-        return gq @ bf16_round(w), gq.t() @ bf16_round(x), g.sum(0)
+        return gq @ bf16_round(w), gq.t() @ bf16_round(x), gq.sum(0)
+
+
+class _SigmaHeadStoredBf16(torch.autograd.Function):
+    """static_sigma in the mixed-precision twins: evaluated in fp32 on the un-rounded output of xyz_encoding_8 (forward and the branch
+    into d(h8)); its WEIGHT gradient reads the activation row as it was stored, i.e. rounded to bf16."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        ctx.save_for_backward(h, w)
+        return F.linear(h, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        return g @ w, g.t() @ bf16_round(h), g.sum(0)
 
 
 def mlp_forward_bf16_train(w, x):
@@ -100,7 +115,7 @@ def mlp_forward_bf16_train(w, x):
         if layer == 5:
             h = torch.cat((xyz, h), dim=1)
         h = F.relu(lin(h, "xyz_encoding_%d.0" % layer))
-    sigma = F.softplus(F.linear(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))
+    sigma = F.softplus(_SigmaHeadStoredBf16.apply(h, w["static_sigma.0.weight"], w["static_sigma.0.bias"]))
     final = lin(h, "xyz_encoding_final")
     g = F.relu(lin(torch.cat((final, x[:, 93:]), dim=1), "dir_encoding.0"))
     feat = torch.sigmoid(lin(g, "static_rgb.0"))
