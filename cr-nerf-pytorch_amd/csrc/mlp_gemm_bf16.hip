@@ -193,8 +193,7 @@ struct GemmJob {
 constexpr int GEMM_LDS_BYTES = 128 * 1024 + 2048;   // fragments + bias / column vector
 constexpr int GEMM_WAVES = 8;     // two per SIMD (< 256 registers): one wave's store phase overlaps another's load phase
 constexpr int GEMM_TILE = 32;     // points per wave tile
-constexpr int GEMM_PF = 8;        // k-steps per prefetch chunk: 8 x 16 B per lane = 8 KiB per wave in flight (~16 MB on the chip); 4 in the
-                                  // sigma-head variant, which otherwise spills
+constexpr int GEMM_PF = 8;        // k-steps per prefetch chunk: 8 x 16 B per lane = 8 KiB per wave in flight (~16 MB on the chip)
 
 // NT feature tiles of 32 per pass: 8 (N = 256), 4 (N = 128), 2 (N = 64).  SEG2 / ACT / MASK (relu' bits in) / R1 (rank-1 term) / SIG
 // (fused sigma head) are compile-time: as run-time switches they became ~1,400 branches and 200 spilled registers in the epilogue,
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hh = lane >> 5;
   const int ks = j.K / 16, ks0 = j.a0.pad / 16;
-  constexpr int PF = SIG ? GEMM_PF / 2 : GEMM_PF;
+  constexpr int PF = GEMM_PF;
   {   // stage the weight fragments: the LDS image is the global image
     const int n16 = NT * ks * 64;
     uint4* dst = (uint4*)gsm;
@@ -285,6 +284,22 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
     const uint32_t bw_in[4] = {bin.x, bin.y, bin.z, bin.w};
     uint32_t bw_out[4] = {0u, 0u, 0u, 0u};
     float sg = 0.0f;
+    if (SIG) {
+      // static_sigma on the un-rounded relu output (nerf.py:146,172), as its own pass over the accumulators: folded into the store
+      // loop below it pushed that loop over the 256-register budget (52 spills, every store behind a scratch reload: 2.8x slower)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int fcol = 32 * t + 8 * q + 4 * hh;
+          const float4 b = *(const float4*)(eb + fcol), cv = *(const float4*)(eb + 256 + fcol);
+          sg = fmaf(cv.x, fmaxf(acc[t][4 * q + 0] + b.x, 0.0f), sg); sg = fmaf(cv.y, fmaxf(acc[t][4 * q + 1] + b.y, 0.0f), sg);
+          sg = fmaf(cv.z, fmaxf(acc[t][4 * q + 2] + b.z, 0.0f), sg); sg = fmaf(cv.w, fmaxf(acc[t][4 * q + 3] + b.w, 0.0f), sg);
+        }
+      asm volatile("" : "+v"(sg));
+      sg += __shfl_xor(sg, 32);
+      if (row_ok && hh == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int tg = t_off + t;                                   // tile index within the point's 256 features
@@ -297,14 +312,10 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
         const float4 b = *(const float4*)(eb + fcol);
         v[4 * q + 0] = acc[t][4 * q + 0] + b.x; v[4 * q + 1] = acc[t][4 * q + 1] + b.y;
         v[4 * q + 2] = acc[t][4 * q + 2] + b.z; v[4 * q + 3] = acc[t][4 * q + 3] + b.w;
-        if (R1 || SIG) {
+        if (R1) {
           const float4 cv = *(const float4*)(eb + 256 + fcol);
-          const float cvs[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (R1) v[4 * q + e] = fmaf(r1, cvs[e], v[4 * q + e]);
-            if (SIG) sg = fmaf(cvs[e], fmaxf(v[4 * q + e], 0.0f), sg);   // static_sigma on the un-rounded relu output (nerf.py:146,172)
-          }
+          v[4 * q + 0] = fmaf(r1, cv.x, v[4 * q + 0]); v[4 * q + 1] = fmaf(r1, cv.y, v[4 * q + 1]);
+          v[4 * q + 2] = fmaf(r1, cv.z, v[4 * q + 2]); v[4 * q + 3] = fmaf(r1, cv.w, v[4 * q + 3]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -333,10 +344,6 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
       uint32_t* bo = j.bits_out + (row * 2 + hh) * 4;
       if (NT == 8) *(uint4*)bo = make_uint4(bw_out[0], bw_out[1], bw_out[2], bw_out[3]);
       else if (NT == 4) { const int w0 = (t_off >> 1) & 3; *(uint2*)(bo + w0) = make_uint2(bw_out[w0], bw_out[w0 + 1]); }
-    }
-    if (SIG) {
-      sg += __shfl_xor(sg, 32);
-      if (row_ok && hh == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
     }
   }
 }
