@@ -18,12 +18,19 @@
 //               A = Wrgb Wunzip T Wcomp (3x64), T = sMatrix cMatrix; folded once per image
 //   apply     : rgb = sigmoid(A x + v)                             (HBM-bound stream: 256 B in, 12 B out)
 // Every kernel takes up to two "jobs" (content grid, style grid) so the single-GPU entry
-// crnerf_crossray_decode_f32 is 6 launches from one host call.
+// crnerf_crossray_decode_f32 is 6 launches from one host call (4 for grids of <= 4096 pixels: the row
+// reduction rides in the fc launch, the fold in the apply launch).
 //
 // gram is the only piece with real arithmetic (18.4 k MAC/pixel): it runs on the fp32 MFMA with the
 // same swapped-operand trick as the NeRF MLP (mlp_core.h): 32 pixels per wavefront, the conv chain's
 // activations stay in registers, the 72 KiB of weights sit in LDS as A-operand fragments, and the
-// 32x32 Gram update itself is 16 more MFMAs per tile (H H^T through a 4 KiB LDS transpose).
+// 32x32 Gram update itself is 16 more MFMAs per tile (H H^T through a 4 KiB LDS transpose).  Grids of
+// <= 4096 pixels (the headline 32x32 grid) take the cooperative variant: one tile per WORKGROUP, its
+// four waves splitting every layer (gram_tiles_coop).
+// (Tried and dropped in round 2: the whole small-grid decode as ONE cooperative launch of 64 co-resident
+// workgroups with device-scope barriers in place of the launch boundaries -- 35.9 us against 37.2 us for
+// the six launches, but every barrier's acquire invalidates the L2, and the render kernel of the next step
+// then re-fetches its 5 MB of weights: +16 us there, a net loss.)
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -143,6 +150,7 @@ struct GramJob {
   float* gram_partial;        // [nblk][1024]
   float* mean_out;            // [64] or null
   int nblk;
+  int coop;                   // != 0: one tile per WORKGROUP (gram_tiles_coop; small grids), nblk <= tiles
 };
 
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
@@ -171,17 +179,10 @@ __device__ __forceinline__ void conv_mfma(const float* frags, int lane, const f3
     }
 }
 
-__global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j1) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const bool second = (int)blockIdx.x >= j0.nblk;
-  const GramJob J = second ? j1 : j0;
-  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = lane & 31, h = lane >> 5;
-
-  // fragments: frag(v,t)[lane = 32kk + i][j] = W[32t + i][8v + 4kk + j]; the four j are contiguous in W, so one 16-byte
-  // load per lane-slot, all 18 of a thread in flight at once (one element per loop iteration was 36 us of serialized
-  // global-load latency -- as long as the render kernel of a 32x32 bf16 batch)
+// the three 1x1-conv matrices as MFMA A-operand fragments + biases into LDS.  frag(v,t)[lane = 32kk + i][j] = W[32t + i][8v + 4kk + j];
+// the four j are contiguous in W, so one 16-byte load per lane-slot, all 18 of a thread in flight at once (one element per loop
+// iteration was 36 us of serialized global-load latency -- as long as the render kernel of a 32x32 bf16 batch)
+__device__ __forceinline__ void gram_stage_weights(const CnnTensors& w, float* sm, int tid) {
   static_assert(GF_B1 == 72 * 256, "fragment area");
   f32x4 stage[18];
 #pragma unroll
@@ -189,34 +190,40 @@ __global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j
     const int idx4 = tid + 256 * it;
     const int frag = idx4 >> 6, l = idx4 & 63, i = l & 31, kk = l >> 5;
     const float* src;
-    if (frag < 32) { const int v = frag >> 2, t = frag & 3; src = J.w.w1 + (32 * t + i) * 64 + 8 * v + 4 * kk; }
-    else if (frag < 64) { const int f = frag - 32, v = f >> 1, t = f & 1; src = J.w.w2 + (32 * t + i) * 128 + 8 * v + 4 * kk; }
-    else { const int v = frag - 64; src = J.w.w3 + i * 64 + 8 * v + 4 * kk; }
+    if (frag < 32) { const int v = frag >> 2, t = frag & 3; src = w.w1 + (32 * t + i) * 64 + 8 * v + 4 * kk; }
+    else if (frag < 64) { const int f = frag - 32, v = f >> 1, t = f & 1; src = w.w2 + (32 * t + i) * 128 + 8 * v + 4 * kk; }
+    else { const int v = frag - 64; src = w.w3 + i * 64 + 8 * v + 4 * kk; }
     stage[it] = *(const f32x4*)src;
   }
 #pragma unroll
   for (int it = 0; it < 18; ++it) *(f32x4*)(sm + 4 * (tid + 256 * it)) = stage[it];
-  if (tid < 128) sm[GF_B1 + tid] = J.w.b1[tid];
-  if (tid < 64) sm[GF_B2 + tid] = J.w.b2[tid];
-  if (tid < 32) sm[GF_B3 + tid] = J.w.b3[tid];
-  // channel means from the partial rows: four row-interleaved partial sums per channel with the loads of a partial in
-  // flight together (a plain row loop is chan_rows dependent L2 round trips -- 64 of them, ~25 us, for a 32x32 grid)
+  if (tid < 128) sm[GF_B1 + tid] = w.b1[tid];
+  if (tid < 64) sm[GF_B2 + tid] = w.b2[tid];
+  if (tid < 32) sm[GF_B3 + tid] = w.b3[tid];
+}
+
+// sm[GF_MEAN .. +64) = (sum of the `rows` partial rows) * inv_count: four row-interleaved partial sums per channel with the loads of
+// a partial in flight together (a plain row loop is `rows` dependent L2 round trips -- 64 of them, ~25 us, for a 32x32 grid).
+// Two __syncthreads inside; uses the (idle) transpose buffers.
+__device__ __forceinline__ void gram_mean_from_partials(const float* chan_partial, int rows, float inv_count, float* mean_out, float* sm, int tid) {
   float part = 0.0f;
-  if (!J.mean) {
-    const int c = tid & 63, q = tid >> 6;
+  const int c = tid & 63, q = tid >> 6;
 #pragma unroll 8
-    for (int r = q; r < J.chan_rows; r += 4) part += J.chan_partial[r * 64 + c];
-    sm[GF_HB + q * 64 + c] = part;     // the transpose buffers are idle until the tile loop
-  }
+  for (int r = q; r < rows; r += 4) part += chan_partial[r * 64 + c];
+  sm[GF_HB + q * 64 + c] = part;
   __syncthreads();
   if (tid < 64) {
-    const float m = J.mean ? J.mean[tid]
-                           : ((sm[GF_HB + tid] + sm[GF_HB + 64 + tid]) + (sm[GF_HB + 128 + tid] + sm[GF_HB + 192 + tid])) * J.inv_count;
+    const float m = ((sm[GF_HB + tid] + sm[GF_HB + 64 + tid]) + (sm[GF_HB + 128 + tid] + sm[GF_HB + 192 + tid])) * inv_count;
     sm[GF_MEAN + tid] = m;
-    if (blk == 0 && J.mean_out) J.mean_out[tid] = m;
+    if (mean_out) mean_out[tid] = m;
   }
   __syncthreads();
+}
 
+// tiles blk*4 + wave, ... of the job through the conv chain; the workgroup's Gram partial -> J.gram_partial[blk]
+__device__ __forceinline__ void gram_tiles(const GramJob& J, int blk, float* sm, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
   float* hb = sm + GF_HB + wave * 32 * 33;
   f32x16 G;
 #pragma unroll
@@ -274,13 +281,152 @@ __global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j
   *(f32x4*)(J.gram_partial + (long)blk * 1024 + tid * 4) = s;
 }
 
+// ---- small grids: the four waves of a workgroup share ONE 32-pixel tile.  With a tile per wave (gram_tiles) a 32 x 32 grid keeps
+// 16 workgroups busy for 11 us each -- the time of one wave's serial chain of 288 MFMAs -- and leaves the other 240 CUs idle.
+// Here wave w computes output tile w of conv1 (128 features), tile w&1 / K-half w>>1 of conv2, K-quarter w of conv3 and steps
+// 4w..4w+3 of the Gram update: 76 MFMAs per wave, activations exchanged through LDS ([feature][pixel] rows, the B-operand shape).
+constexpr int GC_A1 = GF_HB;                 // [128][33] conv1 output
+constexpr int GC_A2 = GC_A1 + 128 * 33;      // [64][33]  conv2 output
+constexpr int GC_H = GC_A2 + 64 * 33;        // [32 px][33] conv3 output, pixel-major (the Gram's operand shape)
+constexpr int GC_P2 = GC_H + 32 * 33;        // conv2 partial sums of the second K half: [2 tiles][16 regs][64 lanes]
+constexpr int GC_P3 = GC_P2 + 2048;          // conv3 partial sums of K quarters 1..3
+constexpr int GC_FLOATS = GC_P3 + 3072;
+static_assert(GC_FLOATS * 4 <= 160 * 1024, "cooperative Gram tile must fit the LDS");
+
+template <int NTT>
+__device__ __forceinline__ void conv_mfma_lds(const float* frags, int lane, int t, int v0, int nv, const float* act, f32x16& acc) {
+  const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (u < nv) {
+      const int v = v0 + u;
+      const f32x4 a = *(const f32x4*)(frags + (v * NTT + t) * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], act[(8 * v + 4 * h + j) * 33 + p], acc);
+    }
+  }
+}
+
+__device__ __forceinline__ void bias_init1(f32x16& acc, const float* bias, int t, int h, bool zero) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *(const f32x4*)(bias + 32 * t + 8 * q + 4 * h);
+    acc[4 * q + 0] = zero ? 0.0f : b[0]; acc[4 * q + 1] = zero ? 0.0f : b[1]; acc[4 * q + 2] = zero ? 0.0f : b[2]; acc[4 * q + 3] = zero ? 0.0f : b[3];
+  }
+}
+
+__device__ __forceinline__ void gram_tiles_coop(const GramJob& J, int blk, float* sm, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) G[r] = 0.0f;
+  const long tiles = (J.HW + 31) / 32;
+  for (long tile = blk; tile < tiles; tile += J.nblk) {
+    const long px = tile * 32 + p;
+    const bool valid = px < J.HW;
+    const float* row = J.x + (valid ? px : 0) * 64;
+    f32x16 xin[2];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const f32x4 xv = *(const f32x4*)(row + 8 * v + 4 * h);
+      const f32x4 mv = *(const f32x4*)(sm + GF_MEAN + 8 * v + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xin[v >> 2][(v & 3) * 4 + j] = xv[j] - mv[j];      // cF - cMean, :59-65
+    }
+    f32x16 acc;
+    // conv1: output tile `wave`
+    bias_init1(acc, sm + GF_B1, wave, h, false);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const f32x4 a = *(const f32x4*)(sm + GF_L1 + (v * 4 + wave) * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], xin[v >> 2][(v & 3) * 4 + j], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm[GC_A1 + (32 * wave + 8 * (r >> 2) + 4 * h + (r & 3)) * 33 + p] = lrelu02(acc[r]);
+    __syncthreads();
+    // conv2: output tile wave & 1, K half wave >> 1
+    const int t2 = wave & 1, kh = wave >> 1;
+    bias_init1(acc, sm + GF_B2, t2, h, kh != 0);
+    conv_mfma_lds<2>(sm + GF_L2, lane, t2, 8 * kh, 8, sm + GC_A1, acc);
+    if (kh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm[GC_P2 + t2 * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (!kh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sm[GC_A2 + (32 * t2 + 8 * (r >> 2) + 4 * h + (r & 3)) * 33 + p] = lrelu02(acc[r] + sm[GC_P2 + t2 * 1024 + r * 64 + lane]);
+    }
+    __syncthreads();
+    // conv3: K quarter `wave`
+    bias_init1(acc, sm + GF_B3, 0, h, wave != 0);
+    conv_mfma_lds<1>(sm + GF_L3, lane, 0, 2 * wave, 2, sm + GC_A2, acc);
+    if (wave) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm[GC_P3 + (wave - 1) * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (!wave) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (acc[r] + sm[GC_P3 + r * 64 + lane]) + (sm[GC_P3 + 1024 + r * 64 + lane] + sm[GC_P3 + 2048 + r * 64 + lane]);
+        sm[GC_H + p * 33 + 8 * (r >> 2) + 4 * h + (r & 3)] = valid ? v : 0.0f;   // padded pixels contribute nothing
+      }
+    }
+    __syncthreads();
+    // G += H H^T, steps 4 wave .. 4 wave + 3 (k = pixels 8 wave .. 8 wave + 7)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = sm[GC_H + (2 * (4 * wave + u) + h) * 33 + p];
+      G = MFMA32(a, a, G);
+    }
+    __syncthreads();   // the buffers are rewritten by the next tile
+  }
+  // cross-wave reduction (fragment area is dead now); D layout: col j = p, row i = (r&3) + 8(r>>2) + 4h
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sm[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + p] = G[r];
+  __syncthreads();
+  const f32x4 sg = *(f32x4*)(sm + tid * 4) + *(f32x4*)(sm + 1024 + tid * 4) + *(f32x4*)(sm + 2048 + tid * 4) + *(f32x4*)(sm + 3072 + tid * 4);
+  *(f32x4*)(J.gram_partial + (long)blk * 1024 + tid * 4) = sg;
+}
+
+__global__ __launch_bounds__(256, 1) void gram_mfma_kernel(GramJob j0, GramJob j1) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const bool second = (int)blockIdx.x >= j0.nblk;
+  const GramJob J = second ? j1 : j0;
+  const int blk = second ? blockIdx.x - j0.nblk : blockIdx.x;
+  const int tid = threadIdx.x;
+  gram_stage_weights(J.w, sm, tid);
+  if (J.mean) {
+    __syncthreads();
+    if (tid < 64) { sm[GF_MEAN + tid] = J.mean[tid]; if (blk == 0 && J.mean_out) J.mean_out[tid] = J.mean[tid]; }
+    __syncthreads();
+  } else {
+    gram_mean_from_partials(J.chan_partial, J.chan_rows, J.inv_count, blk == 0 ? J.mean_out : nullptr, sm, tid);
+  }
+  if (J.coop) gram_tiles_coop(J, blk, sm, tid);
+  else gram_tiles(J, blk, sm, tid);
+}
+
 static int gram_blocks(long HW) {
   const long b = ((HW + 31) / 32 + 3) / 4;
   return (int)(b < CROSSRAY_GRAM_BLOCKS ? (b < 1 ? 1 : b) : CROSSRAY_GRAM_BLOCKS);
 }
 
+// small grids: one tile per workgroup, the four waves sharing it (gram_tiles_coop); at most `cap` workgroups
+constexpr long GRAM_COOP_MAX_PIXELS = 4096;
+static void gram_plan(GramJob& g, int cap = CROSSRAY_GRAM_BLOCKS) {
+  if (g.nblk <= 0 || g.HW > GRAM_COOP_MAX_PIXELS) return;
+  const long tiles = (g.HW + 31) / 32;
+  g.coop = 1;
+  g.nblk = (int)(tiles < cap ? tiles : cap);
+}
+
 static int launch_gram(const GramJob& a, const GramJob& b, hipStream_t stream) {
-  const size_t shmem = (size_t)GF_FLOATS * 4;
+  const size_t shmem = (size_t)((a.coop || b.coop) ? GC_FLOATS : GF_FLOATS) * 4;
   if (int rc = ensure_dynamic_lds((const void*)gram_mfma_kernel, shmem, "gram_mfma_kernel")) return rc;
   hipLaunchKernelGGL(gram_mfma_kernel, dim3(a.nblk + b.nblk), dim3(256), shmem, stream, a, b);
   return 0;
@@ -290,6 +436,7 @@ int launch_crossray_gram(const float* x, long HW, const float* mean, const CnnTe
                          hipStream_t stream) {
   if (HW <= 0) return set_error(-2, "crossray_gram: empty grid");
   GramJob a{x, HW, mean, nullptr, 0, 0.0f, w, workspace, nullptr, gram_blocks(HW)};
+  gram_plan(a);
   GramJob none{};
   none.nblk = 0;
   if (int rc = launch_gram(a, none, stream)) return rc;
@@ -326,69 +473,127 @@ int launch_crossray_matrix(const float* gram_sum, double count, const float* fc_
   return check_launch("crossray_matrix");
 }
 
+// Small grids: the row reduction of the partial Grams and both fc layers in one launch.  (32, 2) workgroups; each sums its job's
+// <= 128 partial rows into LDS (4 KiB per row and workgroup from L2), then 32 rows of M = fc(G_sum / count), 8 per wave, the 16
+// weight loads of four rows in flight together.  Workgroup 0 of a job also stores the summed Gram (the backward reads it).
+struct FcSmallJob { const float* gram_partial; int rows; float* gram_sum; float inv_count; const float* fc_w; const float* fc_b; float* out; };
+
+__global__ __launch_bounds__(256) void gram_fc_small_kernel(FcSmallJob j0, FcSmallJob j1) {
+  __shared__ __attribute__((aligned(16))) float g[1024];
+  const FcSmallJob j = blockIdx.y ? j1 : j0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = blockIdx.x;
+  {
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+    for (int r = 0; r < j.rows; ++r) acc += *(const f32x4*)(j.gram_partial + (long)r * 1024 + tid * 4);
+    *(f32x4*)(g + tid * 4) = acc;
+    if (li == 0) *(f32x4*)(j.gram_sum + tid * 4) = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r0 = 0; r0 < 8; r0 += 4) {
+    f32x4 wv[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wv[rr][k] = *(const f32x4*)(j.fc_w + (long)(li * 32 + wave * 8 + r0 + rr) * 1024 + k * 256 + lane * 4);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 gv = *(const f32x4*)(g + k * 256 + lane * 4);
+        acc = fmaf(wv[rr][k][0], gv[0] * j.inv_count, acc); acc = fmaf(wv[rr][k][1], gv[1] * j.inv_count, acc);
+        acc = fmaf(wv[rr][k][2], gv[2] * j.inv_count, acc); acc = fmaf(wv[rr][k][3], gv[3] * j.inv_count, acc);
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+      const int row = li * 32 + wave * 8 + r0 + rr;
+      if (lane == 0) j.out[row] = acc + j.fc_b[row];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fold: A[3][64], v[3]  (single 256-thread block)
+struct FoldLds {
+  float S[32][33], Cm[32][33], T[32][33], U[3][32], P[3][64], Q[3][32];
+  float Wrgb[3][64], Wun[64][33], Wcomp[32][65], bun[64], bcomp[32], cmean[64];
+};
+
+// Everything the fold reads (two 32x32 matrices, ~4.6k weights) goes to LDS in ONE batch of coalesced loads; the chain of small
+// products then runs out of LDS.  (Read on demand, the last step alone was 160 dependent global loads in three threads: 8 us for
+// 0.1 MFLOP.)  fold_load_weights: what does not depend on the Gram matrices (may run before they exist); fold_compute: the rest.
+// Result: aff[0:192] = A, aff[192:195] = v (any address space the caller likes: LDS for the fused decode, global otherwise).
+__device__ __forceinline__ void fold_load_weights(FoldLds& L, const FoldTensors& w, int t) {
+  for (int e = t; e < 2048; e += 256) {
+    L.Wun[e >> 5][e & 31] = w.unzip_w[e];         // [64][32]
+    L.Wcomp[e >> 6][e & 63] = w.comp_w[e];        // [32][64]
+  }
+  if (t < 192) L.Wrgb[t >> 6][t & 63] = w.rgb_w[t];
+  if (t < 32) L.bcomp[t] = w.comp_b[t];
+}
+
+__device__ __forceinline__ void fold_compute(FoldLds& L, const float* sM, const float* cM, const float* c_mean, const float* s_mean,
+                                             const FoldTensors& w, float* aff, int t) {
+  for (int e = t; e < 1024; e += 256) {
+    L.S[e >> 5][e & 31] = sM[e];
+    L.Cm[e >> 5][e & 31] = cM[e];
+  }
+  if (t < 64) { L.bun[t] = w.unzip_b[t] + s_mean[t]; L.cmean[t] = c_mean[t]; }
+  __syncthreads();
+  // rgb_pre = Wrgb (Wunzip (sMatrix cMatrix (Wcomp x ...))) (linearStyleTransfer.py:86-89 + the rgb conv), folded from the LEFT:
+  // U = Wrgb Wunzip (3x32), then U sMatrix, then (U sMatrix) cMatrix -- three 3-row products instead of the 32x32x32
+  // T = sMatrix cMatrix first (which was most of this kernel's arithmetic and one more pass over LDS)
+  if (t < 96) {
+    const int r = t >> 5, c = t & 31;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) a = fmaf(L.Wrgb[r][k], L.Wun[k][c], a);
+    L.U[r][c] = a;
+  }
+  __syncthreads();
+  if (t < 96) {                                   // U S (3x32), kept in T[0..2]
+    const int r = t >> 5, c = t & 31;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) a = fmaf(L.U[r][k], L.S[k][c], a);
+    L.T[r][c] = a;
+  }
+  __syncthreads();
+  if (t < 96) {                                   // Q = (U S) cMatrix (3x32)
+    const int r = t >> 5, c = t & 31;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) a = fmaf(L.T[r][k], L.Cm[k][c], a);
+    L.Q[r][c] = a;
+  }
+  __syncthreads();
+  if (t < 192) {                                  // A = Q @ Wcomp (3x64)
+    const int r = t >> 6, c = t & 63;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) a = fmaf(L.Q[r][k], L.Wcomp[k][c], a);
+    L.P[r][c] = a;
+    aff[r * 64 + c] = a;
+  }
+  __syncthreads();
+  // v = Q bcomp - A cMean + Wrgb (bunzip + sMean) + brgb: wave r sums row r, one term per lane
+  if (t < 192) {
+    const int r = t >> 6, k = t & 63;
+    float a = (k < 32 ? L.Q[r][k] * L.bcomp[k] : 0.0f) - L.P[r][k] * L.cmean[k] + L.Wrgb[r][k] * L.bun[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if (k == 0) aff[192 + r] = a + w.rgb_b[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ sM, const float* __restrict__ cM, const float* __restrict__ c_mean,
                                                    const float* __restrict__ s_mean, FoldTensors w, float* __restrict__ affine) {
-  // Everything this kernel reads (two 32x32 matrices, ~4.6k weights) goes to LDS in ONE batch of coalesced loads; the
-  // chain of small products then runs out of LDS.  (Read on demand, the last step alone was 160 dependent global loads
-  // in three threads: 8 us for 0.1 MFLOP.)
-  __shared__ float S[32][33], Cm[32][33], T[32][33], U[3][32], P[3][64], Q[3][32];
-  __shared__ float Wrgb[3][64], Wun[64][33], Wcomp[32][65], bun[64], bcomp[32], cmean[64];
+  __shared__ FoldLds L;
   const int t = threadIdx.x;
   if (sM) {
-    for (int e = t; e < 1024; e += 256) {
-      S[e >> 5][e & 31] = sM[e];
-      Cm[e >> 5][e & 31] = cM[e];
-    }
-    for (int e = t; e < 2048; e += 256) {
-      Wun[e >> 5][e & 31] = w.unzip_w[e];         // [64][32]
-      Wcomp[e >> 6][e & 63] = w.comp_w[e];        // [32][64]
-    }
-    if (t < 192) Wrgb[t >> 6][t & 63] = w.rgb_w[t];
-    if (t < 64) { bun[t] = w.unzip_b[t] + s_mean[t]; cmean[t] = c_mean[t]; }
-    if (t < 32) bcomp[t] = w.comp_b[t];
-    __syncthreads();
-    // T = sMatrix @ cMatrix (linearStyleTransfer.py:86) and, alongside, U = Wrgb @ Wunzip (3x32)
-    for (int e = t; e < 1024; e += 256) {
-      const int i = e >> 5, j = e & 31;
-      float a = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) a = fmaf(S[i][k], Cm[k][j], a);
-      T[i][j] = a;
-    }
-    if (t < 96) {
-      const int r = t >> 5, c = t & 31;
-      float a = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < 64; ++k) a = fmaf(Wrgb[r][k], Wun[k][c], a);
-      U[r][c] = a;
-    }
-    __syncthreads();
-    if (t < 96) {                                   // Q = U @ T (3x32)
-      const int r = t >> 5, c = t & 31;
-      float a = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) a = fmaf(U[r][k], T[k][c], a);
-      Q[r][c] = a;
-    }
-    __syncthreads();
-    if (t < 192) {                                  // A = Q @ Wcomp (3x64)
-      const int r = t >> 6, c = t & 63;
-      float a = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) a = fmaf(Q[r][k], Wcomp[k][c], a);
-      P[r][c] = a;
-      affine[r * 64 + c] = a;
-    }
-    __syncthreads();
-    // v = Q bcomp - A cMean + Wrgb (bunzip + sMean) + brgb: wave r sums row r, one term per lane
-    if (t < 192) {
-      const int r = t >> 6, k = t & 63;
-      float a = (k < 32 ? Q[r][k] * bcomp[k] : 0.0f) - P[r][k] * cmean[k] + Wrgb[r][k] * bun[k];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
-      if (k == 0) affine[192 + r] = a + w.rgb_b[r];
-    }
+    fold_load_weights(L, w, t);
+    fold_compute(L, sM, cM, c_mean, s_mean, w, affine, t);
   } else {
     // type == "content": decoder only                          linearStyleTransfer.py:285-287
     if (t < 192) affine[t] = w.rgb_w[t];
@@ -403,13 +608,11 @@ int launch_crossray_fold(const float* sM, const float* cM, const float* c_mean, 
 }
 
 // ---------------------------------------------------------------- apply: rgb[c][px] = sigmoid(A[c] . x[px] + v[c])
-__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x, long HW, const float* __restrict__ affine,
-                                                    float* __restrict__ rgb, long plane_stride) {
-  __shared__ float A[196];
-  if (threadIdx.x < 195) A[threadIdx.x] = affine[threadIdx.x];
-  __syncthreads();
-  const int q = threadIdx.x & 3;  // 4 lanes per pixel, 16 channels each
-  for (long px = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;; px += ((long)gridDim.x * 256) >> 2) {
+// A: the folded affine in LDS.  4 lanes per pixel, 16 channels each; workgroup `blk` of `nblk` strides over the pixels.
+__device__ __forceinline__ void apply_pixels(const float* __restrict__ x, long HW, const float* A, float* __restrict__ rgb, long plane_stride, int blk,
+                                             int nblk, int tid) {
+  const int q = tid & 3;
+  for (long px = ((long)blk * 256 + tid) >> 2;; px += ((long)nblk * 256) >> 2) {
     const bool valid = px < HW;
     if (__all(!valid)) break;
     float r = 0.0f, g = 0.0f, b = 0.0f;
@@ -434,6 +637,29 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
       rgb[q * plane_stride + px] = 1.0f / (1.0f + expf(-pre));
     }
   }
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x, long HW, const float* __restrict__ affine,
+                                                    float* __restrict__ rgb, long plane_stride) {
+  __shared__ float A[196];
+  if (threadIdx.x < 195) A[threadIdx.x] = affine[threadIdx.x];
+  __syncthreads();
+  apply_pixels(x, HW, A, rgb, plane_stride, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
+// Small grids: fold and apply in one launch -- every workgroup folds for itself (12 KiB of L2 reads, a few microseconds of
+// arithmetic) instead of waiting for a one-workgroup launch to do it; workgroup 0 also stores the affine map (the backward reads it).
+__global__ __launch_bounds__(256) void fold_apply_kernel(const float* __restrict__ sM, const float* __restrict__ cM, const float* __restrict__ c_mean,
+                                                         const float* __restrict__ s_mean, FoldTensors w, float* __restrict__ affine,
+                                                         const float* __restrict__ x, long HW, float* __restrict__ rgb, long plane_stride) {
+  __shared__ FoldLds L;
+  __shared__ float A[196];
+  const int t = threadIdx.x;
+  fold_load_weights(L, w, t);
+  fold_compute(L, sM, cM, c_mean, s_mean, w, A, t);
+  __syncthreads();
+  if (blockIdx.x == 0 && t < 195) affine[t] = A[t];
+  apply_pixels(x, HW, A, rgb, plane_stride, blockIdx.x, gridDim.x, t);
 }
 
 int launch_crossray_apply(const float* x, long HW, const float* affine, float* rgb, long plane_stride, hipStream_t stream) {
@@ -468,7 +694,16 @@ int launch_crossray_decode(const DecodeArgs& d, hipStream_t stream) {
   hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(SUM_THREADS), 0, stream, s0, s1);
   GramJob g0{d.content, d.HW, nullptr, ws + WS_SUMP0, s0.nblk, (float)(1.0 / (double)d.HW), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, gram_blocks(d.HW)};
   GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
+  gram_plan(g0); gram_plan(g1);
   if (int rc = launch_gram(g0, g1, stream)) return rc;
+  if (g0.coop && g1.coop) {   // small grids (the headline 32 x 32): four launches instead of six
+    FcSmallJob f0{ws + WS_GRAMP0, g0.nblk, st + ST_CGRAM, (float)(1.0 / (double)d.HW), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
+    FcSmallJob f1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
+    hipLaunchKernelGGL(gram_fc_small_kernel, dim3(32, 2), dim3(256), 0, stream, f0, f1);
+    hipLaunchKernelGGL(fold_apply_kernel, dim3((unsigned)((d.HW + 63) / 64)), dim3(256), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN,
+                       d.lin, st + ST_AFFINE, d.content, d.HW, d.rgb, d.plane_stride);
+    return check_launch("crossray_decode");
+  }
   RedJob r0{ws + WS_GRAMP0, g0.nblk, st + ST_CGRAM}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(16, 2), dim3(RED_THREADS), 0, stream, r0, r1, 1024);
   FcJob f0{st + ST_CGRAM, (float)(1.0 / (double)d.HW), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
@@ -503,6 +738,7 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
   if (phase == 1) {
     GramJob g0{d.content, d.HW, nullptr, xchg, 1, (float)(1.0 / count_global), d.cnet, ws + WS_GRAMP0, st + ST_CMEAN, have ? gram_blocks(d.HW) : 0};
     GramJob g1{d.style, d.HWs, nullptr, ws + WS_SUMP1, s1.nblk, (float)(1.0 / (double)d.HWs), d.snet, ws + WS_GRAMP1, st + ST_SMEAN, gram_blocks(d.HWs)};
+    gram_plan(g0); gram_plan(g1);
     if (int rc = launch_gram(g0, g1, stream)) return rc;
     RedJob r0{ws + WS_GRAMP0, g0.nblk, have ? xchg + 64 : nullptr}, r1{ws + WS_GRAMP1, g1.nblk, st + ST_SGRAM};
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(16, 2), dim3(RED_THREADS), 0, stream, r0, r1, 1024);

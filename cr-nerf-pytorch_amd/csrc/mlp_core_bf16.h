@@ -42,28 +42,34 @@ static_assert(B_TAIL == 8 && STREAMB_USED % B_AHEAD == 0, "tail stage must fit t
 // ---- compile-time schedule over the pass-relative fragment index i (0 <= i < STREAMB_USED) -------------
 // position in the padded stream (the look-ahead past the last fragment lands in the next pass)
 constexpr int b_pos(int i) { return i < STREAMB_USED ? i : i + (STREAMB_FRAGS - STREAMB_USED); }
-// stage advances executed before iteration i's read is issued (advance of stage c sits at slot 14, tail: B_TAIL-2)
-constexpr int b_last_adv() { return (STAGESB_PER_PASS - 1) * STAGE_FRAGS + B_TAIL - 2; }
-constexpr int b_cur_stage(int i) { return (i + 1) / STAGE_FRAGS + (i > b_last_adv() ? 1 : 0); }
-constexpr bool b_advance_at(int i) {
-  return i / STAGE_FRAGS < STAGESB_PER_PASS - 1 ? i % STAGE_FRAGS == STAGE_FRAGS - 2 : i == b_last_adv();
-}
+// The barrier that opens stage c + 1 sits in the LAST k-step of stage c whose look-ahead read still targets stage c (slot
+// 15 - B_AHEAD = 11; in the 8-fragment tail stage slot 3): every read of stage c + 1 is issued behind it.  (Rounds 1-2 had it in
+// slot 14, i.e. BEHIND the first three look-ahead reads of stage c + 1, which were therefore covered by nothing but the ~1 us that
+// had passed since their LDS-DMA was issued: with the weight stream evicted from L2 by other kernels -- the encoder / decoder between
+// two renders -- a late piece was read before it landed and single ray quads came out wrong, about once per ten cold full-image
+// renders.  tools/render_cold2.py is the reproducer; tests/test_gpu_bf16.py::test_render_cold_l2_is_deterministic the guard.)
+constexpr int B_ADV_SLOT = STAGE_FRAGS - 1 - B_AHEAD;
+constexpr int B_ADV_SLOT_TAIL = B_TAIL - 1 - B_AHEAD;
+static_assert(B_ADV_SLOT >= 10 && B_ADV_SLOT_TAIL >= 3, "the barrier must come after the stage's third LDS-DMA piece (slots 9 / 3)");
+constexpr bool b_tail(int i) { return i / STAGE_FRAGS == STAGESB_PER_PASS - 1; }
+constexpr bool b_advance_at(int i) { return i % STAGE_FRAGS == (b_tail(i) ? B_ADV_SLOT_TAIL : B_ADV_SLOT); }
+// stage advances executed before iteration i's read is issued (= the newest stage that read may touch)
+constexpr int b_cur_stage(int i) { return i / STAGE_FRAGS + (i % STAGE_FRAGS > (b_tail(i) ? B_ADV_SLOT_TAIL : B_ADV_SLOT) ? 1 : 0); }
 // LDS-DMA piece (0..3) issued at iteration i, or -1: slots 1, 5, 9, 13 of a stage (k-steps that carry one epilogue
 // quarter in the 16-k-step layers, so piece + quarter + fragment read stay within 4 fillers per MFMA gap)
 constexpr int b_piece_at(int i) {
   const int sl = i % STAGE_FRAGS;
-  if (i / STAGE_FRAGS < STAGESB_PER_PASS - 1) return sl % 4 == 1 ? sl / 4 : -1;
+  if (!b_tail(i)) return sl % 4 == 1 ? sl / 4 : -1;
   return sl == 0 ? 0 : (sl == 1 ? 1 : (sl == 3 ? 2 : (sl == 5 ? 3 : -1)));   // tail stage (B_TAIL = 8 fragments)
 }
 // prefetch-cursor bookkeeping (SALU only) sits in the stage's last k-step, which carries no epilogue work
-constexpr bool b_cursor_at(int i) {
-  return i / STAGE_FRAGS < STAGESB_PER_PASS - 1 ? i % STAGE_FRAGS == STAGE_FRAGS - 1 : i == STREAMB_USED - 1;
-}
+constexpr bool b_cursor_at(int i) { return b_tail(i) ? i == STREAMB_USED - 1 : i % STAGE_FRAGS == STAGE_FRAGS - 1; }
 constexpr bool b_schedule_ok() {
   int pieces = 0, advances = 0, cursors = 0;
   for (int i = 0; i < STREAMB_USED; ++i) {
-    const int d = b_pos(i + B_AHEAD) / STAGE_FRAGS - b_cur_stage(i);
-    if (d < 0 || d > 1) return false;                 // reads stay inside stages c and c+1
+    if (b_cur_stage(i) != advances) return false;
+    const int rs = b_pos(i + B_AHEAD) / STAGE_FRAGS;
+    if (rs > advances || rs < i / STAGE_FRAGS) return false;   // EVERY read targets a stage whose barrier has been passed
     if (b_piece_at(i) >= 0) {
       if (b_piece_at(i) != pieces % 4 || cursors != pieces / 4) return false;   // in order, cursor moved before piece 0
       ++pieces;
@@ -74,8 +80,7 @@ constexpr bool b_schedule_ok() {
     }
     if (b_advance_at(i)) {
       ++advances;
-      if (pieces != 4 * advances) return false;       // exactly 4 pieces between consecutive barriers (vmcnt counting)
-      if (b_pos(i + B_AHEAD) / STAGE_FRAGS > advances) return false;  // never reads stage c+2 before its barrier
+      if (pieces != 4 * advances - 1) return false;   // the barrier follows the stage's third piece: vmcnt(7), see WeightPipeB
     }
   }
   return advances == STAGESB_PER_PASS && cursors == STAGESB_PER_PASS && b_cur_stage(STREAMB_USED - 1) == STAGESB_PER_PASS;
@@ -91,9 +96,10 @@ static_assert(b_schedule_ok(), "bf16 fragment schedule violates the ring protoco
 // wherever it is placed; the dynamic 6-slot ring's 11 instructions per stage cost 2.4 cycles per MFMA).
 // Protocol (as mlp_core.h WeightPipe, with distances for 4 slots): while stage c is multiplied, stage c + 3 is fetched
 // into the slot stage c - 1 has left (its last fragment read was issued before the barrier that opened stage c); the
-// barrier in stage c's k-step 14 waits vmcnt(8) -- stages c + 2 and c + 3 may be in flight, stage c + 1 has landed --
-// and opens stage c + 1 for the look-ahead reads.  Stages 76, 77, 78 are the NEXT tile's first three: they are fetched
-// from `nxt`, the stream of the model the next tile runs (begin_tile).
+// barrier in stage c's k-step 11 -- behind the stage's third piece, in front of the first look-ahead read of stage c + 1 --
+// waits vmcnt(7): stage c + 2 and three pieces of stage c + 3 may be in flight, stage c + 1 (issued >= 30 k-steps ago) has
+// landed.  Stages 76, 77, 78 are the NEXT tile's first three: they are fetched from `nxt`, the stream of the model the
+// next tile runs (begin_tile).
 constexpr int B_RING = 4;
 static_assert(STAGESB_PER_PASS % B_RING == 0, "the static ring needs a whole number of ring turns per pass");
 static_assert(B_RING * STAGE_BYTES <= 65536 && B_RING <= RING_SLOTS, "ds_read offsets are 16 bits; the LDS ring area is shared with the fp32 core");
@@ -152,7 +158,7 @@ struct WeightPipeB {
     asm volatile("" : "+s"(cur), "+s"(nxt));
   }
   __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   // fragment at padded stream position `pos` (tile-relative; 1216.. = the next tile's stage 0)

@@ -179,3 +179,36 @@ def test_reference_signature_with_precision_keyword_and_decoded_image_psnr():
     psnr = {k: float(O.psnr(v, target)) for k, v in imgs.items()}
     assert abs(psnr["bf16"] - psnr["f32"]) <= 0.05, psnr
     assert float((imgs["bf16"] - imgs["f32"]).abs().max()) < 4e-2   # pixels; mean is ~1e-3
+
+
+@pytest.mark.parametrize("precision,passes", [("bf16", 6), ("f32", 2)])
+def test_render_cold_l2_is_deterministic(precision, passes):
+    """Regression guard for the weight-ring protocol (mlp_core_bf16.h): the bf16 renderer's LDS ring used to read the first
+    fragments of a stage in front of the barrier that certifies them; with the weight stream evicted from L2 between launches (other
+    kernels run between two renders in every real pipeline) single ray quads came out wrong about once per ten full images.  Here:
+    the same 262,144 rays rendered in 32,768-ray chunks, L2 thrashed by a 1 GiB copy before every chunk, six times; every output must
+    be bit-identical to the first pass (rays are independent and the kernel is deterministic).  The fp32 renderer's ring certifies
+    two stages ahead by construction (mlp_core.h); it takes the same treatment."""
+    st_c = {k: C(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()}
+    st_f = {k: C(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()}
+    with torch.no_grad():
+        pc, pf = ops.pack_mlp_weights(st_c, precision=precision), ops.pack_mlp_weights(st_f, precision=precision)
+        R = 262144
+        rays = C(synth.rays(R, seed=0, H=512, W=512))
+        z_steps, u = torch.linspace(0, 1, 64, device=DEV), torch.linspace(0, 1, 128, device=DEV)
+        junk_a, junk_b = torch.empty(1 << 28, device=DEV), torch.zeros(1 << 28, device=DEV)   # 1 GiB each: far beyond L2 + MALL
+
+        def run():
+            outs = []
+            for i in range(0, R, 32768):
+                junk_a.copy_(junk_b)
+                outs.append(ops.render_rays(pc, pf, rays[i:i + 32768], 64, 128, z_steps=z_steps, u=u, precision=precision))
+            return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+        ref = run()
+        for it in range(passes):
+            out = run()
+            for k in ref:
+                if not torch.equal(out[k], ref[k]):
+                    d = (out[k] != ref[k]).view(R, -1).any(1).nonzero().flatten()
+                    raise AssertionError("pass %d: %s differs in %d rays (first %s): max |d| %.3e" % (it, k, d.numel(), d[:8].tolist(),
+                                                                                                float((out[k] - ref[k]).abs().max())))

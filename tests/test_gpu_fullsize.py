@@ -92,7 +92,11 @@ def test_config2_full_image_bf16_800x800():
     one = pipeline.batched_inference(models, emb, rays, None, 64, 128, False, R, False, args=hp, a_embedded_from_img=a_emb, precision="bf16")
     rag = pipeline.batched_inference(models, emb, rays, None, 64, 128, False, 50000, False, args=hp, a_embedded_from_img=a_emb, precision="bf16")
     for k in res:
-        assert torch.equal(res[k], one[k]) and torch.equal(res[k], rag[k]), k
+        for name, other in (("one launch", one), ("50,000-ray chunks", rag)):
+            if not torch.equal(res[k], other[k]):
+                d = (res[k] != other[k]).view(R, -1).any(1).nonzero().flatten()
+                raise AssertionError("%s: 32,768-ray chunks vs %s differ in %d rays, first %s last %s, max |d| %.3e" % (
+                    k, name, d.numel(), d[:16].tolist(), d[-4:].tolist(), float((res[k] - other[k]).abs().max())))
     # a 4,096-ray slice (8 scattered blocks of 512 rays) against the bf16 oracle at IDENTICAL depths
     idx = torch.cat([torch.arange(b, b + 512) for b in (0, 99_840, 200_192, 319_744, 320_256, 450_048, 560_128, R - 512)])
     torch.set_num_threads(min(32, os.cpu_count() or 1))
