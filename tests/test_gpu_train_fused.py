@@ -254,3 +254,32 @@ def test_mixed_precision_training_reduces_the_loss(recompute):
         AG.set_training_precision("f32")
         AG.set_training_recompute(False)
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_training_twins_cold_l2_are_deterministic(mixed):
+    """The training twins under the treatment of tests/test_gpu_bf16.py::test_render_cold_l2_is_deterministic: forward-with-save and
+    backward of 200,000 points, L2 thrashed before every call; outputs and all 24 gradients bit-identical across passes (the weight
+    rings certify what they read, the partial-sum reductions have a fixed order)."""
+    st = {k: C(v) for k, v in synth.mlp_state(9, 2.0, 0.5).items()}
+    n = 200_000
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(n, 120, generator=g).to(DEV)
+    d_out = torch.randn(n, 65, generator=g).to(DEV)
+    junk_a, junk_b = torch.empty(1 << 28, device=DEV), torch.zeros(1 << 28, device=DEV)
+
+    def run():
+        junk_a.copy_(junk_b)
+        if mixed:
+            packed, tensors = ops.pack_mlp_weights_mixed(st)
+            out, acts = ops.mlp_forward_train_mixed(packed, tensors, x)
+            junk_a.copy_(junk_b)
+            return [out] + ops.mlp_backward_mixed(packed, tensors, x, out, d_out, acts)
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(st), x)
+        junk_a.copy_(junk_b)
+        return [out] + ops.mlp_backward(ops.pack_mlp_weights_t(st), x, out, d_out, acts)
+    with torch.no_grad():
+        ref = run()
+        for it in range(3):
+            for i, (a, b) in enumerate(zip(run(), ref)):
+                assert torch.equal(a, b), "pass %d: tensor %d differs, max |d| %.3e" % (it, i, float((a - b).abs().max()))
