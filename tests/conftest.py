@@ -27,3 +27,24 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cold_cache_mode():
+    """CRNERF_TEST_COLD_L2=1 (GPU box): a 256 MiB device copy after EVERY call into libcrnerf_hip.so, so that each kernel of the suite
+    starts with its operands and weight streams evicted from L2 -- the condition that exposed the bf16 weight-ring race.
+    Off by default (it roughly doubles the run time); used for the occasional hunt for timing-dependent kernels."""
+    if os.environ.get("CRNERF_TEST_COLD_L2") != "1":
+        yield
+        return
+    import torch
+    from crnerf_amd import _lib
+    a, b = torch.empty(1 << 26, device="cuda:0"), torch.zeros(1 << 26, device="cuda:0")
+    orig = _lib.check
+
+    def check(code, what):
+        orig(code, what)
+        a.copy_(b)
+    _lib.check = check
+    yield
+    _lib.check = orig
