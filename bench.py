@@ -232,8 +232,8 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
                             "multi_pass_16x": {"rays": 16 * R, "launch_ms": ms16, "ms_per_%d_rays" % R: ms16 / 16, "achieved_tflops": tf16,
                                                "frac_nominal_2500": tf16 / PEAK_BF16_MFMA_TFLOPS, "frac_attainable_1890": tf16 / 1890.0},
                             "note": "kernel_ms = launch-to-launch time of 50 back-to-back C-ABI launches (rocprofv3 --kernel-trace reports the kernel itself at "
-                                    "0.2435 ms = 0.53, profiles/r2/kernel_stats_bf16.csv: ~25 us per launch pass between two launches of this "
-                                    "kernel, 4-10 us for the fp32 kernel).  1890 TFLOP/s = bare v_mfma_f32_32x32x16_bf16 stream measured on this part "
+                                    "0.244-0.263 ms = 0.49-0.53 depending on the box, profiles/r2/kernel_stats_bf16*.csv: ~20 us pass between two "
+                                    "launches of this kernel, 4-10 us for the fp32 kernel).  1890 TFLOP/s = bare v_mfma_f32_32x32x16_bf16 stream measured on this part "
                                     "under sustained load (profiles/r1/ubench_mfma_stream.txt); same %d-ray batch and weights as the timed fp32 step" % R,
                             "parity_smooth_nets": {"vs_fp32_oracle_end_to_end": bf["end_to_end"], "vs_bf16_oracle_identical_depths": bf["identical_depths"],
                                                    "image_high_contrast_vs_fp32_oracle": bf["image_high_contrast"]}}
