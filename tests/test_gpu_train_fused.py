@@ -159,7 +159,7 @@ def test_wgrad_bf16_option_changes_only_the_weight_gradients():
             assert float((ge - gm).abs().max()) <= 1e-5 * float(ge.abs().max()) + 1e-7, name
 
 
-@pytest.mark.parametrize("n,gain", [(1000, 1.0), (4133, 2.0)])
+@pytest.mark.parametrize("n,gain", [(1, 1.0), (37, 1.0), (1000, 1.0), (4133, 2.0)])
 def test_mixed_precision_training_twins_vs_bf16_training_oracle(n, gain):
     """crnerf_mlp_forward_train_mixed_f32 / crnerf_mlp_backward_mixed_f32 (opt-in): forward = the bf16 inference arithmetic
     (oracle mlp_forward_bf16), backward = torch autograd through the oracle's bf16-operand Linear (oracle mlp_forward_bf16_train)."""
