@@ -33,17 +33,19 @@ def _launch(script_args, nproc=2, extra_env=None, timeout=900):
     return r.stdout
 
 
-def test_bench_two_ranks_prints_one_valid_json_line():
-    out = _launch(["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"])
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_n_ranks_prints_one_valid_json_line(n):
+    """The driver's N = 2, 4, 8 command line (8 ranks time-slice the one GPU here)."""
+    out = _launch(["bench.py", "--gpus", str(n), "--steps", "4", "--warmup", "2"], nproc=n)
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out                                         # rank 0 only
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "rays/s"
-    assert j["value"] > 0 and abs(j["value"] - 2 * 1024 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]   # whole-job aggregate
+    assert j["n_gpus"] == n and j["steps"] == 4 and j["warmup"] == 2 and j["scaling"] == "weak" and j["unit"] == "rays/s"
+    assert j["value"] > 0 and abs(j["value"] - n * 1024 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]   # whole-job aggregate
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert "cpu_baseline" not in j                                      # N == 1 only
     sums = j["test_rgb_checksum_per_rank"]
-    assert len(sums) == 2 and sums[0] == sums[1] and sums[0][1] == 2048  # both ranks hold the same gathered 2 x 1024-pixel image
+    assert len(sums) == n and all(s == sums[0] for s in sums) and sums[0][1] == n * 1024   # every rank holds the same gathered n x 1024-pixel image
 
 
 def test_train_config3_two_ranks_ray_parallel_replicas_agree():
