@@ -98,10 +98,8 @@ def get_training_recompute():
 def _embed_points(rays, z, view_dir):
     """x[P,120] = cat(PosEmbedding_xyz(o + d z), PosEmbedding_dir(d)) for the wgrad of the layers that read it (rendering.py:108-114);
     rebuilt in backward instead of being stored between forward and backward."""
-    R, N = z.shape
-    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
     demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
-    return torch.cat([ops.posenc(pts, 15), demb[:, None, :].expand(R, N, 27).reshape(R * N, 27)], 1)
+    return ops.embed_points(rays, z, demb)       # one pass, one 480-byte row per point (the torch composition moved ~1.5 KB)
 
 
 class FusedRenderFn(torch.autograd.Function):

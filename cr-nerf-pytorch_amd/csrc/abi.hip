@@ -156,6 +156,13 @@ int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* 
   return launch_posenc(x, out, (long)n, n_freqs, (hipStream_t)stream);
 }
 
+int crnerf_embed_points_f32(const float* rays, const float* z, const float* dir_emb, float* x, int64_t n_rays, int32_t n_samples, void* stream) {
+  if (n_rays == 0 || n_samples == 0) return 0;
+  REQUIRE(rays, "rays"); REQUIRE(z, "z"); REQUIRE(dir_emb, "dir_emb"); REQUIRE(x, "x");
+  if (n_rays < 0 || n_samples < 0) return set_error(CRNERF_ERR_SHAPE, "embed_points: negative size");
+  return launch_embed_points(rays, z, dir_emb, x, (long)n_rays, (int)n_samples, (hipStream_t)stream);
+}
+
 int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
   if (n == 0) return 0;
   REQUIRE(packed, "packed");

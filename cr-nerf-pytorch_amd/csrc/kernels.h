@@ -61,6 +61,7 @@ size_t wgrad_workspace_floats(long P, int M, int N);
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
           hipStream_t st, int bf16 = 0);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
+int launch_embed_points(const float* rays, const float* z, const float* dir_emb, float* x, long R, int N, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
                      float* feature, float* depth, long R, int N, hipStream_t stream);

@@ -177,6 +177,48 @@ __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ o
   }
 }
 
+// x[r*N + n] = cat(PosEmbedding_xyz(o_r + d_r * z[r][n]), dir_emb[r]) -- rendering.py:100-114 (xyz_ = rays_o + rays_d * z_vals, the
+// embedding, the repeat of dir_embedded, the cat) in one pass that writes the 480-byte row once; the torch composition of the
+// same arithmetic moves ~1.5 KB per point (points, embedding, expanded directions, cat).  One thread per (point, output group):
+// 45 groups of (sin, cos) of one argument, 1 group for the identity columns, 7 groups of four direction columns (27 padded to 28).
+__global__ void embed_points_kernel(const float* __restrict__ rays, const float* __restrict__ z, const float* __restrict__ dir_emb,
+                                    float* __restrict__ x, long R, int N) {
+  constexpr int XG = 3 * XYZ_FREQS + 1, G = XG + 7;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * N * G) return;
+  const long pt = idx / G;
+  const int a = (int)(idx - pt * G);
+  const long r = pt / N;
+  float* o = x + pt * IN_DIM;
+  if (a >= XG) {
+    const int c0 = 4 * (a - XG);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < DIR_DIM) o[XYZ_DIM + c0 + e] = dir_emb[r * DIR_DIM + c0 + e];
+    return;
+  }
+  const float* ray = rays + r * 8;
+  const float zz = z[pt];
+  if (a == 3 * XYZ_FREQS) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = ray[d] + ray[3 + d] * zz;     // separate mul and add (-ffp-contract=off), as torch evaluates it
+  } else {
+    const int f = a / 3, d = a % 3;
+    const float v = ray[d] + ray[3 + d] * zz;
+    float sn, cs;
+    sincosf(ldexpf(1.0f, f) * v, &sn, &cs);
+    o[3 + 6 * f + d] = sn;
+    o[3 + 6 * f + 3 + d] = cs;
+  }
+}
+
+int launch_embed_points(const float* rays, const float* z, const float* dir_emb, float* x, long R, int N, hipStream_t stream) {
+  if (R <= 0 || N <= 0) return 0;
+  const long total = R * N * (3 * XYZ_FREQS + 1 + 7);
+  hipLaunchKernelGGL(embed_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays, z, dir_emb, x, R, N);
+  return check_launch("embed_points_kernel");
+}
+
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream) {
   if (n <= 0) return 0;
   if (n_freqs < 0 || n_freqs > 30) return set_error(-2, "posenc: n_freqs must be in [0, 30]");

@@ -48,15 +48,19 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
 
     def run(model, z, noise):
         N = z.shape[1]
-        pts = (o + d * z[..., None]).reshape(-1, 3)
-        if jitter:
-            pts = pts + 0.00001 * torch.rand_like(pts)                       # rendering.py:102-104
-        dirs = demb[:, None, :].expand(R, N, demb.shape[-1]).reshape(R * N, -1)
         # point chunks (rendering.py:110-114) only bound the reference's activation memory; the result is chunk-invariant
         # (SURVEY G7), and every MLP call here costs a weight re-pack (+ a wgrad reduction in training), so never go below 2^20 points
         step = max(int(chunk), 1 << 20)
         with torch.no_grad():                                                # embeddings are inputs, not trained
-            xs = [torch.cat([ops.posenc(pts[i:i + step].contiguous(), 15), dirs[i:i + step]], 1) for i in range(0, R * N, step)]
+            if jitter:
+                pts = (o + d * z[..., None]).reshape(-1, 3)
+                pts = pts + 0.00001 * torch.rand_like(pts)                   # rendering.py:102-104
+                dirs = demb[:, None, :].expand(R, N, demb.shape[-1]).reshape(R * N, -1)
+                xs = [torch.cat([ops.posenc(pts[i:i + step].contiguous(), 15), dirs[i:i + step]], 1) for i in range(0, R * N, step)]
+            else:   # the same rows in one pass per ray block (crnerf_embed_points_f32): points, embedding, repeat and cat fused
+                rstep = max(step // N, 1)
+                zc = z.contiguous()
+                xs = [ops.embed_points(rays[i:i + rstep], zc[i:i + rstep], demb[i:i + rstep]) for i in range(0, R, rstep)]
         if train:   # autograd.Functions over the HIP forward/backward twins (autograd.py)
             from ..autograd import CompositeFn, mlp_forward_with_grad
             raw = torch.cat([mlp_forward_with_grad(model, x) for x in xs], 0)

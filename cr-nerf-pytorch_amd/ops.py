@@ -176,6 +176,19 @@ def posenc(x, n_freqs):
     return out
 
 
+def embed_points(rays, z, dir_emb):
+    """x[R*N,120] = cat(PosEmbedding_xyz(o + d z), dir_emb repeated) in one pass (rendering.py:100-114); dir_emb = posenc(dirs, 4)."""
+    lib = _lib.load()
+    rays, z, dir_emb = _f32c(rays, "rays"), _f32c(z, "z"), _f32c(dir_emb, "dir_emb")
+    R, N = z.shape
+    if tuple(rays.shape) != (R, 8) or tuple(dir_emb.shape) != (R, 27):
+        raise ValueError("embed_points expects rays [R,8], z [R,N], dir_emb [R,27]; got %s %s %s" % (tuple(rays.shape), tuple(z.shape), tuple(dir_emb.shape)))
+    x = torch.empty(R * N, 120, dtype=torch.float32, device=z.device)
+    _lib.check(lib.crnerf_embed_points_f32(_lib.dev_ptr(rays), _lib.dev_ptr(z), _lib.dev_ptr(dir_emb), _lib.dev_ptr(x), R, N, _lib.stream_ptr()),
+               "crnerf_embed_points_f32")
+    return x
+
+
 def mlp_forward(packed, x, sigma_only=False, precision="f32"):
     lib = _lib.load()
     x = _f32c(x, "x")

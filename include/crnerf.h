@@ -56,6 +56,12 @@ int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* str
 /* PosEmbedding.forward, models/nerf.py:17-30 (logscale freqs 2^0..2^(F-1)): x[n,3] -> out[n,6F+3]. */
 int crnerf_posenc_f32(const float* x, float* out, int64_t n, int n_freqs, void* stream);
 
+/* The MLP input of one pass of render_rays_cross_ray, models/rendering.py:100-114 (xyz_ = rays_o + rays_d * z_vals, embedding_xyz,
+ * the repeat of dir_embedded, the cat): rays[R,8] (o, d, near, far), z[R,N], dir_emb[R,27] = crnerf_posenc_f32(view dirs, 4)
+ * -> x[R*N,120], point index = ray*N + sample.  Used by the training backward, which rebuilds x instead of storing it. */
+int crnerf_embed_points_f32(const float* rays, const float* z, const float* dir_emb, float* x, int64_t n_rays, int32_t n_samples,
+                            void* stream);
+
 /* NeRF_sigma.forward, models/nerf.py:157-182: x[n,120] -> out[n,65] (64 features then sigma);
  * sigma_only != 0: x[n,93] -> out[n,1] (models/nerf.py:159-160,173-174). */
 int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream);

@@ -283,3 +283,19 @@ def test_training_twins_cold_l2_are_deterministic(mixed):
         for it in range(3):
             for i, (a, b) in enumerate(zip(run(), ref)):
                 assert torch.equal(a, b), "pass %d: tensor %d differs, max |d| %.3e" % (it, i, float((a - b).abs().max()))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("R,N", [(1, 1), (37, 65), (512, 192)])
+def test_embed_points_equals_the_torch_composition_bitwise(R, N):
+    """crnerf_embed_points_f32 (rendering.py:100-114 in one pass) against the composition it replaces: points by torch broadcasting,
+    crnerf_posenc_f32 on them, the direction embedding repeated, torch.cat -- same arithmetic, so the same bits."""
+    rays = C(synth.rays(R, seed=R, H=1, W=R))
+    z = torch.sort(torch.rand(R, N, generator=torch.Generator().manual_seed(N)) * 4 + 0.5, dim=1).values.to(DEV)
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=torch.Generator().manual_seed(1)), dim=1).to(DEV)
+    for view_dir in (None, vd):
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
+        want = torch.cat([ops.posenc(pts, 15), demb[:, None, :].expand(R, N, 27).reshape(R * N, 27)], 1)
+        got = AG._embed_points(rays, z, view_dir)
+        assert got.shape == (R * N, 120) and torch.equal(got, want)
