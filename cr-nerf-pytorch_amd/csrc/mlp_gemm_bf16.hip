@@ -14,9 +14,10 @@
 //   v_mfma_f32_32x32x16_bf16, swapped operands: a-operand lane (j, hh) = W[feature j][k = 8 hh + e], b-operand lane (i, hh) =
 //   A[point i][k = 8 hh + e]; accumulator register r of lane (i, hh) = C[point i][feature (r&3) + 8 (r>>2) + 4 hh].
 //
-// Storage order of an activation / delta row (256 bf16 = 512 B): within every group of 32 features, feature 8 q + 4 hh + e sits at
-// position 16 hh + 4 q + e -- the 16 values lane (i, hh) holds of a 32-feature tile are then 32 contiguous bytes (two 16-byte
-// stores; in reference order they are four 8-byte pieces 16 bytes apart).  Consumers never see the permutation: the packed weight
+// Storage order of an activation / delta row (256 bf16 = 512 B): within every group of 32 features, feature 8 q + 4 hh + e
+// (q = 2 q1 + q0) sits at position 16 q1 + 8 hh + 4 q0 + e -- the 16 values lane (i, hh) holds of a 32-feature tile are then two
+// 16-byte pieces, and the two lanes of a point write 32 contiguous bytes per store instruction (in reference order: four 8-byte
+// pieces 16 bytes apart).  Consumers never see the permutation: the packed weight
 // fragments carry it in their k index, the weight-gradient kernel un-permutes when it writes dW.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -32,9 +33,11 @@ typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;   // raw storage
 
-__host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 2) & 1) << 4) | (((f >> 3) & 3) << 2) | (f & 3); }      // feature -> position
-__host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 2) & 3) << 3) | (((c >> 4) & 1) << 2) | (c & 3); }    // position -> feature
-static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(8 * 2 + 4 * 1 + 3) == 16 + 4 * 2 + 3, "storage permutation");
+// feature 8 q + 4 hh + e (q = 2 q1 + q0) -> position 16 q1 + 8 hh + 4 q0 + e, and back
+__host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 4) & 1) << 4) | (((f >> 2) & 1) << 3) | (((f >> 3) & 1) << 2) | (f & 3); }
+__host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 4) & 1) << 4) | (((c >> 2) & 1) << 3) | (((c >> 3) & 1) << 2) | (c & 3); }
+static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(8 * 3 + 4 * 1 + 2) == 16 + 8 + 4 + 2 && perm32(8 * 1 + 4 * 0 + 1) == 4 + 1,
+              "storage permutation");
 
 constexpr int XB_W = 128;        // embedded input as bf16: [0, 93) xyz embedding, [93, 96) zero, [96, 123) direction embedding, [123, 128) zero
 constexpr int XB_DIR = 96;
@@ -334,9 +337,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[8 * q + e] = v[4 * q + e];
         } else {
-          bf16_t* o = j.out + row * j.ldo + j.col_off + 32 * t + 16 * hh;
+          bf16_t* o = j.out + row * j.ldo + j.col_off + 32 * t + 8 * hh;   // the two lanes of a point write 32 contiguous bytes per store
           *(uint4*)o = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
-          *(uint4*)(o + 8) = make_uint4(gb_pk(v[8], v[9]), gb_pk(v[10], v[11]), gb_pk(v[12], v[13]), gb_pk(v[14], v[15]));
+          *(uint4*)(o + 16) = make_uint4(gb_pk(v[8], v[9]), gb_pk(v[10], v[11]), gb_pk(v[12], v[13]), gb_pk(v[14], v[15]));
         }
       }
     }
