@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
       }
     }
     // epilogue.  Swapped operands leave lane (i, hh) with point `row` and, in registers 4 q .. 4 q + 3 of tile t, the four consecutive
-    // features 32 t + 8 q + 4 hh + 0..3 -- positions 32 t + 16 hh + 4 q + 0..3 of the stored row.
+    // features 32 t + 8 q + 4 hh + 0..3 -- positions 32 t + 16 (q >> 1) + 8 hh + 4 (q & 1) + 0..3 of the stored row (perm32).
     if (j.dbg & 1) continue;
     const int t_off = j.col_off >> 5;
     const float r1 = R1 ? j.r1_row[rw] : 0.0f;
