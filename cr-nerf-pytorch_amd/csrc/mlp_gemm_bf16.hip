@@ -470,24 +470,71 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
   };
   const bool do_bias = j.bias_partial && blockIdx.z == 0 && wni == 0;
   gb_f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
-  fetch16(p0, dcur, acur);
-  for (long pb = p0; pb < p1; pb += 16) {
-    fetch16(pb + 16, dnxt, anxt);
+  auto multiply = [&](const uint2 (&d)[8], const uint2 (&a)[8]) {
     if (do_bias) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        bsum[0] += gb_lo(dcur[e].x); bsum[1] += gb_hi(dcur[e].x); bsum[2] += gb_lo(dcur[e].y); bsum[3] += gb_hi(dcur[e].y);
+        bsum[0] += gb_lo(d[e].x); bsum[1] += gb_hi(d[e].x); bsum[2] += gb_lo(d[e].y); bsum[3] += gb_hi(d[e].y);
       }
     }
     gb_bf16x8 df[4], af[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { df[t] = frag(dcur, t); af[t] = frag(acur, t); }
+    for (int t = 0; t < 4; ++t) { df[t] = frag(d, t); af[t] = frag(a, t); }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a4 = 0; a4 < 4; ++a4)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a], af[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[a4][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a4], af[b], acc[a4][b], 0, 0, 0);
+  };
+  if (wp == 1) {
+    // Full 256 x 256 block: the four waves multiply the SAME points, so the workgroup fetches each 512-byte row of both operands
+    // ONCE -- 16-byte loads, whole rows per instruction -- into LDS and every wave picks its 8-byte column pieces from there (read
+    // directly, each row half is fetched by two waves, 8 bytes per lane: 3.5 TB/s of HBM reads against 6.3 for a plain row copy,
+    // tools/ubench/row_patterns.hip).  Double-buffered, one __syncthreads per 16-point k-step.
+    __shared__ uint4 sh[2][2][16][33];           // [buffer][D, A][point][32 units of 16 B + pad]
+    const int u = threadIdx.x & 31, rrow = threadIdx.x >> 5;
+    const bf16_t* dglob = j.D + blockIdx.y * 256 + 8 * u;
+    const bf16_t* aglob = j.A + blockIdx.z * 256 + 8 * u;
+    uint4 g[4];
+    auto gfetch = [&](long pb) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const long pt = pb + rrow + 8 * h2;
+        const long pc = pt < plast ? pt : plast;
+        const uint4 dv = *(const uint4*)(dglob + pc * j.ldd);
+        const uint4 av = *(const uint4*)(aglob + pc * j.lda);
+        const bool keep = pt < p1;
+        g[2 * h2] = keep ? dv : make_uint4(0u, 0u, 0u, 0u);
+        g[2 * h2 + 1] = keep ? av : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) { sh[buf][0][rrow + 8 * h2][u] = g[2 * h2]; sh[buf][1][rrow + 8 * h2][u] = g[2 * h2 + 1]; }
+    };
+    gfetch(p0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (long pb = p0; pb < p1; pb += 16) {
+      gfetch(pb + 16);                             // the next k-step's rows fly while this one is multiplied
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dcur[e] = ((const uint2*)&sh[buf][0][8 * kk + e][0])[wmi * 32 + i];
+        acur[e] = ((const uint2*)&sh[buf][1][8 * kk + e][0])[wni * 32 + i];
+      }
+      multiply(dcur, acur);
+      lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    fetch16(p0, dcur, acur);
+    for (long pb = p0; pb < p1; pb += 16) {
+      fetch16(pb + 16, dnxt, anxt);
+      multiply(dcur, acur);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+    }
   }
   if (do_bias) {
 #pragma unroll
