@@ -11,14 +11,16 @@
 // Why un-fused: with the matrix work 16x cheaper these passes are bound by their activation traffic, not by the MFMA; a persistent
 // workgroup keeps the layer's weight matrix in LDS as MFMA operand fragments and streams 32-point tiles (one per wave) through it.
 //   C[P x N] = act(A[P x K] . W[N x K]^T + bias)         A = up to two column segments (the skip / dir concatenations)
-//   v_mfma_f32_32x32x16_bf16, swapped operands: a-operand lane (j, hh) = W[feature j][k = 8 hh + e], b-operand lane (i, hh) =
-//   A[point i][k = 8 hh + e]; accumulator register r of lane (i, hh) = C[point i][feature (r&3) + 8 (r>>2) + 4 hh].
+//   v_mfma_f32_16x16x32_bf16, swapped operands: a-operand lane (i, kq) = W[feature i][k = 8 kq + e], b-operand lane (j, kq) =
+//   A[point j][k = 8 kq + e] (i, j = lane & 15, kq = lane >> 4); accumulator register r of lane (j, q4) = C[point j][feature 4 q4 + r].
+//   Why the 16-wide shape: a load or store instruction moves 16 bytes per lane, and FOUR lanes share a point here -- 64 contiguous
+//   bytes per row and instruction, 16 rows -- against 32 bytes x 32 rows with the 32x32x16 shape (two lanes per point).  A row copy in
+//   the two patterns (tools/ubench/row_patterns.hip): reads 6.2 / 6.3 TB/s, writes 4.5 / 3.8, read + write 5.0 / 4.4.
 //
-// Storage order of an activation / delta row (256 bf16 = 512 B): within every group of 32 features, feature 8 q + 4 hh + e
-// (q = 2 q1 + q0) sits at position 16 q1 + 8 hh + 4 q0 + e -- the 16 values lane (i, hh) holds of a 32-feature tile are then two
-// 16-byte pieces, and the two lanes of a point write 32 contiguous bytes per store instruction (in reference order: four 8-byte
-// pieces 16 bytes apart).  Consumers never see the permutation: the packed weight
-// fragments carry it in their k index, the weight-gradient kernel un-permutes when it writes dW.
+// Storage order of an activation / delta row (256 bf16 = 512 B): within every group of 32 features, feature 16 b + 4 q4 + r sits at
+// position 8 q4 + 4 b + r -- the 8 values lane (j, q4) holds of a group (rows 4 q4 .. 4 q4 + 3 of its two 16-feature tiles) are ONE
+// 16-byte piece, and the four lanes of a point write 64 contiguous bytes per store instruction.  Consumers never see the
+// permutation: the packed weight fragments carry it in their k index, the weight-gradient kernel un-permutes when it writes dW.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -33,10 +35,11 @@ typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;   // raw storage
 
-// feature 8 q + 4 hh + e (q = 2 q1 + q0) -> position 16 q1 + 8 hh + 4 q0 + e, and back
-__host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 4) & 1) << 4) | (((f >> 2) & 1) << 3) | (((f >> 3) & 1) << 2) | (f & 3); }
-__host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 4) & 1) << 4) | (((c >> 2) & 1) << 3) | (((c >> 3) & 1) << 2) | (c & 3); }
-static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(8 * 3 + 4 * 1 + 2) == 16 + 8 + 4 + 2 && perm32(8 * 1 + 4 * 0 + 1) == 4 + 1,
+// feature 16 b + 4 q4 + r of a group of 32  ->  position 8 q4 + 4 b + r, and back (b: which of the group's two 16-feature MFMA tiles,
+// q4 = lane >> 4: the lane quarter that holds accumulator rows 4 q4 .. 4 q4 + 3)
+__host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 2) & 3) << 3) | (((f >> 4) & 1) << 2) | (f & 3); }
+__host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 2) & 1) << 4) | (((c >> 3) & 3) << 2) | (c & 3); }
+static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(16 * 1 + 4 * 2 + 3) == 8 * 2 + 4 + 3 && perm32(16 * 0 + 4 * 3 + 1) == 24 + 1,
               "storage permutation");
 
 constexpr int XB_W = 128;        // embedded input as bf16: [0, 93) xyz embedding, [93, 96) zero, [96, 123) direction embedding, [123, 128) zero
@@ -50,8 +53,8 @@ __device__ __forceinline__ uint32_t gb_pk(float a, float b) {
 __device__ __forceinline__ float gb_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float gb_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// ---- packed weights: per matrix a stream of 1 KiB fragments, frag(t, s)[lane = 32 hh + j][e] = bf16(M[32 t + j][16 s + 8 hh + e]),
-// tile-major (t = feature tile of 32, s = k-step of 16); rows / columns beyond the matrix are zero.  The LDS image is the global image.
+// ---- packed weights: per matrix a stream of 1 KiB fragments, frag(t, s)[lane = 16 kq + i][e] = bf16(M[16 t + i][32 s + 8 kq + e]),
+// tile-major (t = feature tile of 16, s = k-step of 32); rows / columns beyond the matrix are zero.  The LDS image is the global image.
 struct GemmMat { int off_frag; int N; int K; };   // fragment offset in the packed buffer, output features, padded contraction length
 enum {
   GM_L1 = 0, GM_L2, GM_L3, GM_L4, GM_L5, GM_L6, GM_L7, GM_L8, GM_FINAL, GM_DIR, GM_RGB,        // forward: W[N x K]
@@ -59,7 +62,7 @@ enum {
   GM_COUNT
 };
 
-__host__ __device__ constexpr int gm_frags(int N, int K) { return ((N + 31) / 32) * (K / 16); }
+__host__ __device__ constexpr int gm_frags(int N, int K) { return ((N + 15) / 16) * (K / 32); }
 
 struct GemmLayout {
   GemmMat m[GM_COUNT];
@@ -99,16 +102,16 @@ struct PackJob {
 };
 
 __global__ __launch_bounds__(256) void gemm_pack_kernel(PackJob j, uint4* __restrict__ packed) {
-  const int ks = j.K / 16;
-  const int nfrag = ((j.N + 31) / 32) * ks;
+  const int ks = j.K / 32;
+  const int nfrag = ((j.N + 15) / 16) * ks;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nfrag * 64; idx += gridDim.x * 256) {
-    const int frag = idx >> 6, lane = idx & 63, jn = lane & 31, hh = lane >> 5;
+    const int frag = idx >> 6, lane = idx & 63, jn = lane & 15, kq = lane >> 4;
     const int t = frag / ks, s = frag - t * ks;
-    const int r = 32 * t + jn;
+    const int r = 16 * t + jn;
     float e[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = 16 * s + 8 * hh + q;
+      const int c = 32 * s + 8 * kq + q;
       float val = 0.0f;
       if (r < j.rows) {
         if (j.transpose) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void embed_bf16_kernel(const float* __restrict
 }
 
 // ---- the GEMM
-// A column segment: `pad` (multiple of 16) bf16 columns of rows p + row * ld, all physically present (padding columns hold zeros,
+// A column segment: `pad` (multiple of 32) bf16 columns of rows p + row * ld, all physically present (padding columns hold zeros,
 // or meet zero weight columns), 16-byte aligned.
 struct GemmSeg { const bf16_t* p; int ld; int pad; };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
@@ -182,8 +185,8 @@ struct GemmJob {
   int act;
   const uint32_t* bits_in;        // epilogue: C *= relu' from the activity bits the forward wrote (below), or null
   uint32_t* bits_out;             // ACT_RELU forward: activity bits of the output, or null.  Layout per point: 32 bytes =
-                                  // [hh = 0,1][tile t = 0..7] u16, bit 4 q + e <-> feature 32 t + 8 q + 4 hh + e: exactly what
-                                  // lane (point, hh) produces / consumes, so 16 bytes per lane and tile of 32 points
+                                  // [q4 = 0..3][group u = 0..7] u8, bit 4 b + r <-> feature 32 u + 16 b + 4 q4 + r: exactly what
+                                  // lane (point, q4) produces / consumes, 8 bytes per lane
   const float* r1_row;            // epilogue: C += r1_row[row] * colvec[feature]   (the sigma head's branch into d(h8)) or null
   const float* colvec;            // [features]: the rank-1 column vector, or (SIG) static_sigma.weight
   const float* sig_b; float* sig_out;   // SIG: sig_out[row * 65 + 64] = softplus(colvec . relu(C[row]) + sig_b[0]) on the fp32 accumulators
@@ -195,24 +198,25 @@ struct GemmJob {
 
 constexpr int GEMM_LDS_BYTES = 128 * 1024 + 2048;   // fragments + bias / column vector
 constexpr int GEMM_WAVES = 8;     // two per SIMD (< 256 registers): one wave's store phase overlaps another's load phase
-constexpr int GEMM_TILE = 32;     // points per wave tile
-constexpr int GEMM_PF = 8;        // k-steps per prefetch chunk: 8 x 16 B per lane = 8 KiB per wave in flight (~16 MB on the chip)
+constexpr int GEMM_TILE = 32;     // points per wave tile: two groups of 16 (each weight fragment read feeds two MFMAs)
+constexpr int GEMM_PF = 4;        // k-steps (of 32) per prefetch chunk: 8 x 16 B per lane = 8 KiB per wave in flight (~16 MB on the chip)
 
-// NT feature tiles of 32 per pass: 8 (N = 256), 4 (N = 128), 2 (N = 64).  SEG2 / ACT / MASK (relu' bits in) / R1 (rank-1 term) / SIG
+// NT groups of 32 features per pass: 8 (N = 256), 4 (N = 128), 2 (N = 64).  SEG2 / ACT / MASK (relu' bits in) / R1 (rank-1 term) / SIG
 // (fused sigma head) are compile-time: as run-time switches they became ~1,400 branches and 200 spilled registers in the epilogue,
 // and every store sat behind a spill reload's s_waitcnt vmcnt(0) -- i.e. behind the previous store's completion.
 template <int NT, bool SEG2, int ACT, bool MASK, bool R1, bool SIG>
 __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_kernel(GemmJob j) {
   extern __shared__ __attribute__((aligned(16))) char gsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, hh = lane >> 5;
-  const int ks = j.K / 16, ks0 = j.a0.pad / 16;
+  const int jp = lane & 15, q4 = lane >> 4;       // b-operand: point jp, k quarter q4; accumulator: point jp, feature rows 4 q4 .. 4 q4 + 3
+  const int ks = j.K / 32, ks0 = j.a0.pad / 32;
   constexpr int PF = GEMM_PF;
+  constexpr int NT16 = 2 * NT;
   {   // stage the weight fragments: the LDS image is the global image
-    const int n16 = NT * ks * 64;
+    const int n16 = NT16 * ks * 64;
     uint4* dst = (uint4*)gsm;
     for (int idx = tid; idx < n16; idx += 64 * GEMM_WAVES) dst[idx] = j.frags[idx];
-    float* eb = (float*)(gsm + (size_t)NT * ks * 1024);   // behind the fragments: [0, 256) bias of this pass' features, [256, 512) column vector
+    float* eb = (float*)(gsm + (size_t)NT16 * ks * 1024);   // behind the fragments: [0, 256) bias of this pass' features, [256, 512) column vector
     if (tid < 32 * NT) {
       const bool ok = tid < j.N;
       eb[tid] = (j.bias && ok) ? j.bias[j.col_off + tid] : 0.0f;
@@ -220,133 +224,142 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
     }
   }
   __syncthreads();
-  const float* eb = (const float*)(gsm + (size_t)NT * ks * 1024);
+  const float* eb = (const float*)(gsm + (size_t)NT16 * ks * 1024);
   const long tiles = (j.P + GEMM_TILE - 1) / GEMM_TILE;
   const int chunks = (ks + PF - 1) / PF;
   const long tstride = (long)gridDim.x * GEMM_WAVES;
   // operand staging lives ACROSS tiles: the first chunk of the next tile is requested in the last k-chunk of the current one, so loads
   // are in flight during the epilogue's store phase too.  Loads are UNCONDITIONAL (a branch around a load costs a vmcnt(0) at the
   // join and serialises the prefetch): rows are clamped, k-steps past the end re-read the last one, segments are chosen by selects.
-  uint4 nxt[PF];
+  uint4 nxt[PF][2];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) nxt[u] = make_uint4(0u, 0u, 0u, 0u);
-  auto row_of = [&](long tile) { const long rr = tile * GEMM_TILE + i; return rr < j.P ? rr : j.P - 1; };
-  auto fetch = [&](int c, long rw, uint4 (&buf)[PF]) {
+  for (int u = 0; u < PF; ++u) nxt[u][0] = nxt[u][1] = make_uint4(0u, 0u, 0u, 0u);
+  auto row_of = [&](long tile, int g) { const long rr = tile * GEMM_TILE + 16 * g + jp; return rr < j.P ? rr : j.P - 1; };
+  auto fetch = [&](int c, long rw0, long rw1, uint4 (&buf)[PF][2]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int s = c * PF + u < ks ? c * PF + u : ks - 1;
       const bool first = !SEG2 || s < ks0;
       const bf16_t* p = first ? j.a0.p : j.a1.p;
       const int ld = first ? j.a0.ld : j.a1.ld;
-      buf[u] = *(const uint4*)(p + rw * ld + 16 * (first ? s : s - ks0) + 8 * hh);
+      const int col = 32 * (first ? s : s - ks0) + 8 * q4;
+      buf[u][0] = *(const uint4*)(p + rw0 * ld + col);
+      buf[u][1] = *(const uint4*)(p + rw1 * ld + col);
     }
   };
   {
     const long t0 = (long)blockIdx.x * GEMM_WAVES + wave;
-    if (!(j.dbg & 2)) fetch(0, row_of(t0 < tiles ? t0 : 0), nxt);
+    const long tt = t0 < tiles ? t0 : 0;
+    if (!(j.dbg & 2)) fetch(0, row_of(tt, 0), row_of(tt, 1), nxt);
   }
   for (long tile = (long)blockIdx.x * GEMM_WAVES + wave; tile < tiles; tile += tstride) {
-    gb_f32x16 acc[NT];
+    gb_f32x4 acc[2][NT16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    const long row = tile * GEMM_TILE + i;
-    const bool row_ok = row < j.P;
-    const long rw = row_ok ? row : j.P - 1;                // clamped: always readable
-    uint4 bin = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (MASK) bin = *(const uint4*)(j.bits_in + (rw * 2 + hh) * 4);
-    const long rw_next = row_of(tile + tstride < tiles ? tile + tstride : tile);
+      for (int t = 0; t < NT16; ++t) acc[g][t] = gb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const long rw0 = row_of(tile, 0), rw1 = row_of(tile, 1);       // clamped: always readable
+    const long tn = tile + tstride < tiles ? tile + tstride : tile;
+    const long rn0 = row_of(tn, 0), rn1 = row_of(tn, 1);
+    uint2 bin[2] = {make_uint2(~0u, ~0u), make_uint2(~0u, ~0u)};
+    if (MASK) {
+      bin[0] = *(const uint2*)(j.bits_in + (rw0 * 4 + q4) * 2);
+      bin[1] = *(const uint2*)(j.bits_in + (rw1 * 4 + q4) * 2);
+    }
 #pragma unroll 1
     for (int c = 0; c < chunks; ++c) {
-      uint4 cur[PF];
+      uint4 cur[PF][2];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < PF; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
       if (!(j.dbg & 2)) {                                  // the next chunk's operands fly while this one's MFMAs run; after the last chunk,
         const bool last = c + 1 == chunks;                 // the NEXT TILE's first chunk
-        fetch(last ? 0 : c + 1, last ? rw_next : rw, nxt);
+        fetch(last ? 0 : c + 1, last ? rn0 : rw0, last ? rn1 : rw1, nxt);
       }
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int s = c * PF + u;
         if (s < ks && !(j.dbg & 4)) {
-          const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, cur[u]);
+          const gb_bf16x8 b0 = __builtin_bit_cast(gb_bf16x8, cur[u][0]), b1 = __builtin_bit_cast(gb_bf16x8, cur[u][1]);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
+          for (int t = 0; t < NT16; ++t) {
             const gb_bf16x8 wf = *(const gb_bf16x8*)(gsm + ((size_t)(t * ks + s) * 64 + lane) * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, b, acc[t], 0, 0, 0);   // swapped: D[feature][point]
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b0, acc[0][t], 0, 0, 0);   // swapped: D[feature][point]
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b1, acc[1][t], 0, 0, 0);
           }
         }
       }
     }
-    // epilogue.  Swapped operands leave lane (i, hh) with point `row` and, in registers 4 q .. 4 q + 3 of tile t, the four consecutive
-    // features 32 t + 8 q + 4 hh + 0..3 -- positions 32 t + 16 (q >> 1) + 8 hh + 4 (q & 1) + 0..3 of the stored row (perm32).
+    // epilogue.  Swapped operands leave lane (jp, q4) with points 16 g + jp and, in accumulator t, features 16 t + 4 q4 + 0..3; the two
+    // tiles of a 32-feature group are positions 32 u + 8 q4 + 0..7 of the stored row (perm32): one 16-byte store per group.
     if (j.dbg & 1) continue;
-    const int t_off = j.col_off >> 5;
-    const float r1 = R1 ? j.r1_row[rw] : 0.0f;
-    const uint32_t bw_in[4] = {bin.x, bin.y, bin.z, bin.w};
-    uint32_t bw_out[4] = {0u, 0u, 0u, 0u};
-    float sg = 0.0f;
-    if (SIG) {
-      // static_sigma on the un-rounded relu output (nerf.py:146,172), as its own pass over the accumulators: folded into the store
-      // loop below it pushed that loop over the 256-register budget (52 spills, every store behind a scratch reload: 2.8x slower)
+    const int u_off = j.col_off >> 5;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int g = 0; g < 2; ++g) {
+      const long row = tile * GEMM_TILE + 16 * g + jp;
+      const bool row_ok = row < j.P;
+      const long rw = g ? rw1 : rw0;
+      const float r1 = R1 ? j.r1_row[rw] : 0.0f;
+      const unsigned long long bits_in = ((unsigned long long)bin[g].y << 32) | bin[g].x;
+      unsigned long long bits_o = 0ull;
+      if (SIG) {
+        // static_sigma on the un-rounded relu output (nerf.py:146,172), as its own pass over the accumulators: folded into the store
+        // loop below it pushed that loop over the 256-register budget (spills, every store behind a scratch reload: 2.8x slower)
+        float sg = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int fcol = 32 * t + 8 * q + 4 * hh;
-          const float4 b = *(const float4*)(eb + fcol), cv = *(const float4*)(eb + 256 + fcol);
-          sg = fmaf(cv.x, fmaxf(acc[t][4 * q + 0] + b.x, 0.0f), sg); sg = fmaf(cv.y, fmaxf(acc[t][4 * q + 1] + b.y, 0.0f), sg);
-          sg = fmaf(cv.z, fmaxf(acc[t][4 * q + 2] + b.z, 0.0f), sg); sg = fmaf(cv.w, fmaxf(acc[t][4 * q + 3] + b.w, 0.0f), sg);
+        for (int t = 0; t < NT16; ++t) {
+          const float4 b = *(const float4*)(eb + 16 * t + 4 * q4), cv = *(const float4*)(eb + 256 + 16 * t + 4 * q4);
+          sg = fmaf(cv.x, fmaxf(acc[g][t][0] + b.x, 0.0f), sg); sg = fmaf(cv.y, fmaxf(acc[g][t][1] + b.y, 0.0f), sg);
+          sg = fmaf(cv.z, fmaxf(acc[g][t][2] + b.z, 0.0f), sg); sg = fmaf(cv.w, fmaxf(acc[g][t][3] + b.w, 0.0f), sg);
         }
-      asm volatile("" : "+v"(sg));
-      sg += __shfl_xor(sg, 32);
-      if (row_ok && hh == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
-    }
+        asm volatile("" : "+v"(sg));
+        sg += __shfl_xor(sg, 16);
+        sg += __shfl_xor(sg, 32);
+        if (row_ok && q4 == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
+      }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int tg = t_off + t;                                   // tile index within the point's 256 features
-      const uint32_t half_in = MASK ? bw_in[(tg >> 1) & 3] >> ((tg & 1) * 16) : 0xffffu;
-      uint32_t half_out = 0u;
-      float v[16];
+      for (int u = 0; u < NT; ++u) {
+        const int ug = u_off + u;                                   // group index within the point's 256 features
+        const uint32_t byte_in = MASK ? (uint32_t)(bits_in >> (8 * ug)) & 0xffu : 0xffu;
+        uint32_t byte_out = 0u;
+        float v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int fcol = 32 * t + 8 * q + 4 * hh;                 // < 32 NT; features beyond N (multiple of 32 here) do not exist
-        const float4 b = *(const float4*)(eb + fcol);
-        v[4 * q + 0] = acc[t][4 * q + 0] + b.x; v[4 * q + 1] = acc[t][4 * q + 1] + b.y;
-        v[4 * q + 2] = acc[t][4 * q + 2] + b.z; v[4 * q + 3] = acc[t][4 * q + 3] + b.w;
-        if (R1) {
-          const float4 cv = *(const float4*)(eb + 256 + fcol);
-          v[4 * q + 0] = fmaf(r1, cv.x, v[4 * q + 0]); v[4 * q + 1] = fmaf(r1, cv.y, v[4 * q + 1]);
-          v[4 * q + 2] = fmaf(r1, cv.z, v[4 * q + 2]); v[4 * q + 3] = fmaf(r1, cv.w, v[4 * q + 3]);
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int fcol = 32 * u + 16 * b2 + 4 * q4;               // < 32 NT; features beyond N (multiple of 32 here) do not exist
+          const float4 b = *(const float4*)(eb + fcol);
+          v[4 * b2 + 0] = acc[g][2 * u + b2][0] + b.x; v[4 * b2 + 1] = acc[g][2 * u + b2][1] + b.y;
+          v[4 * b2 + 2] = acc[g][2 * u + b2][2] + b.z; v[4 * b2 + 3] = acc[g][2 * u + b2][3] + b.w;
+          if (R1) {
+            const float4 cv = *(const float4*)(eb + 256 + fcol);
+            v[4 * b2 + 0] = fmaf(r1, cv.x, v[4 * b2 + 0]); v[4 * b2 + 1] = fmaf(r1, cv.y, v[4 * b2 + 1]);
+            v[4 * b2 + 2] = fmaf(r1, cv.z, v[4 * b2 + 2]); v[4 * b2 + 3] = fmaf(r1, cv.w, v[4 * b2 + 3]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float& x = v[4 * b2 + e];
+            if (ACT == ACT_RELU) { x = fmaxf(x, 0.0f); byte_out |= (x > 0.0f ? 1u : 0u) << (4 * b2 + e); }
+            else if (ACT == ACT_SIGMOID) x = sigmoid_ref(x);
+            if (MASK) x = ((byte_in >> (4 * b2 + e)) & 1u) ? x : 0.0f;
+          }
         }
+        bits_o |= (unsigned long long)byte_out << (8 * ug);
+        if (row_ok) {
+          if (ACT == ACT_SIGMOID) {
+            float* o = j.out_f + row * j.ldo_f + j.col_off + 32 * u + 4 * q4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float& x = v[4 * q + e];
-          if (ACT == ACT_RELU) { x = fmaxf(x, 0.0f); half_out |= (x > 0.0f ? 1u : 0u) << (4 * q + e); }
-          else if (ACT == ACT_SIGMOID) x = sigmoid_ref(x);
-          if (MASK) x = ((half_in >> (4 * q + e)) & 1u) ? x : 0.0f;
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[16 * b2 + e] = v[4 * b2 + e];
+          } else {
+            bf16_t* o = j.out + row * j.ldo + j.col_off + 32 * u + 8 * q4;   // the four lanes of a point write 64 contiguous bytes
+            *(uint4*)o = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
+          }
         }
       }
-      bw_out[(tg >> 1) & 3] |= half_out << ((tg & 1) * 16);
-      if (row_ok) {
-        if (ACT == ACT_SIGMOID) {
-          float* o = j.out_f + row * j.ldo_f + j.col_off + 32 * t + 4 * hh;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[8 * q + e] = v[4 * q + e];
-        } else {
-          bf16_t* o = j.out + row * j.ldo + j.col_off + 32 * t + 8 * hh;   // the two lanes of a point write 32 contiguous bytes per store
-          *(uint4*)o = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
-          *(uint4*)(o + 16) = make_uint4(gb_pk(v[8], v[9]), gb_pk(v[10], v[11]), gb_pk(v[12], v[13]), gb_pk(v[14], v[15]));
-        }
+      if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the bytes this pass covers: 8 groups = 8 bytes, 4 groups = 4 bytes
+        uint32_t* bo = j.bits_out + (row * 4 + q4) * 2;
+        if (NT == 8) *(uint2*)bo = make_uint2((uint32_t)bits_o, (uint32_t)(bits_o >> 32));
+        else if (NT == 4) bo[u_off >> 2] = (uint32_t)(bits_o >> (8 * u_off));
       }
-    }
-    if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the words this pass covers: 8 tiles = 16 bytes, 4 tiles = 8 bytes
-      uint32_t* bo = j.bits_out + (row * 2 + hh) * 4;
-      if (NT == 8) *(uint4*)bo = make_uint4(bw_out[0], bw_out[1], bw_out[2], bw_out[3]);
-      else if (NT == 4) { const int w0 = (t_off >> 1) & 3; *(uint2*)(bo + w0) = make_uint2(bw_out[w0], bw_out[w0 + 1]); }
     }
   }
 }

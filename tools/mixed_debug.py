@@ -40,7 +40,7 @@ _lib.check(lib.crnerf_mlp_backward_mixed_f32(_lib.ptr_array(tensors, "t"), ctype
                                              _lib.dev_ptr(d_out.to(DEV)), ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
                                              _lib.ptr_array(grads, "g"), n, _lib.stream_ptr()), "bwd")
 torch.cuda.synchronize()
-pos = np.arange(256); featidx = (pos & ~31) | (((pos >> 4) & 1) << 4) | (((pos >> 2) & 1) << 3) | (((pos >> 3) & 1) << 2) | (pos & 3)   # position -> feature
+pos = np.arange(256); featidx = (pos & ~31) | (((pos >> 2) & 1) << 4) | (((pos >> 3) & 3) << 2) | (pos & 3)   # position -> feature
 def rows(buf, slot):
     a = buf[: 10 * n * 512].view(torch.bfloat16).view(10, n, 256)[slot].float().cpu()
     o = torch.empty_like(a); o[:, featidx] = a
