@@ -301,21 +301,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
       const float r1 = R1 ? j.r1_row[rw] : 0.0f;
       const unsigned long long bits_in = ((unsigned long long)bin[g].y << 32) | bin[g].x;
       unsigned long long bits_o = 0ull;
-      if (SIG) {
-        // static_sigma on the un-rounded relu output (nerf.py:146,172), as its own pass over the accumulators: folded into the store
-        // loop below it pushed that loop over the 256-register budget (spills, every store behind a scratch reload: 2.8x slower)
-        float sg = 0.0f;
-#pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-          const float4 b = *(const float4*)(eb + 16 * t + 4 * q4), cv = *(const float4*)(eb + 256 + 16 * t + 4 * q4);
-          sg = fmaf(cv.x, fmaxf(acc[g][t][0] + b.x, 0.0f), sg); sg = fmaf(cv.y, fmaxf(acc[g][t][1] + b.y, 0.0f), sg);
-          sg = fmaf(cv.z, fmaxf(acc[g][t][2] + b.z, 0.0f), sg); sg = fmaf(cv.w, fmaxf(acc[g][t][3] + b.w, 0.0f), sg);
-        }
-        asm volatile("" : "+v"(sg));
-        sg += __shfl_xor(sg, 16);
-        sg += __shfl_xor(sg, 32);
-        if (row_ok && q4 == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
-      }
+      float sg = 0.0f;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int ug = u_off + u;                                   // group index within the point's 256 features
@@ -328,8 +314,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
           const float4 b = *(const float4*)(eb + fcol);
           v[4 * b2 + 0] = acc[g][2 * u + b2][0] + b.x; v[4 * b2 + 1] = acc[g][2 * u + b2][1] + b.y;
           v[4 * b2 + 2] = acc[g][2 * u + b2][2] + b.z; v[4 * b2 + 3] = acc[g][2 * u + b2][3] + b.w;
+          float4 cv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (R1 || SIG) cv = *(const float4*)(eb + 256 + fcol);
           if (R1) {
-            const float4 cv = *(const float4*)(eb + 256 + fcol);
             v[4 * b2 + 0] = fmaf(r1, cv.x, v[4 * b2 + 0]); v[4 * b2 + 1] = fmaf(r1, cv.y, v[4 * b2 + 1]);
             v[4 * b2 + 2] = fmaf(r1, cv.z, v[4 * b2 + 2]); v[4 * b2 + 3] = fmaf(r1, cv.w, v[4 * b2 + 3]);
           }
@@ -339,6 +326,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
             if (ACT == ACT_RELU) { x = fmaxf(x, 0.0f); byte_out |= (x > 0.0f ? 1u : 0u) << (4 * b2 + e); }
             else if (ACT == ACT_SIGMOID) x = sigmoid_ref(x);
             if (MASK) x = ((byte_in >> (4 * b2 + e)) & 1u) ? x : 0.0f;
+          }
+          if (SIG) {   // static_sigma on the un-rounded relu output (nerf.py:146,172)
+            sg = fmaf(cv.x, v[4 * b2 + 0], sg); sg = fmaf(cv.y, v[4 * b2 + 1], sg); sg = fmaf(cv.z, v[4 * b2 + 2], sg); sg = fmaf(cv.w, v[4 * b2 + 3], sg);
           }
         }
         bits_o |= (unsigned long long)byte_out << (8 * ug);
@@ -354,6 +344,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
             *(uint4*)o = make_uint4(gb_pk(v[0], v[1]), gb_pk(v[2], v[3]), gb_pk(v[4], v[5]), gb_pk(v[6], v[7]));
           }
         }
+      }
+      if (SIG) {
+        sg += __shfl_xor(sg, 16);
+        sg += __shfl_xor(sg, 32);
+        if (row_ok && q4 == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
       }
       if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the bytes this pass covers: 8 groups = 8 bytes, 4 groups = 4 bytes
         uint32_t* bo = j.bits_out + (row * 4 + q4) * 2;
