@@ -437,11 +437,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
   const int wm = (bm + 127) / 128, wn = (bn + 127) / 128, wp = 4 / (wm * wn);
   const int wmi = wave % wm, wni = (wave / wm) % wn, wpi = wave / (wm * wn);
   const int m0 = blockIdx.y * 256 + wmi * 128, n0 = blockIdx.z * 256 + wni * 128;
-  const long c0 = (long)blockIdx.x * j.chunk;
-  const long c1 = c0 + j.chunk < j.P ? c0 + j.chunk : j.P;
-  const long sub = ((j.chunk + wp - 1) / wp + 15) / 16 * 16;
-  const long p0 = c0 + wpi * sub < c1 ? c0 + wpi * sub : c1;
-  const long p1 = p0 + sub < c1 ? p0 + sub : c1;                                          // may be empty: the slot is still written (zeros)
+  // Points are dealt out in 16-point k-steps, ROUND-ROBIN over the grid's workgroups (and, in narrow blocks, over the waves that split
+  // the points): at any moment the whole chip reads one neighbourhood of the two operand arrays.  (Contiguous per-workgroup chunks
+  // -- 512 far-apart streams -- ran the full blocks at 4.5 TB/s)
+  const long kstride = (long)gridDim.x * wp;                     // in k-steps
+  const long p0 = ((long)blockIdx.x * wp + wpi) * 16;            // first point of this wave's first k-step (may lie beyond P: no work)
+  const long p1 = j.P;
+  const long pstep = kstride * 16;
   const long slot = (long)blockIdx.x * wp + wpi;
   gb_f32x16 acc[4][4];
 #pragma unroll
@@ -451,99 +453,108 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   const int mc = m0 + 4 * i, nc = n0 + 4 * i;                                             // this lane's first column of each operand
-  const bf16_t* dbase = j.D + (mc < j.Dw ? mc : 0);
-  const bf16_t* abase = j.A + (nc < j.Aw ? nc : 0);
   const long plast = j.P - 1;
-  uint2 dcur[8], acur[8], dnxt[8], anxt[8];
-  auto fetch16 = [&](long pb, uint2 (&d)[8], uint2 (&a)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const long pt = pb + 8 * kk + e;
-      const long pc = pt < plast ? pt : plast;                  // clamped: always a readable row
-      const uint2 dv = *(const uint2*)(dbase + pc * j.ldd);
-      const uint2 av = *(const uint2*)(abase + pc * j.lda);
-      const bool keep = pt < p1;                                // rows past the sub-chunk contribute nothing
-      d[e] = make_uint2(keep ? dv.x : 0u, keep ? dv.y : 0u);
-      a[e] = make_uint2(keep ? av.x : 0u, keep ? av.y : 0u);    // (also the other operand: 0 x garbage of a clamped row could be 0 x inf)
-    }
-  };
-  auto frag = [&](const uint2 (&v)[8], int t) {                 // column t of the lane's four, points 0..7 -> one MFMA operand
-    uint32_t w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t lo = (t >> 1) ? v[2 * q].y : v[2 * q].x, hi = (t >> 1) ? v[2 * q + 1].y : v[2 * q + 1].x;
-      w[q] = __builtin_amdgcn_perm(hi, lo, (t & 1) ? 0x07060302u : 0x05040100u);
-    }
-    return __builtin_bit_cast(gb_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-  };
   const bool do_bias = j.bias_partial && blockIdx.z == 0 && wni == 0;
   gb_f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
-  auto multiply = [&](const uint2 (&d)[8], const uint2 (&a)[8]) {
-    if (do_bias) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bsum[0] += gb_lo(d[e].x); bsum[1] += gb_hi(d[e].x); bsum[2] += gb_lo(d[e].y); bsum[3] += gb_hi(d[e].y);
-      }
-    }
-    gb_bf16x8 df[4], af[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { df[t] = frag(d, t); af[t] = frag(a, t); }
-#pragma unroll
-    for (int a4 = 0; a4 < 4; ++a4)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a4][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a4], af[b], acc[a4][b], 0, 0, 0);
-  };
-  if (wp == 1) {
+  // one k-step: operands d[e], a[e] = this lane's four columns of points 8 kk + e of the step.  Rows past the (sub-)chunk are zeroed
+  // HERE, where they are used -- a select right behind the load sits behind an s_waitcnt for it and exposes the memory latency in
+  // every k-step; the other operand's rows are clamped to real (finite) rows, so 0 x them is 0.
+#define CRNERF_WGB_MULTIPLY(D8, A8, PB)                                                                                              \
+  {                                                                                                                                  \
+    uint2 dm[8];                                                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                                  \
+      const bool keep = (PB) + 8 * kk + e < p1;                                                                                      \
+      dm[e] = make_uint2(keep ? D8[e].x : 0u, keep ? D8[e].y : 0u);                                                                  \
+    }                                                                                                                                \
+    if (do_bias) {                                                                                                                   \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                                \
+        bsum[0] += gb_lo(dm[e].x); bsum[1] += gb_hi(dm[e].x); bsum[2] += gb_lo(dm[e].y); bsum[3] += gb_hi(dm[e].y);                  \
+      }                                                                                                                              \
+    }                                                                                                                                \
+    gb_bf16x8 df[4], af[4];                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                                  \
+      uint32_t wd[4], wa[4];                                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {   /* column t of the lane's four, points 2q, 2q+1 -> one dword of the operand */ \
+        const uint32_t sel = (t & 1) ? 0x07060302u : 0x05040100u;                                                                    \
+        wd[q] = __builtin_amdgcn_perm((t >> 1) ? dm[2 * q + 1].y : dm[2 * q + 1].x, (t >> 1) ? dm[2 * q].y : dm[2 * q].x, sel);      \
+        wa[q] = __builtin_amdgcn_perm((t >> 1) ? A8[2 * q + 1].y : A8[2 * q + 1].x, (t >> 1) ? A8[2 * q].y : A8[2 * q].x, sel);      \
+      }                                                                                                                              \
+      df[t] = __builtin_bit_cast(gb_bf16x8, make_uint4(wd[0], wd[1], wd[2], wd[3]));                                                 \
+      af[t] = __builtin_bit_cast(gb_bf16x8, make_uint4(wa[0], wa[1], wa[2], wa[3]));                                                 \
+    }                                                                                                                                \
+    _Pragma("unroll") for (int a4 = 0; a4 < 4; ++a4)                                                                                 \
+      _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4)                                                                               \
+        acc[a4][b4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a4], af[b4], acc[a4][b4], 0, 0, 0);                                 \
+  }
+  // addresses: 32-bit element offsets from the (sub-)chunk's first row, advanced by a constant per k-step and clamped to the last row of
+  // the array (a 64-bit multiply per load was ~10 VALU instructions x 32 loads per k-step -- as many cycles as the 16 MFMAs)
+  if (wp == 1 && p0 < p1) {
     // Full 256 x 256 block: the four waves multiply the SAME points, so the workgroup fetches each 512-byte row of both operands
     // ONCE -- 16-byte loads, whole rows per instruction -- into LDS and every wave picks its 8-byte column pieces from there (read
     // directly, each row half is fetched by two waves, 8 bytes per lane: 3.5 TB/s of HBM reads against 6.3 for a plain row copy,
     // tools/ubench/row_patterns.hip).  Double-buffered, one __syncthreads per 16-point k-step.
     __shared__ uint4 sh[2][2][16][33];           // [buffer][D, A][point][32 units of 16 B + pad]
     const int u = threadIdx.x & 31, rrow = threadIdx.x >> 5;
-    const bf16_t* dglob = j.D + blockIdx.y * 256 + 8 * u;
-    const bf16_t* aglob = j.A + blockIdx.z * 256 + 8 * u;
-    uint4 g[4];
-    auto gfetch = [&](long pb) {
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const long pt = pb + rrow + 8 * h2;
-        const long pc = pt < plast ? pt : plast;
-        const uint4 dv = *(const uint4*)(dglob + pc * j.ldd);
-        const uint4 av = *(const uint4*)(aglob + pc * j.lda);
-        const bool keep = pt < p1;
-        g[2 * h2] = keep ? dv : make_uint4(0u, 0u, 0u, 0u);
-        g[2 * h2 + 1] = keep ? av : make_uint4(0u, 0u, 0u, 0u);
-      }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) { sh[buf][0][rrow + 8 * h2][u] = g[2 * h2]; sh[buf][1][rrow + 8 * h2][u] = g[2 * h2 + 1]; }
-    };
-    gfetch(p0);
-    lstore(0);
+    const bf16_t* dch = j.D + p0 * j.ldd + blockIdx.y * 256 + 8 * u;
+    const bf16_t* ach = j.A + p0 * j.lda + blockIdx.z * 256 + 8 * u;
+    const uint32_t dlast = (uint32_t)(plast - p0) * (uint32_t)j.ldd, alast = (uint32_t)(plast - p0) * (uint32_t)j.lda;
+    uint32_t do0 = (uint32_t)rrow * j.ldd, do1 = (uint32_t)(rrow + 8) * j.ldd, ao0 = (uint32_t)rrow * j.lda, ao1 = (uint32_t)(rrow + 8) * j.lda;
+    const uint32_t dstep = (uint32_t)pstep * j.ldd, astep = (uint32_t)pstep * j.lda;
+    uint4 g0, g1, g2, g3, h0, h1, h2, h3;          // the rows of k-steps n + 1 (g) and n + 2 (h) in flight while n is multiplied:
+                                                   // one k-step is 16 KiB per workgroup = 4 MB on the chip, ~1 us of HBM at 4 TB/s
+#define CRNERF_WGB_GFETCH(R0, R1, R2, R3)                                       \
+    R0 = *(const uint4*)(dch + (do0 < dlast ? do0 : dlast));                    \
+    R1 = *(const uint4*)(ach + (ao0 < alast ? ao0 : alast));                    \
+    R2 = *(const uint4*)(dch + (do1 < dlast ? do1 : dlast));                    \
+    R3 = *(const uint4*)(ach + (ao1 < alast ? ao1 : alast));                    \
+    do0 += dstep; do1 += dstep; ao0 += astep; ao1 += astep;
+#define CRNERF_WGB_LSTORE(B)                                                    \
+    sh[B][0][rrow][u] = g0; sh[B][1][rrow][u] = g1; sh[B][0][rrow + 8][u] = g2; sh[B][1][rrow + 8][u] = g3;
+    CRNERF_WGB_GFETCH(g0, g1, g2, g3)
+    CRNERF_WGB_LSTORE(0)
+    CRNERF_WGB_GFETCH(g0, g1, g2, g3)
     __syncthreads();
     int buf = 0;
-    for (long pb = p0; pb < p1; pb += 16) {
-      gfetch(pb + 16);                             // the next k-step's rows fly while this one is multiplied
+    for (long pb = p0; pb < p1; pb += pstep) {
+      CRNERF_WGB_GFETCH(h0, h1, h2, h3)
+      uint2 dcur[8], acur[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         dcur[e] = ((const uint2*)&sh[buf][0][8 * kk + e][0])[wmi * 32 + i];
         acur[e] = ((const uint2*)&sh[buf][1][8 * kk + e][0])[wni * 32 + i];
       }
-      multiply(dcur, acur);
-      lstore(buf ^ 1);
+      CRNERF_WGB_MULTIPLY(dcur, acur, pb)
+      CRNERF_WGB_LSTORE(buf ^ 1)
+      g0 = h0; g1 = h1; g2 = h2; g3 = h3;
       __syncthreads();
       buf ^= 1;
     }
-  } else {
-    fetch16(p0, dcur, acur);
-    for (long pb = p0; pb < p1; pb += 16) {
-      fetch16(pb + 16, dnxt, anxt);
-      multiply(dcur, acur);
+#undef CRNERF_WGB_GFETCH
+#undef CRNERF_WGB_LSTORE
+  } else if (wp != 1 && p0 < p1) {
+    const bf16_t* dch = j.D + p0 * j.ldd + (mc < j.Dw ? mc : 0);
+    const bf16_t* ach = j.A + p0 * j.lda + (nc < j.Aw ? nc : 0);
+    const uint32_t dlast = (uint32_t)(plast - p0) * (uint32_t)j.ldd, alast = (uint32_t)(plast - p0) * (uint32_t)j.lda;
+    const uint32_t dstep = (uint32_t)pstep * j.ldd, astep = (uint32_t)pstep * j.lda;
+    uint32_t dof = (uint32_t)(8 * kk) * j.ldd, aof = (uint32_t)(8 * kk) * j.lda;      // offset of point 8 kk of the step being fetched
+    uint2 dcur[8], acur[8], dnxt[8], anxt[8];
+#define CRNERF_WGB_FETCH16(D8, A8)                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
+      const uint32_t od = dof + (uint32_t)e * j.ldd, oa = aof + (uint32_t)e * j.lda;                       \
+      D8[e] = *(const uint2*)(dch + (od < dlast ? od : dlast));                                            \
+      A8[e] = *(const uint2*)(ach + (oa < alast ? oa : alast));                                            \
+    }                                                                                                      \
+    dof += dstep; aof += astep;
+    CRNERF_WGB_FETCH16(dcur, acur)
+    for (long pb = p0; pb < p1; pb += pstep) {
+      CRNERF_WGB_FETCH16(dnxt, anxt)
+      CRNERF_WGB_MULTIPLY(dcur, acur, pb)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
     }
+#undef CRNERF_WGB_FETCH16
   }
+#undef CRNERF_WGB_MULTIPLY
   if (do_bias) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) bsum[t] += __shfl_xor(bsum[t], 32);
@@ -623,6 +634,8 @@ static int wgb_chunk(long P) {   // points per workgroup (multiple of the 16-poi
 
 static int wgrad_b(const bf16_t* D, int ldd, int M, int Dw, int permD, const bf16_t* A, int lda, int N, int Aw, int permA, float* dst, int ldc,
                    float* db, long P, float* ws, hipStream_t st) {
+  if ((unsigned long long)P * (unsigned)(ldd > lda ? ldd : lda) >= (1ull << 32))
+    return set_error(-2, "mlp_backward_mixed: more than 2^24 points per call (the weight-gradient kernel addresses rows with 32-bit offsets)");
   const int chunk = wgb_chunk(P);
   const int nchunk = (int)((P + chunk - 1) / chunk);
   const int slots = nchunk * wgb_wp(M, N);
@@ -708,16 +721,16 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
     if (int rc = dg(GM_T8 + (7 - l), GemmSeg{D(l), ACT_W, 256}, bits(l - 1), nullptr, nullptr, D(l - 1))) return rc;
   if (int rc = check_launch("mlp_backward_mixed")) return rc;
   // weight / bias gradients of the eleven nn.Linear (grads in crnerf.h tensor order)
-  wgrad_b(D(0), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[0], XYZ_DIM, grads[1], P, ws, st);          // xyz_encoding_1
+  if (int rc = wgrad_b(D(0), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[0], XYZ_DIM, grads[1], P, ws, st)) return rc;          // xyz_encoding_1
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {                                                                                              // xyz_encoding_5: cat([xyz, h4])
-      wgrad_b(D(4), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[8], XYZ_DIM + 256, grads[9], P, ws, st);
-      wgrad_b(D(4), ACT_W, 256, 256, 1, A(3), ACT_W, 256, 256, 1, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, st);
+      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[8], XYZ_DIM + 256, grads[9], P, ws, st)) return rc;
+      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, A(3), ACT_W, 256, 256, 1, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, st)) return rc;
     } else {
-      wgrad_b(D(l), ACT_W, 256, 256, 1, A(l - 1), ACT_W, 256, 256, 1, grads[2 * l], 256, grads[2 * l + 1], P, ws, st);
+      if (int rc = wgrad_b(D(l), ACT_W, 256, 256, 1, A(l - 1), ACT_W, 256, 256, 1, grads[2 * l], 256, grads[2 * l + 1], P, ws, st)) return rc;
     }
   }
-  wgrad_b(D(8), ACT_W, 256, 256, 1, A(7), ACT_W, 256, 256, 1, grads[16], 256, grads[17], P, ws, st);             // xyz_encoding_final
+  if (int rc = wgrad_b(D(8), ACT_W, 256, 256, 1, A(7), ACT_W, 256, 256, 1, grads[16], 256, grads[17], P, ws, st)) return rc;             // xyz_encoding_final
   {                                                                                                            // static_sigma
     const long chunk = (P + SIGW_BLOCKS - 1) / SIGW_BLOCKS;
     const int nblk = (int)((P + chunk - 1) / chunk);
@@ -727,9 +740,9 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
     if (int rc = launch_wgrad_reduce(part, nblk, 1, 257, sums, 257, nullptr, nullptr, st)) return rc;
     hipLaunchKernelGGL(sigma_wgrad_finish_kernel, dim3(1), dim3(320), 0, st, sums, grads[18], grads[19]);
   }
-  wgrad_b(D(9), ACT_W, 128, 128, 1, A(8), ACT_W, 256, 256, 1, grads[20], 256 + DIR_DIM, grads[21], P, ws, st);   // dir_encoding: cat([final, dir])
-  wgrad_b(D(9), ACT_W, 128, 128, 1, xb + XB_DIR, XB_W, DIR_DIM, 32, 0, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, st);
-  wgrad_b(d_rgb, DRGB_W, FEAT_DIM, DRGB_W, 0, A(9), ACT_W, 128, 128, 1, grads[22], 128, grads[23], P, ws, st);   // static_rgb
+  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, A(8), ACT_W, 256, 256, 1, grads[20], 256 + DIR_DIM, grads[21], P, ws, st)) return rc;   // dir_encoding: cat([final, dir])
+  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, xb + XB_DIR, XB_W, DIR_DIM, 32, 0, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, st)) return rc;
+  if (int rc = wgrad_b(d_rgb, DRGB_W, FEAT_DIM, DRGB_W, 0, A(9), ACT_W, 128, 128, 1, grads[22], 128, grads[23], P, ws, st)) return rc;   // static_rgb
   return check_launch("mlp_backward_mixed wgrad");
 }
 
