@@ -303,6 +303,8 @@ def test_ray_parallel_training_step_matches_single_process():
         assert grads.keys() == ref_grads.keys()
         for k, gref in ref_grads.items():
             scale = float(np.abs(gref).max()) + 1e-30
-            assert float(np.abs(grads[k] - gref).max()) <= 2e-4 * scale, (r, k, float(np.abs(grads[k] - gref).max()), scale)
+            # + 1e-9 absolute: a tensor whose gradient is itself ~1e-9 (sums of cancelling terms) moves by its terms' rounding when the
+            # partial sums are split over two ranks or the float atomics land in another order -- seen once in a full-suite run
+            assert float(np.abs(grads[k] - gref).max()) <= 2e-4 * scale + 1e-9, (r, k, float(np.abs(grads[k] - gref).max()), scale)
     for k in got[0][2]:
         assert np.array_equal(got[0][2][k], got[1][2][k]), k      # replicas stay bit-identical after the sync
