@@ -180,18 +180,19 @@ __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ o
 // x[r*N + n] = cat(PosEmbedding_xyz(o_r + d_r * z[r][n]), dir_emb[r]) -- rendering.py:100-114 (xyz_ = rays_o + rays_d * z_vals, the
 // embedding, the repeat of dir_embedded, the cat) in one pass that writes the 480-byte row once; the torch composition of the
 // same arithmetic moves ~1.5 KB per point (points, embedding, expanded directions, cat).  One thread per (point, output group):
-// 45 groups of (sin, cos) of one argument, 1 group for the identity columns, 7 groups of four direction columns (27 padded to 28).
+// 15 frequency groups (sin and cos of the three coordinates = 24 contiguous bytes), 1 group for the identity columns, 7 groups of
+// four direction columns (27 padded to 28); neighbouring threads write neighbouring bytes of the row.
 __global__ void embed_points_kernel(const float* __restrict__ rays, const float* __restrict__ z, const float* __restrict__ dir_emb,
                                     float* __restrict__ x, long R, int N) {
-  constexpr int XG = 3 * XYZ_FREQS + 1, G = XG + 7;
+  constexpr int G = 1 + XYZ_FREQS + 7;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * N * G) return;
   const long pt = idx / G;
   const int a = (int)(idx - pt * G);
   const long r = pt / N;
   float* o = x + pt * IN_DIM;
-  if (a >= XG) {
-    const int c0 = 4 * (a - XG);
+  if (a > XYZ_FREQS) {
+    const int c0 = 4 * (a - XYZ_FREQS - 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (c0 + e < DIR_DIM) o[XYZ_DIM + c0 + e] = dir_emb[r * DIR_DIM + c0 + e];
@@ -199,22 +200,25 @@ __global__ void embed_points_kernel(const float* __restrict__ rays, const float*
   }
   const float* ray = rays + r * 8;
   const float zz = z[pt];
-  if (a == 3 * XYZ_FREQS) {
+  float v[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) o[d] = ray[d] + ray[3 + d] * zz;     // separate mul and add (-ffp-contract=off), as torch evaluates it
+  for (int d = 0; d < 3; ++d) v[d] = ray[d] + ray[3 + d] * zz;       // separate mul and add (-ffp-contract=off), as torch evaluates it
+  if (a == 0) {
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
   } else {
-    const int f = a / 3, d = a % 3;
-    const float v = ray[d] + ray[3 + d] * zz;
-    float sn, cs;
-    sincosf(ldexpf(1.0f, f) * v, &sn, &cs);
-    o[3 + 6 * f + d] = sn;
-    o[3 + 6 * f + 3 + d] = cs;
+    const int f = a - 1;
+    const float fr = ldexpf(1.0f, f);
+    float sn[3], cs[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sincosf(fr * v[d], &sn[d], &cs[d]);
+    float* of = o + 3 + 6 * f;
+    of[0] = sn[0]; of[1] = sn[1]; of[2] = sn[2]; of[3] = cs[0]; of[4] = cs[1]; of[5] = cs[2];
   }
 }
 
 int launch_embed_points(const float* rays, const float* z, const float* dir_emb, float* x, long R, int N, hipStream_t stream) {
   if (R <= 0 || N <= 0) return 0;
-  const long total = R * N * (3 * XYZ_FREQS + 1 + 7);
+  const long total = R * N * (1 + XYZ_FREQS + 7);
   hipLaunchKernelGGL(embed_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays, z, dir_emb, x, R, N);
   return check_launch("embed_points_kernel");
 }
