@@ -158,22 +158,28 @@ int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stre
 
 // x[n,3] -> out[n, 6F+3]; one thread per (row, argument) pair; accurate sincosf (see posenc.h).
 __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ out, long n, int F) {
+  // one thread per (row, group): group 0 = the identity columns, group 1 + f = sin and cos of the three coordinates at frequency 2^f
+  // = 24 contiguous bytes (a thread per argument wrote two 4-byte pieces 12 bytes apart)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_row = 3 * F + 1;
+  const int per_row = F + 1;
   if (idx >= n * per_row) return;
   const long row = idx / per_row;
   const int a = (int)(idx % per_row);
   const int D = 6 * F + 3;
   const float* xr = x + row * 3;
   float* o = out + row * D;
-  if (a == 3 * F) {
-    o[0] = xr[0]; o[1] = xr[1]; o[2] = xr[2];
+  const float v0 = xr[0], v1 = xr[1], v2 = xr[2];
+  if (a == 0) {
+    o[0] = v0; o[1] = v1; o[2] = v2;
   } else {
-    const int f = a / 3, d = a % 3;
-    float s, c;
-    sincosf(ldexpf(1.0f, f) * xr[d], &s, &c);
-    o[3 + 6 * f + d] = s;
-    o[3 + 6 * f + 3 + d] = c;
+    const int f = a - 1;
+    const float fr = ldexpf(1.0f, f);
+    float s0, c0, s1, c1, s2, c2;
+    sincosf(fr * v0, &s0, &c0);
+    sincosf(fr * v1, &s1, &c1);
+    sincosf(fr * v2, &s2, &c2);
+    float* of = o + 3 + 6 * f;
+    of[0] = s0; of[1] = s1; of[2] = s2; of[3] = c0; of[4] = c1; of[5] = c2;
   }
 }
 
@@ -226,7 +232,7 @@ int launch_embed_points(const float* rays, const float* z, const float* dir_emb,
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream) {
   if (n <= 0) return 0;
   if (n_freqs < 0 || n_freqs > 30) return set_error(-2, "posenc: n_freqs must be in [0, 30]");
-  const long total = n * (3 * n_freqs + 1);
+  const long total = n * (n_freqs + 1);
   hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, out, n, n_freqs);
   return check_launch("posenc_kernel");
 }
