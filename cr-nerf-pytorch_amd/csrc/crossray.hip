@@ -754,6 +754,11 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
   FcJob f0{xchg + 64, (float)(1.0 / count_global), d.cnet_fc_w, d.cnet_fc_b, st + ST_CMAT};
   FcJob f1{st + ST_SGRAM, (float)(1.0 / (double)d.HWs), d.snet_fc_w, d.snet_fc_b, st + ST_SMAT};
   hipLaunchKernelGGL(gram_fc_kernel, dim3(256, 2), dim3(256), 0, stream, f0, f1);
+  if (d.HW > 0 && d.HW <= GRAM_COOP_MAX_PIXELS) {   // small shards: fold and apply in one launch, as in the single-GPU decode
+    hipLaunchKernelGGL(fold_apply_kernel, dim3((unsigned)((d.HW + 63) / 64)), dim3(256), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN,
+                       d.lin, st + ST_AFFINE, d.content, d.HW, d.rgb, d.plane_stride);
+    return check_launch("crossray_decode_sharded phase 2");
+  }
   hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, st + ST_SMAT, st + ST_CMAT, st + ST_CMEAN, st + ST_SMEAN, d.lin, st + ST_AFFINE);
   if (int rc = check_launch("crossray_decode_sharded phase 2")) return rc;
   return launch_crossray_apply(d.content, d.HW, st + ST_AFFINE, d.rgb, d.plane_stride, stream);
