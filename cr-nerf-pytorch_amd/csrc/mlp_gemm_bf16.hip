@@ -508,27 +508,31 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
     R2 = *(const uint4*)(dch + (do1 < dlast ? do1 : dlast));                    \
     R3 = *(const uint4*)(ach + (ao1 < alast ? ao1 : alast));                    \
     do0 += dstep; do1 += dstep; ao0 += astep; ao1 += astep;
-#define CRNERF_WGB_LSTORE(B)                                                    \
-    sh[B][0][rrow][u] = g0; sh[B][1][rrow][u] = g1; sh[B][0][rrow + 8][u] = g2; sh[B][1][rrow + 8][u] = g3;
+#define CRNERF_WGB_LSTORE(B, R0, R1, R2, R3)                                    \
+    sh[B][0][rrow][u] = R0; sh[B][1][rrow][u] = R1; sh[B][0][rrow + 8][u] = R2; sh[B][1][rrow + 8][u] = R3;
+#define CRNERF_WGB_STEP(PB, BUF, F0, F1, F2, F3, S0, S1, S2, S3)                \
+    {                                                                           \
+      CRNERF_WGB_GFETCH(F0, F1, F2, F3)        /* k-step n + 2 -> the free register set */ \
+      uint2 dcur[8], acur[8];                                                   \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                           \
+        dcur[e] = ((const uint2*)&sh[BUF][0][8 * kk + e][0])[wmi * 32 + i];     \
+        acur[e] = ((const uint2*)&sh[BUF][1][8 * kk + e][0])[wni * 32 + i];     \
+      }                                                                         \
+      CRNERF_WGB_MULTIPLY(dcur, acur, PB)                                       \
+      CRNERF_WGB_LSTORE(BUF ^ 1, S0, S1, S2, S3) /* k-step n + 1, fetched one step ago */  \
+      __syncthreads();                                                          \
+    }
+    // the two register sets swap roles every k-step (loop unrolled by two): rotating them through copies (g = h) made every
+    // iteration wait for the loads it had just issued
     CRNERF_WGB_GFETCH(g0, g1, g2, g3)
-    CRNERF_WGB_LSTORE(0)
+    CRNERF_WGB_LSTORE(0, g0, g1, g2, g3)
     CRNERF_WGB_GFETCH(g0, g1, g2, g3)
     __syncthreads();
-    int buf = 0;
-    for (long pb = p0; pb < p1; pb += pstep) {
-      CRNERF_WGB_GFETCH(h0, h1, h2, h3)
-      uint2 dcur[8], acur[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        dcur[e] = ((const uint2*)&sh[buf][0][8 * kk + e][0])[wmi * 32 + i];
-        acur[e] = ((const uint2*)&sh[buf][1][8 * kk + e][0])[wni * 32 + i];
-      }
-      CRNERF_WGB_MULTIPLY(dcur, acur, pb)
-      CRNERF_WGB_LSTORE(buf ^ 1)
-      g0 = h0; g1 = h1; g2 = h2; g3 = h3;
-      __syncthreads();
-      buf ^= 1;
+    for (long pb = p0; pb < p1; pb += 2 * pstep) {
+      CRNERF_WGB_STEP(pb, 0, h0, h1, h2, h3, g0, g1, g2, g3)
+      if (pb + pstep < p1) CRNERF_WGB_STEP(pb + pstep, 1, g0, g1, g2, g3, h0, h1, h2, h3)
     }
+#undef CRNERF_WGB_STEP
 #undef CRNERF_WGB_GFETCH
 #undef CRNERF_WGB_LSTORE
   } else if (wp != 1 && p0 < p1) {
@@ -546,11 +550,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
     }                                                                                                      \
     dof += dstep; aof += astep;
     CRNERF_WGB_FETCH16(dcur, acur)
-    for (long pb = p0; pb < p1; pb += pstep) {
+    for (long pb = p0; pb < p1; pb += 2 * pstep) {     // the two operand sets swap roles (no copies: a copy waits for its loads)
       CRNERF_WGB_FETCH16(dnxt, anxt)
       CRNERF_WGB_MULTIPLY(dcur, acur, pb)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+      if (pb + pstep < p1) {
+        CRNERF_WGB_FETCH16(dcur, acur)
+        CRNERF_WGB_MULTIPLY(dnxt, anxt, pb + pstep)
+      }
     }
 #undef CRNERF_WGB_FETCH16
   }
