@@ -189,7 +189,10 @@ struct GemmJob {
                                   // lane (point, q4) produces / consumes, 8 bytes per lane
   const float* r1_row;            // epilogue: C += r1_row[row] * colvec[feature]   (the sigma head's branch into d(h8)) or null
   const float* colvec;            // [features]: the rank-1 column vector, or (SIG) static_sigma.weight
-  const float* sig_b; float* sig_out;   // SIG: sig_out[row * 65 + 64] = softplus(colvec . relu(C[row]) + sig_b[0]) on the fp32 accumulators
+  const float* sig_b; float* sig_out;   // SIG: sig_out[row] = softplus(colvec . relu(C[row]) + sig_b[0]) on the fp32 accumulators -- a compact [P]
+                                        // array (sixteen lanes write 64 contiguous bytes); written straight into column 64 of the [P,65] result,
+                                        // one 4-byte piece per 260-byte row, the store cost 60 us per 2^20 points
+  const float* sig_in;                  // ACT_SIGMOID: copied into column 64 of the fp32 rows this pass writes (the rows are then complete)
   bf16_t* out; int ldo;           // bf16 output rows in storage order (ACT_NONE / ACT_RELU)
   float* out_f; int ldo_f;        // fp32 output rows in reference order (ACT_SIGMOID: the [P,65] result)
   long P;
@@ -348,7 +351,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 4) void linear_bf16_k
       if (SIG) {
         sg += __shfl_xor(sg, 16);
         sg += __shfl_xor(sg, 32);
-        if (row_ok && q4 == 0) j.sig_out[row * OUT_DIM + FEAT_DIM] = softplus_ref(sg + j.sig_b[0]);
+        if (row_ok && q4 == 0) j.sig_out[row] = softplus_ref(sg + j.sig_b[0]);
+      }
+      if (ACT == ACT_SIGMOID && j.sig_in) {
+        const float sgv = j.sig_in[rw];
+        if (row_ok && q4 == 0) j.out_f[row * j.ldo_f + FEAT_DIM] = sgv;
       }
       if (ACT == ACT_RELU && j.bits_out && row_ok) {              // the bytes this pass covers: 8 groups = 8 bytes, 4 groups = 4 bytes
         uint32_t* bo = j.bits_out + (row * 4 + q4) * 2;
@@ -651,10 +658,10 @@ static int wgrad_b(const bf16_t* D, int ldd, int M, int Dw, int permD, const bf1
   return launch_wgrad_reduce(ws, slots, M, N, dst, ldc, bws, db, st);
 }
 
-// ---- buffers.  acts: [10][P][256] bf16 activations (storage order) | [10][P] x 32 B relu bits | xb [P][128] bf16.
+// ---- buffers.  acts: [10][P][256] bf16 activations (storage order) | [10][P] x 32 B relu bits | xb [P][128] bf16 | sigma [P] fp32.
 //      scratch: [10][P][256] bf16 deltas | d_rgb [P][64] bf16 | d_sig [P] fp32 | (16-byte aligned) weight-gradient workspace.
 static size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
-size_t mlp_train_mixed_acts_bytes(long P) { return (size_t)P * (ACT_SLOTS * ACT_W * 2 + ACT_SLOTS * 32 + XB_W * 2); }
+size_t mlp_train_mixed_acts_bytes(long P) { return (size_t)P * (ACT_SLOTS * ACT_W * 2 + ACT_SLOTS * 32 + XB_W * 2 + 4); }
 static size_t mixed_ws_offset(long P) { return align16((size_t)P * (ACT_SLOTS * ACT_W * 2 + DRGB_W * 2 + 4)); }
 size_t mlp_train_mixed_scratch_bytes(long P) {
   const int chunk = wgb_chunk(P);
@@ -672,6 +679,7 @@ int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, cons
   uint32_t* bits_base = (uint32_t*)(abase + (size_t)ACT_SLOTS * P * ACT_W);
   auto bits = [&](int slot) { return bits_base + (size_t)slot * P * 8; };   // 32 bytes per point and slot
   bf16_t* xb = (bf16_t*)(bits_base + (size_t)ACT_SLOTS * P * 8);
+  float* sig_tmp = (float*)(xb + (size_t)P * XB_W);
   hipLaunchKernelGGL(embed_bf16_kernel, dim3((unsigned)((P * (XB_W / 8) + 255) / 256)), dim3(256), 0, st, x, xb, P);
   const GemmSeg none{nullptr, 0, 0};
   // tiles [t0, t0 + nt) of matrix `id` as one pass (a 256 x 352 matrix does not fit the 128 KiB of LDS: the skip layer runs as two
@@ -680,7 +688,7 @@ int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, cons
     const int ks = L.m[id].K / 16;
     const int n = L.m[id].N - 32 * t0 < 32 * nt ? L.m[id].N - 32 * t0 : 32 * nt;
     GemmJob j{a0, a1, frag_ptr(packed, id) + (size_t)t0 * ks * 64, n, L.m[id].K, 32 * t0, bias, act, nullptr, bo, nullptr,
-              sig ? t.w_sigma : nullptr, sig ? t.b_sigma : nullptr, sig ? out : nullptr, o, ACT_W, out, OUT_DIM, P, 0};
+              sig ? t.w_sigma : nullptr, sig ? t.b_sigma : nullptr, sig ? sig_tmp : nullptr, act == ACT_SIGMOID ? sig_tmp : nullptr, o, ACT_W, out, OUT_DIM, P, 0};
     return run_gemm(j, st);
   };
   const GemmSeg emb{xb, XB_W, 96};
@@ -716,7 +724,7 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
   hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((P * 33 + 255) / 256)), dim3(256), 0, st, out, d_out, d_rgb, d_sig, P);
   const GemmSeg none{nullptr, 0, 0};
   auto dg = [&](int id, GemmSeg a0, const uint32_t* mask, const float* r1r, const float* r1c, bf16_t* o) {
-    GemmJob j{a0, none, frag_ptr(packed, id), L.m[id].N, L.m[id].K, 0, nullptr, ACT_NONE, mask, nullptr, r1r, r1c, nullptr, nullptr, o, ACT_W,
+    GemmJob j{a0, none, frag_ptr(packed, id), L.m[id].N, L.m[id].K, 0, nullptr, ACT_NONE, mask, nullptr, r1r, r1c, nullptr, nullptr, nullptr, o, ACT_W,
               nullptr, 0, P, 0};
     return run_gemm(j, st);
   };
