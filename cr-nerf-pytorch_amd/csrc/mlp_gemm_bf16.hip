@@ -469,8 +469,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
 #define CRNERF_WGB_MULTIPLY(D8, A8, PB)                                                                                              \
   {                                                                                                                                  \
     uint2 dm[8];                                                                                                                     \
+    const int left = (int)(p1 - (PB) < 16 ? p1 - (PB) : 16) - 8 * kk;   /* valid points of this lane's eight; 8 or more except in the tail */ \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                                  \
-      const bool keep = (PB) + 8 * kk + e < p1;                                                                                      \
+      const bool keep = e < left;                                                                                                    \
       dm[e] = make_uint2(keep ? D8[e].x : 0u, keep ? D8[e].y : 0u);                                                                  \
     }                                                                                                                                \
     if (do_bias) {                                                                                                                   \
