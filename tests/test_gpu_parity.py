@@ -2,7 +2,7 @@
 by the reference and against the CPU oracle on identical inputs.  All comparisons are fp32 with the
 tolerance written next to them (north_star: "pixels within a stated fp32 tolerance").
 
-Two properties of the REFERENCE ITSELF shape the end-to-end tolerances (measured in tools/gpu_report.py):
+Two properties of the REFERENCE ITSELF shape the end-to-end tolerances (measured in tests/_gpu_report.py):
   * N_emb_xyz = 15 puts 2^14 in front of x: a 1-ulp change of a sample depth (~2.4e-7 at z~3) moves
     the highest-frequency sin/cos argument by ~4e-3 rad, i.e. ~1e-4..1e-2 on rendered features;
   * sample_pdf divides by cdf gaps as small as eps=1e-5 and switches formula at `denom < eps`
