@@ -56,8 +56,9 @@ _WGRAD_BF16 = [False]
 
 def set_wgrad_precision(precision="f32"):
     """"f32" (default): every gradient in exact fp32, as the reference's autograd.  "bf16": opt-in mixed precision for the weight
-    gradients of the 256x256 layers only (CRNERF_BWD_WGRAD_BF16, include/crnerf.h): same fp32 operands, rounded to bf16 in
-    registers, bf16 MFMA with fp32 accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
+    gradients of every nn.Linear except static_sigma (CRNERF_BWD_WGRAD_BF16, include/crnerf.h: the full 256x256 blocks AND the
+    narrow edge blocks of the 93/349/283-wide layers): same fp32 operands, rounded to bf16 in registers, bf16 MFMA with fp32
+    accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
     Forward, loss, data gradients, biases and all other tensors are unchanged."""
     _WGRAD_BF16[0] = ops._is_bf16(precision)
 

@@ -35,7 +35,7 @@ int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream);
 size_t mlp_train_acts_bytes(long P);
 size_t mlp_train_scratch_bytes(long P);
 int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream);
-// flags: bit 0 = weight gradients of the 256 x 256 layers from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16)
+// flags: bit 0 = weight gradients of every Linear except static_sigma from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16, include/crnerf.h)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags = 0);
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,

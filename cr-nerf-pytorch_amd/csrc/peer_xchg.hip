@@ -87,13 +87,21 @@ int crnerf_peer_window_create(void** window, void* handle_out) {
   static_assert(sizeof(hipIpcMemHandle_t) == CRNERF_PEER_HANDLE_BYTES, "handle size is part of the ABI");
   void* p = nullptr;
   // uncached (MTYPE UC) memory: writes arriving over xGMI and the owner's polling loads meet in HBM, not in an L2 that the
-  // fabric does not snoop.  CRNERF_PEER_WINDOW_COARSE=1 selects a plain hipMalloc (same-GPU tests, older drivers).
+  // fabric does not snoop.  A plain (coarse-grained, L2-cached) hipMalloc is NOT a safe substitute across GPUs -- polling it can
+  // read stale flags and time out spuriously -- so it is opt-in only: CRNERF_PEER_WINDOW_COARSE=1 (all ranks on ONE GPU, tests).
   const char* coarse = getenv("CRNERF_PEER_WINDOW_COARSE");
-  hipError_t e = hipErrorUnknown;
-  if (!(coarse && coarse[0] == '1')) e = hipExtMallocWithFlags(&p, sizeof(PeerWindow), hipDeviceMallocUncached);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
+  hipError_t e;
+  if (coarse && coarse[0] == '1') {
     e = hipMalloc(&p, sizeof(PeerWindow));
+  } else {
+    e = hipExtMallocWithFlags(&p, sizeof(PeerWindow), hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      char msg[240];
+      snprintf(msg, sizeof(msg), "peer_window_create: hipExtMallocWithFlags(hipDeviceMallocUncached): %s -- no uncached window, use the RCCL "
+               "all-reduce (exchange=None); CRNERF_PEER_WINDOW_COARSE=1 is for single-GPU tests only", hipGetErrorString(e));
+      (void)hipGetLastError();
+      return set_error(CRNERF_ERR_HIP, msg);
+    }
   }
   if (e != hipSuccess) return set_error(CRNERF_ERR_HIP, "peer_window_create: allocation failed");
   if (hipMemset(p, 0, sizeof(PeerWindow)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {

@@ -130,7 +130,14 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(const float* __
                                                                  const float* __restrict__ noise, float noise_std,
                                                                  const float* __restrict__ d_feature, const float* __restrict__ d_depth,
                                                                  const float* __restrict__ d_weights, float* __restrict__ d_raw,
-                                                                 long R, int N, int dbg) {
+                                                                 long R, int N
+#ifdef CRNERF_TIMING
+                                                                 , int dbg   // timing experiments: bit k keeps phase A/B/C/D; results are garbage unless 15
+#endif
+) {
+#ifndef CRNERF_TIMING
+  constexpr int dbg = 15;
+#endif
   // One ray per wavefront.  raw is read ONCE (phase A; a separate strided pass over the sigma column is evicted from L2 before
   // the row pass re-reads the same lines: measured 2x the fetch bytes) and d_raw is written ONCE as a flat stream (phase D).
   extern __shared__ __attribute__((aligned(16))) float smb[];
@@ -257,13 +264,18 @@ int launch_composite_backward(const float* raw, const float* z, const float* noi
   if (R <= 0) return 0;
   if (N < 1) return set_error(-2, "composite_backward: N must be >= 1");
   const size_t shmem = (size_t)4 * (5 * N + 64) * sizeof(float);
-  if (shmem > 160 * 1024) return set_error(-2, "composite_backward: N too large for LDS");
+  if (shmem > 160 * 1024) return set_error(-2, "composite_backward: N too large for LDS (4 rays x (5 N + 64) floats: N <= 2035)");
   if (int rc = ensure_dynamic_lds((const void*)composite_backward_kernel, shmem, "composite_backward_kernel")) return rc;
   const long blocks = (R + 3) / 4;
   const int grid = (int)(blocks < 4096 ? blocks : 4096);
-  static const int dbg = getenv("CRNERF_CB_PHASES") ? atoi(getenv("CRNERF_CB_PHASES")) : 15;   // timing experiments only
+#ifdef CRNERF_TIMING
+  static const int dbg = getenv("CRNERF_CB_PHASES") ? atoi(getenv("CRNERF_CB_PHASES")) : 15;   // -DCRNERF_TIMING builds only (tools/cb_phase_bench.py)
   hipLaunchKernelGGL(composite_backward_kernel, dim3(grid), dim3(256), shmem, stream, raw, z, noise, noise_std, d_feature, d_depth,
                      d_weights, d_raw, R, N, dbg);
+#else
+  hipLaunchKernelGGL(composite_backward_kernel, dim3(grid), dim3(256), shmem, stream, raw, z, noise, noise_std, d_feature, d_depth,
+                     d_weights, d_raw, R, N);
+#endif
   return check_launch("composite_backward_kernel");
 }
 

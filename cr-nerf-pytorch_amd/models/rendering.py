@@ -90,7 +90,9 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
     reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible).
     One keyword beyond the reference's: precision="f32"|"bf16" (default crnerf_amd.get_precision()) selects the
-    matrix-core arithmetic of NeRF_sigma at inference (include/crnerf.h); grad mode always trains in fp32."""
+    matrix-core arithmetic of NeRF_sigma at inference (include/crnerf.h).  Grad mode trains through the exact-fp32 twins unless
+    the caller opted into mixed precision (autograd.set_training_precision("bf16") / CRNERF_TRAIN_BF16=1: bf16-operand GEMM twins,
+    fp32 accumulation; autograd.set_wgrad_precision("bf16"): weight gradients only) -- neither has a counterpart in the reference."""
     args = kwargs['args']
     jitter = bool(getattr(args, 'pertubeCord', False))
     if getattr(args, 'nerf_out_dim', 64) != 64:

@@ -15,16 +15,26 @@ MLP_TENSOR_SHAPES = (
     + [(256, 256), (256,), (1, 256), (1,), (128, 283), (128,), (64, 128), (64,)])
 
 
+def _slots_valid(slots):
+    for d, name, q in slots:
+        if d.get(name) is not q:
+            return False
+    return True
+
+
 def cached_params(module):
     """tuple(module.parameters()) looked up once: nn.Module.parameters() walks the module tree on every call, and the grad-mode
     checks of the shim modules ran it ~6,000 generator steps per training step (1-2 ms of host time at the reference's 1,024-ray
-    batch, where the step is host-bound).  The shim modules create all their parameters in __init__, and nn.Module.to() /
-    load_state_dict() keep the Parameter objects, so the tuple stays valid."""
+    batch, where the step is host-bound).  The cache remembers WHERE each Parameter lives (the owning sub-module's _parameters
+    dict and its name) and every lookup re-checks those slots by identity, so anything that swaps a Parameter object --
+    load_state_dict(assign=True), `layer.weight = nn.Parameter(...)`, to_empty() / meta materialisation,
+    torch.__future__.set_overwrite_module_params_on_conversion -- rebuilds it instead of leaving stale tensors behind."""
     c = module.__dict__.get("_crnerf_pcache")
-    if c is None:
-        c = tuple(module.parameters())
+    if c is None or not _slots_valid(c[0]):
+        slots = tuple((m._parameters, name, q) for m in module.modules() for name, q in m._parameters.items() if q is not None)
+        c = (slots, tuple(s[2] for s in slots))
         module.__dict__["_crnerf_pcache"] = c
-    return c
+    return c[1]
 
 
 def any_requires_grad(module):
@@ -35,13 +45,17 @@ def any_requires_grad(module):
 
 
 def mlp_params(module):
-    """The 24 NeRF_sigma parameters in MLP_TENSOR_NAMES order, looked up once per module."""
+    """The 24 NeRF_sigma parameters in MLP_TENSOR_NAMES order; cached with the same slot-identity check as cached_params."""
     c = module.__dict__.get("_crnerf_mlp_params")
-    if c is None:
-        named = dict(module.named_parameters())
-        c = tuple(named[n] for n in MLP_TENSOR_NAMES)
+    if c is None or not _slots_valid(c[0]):
+        slots = []
+        for n in MLP_TENSOR_NAMES:
+            path, _, leaf = n.rpartition(".")
+            owner = module.get_submodule(path)
+            slots.append((owner._parameters, leaf, owner._parameters[leaf]))
+        c = (tuple(slots), tuple(s[2] for s in slots))
         module.__dict__["_crnerf_mlp_params"] = c
-    return c
+    return c[1]
 
 
 def _f32c(t, name):
@@ -115,7 +129,8 @@ def mlp_forward_train(packed, x):
 
 def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: CRNERF_BWD_WGRAD_BF16
-    (include/crnerf.h) -- the 256x256 layers' weight gradients from bf16-rounded operands, everything else exact fp32."""
+    (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; data gradients,
+    biases and everything else exact fp32."""
     lib = _lib.load()
     x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
     n = x.shape[0]
@@ -300,7 +315,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
             raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
         fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
         name = "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"
-        held = (keep, rays, packed_coarse, packed_fine)      # the argument struct holds raw pointers: keep their tensors alive
+        held = (keep, rays, packed_coarse, packed_fine, out)  # the argument struct holds raw pointers: keep EVERY tensor behind them alive
+        # (the outputs too: a caller that drops `out` must not hand their memory back to the caching allocator while launch() can still write it)
 
         def launch(_held=held):
             _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), name)

@@ -40,11 +40,12 @@ class PeerExchange:
     the 64-byte IPC handles are exchanged through the group itself (all_gather_object).  `all_reduce(t)` then sums a
     contiguous float32 device tensor in place on the CURRENT stream with one kernel launch and no host synchronisation;
     every rank must issue the same sequence of calls.  Sums are formed in rank order on every rank (bit-identical
-    replicas).  A peer that does not arrive within `timeout_s` turns the result into NaN; `check()` (synchronising) raises
-    and names it -- after that the exchange is out of step and must be rebuilt.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on
-    hosts whose driver only supports dmabuf IPC."""
+    replicas).  A peer that does not arrive within `timeout_s` (default 60 s: first-call weight packing, uneven shards and a
+    slow rank easily skew ranks by seconds, and RCCL would simply have waited) turns the result into NaN; `check()`
+    (synchronising) raises and names it -- after that the exchange is out of step and must be rebuilt.  decode_sharded calls
+    check() itself unless told not to.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC."""
 
-    def __init__(self, group=None, timeout_s=5.0):
+    def __init__(self, group=None, timeout_s=60.0):
         from . import _lib
         self._lib_mod = _lib
         lib = _lib.load()
@@ -115,7 +116,8 @@ class _HipKernels:
         return getattr(ops, name)
 
 
-def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False, exchange=None):
+def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False, exchange=None,
+                   check_exchange=True):
     """Cross-ray decode of a ray-sharded feature grid.
 
     net: style_net; feature_local: this rank's [R_local,64] block of feature_fine (pixel-major, rank
@@ -127,7 +129,10 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     Three kernel phases around two all-reduces (crnerf_crossray_decode_sharded_f32): channel sums ->
     all-reduce(64 floats) -> Gram of the centred conv chain -> all-reduce(1024 floats) -> fc / fold /
     apply on the local pixels -> all-gather of RGB.  exchange: a PeerExchange built on the same group carries the two
-    reductions instead of RCCL (default None = RCCL)."""
+    reductions instead of RCCL (default None = RCCL).  check_exchange: with a PeerExchange, finish with exchange.check() -- one
+    device synchronisation -- so that a peer that timed out raises here instead of handing back a NaN image and leaving the
+    exchange out of step; latency-critical loops pass False and call exchange.check() themselves at a point where they
+    synchronise anyway."""
     k = kernels or _HipKernels()
     dev = feature_local.device
     n_local = feature_local.shape[0]
@@ -149,6 +154,8 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     rgb_local = k.crossray_decode_sharded(feature_local, sp, weights, 2, xchg, count)
     if rgb_local is None:
         rgb_local = torch.zeros(3, 0, device=dev)
+    if exchange is not None and check_exchange:
+        exchange.check()
     if not gather:
         return rgb_local
     if equal_shards:

@@ -37,11 +37,24 @@ def get_embeddings(hparams_):
     return {"xyz": PosEmbedding(hparams_.N_emb_xyz - 1, hparams_.N_emb_xyz), "dir": PosEmbedding(hparams_.N_emb_dir - 1, hparams_.N_emb_dir)}
 
 
-def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=()):
-    # the reference's checkpoints are Lightning files: callback / optimizer / scheduler state with non-tensor objects next to
-    # 'state_dict', which torch >= 2.6's weights_only=True default refuses; they are the user's own trusted files, as for the
-    # reference (utils/__init__.py:68 torch.load without restrictions)
-    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(), trust_checkpoint=False):
+    """utils/__init__.py:67-83.  The reference's checkpoints are Lightning files: callback / optimizer / scheduler state and an
+    argparse.Namespace of hyper-parameters next to 'state_dict'.  They are read with torch's restricted unpickler
+    (weights_only=True) with argparse.Namespace allow-listed -- enough for the files the reference's training loop writes
+    (tests/golden/make_golden_trained.py) and for bare state_dict files, and it cannot execute code from the file.
+    trust_checkpoint=True falls back to the unrestricted pickle loader the reference itself uses (torch 1.13's torch.load,
+    utils/__init__.py:68) for files that hold other Python objects: only for files you wrote yourself."""
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not trust_checkpoint:
+            raise RuntimeError("crnerf_amd: %s holds Python objects beyond tensors / containers / argparse.Namespace and the restricted "
+                               "loader refused it (%s).  If the file is your own, pass trust_checkpoint=True to unpickle it without "
+                               "restrictions (this can run code stored in the file)." % (ckpt_path, str(e).splitlines()[0])) from e
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
     ckpt = ckpt.get("state_dict", ckpt)                      # Lightning checkpoint or a bare state_dict
     out = {}
     for key, value in ckpt.items():
@@ -53,9 +66,9 @@ def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(
     return out
 
 
-def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=()):
+def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=(), trust_checkpoint=False):
     state = model.state_dict()
-    state.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore))
+    state.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore, trust_checkpoint))
     model.load_state_dict(state)
 
 

@@ -112,7 +112,8 @@ int crnerf_composite_f32(const float* raw, const float* z, const float* noise, f
                          float* feature, float* depth, int64_t R, int N, void* stream);
 
 /* Backward of the compositing above (what autograd derives from models/rendering.py:121-143 in the reference):
- * d_feature[R,64] (required), d_depth[R] / d_weights[R,N] (optional, NULL = zero) -> d_raw[R,N,65]. */
+ * d_feature[R,64] (required), d_depth[R] / d_weights[R,N] (optional, NULL = zero) -> d_raw[R,N,65].
+ * N <= 2035: a workgroup keeps five N-float rows per ray for its four rays in the 160 KiB LDS (larger N returns CRNERF_ERR_SHAPE). */
 int crnerf_composite_backward_f32(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
                                   const float* d_depth, const float* d_weights, float* d_raw, int64_t R, int N, void* stream);
 

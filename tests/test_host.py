@@ -171,3 +171,59 @@ def test_kernels_with_asm_lds_dma_do_not_use_m0_indexing(tmp_path):
         assert "global_load_lds_dwordx4" in isa, u
         for bad in ("s_set_gpr_idx", "v_movrel"):
             assert bad not in isa, "%s: %s found -- a dynamic register index would collide with the LDS-DMA asm's use of M0" % (u, bad)
+
+
+def test_parameter_caches_follow_replaced_parameters():
+    """ops.mlp_params / cached_params cached Parameter OBJECTS forever; flows that swap the objects
+    (load_state_dict(assign=True), attribute assignment) must be seen by the next lookup."""
+    from crnerf_amd.models.nerf import NeRF_sigma
+    m = NeRF_sigma('coarse', Args(), in_channels_xyz=93, in_channels_dir=27)
+    first = ops.mlp_params(m)
+    allp = ops.cached_params(m)
+    assert len(first) == 24 and [tuple(p.shape) for p in first] == list(ops.MLP_TENSOR_SHAPES)
+    assert ops.mlp_params(m) is first and ops.cached_params(m) is allp           # steady state: no rebuild
+    fresh = {k: torch.from_numpy(v) for k, v in synth.mlp_state(3).items()}
+    m.load_state_dict(fresh, assign=True)
+    second = ops.mlp_params(m)
+    assert all(a is not b for a, b in zip(first, second))
+    named = dict(m.named_parameters())
+    assert all(named[n] is p for n, p in zip(ops.MLP_TENSOR_NAMES, second))
+    assert set(map(id, ops.cached_params(m))) == set(map(id, m.parameters()))
+    m.xyz_encoding_final.weight = torch.nn.Parameter(torch.zeros(256, 256), requires_grad=False)
+    assert ops.mlp_params(m)[16] is m.xyz_encoding_final.weight
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not ops.any_requires_grad(m)
+    m.static_rgb[0].bias = torch.nn.Parameter(torch.zeros(64))
+    assert ops.any_requires_grad(m)
+
+
+class _Opaque:            # module-level so that pickle can find it
+    pass
+
+
+def test_checkpoint_loader_is_restricted_unless_trusted(tmp_path):
+    """load_ckpt must not unpickle arbitrary objects by default.  A Lightning-style file (state_dict + optimizer state +
+    argparse.Namespace hyper-parameters, what the reference's training writes) loads under the restricted unpickler; a file with any
+    other Python object needs trust_checkpoint=True."""
+    import argparse
+    from crnerf_amd import pipeline
+    lin = torch.nn.Linear(4, 3)
+    opt = torch.optim.Adam(lin.parameters(), lr=1e-3)
+    lin(torch.ones(2, 4)).sum().backward()
+    opt.step()
+    ck = {"epoch": 1, "global_step": 7, "pytorch-lightning_version": "1.1.5", "state_dict": {"nerf_coarse." + k: v for k, v in lin.state_dict().items()},
+          "optimizer_states": [opt.state_dict()], "lr_schedulers": [{"T_max": 20, "eta_min": 1e-8, "last_epoch": 1}],
+          "hparams_name": "hparams_", "hyper_parameters": {"hparams_": argparse.Namespace(lr=5e-4, N_samples=64, img_wh=[32, 32])}}
+    path = str(tmp_path / "last.ckpt")
+    torch.save(ck, path)
+    got = pipeline.extract_model_state_dict(path, "nerf_coarse")
+    assert sorted(got) == ["bias", "weight"] and torch.equal(got["weight"], lin.weight)
+    fresh = torch.nn.Linear(4, 3)
+    pipeline.load_ckpt(fresh, path, model_name="nerf_coarse")
+    assert torch.equal(fresh.weight, lin.weight)
+    ck["callbacks"] = {"something": _Opaque()}
+    torch.save(ck, path)
+    with pytest.raises(RuntimeError, match="trust_checkpoint"):
+        pipeline.extract_model_state_dict(path, "nerf_coarse")
+    assert torch.equal(pipeline.extract_model_state_dict(path, "nerf_coarse", trust_checkpoint=True)["bias"], lin.bias)

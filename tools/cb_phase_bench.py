@@ -1,5 +1,6 @@
 """GPU box: composite_backward_kernel with phases switched off (CRNERF_CB_PHASES bit mask: 1 = row pass, 2 = alpha/T, 4 = reverse
-scan, 8 = flat write), to see where its time goes.  usage: CRNERF_CB_PHASES=<mask> python tools/cb_phase_bench.py"""
+scan, 8 = flat write), to see where its time goes.  Needs a library built with -DCRNERF_TIMING (the product build has no phase
+switch).  usage: CRNERF_CB_PHASES=<mask> python tools/cb_phase_bench.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
