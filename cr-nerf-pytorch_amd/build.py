@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "render_fused_bf16.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip",
+SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "render_fused_bf16.hip", "render_fused_bf16p.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip",
            "crossray.hip", "peer_xchg.hip"]
-HEADERS = ["layout.h", "mlp_core.h", "mlp_core16.h", "mlp_train16.h", "mlp_core_bf16.h", "posenc.h", "ray_ops.h", "kernels.h", "crossray.h", "../../include/crnerf.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/crnerf.h"]   # every header: any edit rebuilds
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
 # the kernels call fmaf() explicitly wherever a fused multiply-add is wanted.
 # -fno-honor-nans: lets fmaxf(x, 0) be ONE v_max_f32 (otherwise hipcc canonicalises the MFMA output first).
@@ -24,7 +24,10 @@ FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 
 # -fno-slp-vectorize (bf16 units): hipcc otherwise packs the epilogue's scalar adds into v_pk_add_f32 bundles placed
 # at the END of a layer -- the hand-interleaved epilogue collapses into a serial VALU burst behind the MFMAs.
-PER_FILE_FLAGS = {"mlp_forward_bf16.hip": ["-fno-slp-vectorize"], "render_fused_bf16.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"mlp_forward_bf16.hip": ["-fno-slp-vectorize"], "render_fused_bf16.hip": ["-fno-slp-vectorize"],
+                  # pragma-unroll-threshold: the tile loop of the 22-k-step layer is "too large" for `#pragma unroll` at the default 16k,
+                  # and every ring constant of the pair core depends on full unrolling
+                  "render_fused_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc():

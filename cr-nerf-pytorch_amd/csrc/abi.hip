@@ -215,7 +215,11 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
-  if (bf16) return launch_render_rays_bf16(r, (hipStream_t)stream);
+  if (bf16) {
+    // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
+    static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();
+    return core64 ? launch_render_rays_bf16(r, (hipStream_t)stream) : launch_render_rays_bf16p(r, (hipStream_t)stream);
+  }
   if (acts_c) return launch_render_rays16(r, (hipStream_t)stream);       // the training twin exists on the 16x16x4 core only
   return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
 }

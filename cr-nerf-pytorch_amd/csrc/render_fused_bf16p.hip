@@ -1,0 +1,263 @@
+// Fused volumetric renderer on the bf16 matrix cores, pair core (mlp_core_bf16p.h): the whole of render_rays_cross_ray
+// (models/rendering.py:50-196) in ONE launch, NeRF_sigma in the mixed-precision semantics of include/crnerf.h (bf16 MFMA
+// operands, fp32 accumulate), everything around the MLP in fp32.
+//
+// Work decomposition: workgroup = 8 waves (two per SIMD) = 4 rays; a ray belongs to a PAIR of waves (A = even wave, B = odd
+// wave).  The ray's samples are walked in 64-sample steps; in step k wave A owns samples [64k, 64k+32), wave B
+// [64k+32, 64k+64), each as one 32-point MFMA tile.  The pair exchanges only scalars through LDS: the product of (1 - alpha)
+// over each wave's 32 samples per step (running transmittance), and the per-ray feature / depth partial sums at the end of a
+// pass.  sample_pdf and the merge run on the pair's 128 lanes (pair_ops.h).  All 8 waves execute identical control flow, so
+// plain workgroup barriers order the exchanges.  Per-ray feature sums: the 32 products w_n * feat of a tile are reduced over
+// the wave's 32 point lanes by a transpose-fold (31 cross-lane moves) into ONE register per lane, so that no 32-register
+// accumulator is live across the MLP (the kernel must fit 256 registers for two waves per SIMD).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "mlp_core_bf16p.h"
+#include "pair_ops.h"
+#include "ray_ops.h"
+
+namespace crnerf {
+
+struct RenderParamsP {
+  const char* packed0; const char* packed1;
+  const float* rays; const float* view_dir; const float* z_coarse; const float* z_steps; const float* u; long u_stride;
+  const float* noise_c; const float* noise_f; float noise_std; int use_disp;
+  long R; int Nc, Ni, iters;
+  unsigned int* sched;   // null: static quad -> workgroup map (iters passes); else {next-quad counter, finished-workgroup counter}
+  float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
+};
+
+static __device__ unsigned int crnerf_sched_bf16p[SCHED_SLOTS][2];   // kernels.h "Dynamic work distribution"
+#ifdef CRNERF_TIMING
+static __device__ unsigned long long crnerf_wg_times_p[2 * 1024];
+#endif
+
+constexpr int LDS_DIR_P = LDS_SCRATCH_P + 4 * PAIR_BYTES;        // 8 waves x 64 B: the ray's direction embedding as B operands
+constexpr int LDS_QSLOT_P = LDS_DIR_P + P_WAVES * 64;
+constexpr int LDS_TOTAL_P = LDS_QSLOT_P + 16;
+
+// sum over the 32 lanes of this lane's half of v[idx], idx = p: after the five halving steps lane p holds the total of value p
+__device__ __forceinline__ float fold32(float (&v)[32], int p) {
+#define CRNERF_FOLD(W, BIT)                                         \
+  {                                                                 \
+    const bool up = (p & (BIT)) != 0;                               \
+    _Pragma("unroll") for (int u = 0; u < (W) / 2; ++u) {          \
+      const float lo = v[u], hi = v[u + (W) / 2];                   \
+      v[u] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, (BIT));      \
+    }                                                               \
+  }
+  CRNERF_FOLD(32, 16) CRNERF_FOLD(16, 8) CRNERF_FOLD(8, 4) CRNERF_FOLD(4, 2) CRNERF_FOLD(2, 1)
+#undef CRNERF_FOLD
+  return v[0];
+}
+
+__global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP a) {
+#ifdef CRNERF_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times_p[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* lds = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int pair = wave >> 1, half = wave & 1;
+  const int lane128 = half * 64 + lane;
+  const int Nc = a.Nc, Ni = a.Ni, Nf = Nc + Ni;
+
+  PhaseTimer tm;
+  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
+  load_consts(lds, a.packed0, a.packed1);
+  PairScratch scr;
+  scr.bind(lds + LDS_SCRATCH_P + pair * PAIR_BYTES);
+  lds_char* dirbuf = lds + LDS_DIR_P + wave * 64;
+
+  WeightPipeP pipe;
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, 0, lane, wave);
+  u32x4 q[B_AHEAD];
+  pipe.prime(q);
+  tm.tick(T_RAYLEVEL);
+
+  __attribute__((address_space(3))) unsigned int* qslot = (__attribute__((address_space(3))) unsigned int*)(lds + LDS_QSLOT_P);
+  const long quads = (a.R + 3) / 4;
+  long quad = blockIdx.x;
+#pragma unroll 1
+  for (int it = 0; a.sched ? quad < quads : it < a.iters; ++it) {
+    unsigned int nxt = 0;
+    if (a.sched && threadIdx.x == 0) nxt = gridDim.x + atomicAdd(a.sched, 1u);
+    const long rr = quad * 4 + pair;
+    const bool ray_ok = rr < a.R;
+    const long r = ray_ok ? rr : a.R - 1;
+    const float* ray = a.rays + r * 8;
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float near = ray[6], far = ray[7];
+    {
+      // rendering.py:155  dir_embedded = embedding_dir(kwargs.get('view_dir', rays_d)): a per-ray constant, parked in LDS
+      const float* vd = a.view_dir ? a.view_dir + r * 3 : ray + 3;
+      u32x4 tmp[KS_DIR];
+      posenc_b<DIR_FREQS, KS_DIR>(vd[0], vd[1], vd[2], h, tmp);
+      if (p == 0) {
+#pragma unroll
+        for (int s = 0; s < KS_DIR; ++s) *(__attribute__((address_space(3))) u32x4*)(dirbuf + 32 * s + 16 * h) = tmp[s];
+      }
+    }
+    for (int n = lane128; n < Nc; n += 128)
+      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    wg_barrier();
+
+    const int npass = Ni > 0 ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      const int N = pass ? Nf : Nc;
+      const lds_float* zsrc = pass ? scr.zs : scr.zc;
+      const float* noise_row = pass ? (a.noise_f ? a.noise_f + r * Nf : nullptr) : (a.noise_c ? a.noise_c + r * Nc : nullptr);
+      float* weights_row = pass ? a.weights_f + r * Nf : a.weights_c + r * Nc;
+      double carry = 1.0;
+      float fsum = 0.0f, dacc = 0.0f;
+      const int steps = (N + 63) >> 6;
+#pragma unroll 1
+      for (int k = 0; k < steps; ++k) {
+        const int n = 64 * k + 32 * half + p;
+        const bool valid = n < N;
+        const int nc = valid ? n : N - 1;
+        const float zn = zsrc[nc];
+        const float znext = zsrc[nc + 1 < N ? nc + 1 : N - 1];
+        const float x = ox + dx * zn, y = oy + dy * zn, z = oz + dz * zn;   // rendering.py:178 / :188 (separate mul and add)
+        u32x4 pe[KS_XYZ];
+#ifdef CRNERF_EXP_MLP_ONLY   // (energy / ceiling experiments only, tools/bf16_energy_probe.py: the MLP stream with NO per-ray work)
+#pragma unroll
+        for (int s = 0; s < KS_XYZ; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {   // bf16-looking pseudo-random operands in (-1, 1): 0x3f00..0x3f7f / 0xbf00.. halves
+            const uint32_t hsh = (uint32_t)(lane * 2654435761u) ^ (uint32_t)((4 * s + j + 1) * 40503u) ^ __builtin_bit_cast(uint32_t, x);
+            pe[s][j] = (hsh & 0x807f807fu) | 0x3f003f00u;
+          }
+#else
+        posenc_b<XYZ_FREQS, KS_XYZ>(x, y, z, h, pe);
+#endif
+        tm.tick(T_X0);
+        f32x16 feat[2];
+        float sigma;
+        // the model of the tile after this one: same pass, the fine pass, or the next ray's coarse pass
+        const int next_model = k + 1 < steps ? pass : (pass + 1 < npass ? 1 : 0);
+        mlp_tile_p(pipe, pass, next_model, pe, dirbuf + 16 * h, feat, sigma, h, q, tm);
+#ifdef CRNERF_EXP_MLP_ONLY
+        fsum += feat[0][0] + feat[1][15] + sigma;
+        if (valid && h == 0 && pass == 0) scr.wc[n] = znext;
+        continue;
+#endif
+        // ---- compositing, rendering.py:121-143 (both lane halves evaluate the same 32 samples)
+        const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        const float delta = (n == N - 1) ? 1e2f : znext - zn;
+        const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sigma + noise, 0.0f)) : 0.0f;
+        // inclusive prefix product over the 32 lanes of each half on the DPP network (ray_ops.h composite_tile64)
+        double incl = (double)(1.0f - alpha);
+        incl *= dpp_f64<0x111, 0xf>(incl);   // row_shr:1
+        incl *= dpp_f64<0x112, 0xf>(incl);   // row_shr:2
+        incl *= dpp_f64<0x114, 0xf>(incl);   // row_shr:4
+        incl *= dpp_f64<0x118, 0xf>(incl);   // row_shr:8
+        incl *= dpp_f64<0x142, 0xa>(incl);   // row_bcast:15 -> rows 1, 3
+        double excl = dpp_f64<0x138, 0xf>(incl);   // wave_shr:1
+        if (p == 0) excl = 1.0;
+        const double tot = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incl), 31), __builtin_amdgcn_readlane(__double2loint(incl), 31));
+        if (lane == 0) scr.xprod[half] = tot;
+        wg_barrier();
+        const double other = scr.xprod[half ^ 1];
+        const double prod_a = half ? other : tot, prod_b = half ? tot : other;
+        const float Tr = (float)(half ? carry * prod_a * excl : carry * excl);
+        carry = carry * prod_a * prod_b;
+        const float w = alpha * Tr;
+        float v[32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[16 * t + e] = w * feat[t][e];
+        fsum += fold32(v, p);
+        dacc += w * zn;
+        if (valid && h == 0) {
+          if (ray_ok) weights_row[n] = w;
+          if (pass == 0) scr.wc[n] = w;
+        }
+        tm.tick(T_COMPOSITE);
+      }
+      // lane (p, h) holds the wave's sum of feature 32(p>>4) + 8((p&15)>>2) + 4h + (p&3); pair combine through LDS
+      const int fidx = 32 * (p >> 4) + 8 * ((p & 15) >> 2) + 4 * h + (p & 3);
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) dacc += __shfl_xor(dacc, d);
+      if (half == 1) {
+        scr.xfeat[fidx] = fsum;
+        if (lane == 0) scr.xfeat[64] = dacc;
+      }
+      wg_barrier();
+      if (half == 0 && ray_ok) {
+        ((pass ? a.feature_f : a.feature_c) + r * FEAT_DIM)[fidx] = fsum + scr.xfeat[fidx];
+        if (lane == 0) (pass ? a.depth_f : a.depth_c)[r] = dacc + scr.xfeat[64];
+      }
+      tm.tick(T_X5);
+#ifdef CRNERF_EXP_MLP_ONLY
+      if (pass == 0 && Ni > 0) {
+        for (int n = lane128; n < Nf; n += 128) scr.zs[n] = scr.zc[n % Nc] + 1e-3f * (float)n;
+        wg_barrier();
+        continue;
+      }
+#endif
+      if (pass == 0 && Ni > 0) {
+        sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128);
+        wg_barrier();
+        tm.tick(T_X6);
+        merge_sort_pair(scr, Nc, Ni, lane128);
+        wg_barrier();
+        tm.tick(T_X7);
+        if (a.z_fine && ray_ok)
+          for (int n = lane128; n < Nf; n += 128) a.z_fine[r * Nf + n] = scr.zs[n];
+      }
+      tm.tick(T_RAYLEVEL);
+    }
+    if (a.sched && threadIdx.x == 0) *qslot = nxt;
+    wg_barrier();   // scratch is rewritten by the next ray
+    quad = a.sched ? (long)__builtin_amdgcn_readfirstlane((int)*qslot) : quad + gridDim.x;   // slot rewritten a whole pass later
+  }
+  if (a.sched && threadIdx.x == 0 && atomicAdd(a.sched + 1, 1u) == gridDim.x - 1) {   // last workgroup out: leave the slot zeroed
+    atomicExch(a.sched, 0u);
+    atomicExch(a.sched + 1, 0u);
+  }
+  tm.flush();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CRNERF_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times_p[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
+  if (a.R <= 0) return 0;
+  if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays_bf16: N_samples must be in [2, 256] for the fused kernel");
+  if (a.Ni < 0 || a.Ni > MAX_NI) return set_error(-2, "render_rays_bf16: N_importance must be in [0, 256] for the fused kernel");
+  if (a.Ni > 0 && a.Nc < 3) return set_error(-2, "render_rays_bf16: hierarchical sampling needs N_samples >= 3");
+  if (a.Ni > 0 && !a.packed_fine) return set_error(-3, "render_rays_bf16: N_importance > 0 but no fine model");
+  RenderParamsP k;
+  k.packed0 = (const char*)a.packed_coarse;
+  k.packed1 = (const char*)(a.packed_fine ? a.packed_fine : a.packed_coarse);
+  k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.z_steps = a.z_steps; k.u = a.u; k.u_stride = a.u_stride;
+  k.noise_c = a.noise_coarse; k.noise_f = a.noise_fine; k.noise_std = a.noise_std; k.use_disp = a.use_disp;
+  k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
+  k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
+  k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
+  const long quads = (a.R + 3) / 4;
+  const int cus = num_cus();
+  const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
+  k.iters = (int)((quads + grid - 1) / grid);
+  k.sched = k.iters > 1 ? sched_slot((const void*)crnerf_sched_bf16p) : nullptr;
+  if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16p_kernel, LDS_TOTAL_P, "render_rays_bf16p_kernel")) return rc;
+  hipLaunchKernelGGL(render_rays_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k);
+  return check_launch("render_rays_bf16p_kernel");
+}
+
+#ifdef CRNERF_TIMING
+extern "C" int crnerf_debug_read_wgtimes_bf16p(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_wg_times_p), sizeof(unsigned long long) * 2 * 1024);
+}
+extern "C" int crnerf_debug_read_timing_bf16p(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_timing), sizeof(unsigned long long) * T_COUNT);
+}
+#endif
+
+}  // namespace crnerf
