@@ -11,6 +11,7 @@
 //                   [out,in] layout (saved activations are in reference feature order, so no un-pack);
 //                   db[m] = sum_p delta[p][m]
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "mlp_core16.h"
 #include "mlp_train16.h"
@@ -187,7 +188,7 @@ struct WgradJob {
 
 template <int MT, int NT>
 __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
-                                                    bool bias_wave) {
+                                                    bool bias_wave, int bx, int bz) {
   // k-steps (2 points each) per iteration = prefetch depth: the small blocks are bandwidth-bound, keep more rows in flight
   constexpr int KS = MT * NT >= 8 ? 4 : (MT * NT >= 4 ? 8 : 16);
   int dcol[MT], acol[NT];
@@ -218,7 +219,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
         for (int t = 0; t < NT; ++t) a[e][t] = ar[acol[t]] * amask[t];
       }
     };
-    const bool do_bias16 = j.bias_partial && blockIdx.z == 0 && bias_wave;
+    const bool do_bias16 = j.bias_partial && bz == 0 && bias_wave;
     float bs16[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) bs16[t] = 0.0f;
@@ -260,10 +261,10 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         bs16[t] += __shfl_xor(bs16[t], 32);
-        if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs16[t];
+        if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)bx * j.M + m0 + 32 * t + i] = bs16[t];
       }
     }
-    float* out16 = j.partial + (long)blockIdx.x * j.M * j.N;
+    float* out16 = j.partial + (long)bx * j.M * j.N;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -290,7 +291,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
       for (int t = 0; t < NT; ++t) a[s][t] = ar[acol[t]] * amask[t];
     }
   };
-  const bool do_bias = j.bias_partial && blockIdx.z == 0 && bias_wave;
+  const bool do_bias = j.bias_partial && bz == 0 && bias_wave;
   float bs[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) bs[t] = 0.0f;
@@ -321,10 +322,10 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       bs[t] += __shfl_xor(bs[t], 32);
-      if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)blockIdx.x * j.M + m0 + 32 * t + i] = bs[t];
+      if (kk == 0 && m0 + 32 * t + i < j.M) j.bias_partial[(long)bx * j.M + m0 + 32 * t + i] = bs[t];
     }
   }
-  float* out = j.partial + (long)blockIdx.x * j.M * j.N;
+  float* out = j.partial + (long)bx * j.M * j.N;
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -340,7 +341,9 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 // Per k-step (2 points) a wave loads 4 delta fragments + 4 input fragments (one dword per lane: a 32-float
 // row segment per half-wave, straight from HBM/L2 in MFMA operand shape) for 16 MFMAs; the next
 // iteration's operands are in flight while the current MFMAs run.  Tiles beyond M or N are skipped.
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
+// (bx, by, bz): the workgroup's chunk / row-block / column-block inside job j -- blockIdx for a single-job launch, decoded from a flat
+// block index by the batched launch below.
+__device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
   // The workgroup's 256 x 256 block holds tm x tn live 32 x 32 MFMA tiles (<= 8 x 8).  Its four waves are laid out 2 x 2,
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   // tiles: 256 x 256 layers -> 2 x 2 of 4 x 4 tiles; 256 x 93 (embedding blocks) -> 4 x 1 of 2 x 3; 128 x 256 -> 1 x 4 of
   // 4 x 2; 128 x 27 -> 4 x 1 of 1 x 1; 64 x 128 and 1 x 256 -> 1 x 4.  (With a fixed 2 x 2 layout the narrow blocks ran
   // on two or one of the four SIMDs.)
-  const int tm = (j.M - (int)blockIdx.y * 256 + 31) / 32 < 8 ? (j.M - (int)blockIdx.y * 256 + 31) / 32 : 8;
-  const int tn = (j.N - (int)blockIdx.z * 256 + 31) / 32 < 8 ? (j.N - (int)blockIdx.z * 256 + 31) / 32 : 8;
+  const int tm = (j.M - (int)by * 256 + 31) / 32 < 8 ? (j.M - (int)by * 256 + 31) / 32 : 8;
+  const int tn = (j.N - (int)bz * 256 + 31) / 32 < 8 ? (j.N - (int)bz * 256 + 31) / 32 : 8;
   int wm = 2, wn = 2, best = -1;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -362,9 +365,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   }
   const int wmi = wm == 2 ? (wave & 1) : (wm == 4 ? wave : 0), wni = wm == 2 ? (wave >> 1) : (wn == 4 ? wave : 0);
   const int pm = (tm + wm - 1) / wm, pn = (tn + wn - 1) / wn;
-  const int m0 = blockIdx.y * 256 + wmi * pm * 32;
-  const int n0 = blockIdx.z * 256 + wni * pn * 32;
-  const long p0 = (long)blockIdx.x * j.chunk;
+  const int m0 = by * 256 + wmi * pm * 32;
+  const int n0 = bz * 256 + wni * pn * 32;
+  const long p0 = (long)bx * j.chunk;
   const long p1 = p0 + j.chunk < j.P ? p0 + j.chunk : j.P;
   const int mt = tm - wmi * pm < pm ? tm - wmi * pm : pm;                 // live 32-row tiles of this wave (<= 0: none)
   const int nt = tn - wni * pn < pn ? tn - wni * pn : pn;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
         for (int q = 0; q < 4; ++q) u.h[q] = bf16x2_t{(__bf16)v[2 * q][t], (__bf16)v[2 * q + 1][t]};   // v_cvt_pk_bf16_f32
         return u.v8;
       };
-      const bool do_bias16 = j.bias_partial && blockIdx.z == 0 && bias_wave;
+      const bool do_bias16 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
       fetch16(p0, dcur, acur);
       for (long pb = p0; pb < p1; pb += 16) {
@@ -434,9 +437,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
       if (do_bias16) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) bsum[t] += __shfl_xor(bsum[t], 32);
-        if (kk == 0) *(f32x4*)(j.bias_partial + (long)blockIdx.x * j.M + m0 + 4 * i) = bsum;
+        if (kk == 0) *(f32x4*)(j.bias_partial + (long)bx * j.M + m0 + 4 * i) = bsum;
       }
-      float* outp16 = j.partial + (long)blockIdx.x * j.M * j.N;
+      float* outp16 = j.partial + (long)bx * j.M * j.N;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
         a[s] = av;
       }
     };
-    const bool do_bias4 = j.bias_partial && blockIdx.z == 0 && bias_wave;
+    const bool do_bias4 = j.bias_partial && bz == 0 && bias_wave;
     f32x4 bs4 = {0.0f, 0.0f, 0.0f, 0.0f};
     fetch4(p0, dc, ac);
     for (long pb = p0; pb < p1; pb += 2 * KF) {
@@ -482,9 +485,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
     if (do_bias4) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) bs4[t] += __shfl_xor(bs4[t], 32);
-      if (kk == 0) *(f32x4*)(j.bias_partial + (long)blockIdx.x * j.M + m0 + 4 * i) = bs4;
+      if (kk == 0) *(f32x4*)(j.bias_partial + (long)bx * j.M + m0 + 4 * i) = bs4;
     }
-    float* outp = j.partial + (long)blockIdx.x * j.M * j.N;
+    float* outp = j.partial + (long)bx * j.M * j.N;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -499,17 +502,43 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) {
   // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
   const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, bias_wave); return; }
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
   CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
   CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
 }
 
+
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Every weight gradient of one NeRF_sigma backward in ONE launch: at the reference's 1,024-ray batches a per-layer launch is
+// ~256 workgroups of 256 points each -- fourteen ramp-ups and drains per model, and a [256 chunks][256][256] partial-sum slab
+// per layer that costs as much HBM traffic as the operands.  Batched, the jobs share the chip (a job's workgroups are laid
+// out consecutively, the big jobs first), so a chunk can be ~9x longer and the partial sums ~9x smaller.
+constexpr int WG_MAX_JOBS = 16;
+struct WgradBatch {
+  WgradJob job[WG_MAX_JOBS];
+  int first[WG_MAX_JOBS + 1];   // first flat block of job k; first[njobs] = grid size
+  int nchunk[WG_MAX_JOBS];
+  int my[WG_MAX_JOBS];          // row blocks (ceil(M / 256))
+  int njobs;
+};
+__global__ __launch_bounds__(256, 1) void wgrad_batch_kernel(WgradBatch b) {
+  int k = 0;
+#pragma unroll 1
+  while (k + 1 < b.njobs && (int)blockIdx.x >= b.first[k + 1]) ++k;
+  k = __builtin_amdgcn_readfirstlane(k);
+  const int local = (int)blockIdx.x - b.first[k];
+  const int bx = local % b.nchunk[k], rest = local / b.nchunk[k];
+  wgrad_body(b.job[k], bx, rest % b.my[k], rest / b.my[k]);
+}
+
+struct ReduceJob { const float* partial; const float* bias_partial; float* dst; float* db; int nchunk, M, N, ldc; };
+struct ReduceBatch { ReduceJob job[WG_MAX_JOBS]; int first[WG_MAX_JOBS + 1]; int njobs; };
 // dst[m*ldc + n] = sum_c partial[c][m][n]   (fixed summation tree: deterministic; 8 loads in flight per thread), and in the
 // same launch db[m] = sum_c bias_partial[c][m] (threads M*N .. M*N + M - 1) when db != null
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc,
-                                                           const float* __restrict__ bias_partial, float* __restrict__ db) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc,
+                                                  const float* __restrict__ bias_partial, float* __restrict__ db, int idx) {
   const float* src = partial;
   long stride = (long)M * N;
   float* out;
@@ -527,6 +556,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   for (; c < nchunk; ++c) a[0] += src[c * stride + idx];
   *out = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunk, int M, int N, float* __restrict__ dst, int ldc,
+                                                           const float* __restrict__ bias_partial, float* __restrict__ db) {
+  wgrad_reduce_body(partial, nchunk, M, N, dst, ldc, bias_partial, db, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceBatch b) {
+  int k = 0;
+#pragma unroll 1
+  while (k + 1 < b.njobs && (int)blockIdx.x >= b.first[k + 1]) ++k;
+  const ReduceJob& j = b.job[k];
+  wgrad_reduce_body(j.partial, j.nchunk, j.M, j.N, j.dst, j.ldc, j.bias_partial, j.db, ((int)blockIdx.x - b.first[k]) * 256 + (int)threadIdx.x);
 }
 
 int launch_wgrad_reduce(const float* partial, int nchunk, int M, int N, float* dst, int ldc, const float* bias_partial, float* db, hipStream_t st) {
@@ -560,11 +600,17 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
   return 0;
 }
 
+// workgroups of the batched weight-gradient launch (all jobs together): four per CU -- enough to even out the jobs' different
+// lengths, few enough that the partial sums stay ~100 MB whatever the batch size
+static int wgrad_batch_blocks() { static const int per_cu = [] { const char* e = getenv("CRNERF_WGRAD_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }(); return per_cu * num_cus(); }
+static size_t wgrad_batch_workspace_floats() { return (size_t)(wgrad_batch_blocks() + WG_MAX_JOBS) * (256 * 256 + 256); }
 size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float) + (size_t)ACT_SLOTS * P * 32; }   // activations + relu bits
 size_t mlp_train_scratch_bytes(long P) {
   const int chunk = wg_chunk(P);
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
-  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + nchunk * (256 * 256 + 256) * 4;
+  size_t wsf = nchunk * (size_t)(256 * 256 + 256);                 // per-layer launches (CRNERF_WGRAD_BATCH=0)
+  if (wgrad_batch_workspace_floats() > wsf) wsf = wgrad_batch_workspace_floats();   // the batched launch keeps every job's partial sums
+  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + wsf * 4;
 }
 
 static int launch_core(const void* fn, int grid, size_t shmem) {
@@ -581,12 +627,85 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
   return check_launch("mlp_forward_train16_kernel");
 }
 
+// ---- batched weight gradients -------------------------------------------------------------------------------------------
+struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; };
+
+
+// specs[k].weight: relative cost of one point of job k (1 = a full 256 x 256 block); a job's chunk length is chosen so that
+// every workgroup of the launch carries about the same work
+static int launch_wgrad_batch(const WgradSpec* specs, int n, long P, float* ws, hipStream_t st) {
+  if (n > WG_MAX_JOBS) return set_error(-3, "wgrad batch: too many jobs");
+  int order[WG_MAX_JOBS];
+  for (int k = 0; k < n; ++k) order[k] = k;
+  for (int a = 1; a < n; ++a)                       // stable insertion sort, heaviest first
+    for (int c = a; c > 0 && specs[order[c]].weight > specs[order[c - 1]].weight; --c) { const int t = order[c]; order[c] = order[c - 1]; order[c - 1] = t; }
+  float sumw = 0.0f;
+  for (int k = 0; k < n; ++k) sumw += specs[k].weight;
+  const double per = (double)sumw * (double)P / (double)wgrad_batch_blocks();
+  WgradBatch b;
+  ReduceBatch r;
+  b.njobs = r.njobs = n;
+  int blocks = 0, rblocks = 0;
+  float* w = ws;
+  for (int q = 0; q < n; ++q) {
+    const WgradSpec& sp = specs[order[q]];
+    long chunk = (long)(per / sp.weight);
+    chunk = (chunk + 15) / 16 * 16;
+    if (chunk < 128) chunk = 128;
+    const int nchunk = (int)((P + chunk - 1) / chunk);
+    float* bws = w + (size_t)nchunk * sp.M * sp.N;
+    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, P, (int)chunk, sp.bf16};
+    b.first[q] = blocks;
+    b.nchunk[q] = nchunk;
+    b.my[q] = (sp.M + 255) / 256;
+    blocks += nchunk * ((sp.M + 255) / 256) * ((sp.N + 255) / 256);
+    r.job[q] = ReduceJob{w, sp.db ? bws : nullptr, sp.dst, sp.db, nchunk, sp.M, sp.N, sp.ldc};
+    r.first[q] = rblocks;
+    rblocks += (sp.M * sp.N + (sp.db ? sp.M : 0) + 255) / 256;
+    w = bws + (sp.db ? (size_t)nchunk * sp.M : 0);
+  }
+  b.first[n] = blocks;
+  r.first[n] = rblocks;
+  if ((size_t)(w - ws) > wgrad_batch_workspace_floats()) return set_error(-3, "wgrad batch: workspace too small");
+  hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblocks), dim3(256), 0, st, r);
+  return 0;
+}
+
 // The weight / bias gradients of all eleven nn.Linear from the saved activations and the stored deltas (shared by the fp32 twins and
-// the mixed-precision twins of mlp_gemm_bf16.hip).  wb != 0: bf16-operand path for the 256 x 256 layers.
+// the mixed-precision twins of mlp_gemm_bf16.hip).  wb != 0: bf16-operand path (CRNERF_BWD_WGRAD_BF16).  Two launches in all (every
+// job in one batched launch + one reduction) at small batches.  (An eight-wave variant of the full-block kernel -- two waves per SIMD,
+// 64 x 128 per wave -- was 15 % SLOWER at 2^17 and 2^21 points: the kernel is not short of waves.)
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
                       long P, hipStream_t stream, int wb) {
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
+  // batched below 2^18 points (the reference's 1,024-ray batches: 8.24 -> 8.02 ms per step, 56 launches -> 4); beyond that a
+  // per-layer launch of 256 equal workgroups is already one even wave over the chip and the batched launch's mixed job lengths
+  // only add a tail (16,384-ray step: 103 ms per layer, 108 ms batched).  CRNERF_WGRAD_BATCH=0 / 1 forces either.
+  static const int batch_mode = [] { const char* e = getenv("CRNERF_WGRAD_BATCH"); return e ? atoi(e) : -1; }();
+  const bool batched = batch_mode < 0 ? P <= (1L << 18) : batch_mode != 0;
+  if (batched) {
+    WgradSpec sp[WG_MAX_JOBS];
+    int n = 0;
+    const float W_FULL = 1.0f, W_EMB = 0.52f, W_DIR = 0.66f, W_DIRE = 0.19f, W_RGB = 0.26f, W_SIG = 0.26f;   // measured per-point cost relative to a full block (profiles/r3/train_1024_before_ordered.txt)
+    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb};                               // xyz_encoding_1
+    for (int l = 1; l < 8; ++l) {
+      if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb};
+      } else {
+        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb};
+      }
+    }
+    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb};                                  // xyz_encoding_final
+    sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0};                                         // static_sigma
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb};                         // dir_encoding: cat([final, dir])
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb};
+    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb};                          // static_rgb
+    if (int rc = launch_wgrad_batch(sp, n, P, ws, stream)) return rc;
+    return check_launch("mlp_backward wgrad (batched)");
+  }
   // xyz_encoding_1: input x[:, :93]
   wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb);
   for (int l = 1; l < 8; ++l) {

@@ -229,3 +229,21 @@ def test_cgnet_mirror_has_the_reference_state_dict(golden):
     assert sd["level3_0.conv1x1.conv.weight"].shape == (128, 131, 3, 3) and sd["level2_0.F_sur.conv.weight"].shape == (64, 1, 3, 3)
     with pytest.raises(RuntimeError, match="HIP operators only"):
         net(torch.zeros(1, 3, 16, 16))
+
+
+def test_oracle_on_the_trained_checkpoint_matches_the_reference(golden):
+    """g15 (tests/golden/make_golden_trained.py): weights TRAINED by the reference's own modules and loop.  The oracle restates the
+    reference's arithmetic op for op, so on the reference's checkpoint it must reproduce the reference's render bit for bit
+    (coarse + fine at 64+128, eval.py's perturb = 0 / noise_std = 0 recipe) and its decoded image to fp32 round-off."""
+    g = golden("g15_trained")
+    side = int(g["side"])
+    pick = lambda prefix: {k[len("sd__" + prefix) + 1:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("sd__" + prefix + ".")}  # noqa: E731
+    wc, wf, dec, enc = pick("nerf_coarse"), pick("nerf_fine"), pick("decoder"), pick("enc_a")
+    with torch.no_grad():
+        out = O.render_rays(wc, wf, torch.from_numpy(g["rays"]), 64, 128)
+        for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine"):
+            assert torch.equal(out[k], torch.from_numpy(g["ref__64_128__" + k])), k
+        a = O.encoder_forward(enc, torch.from_numpy(g["style_rgbs"]).t().reshape(1, 3, side, side).contiguous())
+        assert float((a - torch.from_numpy(g["ref__a_embedded"])).abs().max()) <= 1e-6
+        rgb = O.crossray_decode(dec, O.feature_to_grid(out["feature_fine"], side, side), torch.from_numpy(g["ref__a_embedded"]))
+        assert float((rgb.reshape(3, -1).t() - torch.from_numpy(g["ref__64_128__rgb_fine"])).abs().max()) <= 1e-6

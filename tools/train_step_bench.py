@@ -28,14 +28,27 @@ rays = torch.from_numpy(synth.rays(R, H=H, W=W)).to(dev)
 style = torch.rand(1, 64, 32, 32, device=dev)
 target = torch.rand(R, 3, device=dev)
 params = [p for mod in m.values() for p in mod.parameters()]
-opt = torch.optim.Adam(params, lr=5e-4)
+opt = torch.optim.Adam(params, lr=5e-4, fused=os.environ.get("CRNERF_BENCH_ADAM", "fused") == "fused")   # the reference: Adam(lr, eps=1e-8); fused = one multi-tensor launch
+if os.environ.get("CRNERF_TRAIN_BF16"):
+    from crnerf_amd import autograd as _ag
+    _ag.set_training_precision("bf16")
+
+
+class HPL:
+    maskrs_max, maskrs_min, maskrs_k, maskrd, weightKL, weightRecA, weightcontent, mse_on_appearance = 5e-2, 6e-3, 1e-3, 0.0, 1e-5, 1e-3, 1e-4, False
+
+
+from crnerf_amd.losses import loss_dict
+crit = loss_dict["crnerf"](HPL, coef=1)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
     res = render_rays_cross_ray(m, emb, rays, None, 64, False, 1.0, 1.0, 64, 1 << 22, False, args=A())
     dec = lambda f: m["decoder"](f.t().reshape(1, 64, H, W), style).reshape(3, R).t()
-    loss = ((dec(res["feature_coarse"]) - target) ** 2).mean() + ((dec(res["feature_fine"]) - target) ** 2).mean()
+    # CRNeRFLoss's colour terms c_l + f_l (losses.py:61-72) through the fused HIP loss (crnerf_amd.losses)
+    loss_d, _ = crit({"rgb_coarse": dec(res["feature_coarse"]), "rgb_fine": dec(res["feature_fine"])}, target, HPL, 0)
+    loss = sum(loss_d.values())
     loss.backward()
     opt.step()
     return float(loss.detach())
