@@ -50,6 +50,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every rank renders its own --rays batch.  strong: ONE unit of --workload is "
+                         "split over the ranks (the configs BASELINE.json names for 8 GPUs)")
+    ap.add_argument("--workload", choices=["configs2", "configs3"], default="configs2",
+                    help="--scaling strong only.  configs2: one 800x800 frame, 64+128, cross-ray decoder on, --precision (default there: bf16); "
+                         "configs3: one 65,536-ray training batch with grid-sample masking (fwd + bwd + Adam, exact fp32)")
+    ap.add_argument("--frame", default="800x800", help="--workload configs2: frame size HxW")
+    ap.add_argument("--train-rays", type=int, default=65536, help="--workload configs3: rays of the ONE batch that is split over the ranks")
     ap.add_argument("--peer-exchange", action="store_true",
                     help="N > 1: carry the decoder's two reductions through HIP-IPC peer windows (parallel.PeerExchange) instead of RCCL")
     return ap.parse_args()
@@ -278,6 +286,173 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
     return parity, extra
 
 
+def collectives_record(dist, dev, world, rank, test_backend):
+    """What the collective layer saw (every rank contributes, rank 0 keeps it): backend, world size, the device each rank ran on
+    (name, PCI bus id, uuid), the RCCL version torch was built against.  Per-step collective times are added by the caller."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index, "device_name": props.name,
+            "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+            "uuid": str(getattr(props, "uuid", "")), "host": os.uname().nodename}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        rccl = None
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": rccl, "ranks": everyone,
+            "distinct_devices": len({(r["host"], r["pci_bus_id"]) for r in everyone}),
+            "test_hook_backend": test_backend,   # null in a real run; "gloo" = all ranks on one GPU (tests only)
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+
+
+def timed_steps(a, step, use_dist, dist, dev):
+    """The contract's timed region: W untimed steps, then EXACTLY K steps between barrier + synchronize, MAX over ranks."""
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    last = None
+    for _ in range(a.warmup):
+        last = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, last
+
+
+def strong_configs2(a, dev, world, rank, use_dist, dist, exchange):
+    """ONE configs[2] frame (default 800x800 = 640,000 rays, 64+128, cross-ray decoder on) split over the ranks: contiguous ray blocks,
+    32,768-ray render chunks per rank, the decoder's two all-reduces + the RGB all-gather (parallel.decode_sharded)."""
+    import numpy as np
+    import crnerf_amd.synth as synth
+    from crnerf_amd import ops, parallel
+    from crnerf_amd.models.linearStyleTransfer import style_net
+    H, W = (int(v) for v in a.frame.lower().split("x"))
+    R = H * W
+    lo, hi = parallel.shard_bounds(R, world, rank)
+    prec = a.precision
+    to_dev = lambda s: {k: torch.from_numpy(v).to(dev) for k, v in s.items()}  # noqa: E731
+
+    class Args:
+        nerf_out_dim, img_wh = 64, [W, H]
+
+    with torch.no_grad():
+        pc, pf = (ops.pack_mlp_weights(to_dev(synth.mlp_state(sd, 3.0, 1.0)), precision=prec) for sd in (1, 2))
+        net = style_net(Args()).to(dev)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+        rays = torch.from_numpy(synth.rays(R, seed=0, H=H, W=W, near=0.0, far=5.0)[lo:hi]).to(dev)     # this rank's rows of the frame
+        style = torch.rand(1024, 64, generator=torch.Generator().manual_seed(0)).to(dev).view(1, 32, 32, 64).permute(0, 3, 1, 2)
+        z_steps, u_steps = torch.linspace(0, 1, NC, device=dev), torch.linspace(0, 1, NI, device=dev)
+        ev = []
+
+        def step():
+            feats = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(0, hi - lo, 32768):
+                feats.append(ops.render_rays(pc, pf, rays[i:i + 32768], NC, NI, z_steps=z_steps, u=u_steps, precision=prec)["feature_fine"])
+            e1.record()
+            ev.append((e0, e1))
+            feat = torch.cat(feats) if len(feats) != 1 else feats[0]
+            if use_dist:
+                return parallel.decode_sharded(net, feat, style, gather=True, equal_shards=(R % world == 0), exchange=exchange, check_exchange=False)
+            return net(feat.t().reshape(1, 64, H, W), style)
+
+        dt, last = timed_steps(a, step, use_dist, dist, dev)
+        torch.cuda.synchronize()
+        render_ms = sum(s.elapsed_time(e) for s, e in ev[-a.steps:]) / a.steps
+    flops_local = FLOP_PER_POINT * (NC + NC + NI) * (hi - lo)
+    peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
+    achieved = flops_local / (render_ms * 1e-3) / 1e12
+    return {"metric": "rays/sec (64+128 samples, 8-layer W=256 MLP)", "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": prec,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: ONE %dx%d frame (%d rays) x (%d coarse + %d fine) split over %d rank(s) in contiguous ray blocks, "
+                                   "32,768-ray render chunks, cross-ray decode of the whole frame (two all-reduces + RGB all-gather)" % (H, W, R, NC, NI, world),
+                       "rays_total": R, "rays_this_rank": hi - lo, "n_samples": NC, "n_importance": NI,
+                       "parallelism": "one frame's rays sharded %d-way, weights replicated" % world,
+                       "reductions": "none" if world == 1 else ("peer windows (HIP IPC)" if exchange is not None else "RCCL all-reduce")},
+            "roofline": {"bound": "mfma", "kernel": "render_rays_bf16p_kernel" if prec == "bf16" else "render_rays16_kernel", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "traffic_source": None, "kernel_ms": render_ms,
+                         "flops_per_launch": flops_local, "note": "rank 0's render chunks of one frame (HIP events around the chunk loop)"},
+            "image_checksum": float(last.double().sum())}
+
+
+def strong_configs3(a, dev, world, rank, use_dist, dist):
+    """ONE configs[3] training batch (default 65,536 rays = a 256x256 grid-sample batch with transient masking, 64+64 samples as
+    command/train.sh trains) split over the ranks: ray-parallel TrainingSystem (parallel.GatherRays + sync_gradients), exact fp32,
+    forward + backward + Adam per step."""
+    import numpy as np
+    import crnerf_amd.synth as synth
+    from crnerf_amd import pipeline
+    from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
+    R = a.train_rays
+    side = int(R ** 0.5)
+    nc, ni = 64, 64
+
+    class HP:
+        maskrs_max, maskrs_min, maskrs_k, maskrd = 5e-2, 6e-3, 1e-3, 0.0
+        weightKL, weightRecA, weightcontent, mse_on_appearance = 1e-5, 1e-3, 1e-4, False
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [side, side], nc, ni, 1.0, 1.0, 8 * 1024, 1500
+        use_mask, encode_c = True, True
+
+    hp = HP()
+    torch.manual_seed(0)
+    sysm = pipeline.TrainingSystem(hp, device=dev, ray_parallel_group=None if use_dist and world > 1 else False)
+    sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
+    sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
+    sysm.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    sysm.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+    sysm.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
+    n_img, iw, ih = 8, 512, 384
+    rays = torch.cat([torch.cat([torch.from_numpy(synth.rays(iw * ih, seed=i, H=ih, W=iw)), torch.full((iw * ih, 1), float(i))], 1) for i in range(n_img)]).to(dev)
+    rgbs = torch.rand(n_img * iw * ih, 3, device=dev)
+    imgs = [torch.rand(1, 3, ih // 8, iw // 8, device=dev) * 2 - 1 for _ in range(n_img)]
+    batcher = GridSampleBatcher(rays, rgbs, np.array([[iw, ih]] * n_img), batch_size=R, all_imgs=imgs)
+    opt = torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True)
+    counter = [0]
+
+    def step():
+        batch = batcher.__getitem__(counter[0], 0)
+        counter[0] += 1
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = sysm.training_step(batch)
+        loss.backward()
+        if use_dist and world > 1:
+            sysm.sync_gradients()
+        opt.step()
+        return loss.detach()
+
+    dt, last = timed_steps(a, step, use_dist, dist, dev)
+    pts = R * (nc + nc + ni)
+    achieved = 3 * pts * FLOP_PER_POINT / dt * a.steps / 1e12 / world      # per GPU
+    line = {"metric": "rays/sec (64+64 samples, training step: fwd + bwd + Adam)", "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: ONE %d-ray grid-sample training batch (%dx%d grid, transient mask, encode_a / encode_c / "
+                                   "encode_random) x (%d+%d) split over %d rank(s): rays sharded, feature rows all-gathered, decoder / encoders / mask "
+                                   "network replicated, one flat gradient all-reduce" % (R, side, side, nc, ni, world),
+                       "rays_total": R, "n_samples": nc, "n_importance": ni, "parallelism": "one batch's rays sharded %d-way" % world},
+            "roofline": {"bound": "mfma", "kernel": "render_rays_train16_kernel + mlp_backward16_kernel + wgrad_kernel", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
+                         "note": "whole step per GPU: 3 x the forward's MLP FLOPs of this rank's rays / step time (decoder, encoders, mask network and Adam included in the time)"},
+            "loss": float(last), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+    if use_dist and world > 1:
+        chk = torch.tensor([float(last), float(sum(p.detach().double().sum() for p in sysm.parameters()))], dtype=torch.float64, device=dev)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        line["replicas_identical"] = bool(all(torch.equal(allc[0], c) for c in allc))
+    return line
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,10 +481,37 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crnerf_amd.synth as synth
-    from crnerf_amd import ops
+    from crnerf_amd import ops, parallel
     from crnerf_amd.models.linearStyleTransfer import style_net
     from crnerf_amd.parallel import PeerExchange, decode_sharded
     exchange = PeerExchange() if (use_dist and world > 1 and a.peer_exchange) else None
+    coll = collectives_record(dist, dev, world, rank, test_backend) if use_dist else None
+    if use_dist:
+        parallel.collect_collective_times(True)     # event pairs around every collective of the timed steps
+
+    def finish(line):
+        """rank 0 prints the ONE JSON line; every rank leaves the process group."""
+        if use_dist:
+            times = parallel.collective_times_ms()
+            if rank == 0:
+                coll["per_call_ms"] = times
+                coll["note"] = ("HIP events on the launch stream around each collective, averaged over warm-up + timed steps of rank 0; "
+                                "expected on xGMI (DESIGN section 4): ~10-25 us per tiny all-reduce, all-gather ~ 12 B/pixel / link rate + ~20 us")
+                line["collectives"] = coll
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if exchange is not None:
+            exchange.check()
+            exchange.close()
+        if use_dist:
+            dist.destroy_process_group()
+
+    if a.scaling == "strong":
+        if a.workload == "configs2":
+            if "--precision" not in sys.argv:
+                a.precision = "bf16"                 # BASELINE configs[2]: "1x MI355X bf16"
+            return finish(strong_configs2(a, dev, world, rank, use_dist, dist, exchange))
+        return finish(strong_configs3(a, dev, world, rank, use_dist, dist))
 
     R = a.rays
     W = int(R ** 0.5)
@@ -363,8 +565,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
-        if exchange is not None:
-            exchange.check()
         rgb_sums = None
         if use_dist and test_backend:      # test hook only: every rank must hold the same gathered image
             mine = torch.tensor([float(last_rgb.double().sum()), float(last_rgb.shape[-1])], dtype=torch.float64, device=dev)
@@ -377,7 +577,7 @@ def main():
         achieved = flops / (kern_ms * 1e-3) / 1e12
         bf16 = a.precision == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kernel = "render_rays_bf16_kernel" if bf16 else ("render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel")
+        kernel = ("render_rays_bf16_kernel" if os.environ.get("CRNERF_BF16_CORE") == "64" else "render_rays_bf16p_kernel") if bf16 else ("render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "render_rays_hbm_bytes.json")   # written from a rocprofv3 --pmc pass (profiles/README.md)
         if os.path.exists(pmc):
@@ -395,8 +595,10 @@ def main():
                        "parallelism": "rays sharded %d-way, weights replicated" % world,
                        "reductions": "none" if world == 1 else ("peer windows (HIP IPC)" if exchange is not None else "RCCL all-reduce")},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "kernel_ms": kern_ms,
-                         "flops_per_launch": flops},
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": (None if traffic is None else "profiles/render_rays_hbm_bytes.json: a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                                          "pass over this command (profiles/README.md), not measured in this run"),
+                         "kernel_ms": kern_ms, "flops_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:
             # untimed legs; the headline line above must be printed whatever happens in them
@@ -410,11 +612,7 @@ def main():
                 line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rgb_sums is not None:
             line["test_rgb_checksum_per_rank"] = rgb_sums
-        print(json.dumps(line), flush=True)
-    if exchange is not None:
-        exchange.close()
-    if use_dist:
-        dist.destroy_process_group()
+    finish(line if rank == 0 else None)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,36 @@ import torch
 import torch.distributed as dist
 
 
+# ---- optional timing of the collectives (bench.py's `collectives` record): HIP events on the current stream around every
+# collective this module issues, so that a multi-GPU run can show what the exchange steps cost per step.  Off by default.
+_TIMERS = None
+
+
+def collect_collective_times(enable=True):
+    """Start (or stop) recording an event pair around every collective issued through this module."""
+    global _TIMERS
+    _TIMERS = {} if enable else None
+
+
+def collective_times_ms():
+    """{name: {"calls": n, "ms_per_call": t}} of what was recorded since collect_collective_times(); synchronises the device."""
+    if not _TIMERS:
+        return {}
+    torch.cuda.synchronize()
+    return {k: {"calls": len(v), "ms_per_call": sum(a.elapsed_time(b) for a, b in v) / len(v)} for k, v in _TIMERS.items()}
+
+
+def _timed(name, fn, device):
+    if _TIMERS is None or torch.device(device).type != "cuda":
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    _TIMERS.setdefault(name, []).append((e0, e1))
+    return out
+
+
 def shard_bounds(n, world_size, rank):
     """Contiguous near-equal block [lo, hi) of n items for `rank` (the first n % world_size ranks get one extra)."""
     base, extra = divmod(n, world_size)
@@ -141,16 +171,16 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
         count = float(n_local * ws)
     else:
         cnt = torch.tensor([float(n_local)], device=dev)
-        dist.all_reduce(cnt, group=group)
+        _timed("allreduce_pixel_count_1f", lambda: dist.all_reduce(cnt, group=group), dev)
         count = float(cnt.item())
     sp = style_feature.permute(0, 2, 3, 1).reshape(-1, style_feature.shape[1]).contiguous()
     weights = net.decoder_tensors()
     xchg = torch.zeros(64 + 1024, dtype=torch.float32, device=dev)
     k.crossray_decode_sharded(feature_local, sp, weights, 0, xchg, count)
     reduce = exchange.all_reduce if exchange is not None else (lambda t: dist.all_reduce(t, group=group))
-    reduce(xchg[:64])                                 # reduction 1: channel sums -> global mean  (linearStyleTransfer.py:59-65)
+    _timed("allreduce_channel_sums_64f", lambda: reduce(xchg[:64]), dev)     # reduction 1: channel sums -> global mean  (linearStyleTransfer.py:59-65)
     k.crossray_decode_sharded(feature_local, sp, weights, 1, xchg, count)
-    reduce(xchg[64:])                                 # reduction 2: Gram of the centred conv chain (linearStyleTransfer.py:29-34)
+    _timed("allreduce_gram_1024f", lambda: reduce(xchg[64:]), dev)          # reduction 2: Gram of the centred conv chain (linearStyleTransfer.py:29-34)
     rgb_local = k.crossray_decode_sharded(feature_local, sp, weights, 2, xchg, count)
     if rgb_local is None:
         rgb_local = torch.zeros(3, 0, device=dev)
@@ -160,7 +190,7 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
         return rgb_local
     if equal_shards:
         full = torch.empty(ws * 3, n_local, device=dev)
-        dist.all_gather_into_tensor(full, rgb_local.contiguous(), group=group)
+        _timed("allgather_rgb_12B_per_pixel", lambda: dist.all_gather_into_tensor(full, rgb_local.contiguous(), group=group), dev)
         return full.view(ws, 3, n_local).permute(1, 0, 2).reshape(3, ws * n_local)
     sizes = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(ws)]
     dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.long, device=dev), group=group)
@@ -169,7 +199,7 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     pad = torch.zeros(3, width, device=dev)
     pad[:, :n_local] = rgb_local
     parts = [torch.empty(3, width, device=dev) for _ in range(ws)]
-    dist.all_gather(parts, pad, group=group)
+    _timed("allgather_rgb_12B_per_pixel", lambda: dist.all_gather(parts, pad, group=group), dev)
     return torch.cat([q[:, :s] for q, s in zip(parts, sizes)], dim=1)
 
 
@@ -182,7 +212,7 @@ def allreduce_gradients(modules, group=None, average=True):
     if not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, group=group)
+    _timed("allreduce_gradients_flat_%dMB" % round(flat.numel() * 4 / 2 ** 20), lambda: dist.all_reduce(flat, group=group), flat.device)
     if average:
         flat /= dist.get_world_size(group)
     off = 0
@@ -216,7 +246,7 @@ class GatherRays(torch.autograd.Function):
         if mine.shape[0] < biggest:                       # uneven split: pad to the largest block
             mine = torch.cat([mine, mine.new_zeros((biggest - mine.shape[0],) + tuple(mine.shape[1:]))])
         parts = [torch.empty_like(mine) for _ in range(ws)]
-        dist.all_gather(parts, mine, group=group)
+        _timed("allgather_feature_rows", lambda: dist.all_gather(parts, mine, group=group), mine.device)
         return torch.cat([p[:shard_bounds(n_total, ws, r)[1] - shard_bounds(n_total, ws, r)[0]] for r, p in enumerate(parts)])
 
     @staticmethod

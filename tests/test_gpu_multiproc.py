@@ -46,6 +46,44 @@ def test_bench_n_ranks_prints_one_valid_json_line(n):
     assert "cpu_baseline" not in j                                      # N == 1 only
     sums = j["test_rgb_checksum_per_rank"]
     assert len(sums) == n and all(s == sums[0] for s in sums) and sums[0][1] == n * 1024   # every rank holds the same gathered n x 1024-pixel image
+    # the self-proving record of what the collective layer saw (round-2 verdict, next #5)
+    c = j["collectives"]
+    assert c["backend"] == "gloo" and c["test_hook_backend"] == "gloo" and c["world_size"] == n and len(c["ranks"]) == n
+    assert [r["rank"] for r in c["ranks"]] == list(range(n)) and all(r["device_name"] and r["pci_bus_id"] for r in c["ranks"])
+    assert c["distinct_devices"] == 1                                  # here: n ranks time-slice ONE GPU; a real run must show n
+    times = c["per_call_ms"]
+    for name in ("allreduce_channel_sums_64f", "allreduce_gram_1024f", "allgather_rgb_12B_per_pixel"):
+        assert times[name]["calls"] == 6 and times[name]["ms_per_call"] > 0, times      # 2 warm-up + 4 timed steps
+    assert j["roofline"]["traffic_source"] is None or "not measured in this run" in j["roofline"]["traffic_source"]
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_one_frame_split_over_two_ranks():
+    """--scaling strong --workload configs2: ONE frame's rays split over the ranks; the gathered image is the single-process image."""
+    args = ["bench.py", "--scaling", "strong", "--workload", "configs2", "--frame", "120x160", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    one = _json_line(r.stdout)
+    two = _json_line(_launch(args + ["--gpus", "2"]))
+    for j, n in ((one, 1), (two, 2)):
+        assert j["scaling"] == "strong" and j["n_gpus"] == n and j["dtype"] == "bf16" and j["config"]["rays_total"] == 120 * 160
+        assert abs(j["value"] - 120 * 160 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]          # whole-job rays/s of the ONE frame
+    assert two["config"]["rays_this_rank"] == 120 * 160 // 2 and "collectives" in two and "collectives" not in one
+    assert abs(two["image_checksum"] - one["image_checksum"]) <= 1e-5 * abs(one["image_checksum"])        # same frame (reduction order differs)
+
+
+def test_bench_strong_scaling_one_training_batch_split_over_two_ranks():
+    """--scaling strong --workload configs3: ONE grid-sample training batch split over the ranks (ray-parallel TrainingSystem)."""
+    j = _json_line(_launch(["bench.py", "--gpus", "2", "--scaling", "strong", "--workload", "configs3", "--train-rays", "4096", "--steps", "2", "--warmup", "1"]))
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["dtype"] == "f32" and j["config"]["rays_total"] == 4096
+    assert j["replicas_identical"] is True and j["loss"] > 0
+    times = j["collectives"]["per_call_ms"]
+    assert any(k.startswith("allreduce_gradients_flat") for k in times) and times["allgather_feature_rows"]["calls"] >= 6, times
 
 
 def test_train_config3_two_ranks_ray_parallel_replicas_agree():
