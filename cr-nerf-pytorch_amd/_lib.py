@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcrnerf_hip.so")
 EXPORTS = [
     "crnerf_abi_version", "crnerf_last_error", "crnerf_packed_mlp_bytes", "crnerf_pack_mlp_weights",
     "crnerf_posenc_f32", "crnerf_embed_points_f32", "crnerf_mlp_forward_f32", "crnerf_composite_f32", "crnerf_composite_backward_f32", "crnerf_sample_pdf_merge_f32",
-    "crnerf_render_rays_f32", "crnerf_render_rays_train_f32", "crnerf_mlp_backward_ex_f32", "crnerf_packed_mlp_mixed_bytes",
+    "crnerf_render_rays_f32", "crnerf_render_rays_train_f32", "crnerf_rng_fill_f32", "crnerf_mlp_backward_ex_f32", "crnerf_packed_mlp_mixed_bytes",
     "crnerf_pack_mlp_weights_mixed", "crnerf_mlp_train_mixed_acts_bytes", "crnerf_mlp_train_mixed_scratch_bytes", "crnerf_mlp_forward_train_mixed_f32", "crnerf_mlp_backward_mixed_f32", "crnerf_crossray_workspace_bytes", "crnerf_crossray_chansum_f32",
     "crnerf_crossray_gram_f32", "crnerf_crossray_matrix_f32", "crnerf_crossray_fold_f32",
     "crnerf_crossray_apply_f32", "crnerf_crossray_decode_f32",
@@ -47,7 +47,12 @@ class RenderArgs(ctypes.Structure):
         ("n_rays", ctypes.c_int64), ("n_samples", ctypes.c_int32), ("n_importance", ctypes.c_int32),
         ("weights_coarse", _c_fp), ("feature_coarse", _c_fp), ("depth_coarse", _c_fp),
         ("weights_fine", _c_fp), ("feature_fine", _c_fp), ("depth_fine", _c_fp), ("z_fine", _c_fp),
+        ("rng_seed", ctypes.c_uint64), ("rng_ray_offset", ctypes.c_int64), ("rng_flags", ctypes.c_int32), ("perturb", ctypes.c_float),
+        ("z_coarse_out", _c_fp), ("noise_coarse_out", _c_fp), ("noise_fine_out", _c_fp),
     ]
+
+
+RNG_JITTER, RNG_U, RNG_NOISE = 1, 2, 4     # CRNERF_RNG_* (include/crnerf.h)
 
 
 class LossArgs(ctypes.Structure):
@@ -139,6 +144,7 @@ def load():
             "crnerf_composite_backward_f32": (ctypes.c_int, [vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
             "crnerf_sample_pdf_merge_f32": (ctypes.c_int, [vp, vp, vp, i64, vp, vp, i64, i32, i32, vp]),
             "crnerf_render_rays_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
+            "crnerf_rng_fill_f32": (ctypes.c_int, [vp, i64, i32, ctypes.c_uint64, i32, i64, vp]),
             "crnerf_render_rays_train_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp, vp, vp, vp, vp]),
             "crnerf_render_rays_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
             "crnerf_packed_mlp_bf16_bytes": (ctypes.c_size_t, []),

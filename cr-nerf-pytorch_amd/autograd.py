@@ -122,7 +122,10 @@ class FusedRenderFn(torch.autograd.Function):
         recompute = get_training_recompute()
         out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                               z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
-                              noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute)
+                              noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"))
+        if cfg.get("rng") is not None:       # what the kernel drew is what the backward composites with (a few KB per ray chunk)
+            cfg = dict(cfg, z_coarse_bwd=out["z_coarse_used"], noise_c_bwd=out.get("noise_coarse_used", cfg["noise_c"]),
+                       noise_f_bwd=out.get("noise_fine_used", cfg["noise_f"]))
         ctx.cfg, ctx.recompute, ctx.n_models = cfg, recompute, n_models
         keep = [rays, out["z_fine"] if Ni > 0 else rays.new_empty(0)]
         if not recompute:
@@ -146,7 +149,7 @@ class FusedRenderFn(torch.autograd.Function):
             packed = [ops.pack_mlp_weights(st) for st in states]
             out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                                   z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
-                                  noise_std=cfg["noise_std"], train=True)
+                                  noise_std=cfg["noise_std"], train=True, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"))   # same (seed, ray, sample) -> same draws
             per_pass = [(out["acts_coarse"], out["raw_coarse"])] + ([(out["acts_fine"], out["raw_fine"])] if Ni > 0 else [])
             z_fine = out["z_fine"] if Ni > 0 else z_fine
             del out
@@ -155,8 +158,8 @@ class FusedRenderFn(torch.autograd.Function):
         grads = []
         for m, (acts, raw) in enumerate(per_pass):
             d_w, d_f, d_d = g[3 * m], g[3 * m + 1], g[3 * m + 2]
-            z = z_fine if m == 1 else cfg["z_coarse"]
-            noise = cfg["noise_f"] if m == 1 else cfg["noise_c"]
+            z = z_fine if m == 1 else cfg.get("z_coarse_bwd", cfg["z_coarse"])
+            noise = cfg.get("noise_f_bwd", cfg["noise_f"]) if m == 1 else cfg.get("noise_c_bwd", cfg["noise_c"])
             if d_w is None and d_f is None and d_d is None:
                 grads += [None] * 24
                 continue
@@ -225,13 +228,14 @@ class MixedRecomputeRenderFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std):
+def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, rng=None):
     """Grad-mode render of `rays` in ray chunks of ~2^20 fine sample points (rays are independent; the chunk bounds the
     backward's scratch -- 10 KB of layer deltas per point -- and, in recompute mode, the live activations)."""
     from .models.rendering import _linspace_tables
     R = rays.shape[0]
     z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
-    if z_coarse is None:                      # rendering.py:160-167, the reference's own un-fused arithmetic
+    jitter_in_kernel = rng is not None and rng.get("jitter")
+    if z_coarse is None and not jitter_in_kernel:   # rendering.py:160-167, the reference's own un-fused arithmetic
         near, far = rays[:, 6:7], rays[:, 7:8]
         z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
         z_coarse = z_coarse.expand(R, Nc).contiguous()
@@ -245,6 +249,11 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
         cfg = {"Nc": Nc, "Ni": Ni, "use_disp": use_disp, "view_dir": sl(view_dir), "z_coarse": sl(z_coarse),
                "u": (u_steps if u is None else sl(u)) if Ni > 0 else None, "noise_c": sl(noise_c), "noise_f": sl(noise_f),
                "noise_std": float(noise_std), "modules": (coarse, fine)}
+        if rng is not None:
+            cfg["rng"] = dict(rng, ray_offset=int(rng.get("ray_offset", 0)) + lo)
+            cfg["z_steps"] = z_steps          # the reference's torch.linspace table (rendering.py:160): the jitter is formed from it in-kernel
+            if rng.get("u") and Ni > 0:
+                cfg["u"] = None
         fn = MixedRecomputeRenderFn if (get_training_bf16() and get_training_recompute()) else FusedRenderFn
         parts.append(fn.apply(cfg, rays[lo:hi].contiguous(), *params))
     keys = ["weights_coarse", "feature_coarse", "depth_coarse"] + (["weights_fine", "feature_fine", "depth_fine"] if Ni > 0 else [])

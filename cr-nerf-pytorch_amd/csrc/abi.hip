@@ -215,6 +215,15 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.weights_coarse = a->weights_coarse; r.feature_coarse = a->feature_coarse; r.depth_coarse = a->depth_coarse;
   r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
+  if (a->rng_flags) {
+    if (a->rng_flags & ~(CRNERF_RNG_JITTER | CRNERF_RNG_U | CRNERF_RNG_NOISE)) return set_error(CRNERF_ERR_CONFIG, "render_rays: unknown rng_flags bits");
+    if (bf16 || !(acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 kernels only");
+    if ((a->rng_flags & CRNERF_RNG_JITTER) && a->z_coarse) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_JITTER and z_coarse are exclusive");
+    if ((a->rng_flags & CRNERF_RNG_U) && a->u) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_U and u are exclusive");
+    if ((a->rng_flags & CRNERF_RNG_NOISE) && (a->noise_coarse || a->noise_fine)) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_NOISE and noise_* are exclusive");
+    r.rng_seed = a->rng_seed; r.rng_ray_offset = (long)a->rng_ray_offset; r.rng_flags = a->rng_flags; r.perturb = a->perturb;
+  }
+  r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
   if (bf16) {
     // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
     static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();
@@ -225,6 +234,14 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
 }
 
 int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false); }
+int crnerf_rng_fill_f32(float* out, int64_t n_rays, int n, uint64_t seed, int stream_id, int64_t ray_offset, void* stream) {
+  if (n_rays == 0 || n == 0) return 0;
+  REQUIRE(out, "out");
+  if (n_rays < 0 || n < 0) return set_error(CRNERF_ERR_SHAPE, "rng_fill: negative size");
+  if (stream_id < 0 || stream_id > 3) return set_error(CRNERF_ERR_CONFIG, "rng_fill: stream must be 0..3");
+  return launch_rng_fill(out, (long)n_rays, n, seed, stream_id, (long)ray_offset, (hipStream_t)stream);
+}
+
 int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
 
 size_t crnerf_packed_mlp_mixed_bytes(void) { return gemm_packed_bytes(); }

@@ -92,6 +92,14 @@ struct RenderArgs {
   float* feature_fine;         // [R,64]
   float* depth_fine;           // [R]
   float* z_fine;               // [R,Nc+Ni] optional (null to skip)
+  // in-kernel random draws (include/crnerf.h, ABI 2; philox.h)
+  unsigned long long rng_seed = 0;
+  long rng_ray_offset = 0;
+  int rng_flags = 0;
+  float perturb = 0.0f;
+  float* z_coarse_out = nullptr;
+  float* noise_coarse_out = nullptr;
+  float* noise_fine_out = nullptr;
   // training twin (crnerf_render_rays_train_f32; all null for inference): saved activations + raw MLP outputs per pass
   void* train_acts_coarse = nullptr;   // crnerf_mlp_train_acts_bytes(R*Nc)
   void* train_acts_fine = nullptr;     // crnerf_mlp_train_acts_bytes(R*(Nc+Ni))
@@ -104,7 +112,8 @@ int launch_mlp_forward16(const void* packed, const float* x, float* out, long P,
 int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);    // one ray per wave, 64-point tiles, one wave per SIMD (render_fused_bf16.hip)
-int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);   // one ray per wave PAIR, 32-point tiles, two waves per SIMD (render_fused_bf16p.hip)
+int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);
+int launch_rng_fill(float* out, long R, int n, unsigned long long seed, int stream_id, long ray_offset, hipStream_t stream);   // one ray per wave PAIR, 32-point tiles, two waves per SIMD (render_fused_bf16p.hip)
 
 
 size_t content_backward_workspace_floats(long HW);

@@ -3,6 +3,7 @@
 // Reference: models/rendering.py:7-46 (sample_pdf), :187 (sort(cat)).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "philox.h"
 #include "ray_ops.h"
 
 namespace crnerf {
@@ -33,7 +34,9 @@ __device__ __forceinline__ void wg_barrier() {
 
 // sample_pdf on the pair's 128 lanes (rendering.py:7-46).  Both waves build the cdf redundantly
 // (identical values) so only the sample / merge phases need the partner.
-__device__ __forceinline__ void sample_pdf_pair(PairScratch& s, int Nc, int Ni, const float* u_row, int lane, int lane128) {
+// rng != null: the uniforms are drawn in-kernel (philox.h, stream RNG_STREAM_U, ray index rng_ray) instead of read from u_row.
+__device__ __forceinline__ void sample_pdf_pair(PairScratch& s, int Nc, int Ni, const float* u_row, int lane, int lane128, const RayRng* rng = nullptr,
+                                                long rng_ray = 0) {
   const int n_ = Nc - 2;
   const float eps = 1e-5f;
   float part = 0.0f;
@@ -58,7 +61,7 @@ __device__ __forceinline__ void sample_pdf_pair(PairScratch& s, int Nc, int Ni, 
   if (lane == 0) s.cdf[0] = 0.0f;
   wave_lds_fence();
   for (int k = lane128; k < Ni; k += 128) {
-    const float u = u_row ? u_row[k] : linspace01(k, Ni);
+    const float u = rng ? rng->uniform(RNG_STREAM_U, rng_ray, k) : (u_row ? u_row[k] : linspace01(k, Ni));
     int lo = 0, hi = n_ + 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "kernels.h"
+#include "philox.h"
 #include "ray_ops.h"
 
 namespace crnerf {
@@ -277,6 +278,24 @@ int launch_composite_backward(const float* raw, const float* z, const float* noi
                      d_weights, d_raw, R, N);
 #endif
   return check_launch("composite_backward_kernel");
+}
+
+// The renderer's in-kernel draws as a tensor (crnerf_rng_fill_f32): out[r * n + s] = draw(seed, stream, ray_offset + r, s).
+__global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, long total, int n, RayRng rng, int stream_id, long ray_offset) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / n;
+    const int s = (int)(idx - r * n);
+    out[idx] = stream_id >= RNG_STREAM_NOISE_COARSE ? rng.normal(stream_id, ray_offset + r, s) : rng.uniform(stream_id, ray_offset + r, s);
+  }
+}
+
+int launch_rng_fill(float* out, long R, int n, unsigned long long seed, int stream_id, long ray_offset, hipStream_t stream) {
+  const long total = R * (long)n;
+  if (total <= 0) return 0;
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, out, total, n,
+                     RayRng{(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)}, stream_id, ray_offset);
+  return check_launch("rng_fill_kernel");
 }
 
 }  // namespace crnerf

@@ -24,6 +24,9 @@ struct RenderParams16 {
   long R; int Nc, Ni, iters;
   unsigned int* sched;   // null: static quad -> workgroup map (iters passes); else {next-quad counter, finished-workgroup counter}
   float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
+  // in-kernel random draws (include/crnerf.h, philox.h); rng_flags == 0: none
+  unsigned long long rng_seed; long rng_ray_offset; int rng_flags; float perturb;
+  float* z_coarse_out; float* noise_c_out; float* noise_f_out;
 };
 
 static __device__ unsigned int crnerf_sched16[SCHED_SLOTS][2];   // kernels.h "Dynamic work distribution"
@@ -52,7 +55,10 @@ struct TrainHook {
   }
 };
 
-template <class HOOK>
+// RNG: the instantiation with the in-kernel random draws (philox.h).  It is a template parameter, not a runtime flag: the keys, the
+// global ray index and three more output pointers would otherwise be live across the MLP of EVERY launch (measured: 10 -> 20
+// spilled registers in the inference kernel, 77 -> 90 in the training twin).
+template <bool RNG, class HOOK>
 __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, const HOOK& hook) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
@@ -102,8 +108,22 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
       }
     }
     const DirLds dirsrc{dirbuf + 8 * g};
-    for (int n = lane128; n < Nc; n += 128)
-      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    const RayRng rng{(uint32_t)(a.rng_seed & 0xffffffffu), (uint32_t)(a.rng_seed >> 32)};
+    const long rng_ray = a.rng_ray_offset + r;
+    for (int n = lane128; n < Nc; n += 128) {
+      auto zlin = [&](int k) { return coarse_depth(near, far, a.z_steps ? a.z_steps[k] : linspace01(k, Nc), a.use_disp); };
+      float zv;
+      if (a.z_coarse) zv = a.z_coarse[r * Nc + n];
+      else if (RNG && (a.rng_flags & 1)) {
+        // rendering.py:169-176: mid-points, lower / upper interval ends, z = lower + (upper - lower) * (perturb * U[0,1))
+        const float z0 = zlin(n);
+        const float lower = n == 0 ? z0 : 0.5f * (zlin(n - 1) + z0);
+        const float upper = n == Nc - 1 ? z0 : 0.5f * (z0 + zlin(n + 1));
+        zv = lower + (upper - lower) * (a.perturb * rng.uniform(RNG_STREAM_JITTER, rng_ray, n));
+      } else zv = zlin(n);
+      scr.zc[n] = zv;
+      if (RNG && a.z_coarse_out && ray_ok) a.z_coarse_out[r * Nc + n] = zv;
+    }
     wg_barrier();
 
     const int npass = Ni > 0 ? 2 : 1;
@@ -133,7 +153,13 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
         mlp_tile16(pipe, pass, pe, dirsrc, feat, sigma, g, q, tm, hook.saver(pass, r, N, n, valid && ray_ok, g));
         hook.raw(pass, r, N, n, valid && ray_ok, g, feat, sigma);
         // ---- compositing, rendering.py:121-143
-        const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        if (RNG && (a.rng_flags & 4) && valid) {          // rendering.py:125  noise = randn_like(sigma) * noise_std
+          const float draw = rng.normal(pass ? RNG_STREAM_NOISE_FINE : RNG_STREAM_NOISE_COARSE, rng_ray, n);
+          noise = draw * a.noise_std;
+          float* no = pass ? a.noise_f_out : a.noise_c_out;
+          if (no && ray_ok && g == 0) no[r * N + n] = draw;
+        }
         const float delta = (n == N - 1) ? 1e2f : znext - zn;
         const float alpha = valid ? 1.0f - expf(-delta * fmaxf(sigma + noise, 0.0f)) : 0.0f;
         double incl = (double)(1.0f - alpha);
@@ -188,7 +214,7 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
         if (g == 0) (pass ? a.depth_f : a.depth_c)[r] = dacc + scr.xfeat[64];
       }
       if (pass == 0 && Ni > 0) {
-        sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128);
+        sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128, (RNG && (a.rng_flags & 2)) ? &rng : nullptr, rng_ray);
         wg_barrier();
         merge_sort_pair(scr, Nc, Ni, lane128);
         wg_barrier();
@@ -209,11 +235,13 @@ __device__ __forceinline__ void render_rays16_impl(const RenderParams16& a, cons
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a) { render_rays16_impl(a, NoHook{}); }
+__global__ __launch_bounds__(512, 2) void render_rays16_kernel(RenderParams16 a) { render_rays16_impl<false>(a, NoHook{}); }
+__global__ __launch_bounds__(512, 2) void render_rays16_rng_kernel(RenderParams16 a) { render_rays16_impl<true>(a, NoHook{}); }
 
 // Fused TRAINING forward: the same launch (posenc -> MLP -> compositing, coarse -> sample_pdf -> fine) that also keeps what
 // the backward twins need -- no [P,93] / [P,120] embeddings and no separate compositing pass ever exist in HBM.
-__global__ __launch_bounds__(512, 2) void render_rays_train16_kernel(RenderParams16 a, TrainHook h) { render_rays16_impl(a, h); }
+__global__ __launch_bounds__(512, 2) void render_rays_train16_kernel(RenderParams16 a, TrainHook h) { render_rays16_impl<false>(a, h); }
+__global__ __launch_bounds__(512, 2) void render_rays_train16_rng_kernel(RenderParams16 a, TrainHook h) { render_rays16_impl<true>(a, h); }
 
 int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
@@ -229,6 +257,8 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
   k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
+  k.rng_seed = a.rng_seed; k.rng_ray_offset = a.rng_ray_offset; k.rng_flags = a.rng_flags; k.perturb = a.perturb;
+  k.z_coarse_out = a.z_coarse_out; k.noise_c_out = a.noise_coarse_out; k.noise_f_out = a.noise_fine_out;
   const long quads = (a.R + 3) / 4;
   const int cus = num_cus();
   const int grid = (int)(quads < cus ? quads : cus);
@@ -239,12 +269,18 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train: raw_coarse is NULL");
     TrainHook h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
-    if (int rc = ensure_dynamic_lds((const void*)render_rays_train16_kernel, shmem, "render_rays_train16_kernel")) return rc;
-    hipLaunchKernelGGL(render_rays_train16_kernel, dim3(grid), dim3(512), shmem, stream, k, h);
+    const bool rngk = a.rng_flags != 0 || a.z_coarse_out;
+    const void* fn = rngk ? (const void*)render_rays_train16_rng_kernel : (const void*)render_rays_train16_kernel;
+    if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_train16_kernel")) return rc;
+    if (rngk) hipLaunchKernelGGL(render_rays_train16_rng_kernel, dim3(grid), dim3(512), shmem, stream, k, h);
+    else hipLaunchKernelGGL(render_rays_train16_kernel, dim3(grid), dim3(512), shmem, stream, k, h);
     return check_launch("render_rays_train16_kernel");
   }
-  if (int rc = ensure_dynamic_lds((const void*)render_rays16_kernel, shmem, "render_rays16_kernel")) return rc;
-  hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
+  const bool rngk = a.rng_flags != 0 || a.z_coarse_out;
+  const void* fn = rngk ? (const void*)render_rays16_rng_kernel : (const void*)render_rays16_kernel;
+  if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays16_kernel")) return rc;
+  if (rngk) hipLaunchKernelGGL(render_rays16_rng_kernel, dim3(grid), dim3(512), shmem, stream, k);
+  else hipLaunchKernelGGL(render_rays16_kernel, dim3(grid), dim3(512), shmem, stream, k);
   return check_launch("render_rays16_kernel");
 }
 

@@ -115,23 +115,31 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     R = rays.shape[0]
     view_dir = kwargs.get('view_dir', None)
     z_coarse = u = noise_c = noise_f = None
-    if perturb > 0:
+    from ..autograd import get_training_bf16, get_training_recompute
+    fused_train = (train and not get_training_bf16() and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
+                   and (N_importance == 0 or N_samples >= 3))
+    rng = None
+    if fused_train and (perturb > 0 or noise_std != 0) and ops.in_kernel_rng():
+        # the fused fp32 training kernel draws the jitter / sample_pdf uniforms / density noise itself (csrc/philox.h): no [R,N] random
+        # tensors, no launches for them.  The seed comes from torch's CPU generator, so torch.manual_seed() governs the run.
+        rng = {"seed": int(torch.randint(0, 2 ** 62, (1,), device="cpu")), "perturb": float(perturb), "jitter": perturb > 0, "u": perturb > 0,
+               "noise": noise_std != 0}
+    if rng is None and perturb > 0:
         z_coarse = _coarse_depths(rays, N_samples, use_disp, perturb)
         if N_importance > 0:
             u = torch.rand(R, N_importance, device=rays.device)
-    if noise_std != 0:
+    if noise_std != 0 and rng is None:
         noise_c = torch.randn(R, N_samples, device=rays.device)
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    from ..autograd import get_training_bf16, get_training_recompute
     if (train and (not get_training_bf16() or get_training_recompute()) and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
             and (N_importance == 0 or N_samples >= 3)):
         # training: the fused renderer's training twin (one launch per ray chunk: posenc + MLPs + activation save + compositing +
         # sample_pdf/merge) as one autograd node whose backward runs the HIP backward twins (autograd.FusedRenderFn)
         from ..autograd import fused_render_with_grad
         out = fused_render_with_grad(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
-                                     float(noise_std))
+                                     float(noise_std), rng=rng)
     elif train or N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
         # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
         # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)

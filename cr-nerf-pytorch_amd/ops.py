@@ -272,10 +272,14 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
 
 
 def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
-                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False, launcher=False):
+                noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False, launcher=False, rng=None):
     """Fused renderer.  Returns a dict of freshly allocated tensors.  train=True (fp32 only): the training twin
     crnerf_render_rays_train_f32 -- the dict additionally holds what the backward needs: z_coarse (as used), z_fine,
-    acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65]."""
+    acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65].
+    rng (fp32 only): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
+    steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
+    handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
+    "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
     bf16 = _is_bf16(precision)
     if train and bf16:
@@ -310,6 +314,19 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine"):
         setattr(a, k, out[k].data_ptr() if k in out else None)
+    if rng is not None:
+        if bf16:
+            raise ValueError("crnerf_amd: in-kernel random draws exist in the fp32 kernels only")
+        flags = (_lib.RNG_JITTER if rng.get("jitter") else 0) | (_lib.RNG_U if (rng.get("u") and Ni > 0) else 0) | (_lib.RNG_NOISE if rng.get("noise") else 0)
+        a.rng_seed, a.rng_ray_offset, a.rng_flags, a.perturb = int(rng["seed"]) & (2 ** 64 - 1), int(rng.get("ray_offset", 0)), flags, float(rng.get("perturb", 1.0))
+        out["z_coarse_used"] = new(R, Nc)
+        a.z_coarse_out = out["z_coarse_used"].data_ptr()
+        if flags & _lib.RNG_NOISE:
+            out["noise_coarse_used"] = new(R, Nc)
+            a.noise_coarse_out = out["noise_coarse_used"].data_ptr()
+            if Ni > 0:
+                out["noise_fine_used"] = new(R, Nc + Ni)
+                a.noise_fine_out = out["noise_fine_used"].data_ptr()
     if launcher:      # measurement helper: re-launch the same call on the same buffers with nothing but the C call on the host side
         if train:
             raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
@@ -334,6 +351,34 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
         return out
     fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
+    return out
+
+
+_IN_KERNEL_RNG = [None]
+
+
+def set_in_kernel_rng(on=True):
+    """True (default): grad-mode renders through the fused fp32 kernel draw their stratified jitter / sample_pdf uniforms / density
+    noise inside the kernel (Philox keyed on (seed, ray, sample)); False: torch.rand / torch.randn tensors handed to the kernel, the
+    round-1/2 path.  CRNERF_IN_KERNEL_RNG=0 does the same from the environment."""
+    _IN_KERNEL_RNG[0] = bool(on)
+
+
+def in_kernel_rng():
+    import os
+    if _IN_KERNEL_RNG[0] is not None:
+        return _IN_KERNEL_RNG[0]
+    return os.environ.get("CRNERF_IN_KERNEL_RNG", "1") not in ("0", "")
+
+
+def rng_fill(n_rays, n, seed, stream, ray_offset=0, device="cuda"):
+    """The renderer's in-kernel draws as a tensor [n_rays, n] (crnerf_rng_fill_f32): stream 0 = jitter uniforms, 1 = sample_pdf
+    uniforms, 2 = coarse noise, 3 = fine noise.  Feeding these through render_rays' tensor arguments reproduces the in-kernel
+    path bit for bit (tests/test_gpu_rng.py)."""
+    lib = _lib.load()
+    out = torch.empty(int(n_rays), int(n), dtype=torch.float32, device=device)
+    _lib.check(lib.crnerf_rng_fill_f32(ctypes.c_void_p(out.data_ptr()), int(n_rays), int(n), int(seed) & (2 ** 64 - 1), int(stream), int(ray_offset),
+                                       _lib.stream_ptr()), "crnerf_rng_fill_f32")
     return out
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CRNERF_ABI_VERSION 1
+#define CRNERF_ABI_VERSION 2    /* 2: crnerf_render_args grew the in-kernel random-draw fields (appended), crnerf_rng_fill_f32 */
 
 #define CRNERF_OK 0
 #define CRNERF_ERR_NULL (-1)     /* required pointer is NULL */
@@ -149,7 +149,24 @@ typedef struct crnerf_render_args {
   float* feature_fine;          /* [R,64] */
   float* depth_fine;            /* [R] */
   float* z_fine;                /* [R,Nc+Ni] optional debug/test output, NULL to skip */
+  /* ---- in-kernel random draws (ABI 2; crnerf_render_rays_f32 and crnerf_render_rays_train_f32 only).  rng_flags == 0: everything
+   * above is used as given.  Draws are Philox4x32-10 keyed on rng_seed, counter = (sample, stream, rng_ray_offset + ray): a pure
+   * function of the GLOBAL ray index, so ray chunks and the backward's recomputation see the same numbers.  The same draws as
+   * tensors: crnerf_rng_fill_f32 (feeding them through z_coarse / u / noise_* gives bit-identical results). */
+  uint64_t rng_seed;
+  int64_t rng_ray_offset;       /* index of rays[0] in the caller's batch */
+  int32_t rng_flags;            /* CRNERF_RNG_* below */
+  float perturb;                /* jitter amplitude, rendering.py:175 (CRNERF_RNG_JITTER) */
+  float* z_coarse_out;          /* [R,Nc] optional: the coarse depths used (the backward composites at them) */
+  float* noise_coarse_out;      /* [R,Nc] optional: the standard-normal draws used by the coarse pass (CRNERF_RNG_NOISE) */
+  float* noise_fine_out;        /* [R,Nc+Ni] optional */
 } crnerf_render_args;
+#define CRNERF_RNG_JITTER 1     /* stratified jitter of the coarse depths, rendering.py:169-176: z_coarse must be NULL */
+#define CRNERF_RNG_U 2          /* sample_pdf's uniforms (det = False), rendering.py:30: u must be NULL */
+#define CRNERF_RNG_NOISE 4      /* density noise randn * noise_std, rendering.py:125: noise_coarse / noise_fine must be NULL */
+/* The draws of stream `stream` (0 jitter uniforms, 1 sample_pdf uniforms, 2 coarse noise, 3 fine noise) as a tensor:
+ * out[r * n + s] = draw(seed, stream, ray_offset + r, s); streams 0 / 1 are U[0,1) on the 2^-24 grid, 2 / 3 standard normal. */
+int crnerf_rng_fill_f32(float* out, int64_t n_rays, int n, uint64_t seed, int stream, int64_t ray_offset, void* stream_handle);
 int crnerf_render_rays_f32(const crnerf_render_args* args, void* stream);
 
 /* Training twin of the call above (the reference trains THROUGH render_rays_cross_ray under autograd, rendering.py:100-143):

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_symbols():
         assert hasattr(lib, name), name
     lib.crnerf_abi_version.restype = ctypes.c_int
-    assert lib.crnerf_abi_version() == 1
+    assert lib.crnerf_abi_version() == 2
     lib.crnerf_packed_mlp_bytes.restype = ctypes.c_size_t
     assert lib.crnerf_packed_mlp_bytes() == 11264 + 2416 * 1024
     # error path without touching a device: NULL arguments are rejected with a message
