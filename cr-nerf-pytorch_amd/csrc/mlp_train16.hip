@@ -675,7 +675,10 @@ static int launch_wgrad_batch(const WgradSpec* specs, int n, long P, float* ws, 
 // The weight / bias gradients of all eleven nn.Linear from the saved activations and the stored deltas (shared by the fp32 twins and
 // the mixed-precision twins of mlp_gemm_bf16.hip).  wb != 0: bf16-operand path (CRNERF_BWD_WGRAD_BF16).  Two launches in all (every
 // job in one batched launch + one reduction) at small batches.  (An eight-wave variant of the full-block kernel -- two waves per SIMD,
-// 64 x 128 per wave -- was 15 % SLOWER at 2^17 and 2^21 points: the kernel is not short of waves.)
+// 64 x 128 per wave -- was 15 % SLOWER at 2^17 and 2^21 points, and a dedicated full-block kernel with the operand rows of 8 or 12
+// k-steps in flight instead of 4 changed nothing: the kernel is short of neither waves nor prefetch depth.  Counters
+// (profiles/r3/pmc_train_sq.txt): matrix pipe busy 85.6 % of the kernel's cycles at a shader clock of 2.07 GHz -- the 2.4 TB/s of
+// operand traffic costs clock, not issue slots; 0.856 x 2.07 / 2.4 = the measured 74 % of the 157.3 TFLOP/s figure.)
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
                       long P, hipStream_t stream, int wb) {
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
