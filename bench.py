@@ -241,10 +241,13 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
                             "frac_attainable_1890": tf / 1890.0, "rays_per_s_kernel_only": R / (ms * 1e-3),
                             "multi_pass_16x": {"rays": 16 * R, "launch_ms": ms16, "ms_per_%d_rays" % R: ms16 / 16, "achieved_tflops": tf16,
                                                "frac_nominal_2500": tf16 / PEAK_BF16_MFMA_TFLOPS, "frac_attainable_1890": tf16 / 1890.0},
-                            "note": "kernel_ms = launch-to-launch time of 50 back-to-back C-ABI launches (rocprofv3 --kernel-trace reports the kernel itself at "
-                                    "0.244-0.263 ms = 0.49-0.53 depending on the box, profiles/r2/kernel_stats_bf16*.csv: ~20 us pass between two "
-                                    "launches of this kernel, 4-10 us for the fp32 kernel).  1890 TFLOP/s = bare v_mfma_f32_32x32x16_bf16 stream measured on this part "
-                                    "under sustained load (profiles/r1/ubench_mfma_stream.txt); same %d-ray batch and weights as the timed fp32 step" % R,
+                            "note": "kernel_ms = launch-to-launch time of 50 back-to-back C-ABI launches of the pair core (render_rays_bf16p_kernel: one ray per wave "
+                                    "pair, two waves per SIMD; CRNERF_BF16_CORE=64 selects the round-2 kernel).  The kernel is POWER-governed on this part "
+                                    "(profiles/r3/energy_probe.txt, DESIGN 3.7): the pair core spends 372k cycles per ray pair against 426k for the round-2 kernel "
+                                    "(matrix pipe busy 88 %% vs 72 %%) and the shader clock drops from 1.85 to 1.65 GHz, same wall time; with all-zero operands the SAME "
+                                    "binary runs at 2.4 GHz = 0.78 (single launch) / 0.82 (multi-pass) of the nominal 2.5 PFLOP/s; the MLP stream alone (no per-ray "
+                                    "work, same ring) caps at 0.57 / 0.59 with random operands.  1890 TFLOP/s = bare v_mfma_f32_32x32x16_bf16 stream under sustained "
+                                    "load (profiles/r1/ubench_mfma_stream.txt); same %d-ray batch and weights as the timed fp32 step" % R,
                             "parity_smooth_nets": {"vs_fp32_oracle_end_to_end": bf["end_to_end"], "vs_bf16_oracle_identical_depths": bf["identical_depths"],
                                                    "image_high_contrast_vs_fp32_oracle": bf["image_high_contrast"]}}
 
