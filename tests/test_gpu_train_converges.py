@@ -1,0 +1,49 @@
+"""Does the drop-in TRAIN like the reference?  tests/golden/g15_trained.npz holds the loss / PSNR curve of the reference's own
+modules trained on the procedural scene of tests/_procedural_scene.py (CPU, 1,500 steps, command/train.sh's configuration: encode_a,
+encode_c, encode_random, use_mask, Adam lr 5e-4, perturb = 1, noise_std = 1, 32+32 samples).  Here pipeline.TrainingSystem -- the
+NeRFSystem mirror on the HIP twins: fused training renderer with in-kernel jitter / noise, four decodes, three encoder passes, the
+CGNet mask, the fused CRNeRF loss, backward through every twin, torch's fused Adam -- is trained on the IDENTICAL images from its own
+default initialisation.  Random streams differ (initial weights, jitter, noise, image order), so the curves are compared as curves:
+the window means of the fine-image PSNR must track the reference's within 1.5 dB, and the loss must fall like the reference's."""
+import numpy as np
+import pytest
+import torch
+
+import _procedural_scene as S
+from crnerf_amd import pipeline
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_training_system_learns_the_scene_like_the_reference(golden):
+    ref = golden("g15_trained")["train_log"]                    # [1500, 3]: step, loss, psnr_fine of the batch
+    torch.manual_seed(11)
+    rng = np.random.default_rng(7)
+    data = S.make_dataset(rng)[:S.N_IMAGES]                     # the same generator state as the fixture's run: identical images
+    hp = S.hparams()
+    sysm = pipeline.TrainingSystem(hp, device=DEV)
+    opt = torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
+    idx = torch.arange(S.SIDE * S.SIDE, device=DEV)
+    batches = [dict(rays=b["rays"].to(DEV), ts=b["ts"].to(DEV), rgbs=b["rgbs"].to(DEV), whole_img=S.whole_image(b["rgbs"]).to(DEV), rgb_idx=idx,
+                    img_wh=(S.SIDE, S.SIDE)) for b in data]
+    steps = 600
+    log = np.zeros((steps, 2))
+    for step in range(steps):
+        b = batches[int(rng.integers(S.N_IMAGES))]
+        opt.zero_grad(set_to_none=True)
+        loss, loss_d, res = sysm.training_step(b)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            log[step] = float(loss), float(-10 * torch.log10(((res["rgb_fine"] - b["rgbs"]) ** 2).mean()))
+    assert np.isfinite(log).all()
+    windows = ((0, 50), (200, 300), (300, 400), (400, 600))
+    ours = [log[a:b, 1].mean() for a, b in windows]
+    theirs = [ref[a:b, 2].mean() for a, b in windows]
+    print("PSNR window means  HIP %s  reference %s" % (np.round(ours, 2), np.round(theirs, 2)))
+    print("loss window means  HIP %s  reference %s" % (np.round([log[a:b, 0].mean() for a, b in windows], 5), np.round([ref[a:b, 1].mean() for a, b in windows], 5)))
+    for o, t, w in zip(ours, theirs, windows):
+        assert abs(o - t) <= 1.5, (w, o, t)
+    assert ours[-1] - ours[0] >= 0.6 * (theirs[-1] - theirs[0]) > 1.0          # it learns, at the reference's pace
+    assert log[400:, 0].mean() <= 1.25 * ref[400:600, 1].mean()                 # and the total loss (all seven terms) falls like the reference's
