@@ -28,7 +28,7 @@ EXPORTS = [
     "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
-    "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
+    "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_train_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
     "crnerf_fglo_f32", "crnerf_fglo_backward_f32", "crnerf_bilinear_gather_f32", "crnerf_bilinear_gather_backward_f32",
     "crnerf_peer_window_bytes", "crnerf_peer_window_create", "crnerf_peer_window_open", "crnerf_peer_window_close", "crnerf_peer_window_destroy",
     "crnerf_peer_window_status", "crnerf_peer_allreduce_f32",
@@ -172,6 +172,7 @@ def load():
             "crnerf_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp]),
             "crnerf_conv2d_backward_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp, vp, vp]),
             "crnerf_bn_prelu_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, vp]),
+            "crnerf_bn_prelu_train_f32": (ctypes.c_int, [vp] * 11 + [f32, i32, i64, f32, vp]),
             "crnerf_bn_prelu_backward_f32": (ctypes.c_int, [vp] * 11 + [i32, i64, i32, vp]),
             "crnerf_avgpool3s2_f32": (ctypes.c_int, [vp, vp, i32, i32, i32, i32, vp]),
             "crnerf_fglo_f32": (ctypes.c_int, [vp] * 7 + [i32, i32, i64, vp]),

@@ -352,8 +352,12 @@ class BNPReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, alpha, bn):
         training = bn.training or bn.running_mean is None
-        y, mean, invstd, var_u = ops.bn_prelu(x, gamma, beta, alpha, bn.eps, training, bn.running_mean, bn.running_var)
-        if training and bn.track_running_stats and bn.running_mean is not None:
+        fused_update = (training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+                        and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_cuda
+                        and (bn.num_batches_tracked is None or (bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64)))
+        y, mean, invstd, var_u = ops.bn_prelu(x, gamma, beta, alpha, bn.eps, training, bn.running_mean, bn.running_var,
+                                              update=(bn.momentum, bn.num_batches_tracked) if fused_update else None)
+        if training and bn.track_running_stats and bn.running_mean is not None and not fused_update:
             with torch.no_grad():
                 bn.num_batches_tracked += 1
                 m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)

@@ -534,6 +534,17 @@ int crnerf_bn_prelu_f32(const float* x, const float* gamma, const float* beta, c
   return launch_cg_bn_prelu_forward(x, gamma, beta, alpha, mean, invstd, var_unbiased, y, C, (int)HW, eps, training, (hipStream_t)stream);
 }
 
+int crnerf_bn_prelu_train_f32(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
+                              float* y, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, int C, int64_t HW, float eps,
+                              void* stream) {
+  REQUIRE(x, "x"); REQUIRE(gamma, "gamma"); REQUIRE(beta, "beta"); REQUIRE(alpha, "alpha"); REQUIRE(mean, "mean"); REQUIRE(invstd, "invstd"); REQUIRE(y, "y");
+  REQUIRE(var_unbiased, "var_unbiased"); REQUIRE(running_mean, "running_mean"); REQUIRE(running_var, "running_var");
+  if (C <= 0 || HW <= 0 || HW > (1 << 30)) return set_error(CRNERF_ERR_SHAPE, "bn_prelu_train: C and HW must be positive");
+  if (!(momentum >= 0.0f && momentum <= 1.0f)) return set_error(CRNERF_ERR_CONFIG, "bn_prelu_train: momentum must be in [0, 1]");
+  return launch_cg_bn_prelu_forward(x, gamma, beta, alpha, mean, invstd, var_unbiased, y, C, (int)HW, eps, 1, (hipStream_t)stream, running_mean, running_var,
+                                    (long long*)num_batches_tracked, momentum);
+}
+
 int crnerf_bn_prelu_backward_f32(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean, const float* invstd,
                                  const float* d_y, float* d_x, float* d_gamma, float* d_beta, float* d_alpha, int C, int64_t HW, int training,
                                  void* stream) {

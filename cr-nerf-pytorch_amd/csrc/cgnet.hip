@@ -146,7 +146,9 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 // training: batch statistics (biased variance for the normalisation), written to mean / invstd; eval: mean / invstd given
 __global__ __launch_bounds__(256) void cg_bn_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ alpha, float* __restrict__ mean, float* __restrict__ invstd,
-                                                              float* __restrict__ var_unbiased, float* __restrict__ y, int HW, float eps, int training) {
+                                                              float* __restrict__ var_unbiased, float* __restrict__ y, int HW, float eps, int training,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ n_tracked,
+                                                              float momentum) {
   __shared__ float red[4];
   const int c = blockIdx.x;
   const float* xc = x + (long)c * HW;
@@ -159,7 +161,15 @@ __global__ __launch_bounds__(256) void cg_bn_prelu_fwd_kernel(const float* __res
     for (int p = threadIdx.x; p < HW; p += 256) { const float d = xc[p] - m; q += d * d; }
     const float ss = block_sum256(q, red);
     is = rsqrtf(ss / (float)HW + eps);
-    if (threadIdx.x == 0) { mean[c] = m; invstd[c] = is; var_unbiased[c] = HW > 1 ? ss / (float)(HW - 1) : ss; }
+    if (threadIdx.x == 0) {
+      const float vu = HW > 1 ? ss / (float)(HW - 1) : ss;
+      mean[c] = m; invstd[c] = is; var_unbiased[c] = vu;
+      if (run_mean) {   // nn.BatchNorm2d's momentum update of the running buffers (torch: running.mul_(1 - momentum).add_(stat, alpha=momentum))
+        run_mean[c] = fmaf(momentum, m, run_mean[c] * (1.0f - momentum));
+        run_var[c] = fmaf(momentum, vu, run_var[c] * (1.0f - momentum));
+        if (c == 0 && n_tracked) n_tracked[0] += 1;
+      }
+    }
   } else {
     m = mean[c];
     is = invstd[c];
@@ -202,8 +212,10 @@ __global__ __launch_bounds__(256) void cg_bn_prelu_bwd_kernel(const float* __res
 }
 
 int launch_cg_bn_prelu_forward(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
-                               float* y, int C, int HW, float eps, int training, hipStream_t st) {
-  hipLaunchKernelGGL(cg_bn_prelu_fwd_kernel, dim3(C), dim3(256), 0, st, x, gamma, beta, alpha, mean, invstd, var_unbiased, y, HW, eps, training);
+                               float* y, int C, int HW, float eps, int training, hipStream_t st, float* run_mean, float* run_var, long long* n_tracked,
+                               float momentum) {
+  hipLaunchKernelGGL(cg_bn_prelu_fwd_kernel, dim3(C), dim3(256), 0, st, x, gamma, beta, alpha, mean, invstd, var_unbiased, y, HW, eps, training, run_mean,
+                     run_var, n_tracked, momentum);
   return check_launch("cg_bn_prelu_forward");
 }
 int launch_cg_bn_prelu_backward(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean, const float* invstd,

@@ -130,7 +130,8 @@ struct ConvGeom { int cin, cout, H, W, Ho, Wo, k, stride, pad, dil, depthwise; }
 int launch_cg_conv_forward(const ConvGeom& g, const float* x, const float* w, float* y, hipStream_t st);
 int launch_cg_conv_backward(const ConvGeom& g, const float* x, const float* w, const float* dy, float* dx, float* dw, hipStream_t st);
 int launch_cg_bn_prelu_forward(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
-                               float* y, int C, int HW, float eps, int training, hipStream_t st);
+                               float* y, int C, int HW, float eps, int training, hipStream_t st, float* run_mean = nullptr, float* run_var = nullptr,
+                               long long* n_tracked = nullptr, float momentum = 0.0f);
 int launch_cg_bn_prelu_backward(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean, const float* invstd,
                                 const float* dy, float* dx, float* dgamma, float* dbeta, float* dalpha, int C, int HW, int training, hipStream_t st);
 int launch_cg_avgpool(const float* in, float* out, int C, int H, int W, int backward, hipStream_t st);

@@ -706,11 +706,25 @@ def conv2d_backward(x, w, d_y, stride=1, padding=0, dilation=1, groups=1, want_d
     return dx, dw
 
 
-def bn_prelu(x, gamma, beta, alpha, eps, training, running_mean=None, running_var=None):
-    """BatchNorm2d + PReLU.  Returns (y, mean, invstd, var_unbiased); eval mode reads the running statistics."""
+def bn_prelu(x, gamma, beta, alpha, eps, training, running_mean=None, running_var=None, update=None):
+    """BatchNorm2d + PReLU.  Returns (y, mean, invstd, var_unbiased); eval mode reads the running statistics.
+    update=(momentum, num_batches_tracked or None) in training mode: the momentum update of running_mean / running_var (and the step
+    counter) happens in the SAME launch (crnerf_bn_prelu_train_f32) instead of five element-wise launches per layer."""
     lib = _lib.load()
     x, (C, H, W) = _chw(x, "x")
     y = torch.empty_like(x)
+    if training and update is not None:
+        mean, invstd, var_u = (torch.empty(C, device=x.device) for _ in range(3))
+        momentum, nbt = update
+        for t, n in ((running_mean, "running_mean"), (running_var, "running_var")):
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("crnerf_amd: %s must be a contiguous float32 GPU buffer" % n)
+        _lib.check(lib.crnerf_bn_prelu_train_f32(_lib.dev_ptr(x), _lib.dev_ptr(_f32c(gamma, "bn.weight")), _lib.dev_ptr(_f32c(beta, "bn.bias")),
+                                                 _lib.dev_ptr(_f32c(alpha, "act.weight")), _lib.dev_ptr(mean), _lib.dev_ptr(invstd), _lib.dev_ptr(var_u),
+                                                 _lib.dev_ptr(y), _lib.dev_ptr(running_mean), _lib.dev_ptr(running_var),
+                                                 ctypes.c_void_p(nbt.data_ptr()) if nbt is not None else None, float(momentum), C, H * W, float(eps),
+                                                 _lib.stream_ptr()), "crnerf_bn_prelu_train_f32")
+        return y, mean, invstd, var_u
     if training:
         mean, invstd, var_u = (torch.empty(C, device=x.device) for _ in range(3))
     else:

@@ -352,6 +352,11 @@ int crnerf_conv2d_backward_f32(const crnerf_conv_geom* geom, const float* x, con
  * update of running_mean / running_var with them); training == 0: mean / invstd are READ (running statistics). */
 int crnerf_bn_prelu_f32(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd,
                         float* var_unbiased, float* y, int C, int64_t HW, float eps, int training, void* stream);
+/* The training-mode call that ALSO applies nn.BatchNorm2d's momentum update in the same launch (lightweight_seg.py BatchNorm2d defaults:
+ * momentum 0.1): running = running * (1 - momentum) + momentum * batch statistic (unbiased variance), num_batches_tracked += 1 (may be NULL). */
+int crnerf_bn_prelu_train_f32(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd,
+                              float* var_unbiased, float* y, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, int C, int64_t HW, float eps, void* stream);
 int crnerf_bn_prelu_backward_f32(const float* x, const float* gamma, const float* beta, const float* alpha, const float* mean,
                                  const float* invstd, const float* d_y, float* d_x, float* d_gamma, float* d_beta, float* d_alpha, int C,
                                  int64_t HW, int training, void* stream);

@@ -14,7 +14,7 @@ pc, pf = ops.pack_mlp_weights(C(synth.mlp_state(1, 3.0, 1.0)), precision="bf16")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rays = torch.from_numpy(synth.rays(R)).to(dev)
 lib = _lib.load()
-fn = lib.crnerf_debug_read_wgtimes_bf16
+fn = lib.crnerf_debug_read_wgtimes_bf16 if os.environ.get("CRNERF_BF16_CORE") == "64" else lib.crnerf_debug_read_wgtimes_bf16p
 fn.argtypes = [ctypes.c_void_p]
 for rep in range(4):
     for _ in range(3):
