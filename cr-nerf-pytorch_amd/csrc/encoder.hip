@@ -12,6 +12,9 @@
 
 namespace crnerf {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.2f * v; }
 __device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }   // ReflectionPad2d(1)
 
@@ -98,6 +101,92 @@ __global__ __launch_bounds__(256) void conv_kernel(const float* __restrict__ in,
   }
 }
 
+// ---- the wide layers (cin >= 64) as GEMMs on the fp32 matrix cores -------------------------------------------------------
+// At the sizes this encoder sees (32x32 ... 64x48 photos: 64 ... 3,072 pixels per layer) the direct kernel above is bound by
+// the length of one wave's dependent load -> FMA chain (16 ... 36 us per layer whatever the map size; the data gradient twice
+// that).  A 3x3 convolution over reflection-padded patches IS a GEMM over the patch matrix X[px][c*9+tap] that the backward
+// builds for the weight gradient anyway, with the ORIGINAL weight tensor w[cout][cin][3][3] = W[cout][cin*9] as second operand.
+//
+// C[m][n] = act(bias[n] + sum_k A[m][k] * B[n][k]): both operands K-contiguous ("NT").  One workgroup = ONE 32 x 32 tile of C;
+// its four waves split K (fixed ranges; partial tiles are added in wave order through LDS: deterministic).  v_mfma_f32_32x32x2_f32:
+// lane (i, kk) loads 16 bytes of row i of A and of row i of B at k = 8s + 4kk .. + 3 and issues four MFMAs (k pairs {8s + t,
+// 8s + 4 + t}; the order of k inside a dot product is free as long as both operands agree).  K % 8 == 0, lda / ldb % 4 == 0.
+template <bool ACT>
+__global__ __launch_bounds__(256) void enc_gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N, int K) {
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int mr = m0 + i < M ? m0 + i : M - 1, nr = n0 + i < N ? n0 + i : N - 1;   // clamped rows: always readable, dropped at the store
+  const int chunks = K >> 3, q = chunks >> 2, r = chunks & 3;
+  const int s0 = wave * q + (wave < r ? wave : r), s1 = s0 + q + (wave < r ? 1 : 0);
+  const float* ap = A + (long)mr * lda + 4 * kk;
+  const float* bp = B + (long)nr * ldb + 4 * kk;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  constexpr int U = 4;                                    // chunks in flight: 8 loads ahead of their 16 MFMAs
+  f32x4 a[U], b[U];
+  int s = s0;
+  for (; s + U <= s1; s += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) { a[u] = *(const f32x4*)(ap + 8 * (s + u)); b[u] = *(const f32x4*)(bp + 8 * (s + u)); }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u][t], acc, 0, 0, 0);
+  }
+  for (; s < s1; ++s) {
+    const f32x4 av = *(const f32x4*)(ap + 8 * s), bv = *(const f32x4*)(bp + 8 * s);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = n0 + i;
+    const float bv = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * kk;            // 32x32 C/D layout: register e of lane (i, kk) = row, column i
+      const float v = bv + (((acc[e] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane]);
+      if (m < M && n < N) C[(long)m * ldc + n] = ACT ? lrelu(v) : v;
+    }
+  }
+}
+
+// X[px][c * 9 + tap] = in[reflect(px + tap)][c]: the reflection-padded 3x3 patches as a [HW, 9 cin] matrix
+__global__ void enc_im2col_kernel(const float* __restrict__ in, float* __restrict__ X, int H, int W, int cin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)H * W * cin * 9;
+  if (idx >= n) return;
+  const int col = (int)(idx % (cin * 9)), c = col / 9, tap = col % 9;
+  const long px = idx / (cin * 9);
+  const int py = (int)(px / W), pxx = (int)(px % W);
+  X[idx] = in[((long)reflect(py + tap / 3 - 1, H) * W + reflect(pxx + tap % 3 - 1, W)) * cin + c];
+}
+
+void enc_im2col(const float* in, float* X, int H, int W, int cin, hipStream_t st) {
+  const long nx = (long)H * W * cin * 9;
+  hipLaunchKernelGGL(enc_im2col_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, in, X, H, W, cin);
+}
+void enc_gemm_nt(bool act, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, hipStream_t st) {
+  const dim3 grid((M + 31) / 32, (N + 31) / 32);
+  if (act) hipLaunchKernelGGL(enc_gemm_nt_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, bias, C, ldc, M, N, K);
+  else hipLaunchKernelGGL(enc_gemm_nt_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, bias, C, ldc, M, N, K);
+}
+// a 3x3 (xcol = patch matrix to fill; kept by the training forward for the weight gradient) or 1x1 (xcol = null) layer with cin >= 64:
+// out[px][o] = lrelu(b[o] + sum X[px][k] w[o][k]),  w = the module's own [cout][cin][k][k] tensor
+void enc_conv_gemm(int taps, const float* in, float* xcol, const float* w, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st) {
+  const float* X = in;
+  if (taps == 9) { enc_im2col(in, xcol, H, W, cin, st); X = xcol; }
+  enc_gemm_nt(true, X, cin * taps, w, cin * taps, b, out, cout, H * W, cout, cin * taps, st);
+}
+
 // MaxPool2d(2,2), floor mode
 __global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;
@@ -149,7 +238,9 @@ size_t encoder_workspace_bytes(int H, int W) {
   size_t wt = 0;
   for (int l = 0; l < 7; ++l) wt += (size_t)ENC_CIN[l] * ENC_COUT[l] * ENC_TAPS[l];
   const size_t act = (size_t)H * W * 128 > (size_t)32 * 32 * 128 ? (size_t)H * W * 128 : (size_t)32 * 32 * 128;
-  return (wt + 2 * act) * sizeof(float);
+  size_t xcol = (size_t)H * W * 64 * 9;                                   // conv3's patch matrix; conv5's is (H/2)(W/2) x 1152
+  if ((size_t)(H / 2) * (W / 2) * 128 * 9 > xcol) xcol = (size_t)(H / 2) * (W / 2) * 128 * 9;
+  return (wt + 2 * act + xcol) * sizeof(float);
 }
 
 template <int TAPS, bool ACT>
@@ -166,25 +257,27 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
   for (int l = 0; l < 7; ++l) {
     wt[l] = p;
     const int n = ENC_CIN[l] * ENC_COUT[l] * ENC_TAPS[l];
-    hipLaunchKernelGGL(transpose_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2 * l], wt[l], ENC_COUT[l], ENC_CIN[l], ENC_TAPS[l]);
+    if (l < 2)   // only the two 3-channel layers still run on the direct kernel (which reads [cin][tap][cout])
+      hipLaunchKernelGGL(transpose_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2 * l], wt[l], ENC_COUT[l], ENC_CIN[l], ENC_TAPS[l]);
     p += n;
   }
   const size_t act = (size_t)H * W * 128 > (size_t)32 * 32 * 128 ? (size_t)H * W * 128 : (size_t)32 * 32 * 128;
   float* a = p;
   float* b = p + act;
+  float* xc = b + act;                                          // patch matrix of the layer in flight
   hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((3 * H * W + 255) / 256), dim3(256), 0, st, img, a, 3, H * W);
   conv<1, false>(a, wt[0], w[1], b, H, W, 3, 3, st);            // conv1
   conv<9, true>(b, wt[1], w[3], a, H, W, 3, 64, st);            // conv2 + relu2
-  conv<9, true>(a, wt[2], w[5], b, H, W, 64, 64, st);           // conv3 + relu3
+  enc_conv_gemm(9, a, xc, w[4], w[5], b, H, W, 64, 64, st);     // conv3 + relu3 (fp32 MFMA GEMM over the patch matrix)
   hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * 64 + 255) / 256), dim3(256), 0, st, b, a, H, W, 64);
   const int H2 = H / 2, W2 = W / 2;
-  conv<9, true>(a, wt[3], w[7], b, H2, W2, 64, 128, st);        // conv4 + relu4
-  conv<9, true>(b, wt[4], w[9], a, H2, W2, 128, 128, st);       // conv5 + relu5
+  enc_conv_gemm(9, a, xc, w[6], w[7], b, H2, W2, 64, 128, st);  // conv4 + relu4
+  enc_conv_gemm(9, b, xc, w[8], w[9], a, H2, W2, 128, 128, st); // conv5 + relu5
   hipLaunchKernelGGL(maxpool2_kernel, dim3(((H2 / 2) * (W2 / 2) * 128 + 255) / 256), dim3(256), 0, st, a, b, H2, W2, 128);
   const int H4 = H2 / 2, W4 = W2 / 2;
-  conv<9, true>(b, wt[5], w[11], a, H4, W4, 128, 128, st);      // conv6 + relu6
+  enc_conv_gemm(9, b, xc, w[10], w[11], a, H4, W4, 128, 128, st);   // conv6 + relu6
   hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((32 * 32 * 128 + 255) / 256), dim3(256), 0, st, a, b, H4, W4, 128, 32);
-  conv<1, true>(b, wt[6], w[13], out, 32, 32, 128, 64, st);     // conv7 + relu7
+  enc_conv_gemm(1, b, nullptr, w[12], w[13], out, 32, 32, 128, 64, st);   // conv7 + relu7
   return check_launch("encoder_forward");
 }
 

@@ -17,11 +17,14 @@ void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int tap
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st);
 void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st);
 void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st);
+void enc_im2col(const float* in, float* X, int H, int W, int cin, hipStream_t st);
+void enc_gemm_nt(bool act, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, hipStream_t st);
+void enc_conv_gemm(int taps, const float* in, float* xcol, const float* w, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st);
 
 static const int TCIN[7] = {3, 3, 64, 64, 128, 128, 128}, TCOUT[7] = {3, 64, 64, 128, 128, 128, 64}, TTAPS[7] = {1, 9, 9, 9, 9, 9, 1};
 
-struct EncLayout {   // float offsets of the saved activations
-  size_t a0, y1, y2, y3, p3, y4, y5, p5, y6, p6, end;
+struct EncLayout {   // float offsets of the saved activations; x3..x6: the patch matrices of conv3..conv6 (kept for the weight gradients)
+  size_t a0, y1, y2, y3, p3, y4, y5, p5, y6, p6, x3, x4, x5, x6, end;
   int H, W, H2, W2, H4, W4;
 };
 static EncLayout enc_layout(int H, int W) {
@@ -32,6 +35,7 @@ static EncLayout enc_layout(int H, int W) {
   L.a0 = o; o += n0 * 3;   L.y1 = o; o += n0 * 3;   L.y2 = o; o += n0 * 64;  L.y3 = o; o += n0 * 64;
   L.p3 = o; o += n2 * 64;  L.y4 = o; o += n2 * 128; L.y5 = o; o += n2 * 128;
   L.p5 = o; o += n4 * 128; L.y6 = o; o += n4 * 128; L.p6 = o; o += (size_t)1024 * 128;
+  L.x3 = o; o += n0 * 576; L.x4 = o; o += n2 * 576; L.x5 = o; o += n2 * 1152; L.x6 = o; o += n4 * 1152;
   L.end = o;
   return L;
 }
@@ -70,14 +74,15 @@ int launch_encoder_forward_train(const float* img, int H, int W, const float* co
   enc_chw_to_hwc(img, s + L.a0, 3, H * W, st);
   enc_conv(1, false, s + L.a0, wt[0], w[1], s + L.y1, H, W, 3, 3, st);
   enc_conv(9, true, s + L.y1, wt[1], w[3], s + L.y2, H, W, 3, 64, st);
-  enc_conv(9, true, s + L.y2, wt[2], w[5], s + L.y3, H, W, 64, 64, st);
+  // cin >= 64: fp32 MFMA GEMMs over the patch matrices (encoder.hip), which stay in `saved` for the weight gradients
+  enc_conv_gemm(9, s + L.y2, s + L.x3, w[4], w[5], s + L.y3, H, W, 64, 64, st);
   enc_maxpool2(s + L.y3, s + L.p3, H, W, 64, st);
-  enc_conv(9, true, s + L.p3, wt[3], w[7], s + L.y4, L.H2, L.W2, 64, 128, st);
-  enc_conv(9, true, s + L.y4, wt[4], w[9], s + L.y5, L.H2, L.W2, 128, 128, st);
+  enc_conv_gemm(9, s + L.p3, s + L.x4, w[6], w[7], s + L.y4, L.H2, L.W2, 64, 128, st);
+  enc_conv_gemm(9, s + L.y4, s + L.x5, w[8], w[9], s + L.y5, L.H2, L.W2, 128, 128, st);
   enc_maxpool2(s + L.y5, s + L.p5, L.H2, L.W2, 128, st);
-  enc_conv(9, true, s + L.p5, wt[5], w[11], s + L.y6, L.H4, L.W4, 128, 128, st);
+  enc_conv_gemm(9, s + L.p5, s + L.x6, w[10], w[11], s + L.y6, L.H4, L.W4, 128, 128, st);
   enc_adaptive_avgpool(s + L.y6, s + L.p6, L.H4, L.W4, 128, 32, st);
-  enc_conv(1, true, s + L.p6, wt[6], w[13], out, 32, 32, 128, 64, st);
+  enc_conv_gemm(1, s + L.p6, nullptr, w[12], w[13], out, 32, 32, 128, 64, st);
   return check_launch("encoder_forward_train");
 }
 
@@ -89,17 +94,34 @@ __global__ void enc_act_grad_kernel(const float* __restrict__ d_out, const float
   g[idx] = y ? d_out[idx] * lrelu_grad(y[idx]) : d_out[idx];
 }
 
-// X[px][c * 9 + tap] = in[reflect(px + tap)][c]: the reflection-padded 3x3 patches as a [HW, 9 cin] matrix, so that the
-// weight gradient is the point-reduction GEMM dW[o][c*9+tap] = sum_px g[px][o] X[px][c*9+tap] -- exactly the shape (and
-// the output layout, [cout][cin][3][3]) of the MLP's MFMA wgrad kernel (mlp_train16.hip), which is reused as is.
-__global__ void enc_im2col_kernel(const float* __restrict__ in, float* __restrict__ X, int H, int W, int cin) {
+// The patch matrix X[px][c * 9 + tap] = in[reflect(px + tap)][c] (enc_im2col, encoder.hip) makes the weight gradient the
+// point-reduction GEMM dW[o][c*9+tap] = sum_px g[px][o] X[px][c*9+tap] -- exactly the shape (and the output layout,
+// [cout][cin][3][3]) of the MLP's MFMA wgrad kernel (mlp_train16.hip), which is reused as is.
+
+// d_in[px][c] = sum over (patch row q, tap) with reflect(q + tap) == px of dX[q][c*9 + tap]: the adjoint of the reflection-padded
+// gather, applied to the patch-matrix gradient dX = g W that the GEMM path produces (pixels in row / column 1 and n-2 also
+// collect what the padding mirrored)
+__global__ void enc_col2im_kernel(const float* __restrict__ dX, float* __restrict__ d_in, int H, int W, int cin) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n = (long)H * W * cin * 9;
-  if (idx >= n) return;
-  const int col = (int)(idx % (cin * 9)), c = col / 9, tap = col % 9;
-  const long px = idx / (cin * 9);
-  const int py = (int)(px / W), pxx = (int)(px % W);
-  X[idx] = in[((long)reflect1(py + tap / 3 - 1, H) * W + reflect1(pxx + tap % 3 - 1, W)) * cin + c];
+  if (idx >= (long)H * W * cin) return;
+  const int c = (int)(idx % cin);
+  const int px = (int)(idx / cin), py = px / W, pxx = px % W;
+  int ty[3], tx[3], nty = 0, ntx = 0;                    // padded coordinates that map onto (py, pxx)
+  ty[nty++] = py; if (py == 1) ty[nty++] = -1; if (py == H - 2) ty[nty++] = H;
+  tx[ntx++] = pxx; if (pxx == 1) tx[ntx++] = -1; if (pxx == W - 2) tx[ntx++] = W;
+  float acc = 0.0f;
+  for (int a = 0; a < nty; ++a)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int qy = ty[a] - ky + 1;
+      if (qy < 0 || qy >= H) continue;
+      for (int b = 0; b < ntx; ++b)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int qx = tx[b] - kx + 1;
+          if (qx < 0 || qx >= W) continue;
+          acc += dX[((long)qy * W + qx) * cin * 9 + c * 9 + ky * 3 + kx];
+        }
+    }
+  d_in[idx] = acc;
 }
 
 // w[o][c][tap] -> wd[tap][o][c]
@@ -196,23 +218,34 @@ __global__ void enc_hwc_to_chw_kernel(const float* __restrict__ in, float* __res
 
 struct BwdBufs { float* g; float* X; float* wd; float* ws; };
 
+// xsaved: the layer's patch matrix kept by the forward (GEMM layers) or null (built here); wt: the forward's [cin*taps][cout]
+// re-layout of the weights (kept in `saved`): for cin >= 64 the data gradient is the GEMM dX[px][k] = sum_o g[px][o] wt[k][o] on the
+// fp32 matrix cores + the gather over the padding's adjoint, instead of a 1,152-step dependent chain per pixel
 template <int TAPS>
 static void conv_bwd(const float* d_out, const float* y, const float* in, const float* w, const BwdBufs& B, float* dW, float* db, float* d_in, int H,
-                     int W, int cin, int cout, hipStream_t st) {
+                     int W, int cin, int cout, hipStream_t st, const float* xsaved = nullptr, const float* wt = nullptr) {
   const long n = (long)H * W * cout;
   hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, y, B.g, n);
   const float* X = in;
   if (TAPS == 9) {
-    const long nx = (long)H * W * cin * 9;
-    hipLaunchKernelGGL(enc_im2col_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, in, B.X, H, W, cin);
-    X = B.X;
+    if (xsaved) X = xsaved;
+    else { enc_im2col(in, B.X, H, W, cin, st); X = B.X; }
   }
   wgrad(B.g, cout, cout, X, cin * TAPS, cin * TAPS, dW, cin * TAPS, db, (long)H * W, B.ws, st);   // MFMA point-reduction GEMM (+ bias sums)
-  if (d_in) {
-    const int nw = cout * cin * TAPS;
-    hipLaunchKernelGGL(enc_weights_for_dgrad_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, w, B.wd, cout, cin, TAPS);
-    hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, B.g, B.wd, d_in, H, W, cin, cout);
+  if (!d_in) return;
+  if (wt && cin >= 64 && (cout & 7) == 0) {
+    if (TAPS == 9) {
+      enc_gemm_nt(false, B.g, cout, wt, cout, nullptr, B.X, cin * 9, H * W, cin * 9, cout, st);   // B.X is free: the patch matrix came from `saved`
+      const long nd = (long)H * W * cin;
+      hipLaunchKernelGGL(enc_col2im_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, B.X, d_in, H, W, cin);
+    } else {
+      enc_gemm_nt(false, B.g, cout, wt, cout, nullptr, d_in, cin, H * W, cin, cout, st);
+    }
+    return;
   }
+  const int nw = cout * cin * TAPS;
+  hipLaunchKernelGGL(enc_weights_for_dgrad_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, w, B.wd, cout, cin, TAPS);
+  hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, B.g, B.wd, d_in, H, W, cin, cout);
 }
 
 // saved: from launch_encoder_forward_train; out: its output (for lrelu7'); d_out[1024,64]; grads[14] in weight order;
@@ -227,16 +260,21 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
   float* gb = base + SL.gb;
   const BwdBufs B{base + SL.g, base + SL.X, base + SL.wd, base + SL.ws};
   const int n0 = H * W, n2 = L.H2 * L.W2, n4 = L.H4 * L.W4;
-  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, grads[12], grads[13], ga, 32, 32, 128, 64, st);                    // conv7 -> d p6
+  const float* wt[7];                                    // the forward's transposed weights, behind the activations in `saved`
+  {
+    const float* p = s + L.end;
+    for (int l = 0; l < 7; ++l) { wt[l] = p; p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
+  }
+  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, grads[12], grads[13], ga, 32, 32, 128, 64, st, nullptr, wt[6]);     // conv7 -> d p6
   hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, gb, L.H4, L.W4, 128, 32); // -> d y6
-  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st);              // conv6 -> d p5
+  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);   // conv6 -> d p5
   (void)hipMemsetAsync(gb, 0, (size_t)n2 * 128 * sizeof(float), st);
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, gb, L.H2, L.W2, 128);  // -> d y5
-  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st);                 // conv5 -> d y4
-  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st);                  // conv4 -> d p3
+  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);   // conv5 -> d y4
+  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);    // conv4 -> d p3
   (void)hipMemsetAsync(ga, 0, (size_t)n0 * 64 * sizeof(float), st);
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, ga, H, W, 64);  // -> d y3
-  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, grads[4], grads[5], gb, H, W, 64, 64, st);                         // conv3 -> d y2
+  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, grads[4], grads[5], gb, H, W, 64, 64, st, s + L.x3, wt[2]);         // conv3 -> d y2
   conv_bwd<9>(gb, s + L.y2, s + L.y1, w[2], B, grads[2], grads[3], ga, H, W, 3, 64, st);                          // conv2 -> d y1
   conv_bwd<1>(ga, nullptr, s + L.a0, w[0], B, grads[0], grads[1], d_img ? gb : nullptr, H, W, 3, 3, st);         // conv1 -> d a0
   if (d_img) hipLaunchKernelGGL(enc_hwc_to_chw_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, st, gb, d_img, 3, n0);
