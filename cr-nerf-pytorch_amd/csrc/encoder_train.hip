@@ -45,20 +45,30 @@ static size_t enc_weight_floats() {
   return n;
 }
 size_t encoder_train_saved_bytes(int H, int W) { return (enc_layout(H, W).end + enc_weight_floats()) * sizeof(float); }
-struct ScratchLayout { size_t ga, gb, g, X, wd, ws, end; };
+struct ScratchLayout { size_t ga, gb, g[7], X, wd, ws, ws_floats, end; };
+static void enc_wgrad_specs(int H, int W, WgradSpec* sp) {   // shapes only (pointers null): the seven weight-gradient jobs of one backward
+  const long n0 = (long)H * W, n2 = (long)(H / 2) * (W / 2), n4 = (long)(H / 4) * (W / 4);
+  const long P[7] = {n0, n0, n0, n2, n2, n4, 1024};
+  for (int l = 0; l < 7; ++l) {
+    const int K = TCIN[l] * TTAPS[l];
+    sp[l] = WgradSpec{nullptr, TCOUT[l], TCOUT[l], nullptr, K, K, nullptr, K, (float*)1, wgrad_job_weight(TCOUT[l], K), 0, P[l]};
+  }
+}
 static ScratchLayout enc_scratch(int H, int W) {
   const size_t n0 = (size_t)H * W, n2 = (size_t)(H / 2) * (W / 2), n4 = (size_t)(H / 4) * (W / 4);
   const size_t gmap = n0 * 64 > (size_t)1024 * 128 ? n0 * 64 : (size_t)1024 * 128;   // largest gradient map (>= n2*128, n4*128)
   size_t xcol = n0 * 64 * 9;                                                           // conv3's patch matrix is the largest
   if (n2 * 128 * 9 > xcol) xcol = n2 * 128 * 9;
-  size_t ws = 0;                                                                       // MFMA wgrad partial sums
-  const size_t cand[7] = {wgrad_workspace_floats((long)n0, 3, 3), wgrad_workspace_floats((long)n0, 64, 27), wgrad_workspace_floats((long)n0, 64, 576),
-                          wgrad_workspace_floats((long)n2, 128, 576), wgrad_workspace_floats((long)n2, 128, 1152),
-                          wgrad_workspace_floats((long)n4, 128, 1152), wgrad_workspace_floats(1024, 64, 128)};
-  for (size_t c : cand) ws = c > ws ? c : ws;
+  WgradSpec sp[7];
+  enc_wgrad_specs(H, W, sp);
+  const size_t np[7] = {n0, n0, n0, n2, n2, n4, 1024};
   ScratchLayout L;
   size_t o = 0;
-  L.ga = o; o += gmap; L.gb = o; o += gmap; L.g = o; o += gmap; L.X = o; o += xcol; L.wd = o; o += 128 * 128 * 9; L.ws = o; o += ws;
+  L.ga = o; o += gmap; L.gb = o; o += gmap;
+  for (int l = 0; l < 7; ++l) { L.g[l] = o; o += np[l] * TCOUT[l]; }                   // lrelu'-scaled upstream gradient of every layer: read by the
+  L.X = o; o += xcol; L.wd = o; o += 128 * 128 * 9;                                    // batched weight-gradient launch at the end of the backward
+  L.ws_floats = wgrad_batch_ws_floats(sp, 7);
+  L.ws = o; o += L.ws_floats;
   L.end = o;
   return L;
 }
@@ -216,36 +226,38 @@ __global__ void enc_hwc_to_chw_kernel(const float* __restrict__ in, float* __res
   out[idx] = in[(long)px * C + c];
 }
 
-struct BwdBufs { float* g; float* X; float* wd; float* ws; };
+struct BwdBufs { float* X; float* wd; WgradSpec* specs; int* nspec; };
 
 // xsaved: the layer's patch matrix kept by the forward (GEMM layers) or null (built here); wt: the forward's [cin*taps][cout]
 // re-layout of the weights (kept in `saved`): for cin >= 64 the data gradient is the GEMM dX[px][k] = sum_o g[px][o] wt[k][o] on the
 // fp32 matrix cores + the gather over the padding's adjoint, instead of a 1,152-step dependent chain per pixel
 template <int TAPS>
-static void conv_bwd(const float* d_out, const float* y, const float* in, const float* w, const BwdBufs& B, float* dW, float* db, float* d_in, int H,
-                     int W, int cin, int cout, hipStream_t st, const float* xsaved = nullptr, const float* wt = nullptr) {
+static void conv_bwd(const float* d_out, const float* y, const float* in, const float* w, const BwdBufs& B, float* g, float* dW, float* db, float* d_in,
+                     int H, int W, int cin, int cout, hipStream_t st, const float* xsaved = nullptr, const float* wt = nullptr) {
   const long n = (long)H * W * cout;
-  hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, y, B.g, n);
+  hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, y, g, n);
   const float* X = in;
   if (TAPS == 9) {
     if (xsaved) X = xsaved;
     else { enc_im2col(in, B.X, H, W, cin, st); X = B.X; }
   }
-  wgrad(B.g, cout, cout, X, cin * TAPS, cin * TAPS, dW, cin * TAPS, db, (long)H * W, B.ws, st);   // MFMA point-reduction GEMM (+ bias sums)
+  // dW[o][k] = sum_px g[px][o] X[px][k] (+ bias sums): the MFMA point-reduction GEMM of mlp_train16.hip, queued -- all seven
+  // layers run in ONE batched launch at the end of the backward (g and X of every layer stay untouched until then)
+  B.specs[(*B.nspec)++] = WgradSpec{g, cout, cout, X, cin * TAPS, cin * TAPS, dW, cin * TAPS, db, wgrad_job_weight(cout, cin * TAPS), 0, (long)H * W};
   if (!d_in) return;
   if (wt && cin >= 64 && (cout & 7) == 0) {
     if (TAPS == 9) {
-      enc_gemm_nt(false, B.g, cout, wt, cout, nullptr, B.X, cin * 9, H * W, cin * 9, cout, st);   // B.X is free: the patch matrix came from `saved`
+      enc_gemm_nt(false, g, cout, wt, cout, nullptr, B.X, cin * 9, H * W, cin * 9, cout, st);   // B.X is free: the patch matrix came from `saved`
       const long nd = (long)H * W * cin;
       hipLaunchKernelGGL(enc_col2im_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, B.X, d_in, H, W, cin);
     } else {
-      enc_gemm_nt(false, B.g, cout, wt, cout, nullptr, d_in, cin, H * W, cin, cout, st);
+      enc_gemm_nt(false, g, cout, wt, cout, nullptr, d_in, cin, H * W, cin, cout, st);
     }
     return;
   }
   const int nw = cout * cin * TAPS;
   hipLaunchKernelGGL(enc_weights_for_dgrad_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, w, B.wd, cout, cin, TAPS);
-  hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, B.g, B.wd, d_in, H, W, cin, cout);
+  hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, g, B.wd, d_in, H, W, cin, cout);
 }
 
 // saved: from launch_encoder_forward_train; out: its output (for lrelu7'); d_out[1024,64]; grads[14] in weight order;
@@ -258,26 +270,29 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
   float* base = (float*)scratch;
   float* ga = base + SL.ga;
   float* gb = base + SL.gb;
-  const BwdBufs B{base + SL.g, base + SL.X, base + SL.wd, base + SL.ws};
+  WgradSpec specs[7];
+  int nspec = 0;
+  const BwdBufs B{base + SL.X, base + SL.wd, specs, &nspec};
   const int n0 = H * W, n2 = L.H2 * L.W2, n4 = L.H4 * L.W4;
   const float* wt[7];                                    // the forward's transposed weights, behind the activations in `saved`
   {
     const float* p = s + L.end;
     for (int l = 0; l < 7; ++l) { wt[l] = p; p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
   }
-  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, grads[12], grads[13], ga, 32, 32, 128, 64, st, nullptr, wt[6]);     // conv7 -> d p6
+  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, base + SL.g[6], grads[12], grads[13], ga, 32, 32, 128, 64, st, nullptr, wt[6]);     // conv7 -> d p6
   hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, gb, L.H4, L.W4, 128, 32); // -> d y6
-  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);   // conv6 -> d p5
+  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, base + SL.g[5], grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);   // conv6 -> d p5
   (void)hipMemsetAsync(gb, 0, (size_t)n2 * 128 * sizeof(float), st);
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, gb, L.H2, L.W2, 128);  // -> d y5
-  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);   // conv5 -> d y4
-  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);    // conv4 -> d p3
+  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, base + SL.g[4], grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);   // conv5 -> d y4
+  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, base + SL.g[3], grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);    // conv4 -> d p3
   (void)hipMemsetAsync(ga, 0, (size_t)n0 * 64 * sizeof(float), st);
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, ga, H, W, 64);  // -> d y3
-  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, grads[4], grads[5], gb, H, W, 64, 64, st, s + L.x3, wt[2]);         // conv3 -> d y2
-  conv_bwd<9>(gb, s + L.y2, s + L.y1, w[2], B, grads[2], grads[3], ga, H, W, 3, 64, st);                          // conv2 -> d y1
-  conv_bwd<1>(ga, nullptr, s + L.a0, w[0], B, grads[0], grads[1], d_img ? gb : nullptr, H, W, 3, 3, st);         // conv1 -> d a0
+  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, base + SL.g[2], grads[4], grads[5], gb, H, W, 64, 64, st, s + L.x3, wt[2]);         // conv3 -> d y2
+  conv_bwd<9>(gb, s + L.y2, s + L.y1, w[2], B, base + SL.g[1], grads[2], grads[3], ga, H, W, 3, 64, st);                          // conv2 -> d y1
+  conv_bwd<1>(ga, nullptr, s + L.a0, w[0], B, base + SL.g[0], grads[0], grads[1], d_img ? gb : nullptr, H, W, 3, 3, st);         // conv1 -> d a0
   if (d_img) hipLaunchKernelGGL(enc_hwc_to_chw_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, st, gb, d_img, 3, n0);
+  if (int rc = wgrad_batch(specs, nspec, base + SL.ws, SL.ws_floats, st)) return rc;        // the seven weight / bias gradients: two launches
   return check_launch("encoder_backward");
 }
 

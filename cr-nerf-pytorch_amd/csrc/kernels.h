@@ -60,6 +60,11 @@ size_t wgrad_workspace_floats(long P, int M, int N);
 // bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
           hipStream_t st, int bf16 = 0);
+// several such products in ONE launch + ONE reduction (small batches: a launch per job is mostly ramp-up and drain); at most 16 jobs
+struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; };
+float wgrad_job_weight(int M, int N);                              // per-point cost of a job relative to a full 256 x 256 block
+size_t wgrad_batch_ws_floats(const WgradSpec* specs, int n);       // partial-sum workspace the plan for these jobs needs
+int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipStream_t st);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_embed_points(const float* rays, const float* z, const float* dir_emb, float* x, long R, int N, hipStream_t stream);
 int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);

@@ -628,20 +628,45 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
 }
 
 // ---- batched weight gradients -------------------------------------------------------------------------------------------
-struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; };
-
-
 // specs[k].weight: relative cost of one point of job k (1 = a full 256 x 256 block); a job's chunk length is chosen so that
-// every workgroup of the launch carries about the same work
-static int launch_wgrad_batch(const WgradSpec* specs, int n, long P, float* ws, hipStream_t st) {
+// every workgroup of the launch carries about the same work.  Jobs may have different point counts (specs[k].P).
+static void wgrad_batch_plan(const WgradSpec* specs, int n, long* chunk, int* nchunk) {
+  double total = 0.0;
+  for (int k = 0; k < n; ++k) total += (double)specs[k].weight * (double)specs[k].P;
+  const double per = total / (double)wgrad_batch_blocks();
+  for (int k = 0; k < n; ++k) {
+    long c = (long)(per / specs[k].weight);
+    c = (c + 15) / 16 * 16;
+    if (c < 128) c = 128;
+    chunk[k] = c;
+    nchunk[k] = (int)((specs[k].P + c - 1) / c);
+  }
+}
+float wgrad_job_weight(int M, int N) {
+  const float w = (float)(((M + 31) / 32) * ((N + 31) / 32)) / 64.0f;      // live 32 x 32 MFMA tiles of the 256 x 256 block(s)
+  return w < 0.1f ? 0.1f : w;
+}
+size_t wgrad_batch_ws_floats(const WgradSpec* specs, int n) {
+  long chunk[WG_MAX_JOBS];
+  int nchunk[WG_MAX_JOBS];
+  if (n > WG_MAX_JOBS) return 0;
+  wgrad_batch_plan(specs, n, chunk, nchunk);
+  size_t f = 0;
+  for (int k = 0; k < n; ++k) f += (size_t)nchunk[k] * ((size_t)specs[k].M * specs[k].N + (specs[k].db ? specs[k].M : 0));
+  return f;
+}
+int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipStream_t st) {
   if (n > WG_MAX_JOBS) return set_error(-3, "wgrad batch: too many jobs");
+  if (n <= 0) return 0;
+  long chunk[WG_MAX_JOBS];
+  int nchunk[WG_MAX_JOBS];
+  wgrad_batch_plan(specs, n, chunk, nchunk);
   int order[WG_MAX_JOBS];
   for (int k = 0; k < n; ++k) order[k] = k;
-  for (int a = 1; a < n; ++a)                       // stable insertion sort, heaviest first
-    for (int c = a; c > 0 && specs[order[c]].weight > specs[order[c - 1]].weight; --c) { const int t = order[c]; order[c] = order[c - 1]; order[c - 1] = t; }
-  float sumw = 0.0f;
-  for (int k = 0; k < n; ++k) sumw += specs[k].weight;
-  const double per = (double)sumw * (double)P / (double)wgrad_batch_blocks();
+  for (int a = 1; a < n; ++a)                       // stable insertion sort, longest workgroups first
+    for (int c = a; c > 0 && specs[order[c]].weight * chunk[order[c]] > specs[order[c - 1]].weight * chunk[order[c - 1]]; --c) {
+      const int t = order[c]; order[c] = order[c - 1]; order[c - 1] = t;
+    }
   WgradBatch b;
   ReduceBatch r;
   b.njobs = r.njobs = n;
@@ -649,24 +674,21 @@ static int launch_wgrad_batch(const WgradSpec* specs, int n, long P, float* ws, 
   float* w = ws;
   for (int q = 0; q < n; ++q) {
     const WgradSpec& sp = specs[order[q]];
-    long chunk = (long)(per / sp.weight);
-    chunk = (chunk + 15) / 16 * 16;
-    if (chunk < 128) chunk = 128;
-    const int nchunk = (int)((P + chunk - 1) / chunk);
-    float* bws = w + (size_t)nchunk * sp.M * sp.N;
-    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, P, (int)chunk, sp.bf16};
+    const int nc = nchunk[order[q]];
+    float* bws = w + (size_t)nc * sp.M * sp.N;
+    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16};
     b.first[q] = blocks;
-    b.nchunk[q] = nchunk;
+    b.nchunk[q] = nc;
     b.my[q] = (sp.M + 255) / 256;
-    blocks += nchunk * ((sp.M + 255) / 256) * ((sp.N + 255) / 256);
-    r.job[q] = ReduceJob{w, sp.db ? bws : nullptr, sp.dst, sp.db, nchunk, sp.M, sp.N, sp.ldc};
+    blocks += nc * ((sp.M + 255) / 256) * ((sp.N + 255) / 256);
+    r.job[q] = ReduceJob{w, sp.db ? bws : nullptr, sp.dst, sp.db, nc, sp.M, sp.N, sp.ldc};
     r.first[q] = rblocks;
     rblocks += (sp.M * sp.N + (sp.db ? sp.M : 0) + 255) / 256;
-    w = bws + (sp.db ? (size_t)nchunk * sp.M : 0);
+    w = bws + (sp.db ? (size_t)nc * sp.M : 0);
   }
   b.first[n] = blocks;
   r.first[n] = rblocks;
-  if ((size_t)(w - ws) > wgrad_batch_workspace_floats()) return set_error(-3, "wgrad batch: workspace too small");
+  if ((size_t)(w - ws) > ws_floats) return set_error(-3, "wgrad batch: workspace too small");
   hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblocks), dim3(256), 0, st, r);
   return 0;
@@ -692,21 +714,21 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     WgradSpec sp[WG_MAX_JOBS];
     int n = 0;
     const float W_FULL = 1.0f, W_EMB = 0.52f, W_DIR = 0.66f, W_DIRE = 0.19f, W_RGB = 0.26f, W_SIG = 0.26f;   // measured per-point cost relative to a full block (profiles/r3/train_1024_before_ordered.txt)
-    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb};                               // xyz_encoding_1
+    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P};                               // xyz_encoding_1
     for (int l = 1; l < 8; ++l) {
       if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb};
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P};
       } else {
-        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb};
+        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P};
       }
     }
-    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb};                                  // xyz_encoding_final
-    sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0};                                         // static_sigma
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb};                         // dir_encoding: cat([final, dir])
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb};
-    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb};                          // static_rgb
-    if (int rc = launch_wgrad_batch(sp, n, P, ws, stream)) return rc;
+    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P};                                  // xyz_encoding_final
+    sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0, P};                                         // static_sigma
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P};                         // dir_encoding: cat([final, dir])
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P};
+    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb, P};                          // static_rgb
+    if (int rc = wgrad_batch(sp, n, ws, wgrad_batch_workspace_floats(), stream)) return rc;
     return check_launch("mlp_backward wgrad (batched)");
   }
   // xyz_encoding_1: input x[:, :93]
