@@ -1186,13 +1186,28 @@ __global__ void dec_bwd_finish_kernel(float* __restrict__ dst, const float* __re
   dst[idx] = accumulate ? dst[idx] + v : v;
 }
 
+// the six 1x1-conv weight-gradient jobs of the two CNN chains (snet on the style grid, cnet on the content grid): shapes for the plan
+static void dec_conv_wgrad_specs(long HW, long HWs, WgradSpec* sp) {
+  int n = 0;
+  for (int net = 0; net < 2; ++net) {
+    const long P = net ? HWs : HW;
+    sp[n++] = WgradSpec{nullptr, 128, 128, nullptr, 64, 64, nullptr, 64, (float*)1, wgrad_job_weight(128, 64), 0, P};
+    sp[n++] = WgradSpec{nullptr, 64, 64, nullptr, 128, 128, nullptr, 128, (float*)1, wgrad_job_weight(64, 128), 0, P};
+    sp[n++] = WgradSpec{nullptr, 32, 32, nullptr, 64, 64, nullptr, 64, (float*)1, wgrad_job_weight(32, 64), 0, P};
+  }
+}
+
 size_t crossray_backward_workspace_floats(long HW, long HWs) {
   const long P = HW + HWs;
   size_t n = CROSSRAY_WORKSPACE_BYTES / 4;                       // forward decode workspace (stats live here)
   n += (size_t)3 * HW + 4 * (size_t)HW;                          // scratch rgb, d_pre[HW,4]
   n += (size_t)P * (64 + 128 + 64 + 128 + 64 + 32 + 64);         // xc, h1, h2, d1, d2, d3, dxc
   n += 4096 + 2 * 2048 + 1024;                                   // dA/dv, dm, S/dg buffers, mean terms, column sums
-  n += wgrad_workspace_floats(P > HW ? P : HW, 128, 128) + wgrad_workspace_floats(HW, 4, 64) + 64 * (size_t)CROSSRAY_SUM_BLOCKS * 2;
+  WgradSpec sp[6];
+  dec_conv_wgrad_specs(HW, HWs, sp);
+  size_t wg = wgrad_batch_ws_floats(sp, 6);
+  if (wgrad_workspace_floats(HW, 4, 64) > wg) wg = wgrad_workspace_floats(HW, 4, 64);
+  n += wg + 64 * (size_t)CROSSRAY_SUM_BLOCKS * 2;
   return n;
 }
 
@@ -1255,12 +1270,18 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
     hipLaunchKernelGGL(dec_bwd_chain_mfma_kernel, dim3(jc.nblk + js.nblk), dim3(256), shmem, stream, jc, js);
   }
   // 6. conv weight / bias gradients: snet = grads[0..5], cnet = grads[8..13]
-  for (int net = 0; net < 2; ++net) {
-    const long P = net ? HWs : HW;
-    float* const* g = grads + (net ? 0 : 8);
-    wgrad(d1[net], 128, 128, xc[net], 64, 64, g[0], 64, g[1], P, wws, stream);
-    wgrad(d2[net], 64, 64, h1[net], 128, 128, g[2], 128, g[3], P, wws, stream);
-    wgrad(d3[net], 32, 32, h2[net], 64, 64, g[4], 64, g[5], P, wws, stream);
+  // (one batched launch + one reduction for the six jobs: at these grid sizes a launch per job is mostly ramp-up and drain)
+  {
+    WgradSpec sp[6];
+    dec_conv_wgrad_specs(HW, HWs, sp);
+    for (int net = 0; net < 2; ++net) {
+      float* const* g = grads + (net ? 0 : 8);
+      WgradSpec* q = sp + 3 * net;
+      q[0].D = d1[net]; q[0].A = xc[net]; q[0].dst = g[0]; q[0].db = g[1];
+      q[1].D = d2[net]; q[1].A = h1[net]; q[1].dst = g[2]; q[1].db = g[3];
+      q[2].D = d3[net]; q[2].A = h2[net]; q[2].dst = g[4]; q[2].db = g[5];
+    }
+    if (int rc = wgrad_batch(sp, 6, wws, wgrad_batch_ws_floats(sp, 6), stream)) return rc;
   }
   // 7. centering terms
   SumJob s0{dxc[0], HW, sum_ws, chansum_blocks(HW)}, s1{dxc[1], HWs, sum_ws + 64 * CROSSRAY_SUM_BLOCKS, chansum_blocks(HWs)};
