@@ -126,12 +126,29 @@ __device__ __forceinline__ void init_acc16(f32x4 (&acc)[NT], const lds_float* bi
 // the following NGB groups from srcB[u-NGA].  Fragments are consumed in stream order (group-major,
 // tile-minor); q[] always holds the next V16_AHEAD fragments of the STREAM (it runs on into the next
 // layer / pass), so no LDS latency is exposed at stage or layer boundaries.
-template <int NT, int NGA, int NGB, int NA, int NB>
+// Deferred stores of the PREVIOUS layer's output (training twins, mlp_train16.h ActSaver): nothing at inference.
+struct NoDeferred {
+  static constexpr int pieces = 0;
+  __device__ __forceinline__ void piece(int) const {}
+};
+template <class SAVE, int ND>
+struct DeferredActs {   // the ND tiles of `a` go to `row`, one piece per call
+  static constexpr int pieces = ND;
+  const SAVE& save;
+  float* row;
+  const f32x4 (&a)[16];
+  __device__ __forceinline__ void piece(int T) const { save.piece(row, T, a[T]); }
+};
+
+template <int NT, int NGA, int NGB, int NA, int NB, class DEF = NoDeferred>
 __device__ __forceinline__ void mma_layer16(WeightPipe16& p, const f32x4 (&srcA)[NA], const f32x4 (&srcB)[NB], f32x4 (&acc)[NT],
-                                            f32x4 (&q)[V16_AHEAD]) {
+                                            f32x4 (&q)[V16_AHEAD], const DEF& def = DEF()) {
   static_assert(NGA <= NA && NGB <= NB, "source too small");
   constexpr int NF = (NGA + NGB) * NT;
   static_assert(NF % STAGE_FRAGS == 0 && NT % 2 == 0, "layer must be whole stages");
+  constexpr int STEPS = NF / 2;                                        // fragment-pair steps of this layer (8 MFMAs each)
+  constexpr int STRIDE = DEF::pieces > 0 ? (STEPS / DEF::pieces >= 4 ? 4 : (STEPS / DEF::pieces >= 2 ? 2 : 1)) : 1;
+  static_assert(DEF::pieces == 0 || STRIDE * DEF::pieces <= STEPS, "not enough steps to carry the deferred stores");
 #pragma unroll
   for (int u = 0; u < NGA + NGB; ++u) {
 #pragma unroll
@@ -151,6 +168,10 @@ __device__ __forceinline__ void mma_layer16(WeightPipe16& p, const f32x4 (&srcA)
         acc[T + 1] = CRNERF_MFMA16(a1[r], b, acc[T + 1]);
       }
       if (s == STAGE_FRAGS - 2) p.advance();
+      if (DEF::pieces > 0) {          // one deferred store every STRIDE steps (>= 8 x 64 cycles of store data path between a wave's stores)
+        const int step = f / 2;
+        if (step % STRIDE == 0 && step / STRIDE < DEF::pieces) def.piece(step / STRIDE);
+      }
     }
   }
 }
@@ -168,6 +189,9 @@ __device__ __forceinline__ void store_act16(const f32x4 (&acc)[NT], f32x4 (&act)
 struct NoSave {   // inference: nothing is materialised
   template <int NT>
   __device__ __forceinline__ void operator()(int, const f32x4 (&)[NT]) const {}
+  template <int NT>
+  __device__ __forceinline__ float* begin(int, const f32x4 (&)[NT]) const { return nullptr; }
+  __device__ __forceinline__ void piece(float*, int, const f32x4&) const {}
 };
 
 // Where the direction embedding comes from when the dir layer needs it (late in the tile): registers
@@ -193,34 +217,37 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
   f32x4 act[16], acc[16];
   tm.tick(T_PROLOGUE);
 
+  // Training twins: the output of layer l is stored BEHIND the MFMAs of layer l + 1 (DeferredActs, see ActSaver in mlp_train16.h);
+  // `row` is the row pointer save.begin() returned for the slot whose pieces are pending.
+  typedef DeferredActs<SAVE, 16> Def16;
   init_acc16<16>(acc, C + C_BIAS, g);                    // xyz_encoding_1
   mma_layer16<16, U_XYZ, 0>(p, pe, pe, acc, q);
   tm.tick(T_MMA);
   store_act16<16, true>(acc, act);
-  save(0, act);
+  float* row = save.begin(0, act);
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4
     init_acc16<16>(acc, C + C_BIAS + l * W_HIDDEN, g);
     tm.tick(T_EPILOGUE);
-    mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
+    mma_layer16<16, U_HID, 0>(p, act, act, acc, q, Def16{save, row, act});
     tm.tick(T_MMA);
     store_act16<16, true>(acc, act);
-    save(l, act);
+    row = save.begin(l, act);
   }
   init_acc16<16>(acc, C + C_BIAS + 4 * W_HIDDEN, g);     // xyz_encoding_5 = Linear(cat[xyz, h])
   tm.tick(T_EPILOGUE);
-  mma_layer16<16, U_XYZ, U_HID>(p, pe, act, acc, q);
+  mma_layer16<16, U_XYZ, U_HID>(p, pe, act, acc, q, Def16{save, row, act});
   tm.tick(T_MMA);
   store_act16<16, true>(acc, act);
-  save(4, act);
+  row = save.begin(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
     init_acc16<16>(acc, C + C_BIAS + l * W_HIDDEN, g);
     tm.tick(T_EPILOGUE);
-    mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
+    mma_layer16<16, U_HID, 0>(p, act, act, acc, q, Def16{save, row, act});
     tm.tick(T_MMA);
     store_act16<16, true>(acc, act);
-    save(l, act);
+    row = save.begin(l, act);
   }
   {                                                      // static_sigma: 256 -> 1 on the VALU
     float s0 = 0.0f, s1 = 0.0f;
@@ -241,25 +268,25 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
   }
   tm.tick(T_SIGMA);
   init_acc16<16>(acc, C + C_BFIN, g);                    // xyz_encoding_final (no activation)
-  mma_layer16<16, U_HID, 0>(p, act, act, acc, q);
+  mma_layer16<16, U_HID, 0>(p, act, act, acc, q, Def16{save, row, act});
   tm.tick(T_MMA);
   store_act16<16, false>(acc, act);
-  save(8, act);
+  row = save.begin(8, act);
   {
     f32x4 acc8[8], dv[2];                                // dir_encoding = relu(Linear(cat[final, dir]))
     dir.get(dv);
     init_acc16<8>(acc8, C + C_BDIR, g);
     tm.tick(T_EPILOGUE);
-    mma_layer16<8, U_HID, U_DIR>(p, act, dv, acc8, q);
+    mma_layer16<8, U_HID, U_DIR>(p, act, dv, acc8, q, Def16{save, row, act});
     tm.tick(T_MMA);
     store_act16<8, true>(acc8, act);
-    save(9, act);                                        // only tiles 0..7 (128 features) are meaningful
+    row = save.begin(9, act);                            // only tiles 0..7 (128 features) are meaningful
   }
   {
     f32x4 acc4[4];                                       // static_rgb = sigmoid(Linear)
     init_acc16<4>(acc4, C + C_BRGB, g);
     tm.tick(T_EPILOGUE);
-    mma_layer16<4, U_HALF, 0>(p, act, act, acc4, q);
+    mma_layer16<4, U_HALF, 0>(p, act, act, acc4, q, DeferredActs<SAVE, 8>{save, row, act});
     tm.tick(T_MMA);
 #pragma unroll
     for (int T = 0; T < 4; ++T)

@@ -18,19 +18,25 @@ __device__ __forceinline__ unsigned long long* mask_slot(float* acts, long P, in
   return (unsigned long long*)(acts + (size_t)ACT_SLOTS * P * ACT_W) + ((size_t)slot * P + n) * 4 + g;
 }
 
+// Stores of a 16-point tile's layer output: 16 row pieces (64 B per point and instruction) + the relu bits.  A global store
+// wave-instruction occupies the CU's store data path for ~64 cycles (1 KiB at 16 B/clk), and a wave cannot issue anything else
+// until its store has been taken: issued as a burst behind a layer (8 waves x 17 stores, all waves at the same program point)
+// the matrix pipe idled ~8.7 k cycles per layer = 11 % of the forward (ablations, 2^20 points: no stores 9.09 ms, burst 10.30 ms,
+// the same burst into an L2-resident window 10.16 ms, the ring's vmcnt wait relaxed by 20: 10.28 ms -- neither HBM bandwidth nor
+// the vmcnt coupling).  So the pieces are DEFERRED into the next layer's MFMA loop, one piece every few fragment steps
+// (mma_layer16's `def` argument): the 64 cycles of each store pass under the MFMAs of both waves of the SIMD.
 struct ActSaver {
   float* base; long P; long n; bool valid; int g;
+  // relu bits of the whole tile + the row pointer; call once, before the pieces
   template <int NT>
-  __device__ __forceinline__ void operator()(int slot, const f32x4 (&a)[NT]) const {
-    if (!valid) return;
+  __device__ __forceinline__ float* begin(int slot, const f32x4 (&a)[NT]) const {
     float* row = base + ((long)slot * P + n) * ACT_W + 4 * g;
-    const int nt = slot == 9 ? 8 : NT;
-    uint32_t lo = 0, hi = 0;
+    if (slot != 8) {   // xyz_encoding_final is linear: no mask
+      const int nt = slot == 9 ? 8 : NT;
+      uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int T = 0; T < NT; ++T)
-      if (T < nt) {
-        *(f32x4*)(row + 16 * T) = a[T];
-        if (slot != 8) {   // xyz_encoding_final is linear: no mask
+      for (int T = 0; T < NT; ++T)
+        if (T < nt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t bit = a[T][r] > 0.0f ? 1u : 0u;       // post-relu values: > 0 <=> pre-activation > 0
@@ -38,8 +44,21 @@ struct ActSaver {
             if (k < 32) lo |= bit << k; else hi |= bit << (k - 32);
           }
         }
-      }
-    if (slot != 8) *mask_slot(base, P, slot, n, g) = ((unsigned long long)hi << 32) | lo;
+      if (valid) *mask_slot(base, P, slot, n, g) = ((unsigned long long)hi << 32) | lo;
+    }
+    return row;
+  }
+  __device__ __forceinline__ void piece(float* row, int T, const f32x4& v) const {
+    if (valid) *(f32x4*)(row + 16 * T) = v;
+  }
+  // everything at once (module-entry tail, tests)
+  template <int NT>
+  __device__ __forceinline__ void operator()(int slot, const f32x4 (&a)[NT]) const {
+    float* row = begin(slot, a);
+    const int nt = slot == 9 ? 8 : NT;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+      if (T < nt) piece(row, T, a[T]);
   }
 };
 
