@@ -95,9 +95,19 @@ __device__ __forceinline__ void finish_delta(const f32x4 (&acc)[NT], f32x4 (&dl)
       }
     }
     dl[T] = d;
-    if (valid) *(f32x4*)(delta_row + 16 * T) = d;
+    if (delta_row && valid) *(f32x4*)(delta_row + 16 * T) = d;     // delta_row == null: the caller defers the stores (DeltaSaver)
   }
 }
+
+// The deltas of a layer are stored BEHIND the MFMAs of the next (transposed) layer, one 64-byte-per-point piece every four
+// fragment steps, for the reason given at ActSaver (mlp_train16.h): a burst of 16 stores per wave behind every layer stalls
+// all eight waves of the workgroup on the CU's store path.
+struct DeltaSaver {
+  bool valid;
+  __device__ __forceinline__ void piece(float* row, int T, const f32x4& v) const {
+    if (valid) *(f32x4*)(row + 16 * T) = v;
+  }
+};
 
 __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __restrict__ packedT, const float* __restrict__ out,
                                                                 const float* __restrict__ d_out, const float* __restrict__ acts,
@@ -149,29 +159,36 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16_kernel(const char* __re
       f32x4 acc8[8];
       zero_acc16<8>(acc8);
       mma_layer16<8, 4, 0>(pipe, drgb, drgb, acc8, q);
-      finish_delta<8, true>(acc8, dl, bits[9], del_row(9), valid);
+      finish_delta<8, true>(acc8, dl, bits[9], nullptr, valid);
     }
+    const DeltaSaver ds{valid};
+    float* pending = del_row(9);                       // the row whose pieces ride in the next layer's MFMA loop
     zero_acc16<16>(acc);                               // through dir_encoding^T[:, :256] -> xyz_encoding_final output (linear)
-    mma_layer16<16, 8, 0>(pipe, dl, dl, acc, q);
-    finish_delta<16, false>(acc, dl, 0ull, del_row(8), valid);
+    mma_layer16<16, 8, 0>(pipe, dl, dl, acc, q, DeferredActs<DeltaSaver, 8>{ds, pending, dl});
+    finish_delta<16, false>(acc, dl, 0ull, nullptr, valid);
+    pending = del_row(8);
     zero_acc16<16>(acc);                               // through xyz_encoding_final^T, + sigma head -> h8 (relu)
-    mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
+    mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q, DeferredActs<DeltaSaver, 16>{ds, pending, dl});
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
       const f32x4 w = *(const __attribute__((address_space(3))) f32x4*)(C + C_WSIG + 16 * T + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[T][r] = fmaf(w[r], dsp, acc[T][r]);
     }
-    finish_delta<16, true>(acc, dl, bits[7], del_row(7), valid);
+    finish_delta<16, true>(acc, dl, bits[7], nullptr, valid);
+    pending = del_row(7);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                     // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2
       zero_acc16<16>(acc);
-      mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q);
+      mma_layer16<16, 16, 0>(pipe, dl, dl, acc, q, DeferredActs<DeltaSaver, 16>{ds, pending, dl});
       unsigned long long bl = bits[0];   // bits[l - 1] by selects: a dynamic register index would go through M0, which the
 #pragma unroll                           // LDS-DMA asm (glds16) rewrites behind the compiler's back
       for (int t = 1; t < 7; ++t) bl = (l - 1 == t) ? bits[t] : bl;
-      finish_delta<16, true>(acc, dl, bl, del_row(l - 1), valid);
+      finish_delta<16, true>(acc, dl, bl, nullptr, valid);
+      pending = del_row(l - 1);
     }
+#pragma unroll
+    for (int T = 0; T < 16; ++T) ds.piece(pending, T, dl[T]);   // the first layer's deltas: nothing left to hide them behind
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
