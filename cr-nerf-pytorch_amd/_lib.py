@@ -16,7 +16,7 @@ EXPORTS = [
     "crnerf_abi_version", "crnerf_last_error", "crnerf_packed_mlp_bytes", "crnerf_pack_mlp_weights",
     "crnerf_posenc_f32", "crnerf_embed_points_f32", "crnerf_mlp_forward_f32", "crnerf_composite_f32", "crnerf_composite_backward_f32", "crnerf_sample_pdf_merge_f32",
     "crnerf_render_rays_f32", "crnerf_render_rays_train_f32", "crnerf_rng_fill_f32", "crnerf_mlp_backward_ex_f32", "crnerf_packed_mlp_mixed_bytes",
-    "crnerf_pack_mlp_weights_mixed", "crnerf_mlp_train_mixed_acts_bytes", "crnerf_mlp_train_mixed_scratch_bytes", "crnerf_mlp_forward_train_mixed_f32", "crnerf_mlp_backward_mixed_f32", "crnerf_crossray_workspace_bytes", "crnerf_crossray_chansum_f32",
+    "crnerf_pack_mlp_weights_mixed", "crnerf_mlp_train_mixed_acts_bytes", "crnerf_mlp_train_mixed_scratch_bytes", "crnerf_mlp_forward_train_mixed_f32", "crnerf_mlp_backward_mixed_f32", "crnerf_mlp_backward_mixed_ex_f32", "crnerf_render_rays_train_bf16", "crnerf_crossray_workspace_bytes", "crnerf_crossray_chansum_f32",
     "crnerf_crossray_gram_f32", "crnerf_crossray_matrix_f32", "crnerf_crossray_fold_f32",
     "crnerf_crossray_apply_f32", "crnerf_crossray_decode_f32",
     "crnerf_packed_mlp_t_bytes", "crnerf_pack_mlp_weights_t", "crnerf_mlp_train_acts_bytes", "crnerf_mlp_train_scratch_bytes",
@@ -132,6 +132,7 @@ def load():
             "crnerf_mlp_train_mixed_scratch_bytes": (ctypes.c_size_t, [i64]),
             "crnerf_mlp_forward_train_mixed_f32": (ctypes.c_int, [pp, vp, vp, vp, vp, i64, vp]),
             "crnerf_mlp_backward_mixed_f32": (ctypes.c_int, [pp, vp, vp, vp, vp, vp, vp, pp, i64, vp]),
+            "crnerf_mlp_backward_mixed_ex_f32": (ctypes.c_int, [pp, vp, vp, vp, vp, vp, pp, i64, ctypes.c_int, vp]),
             "crnerf_posenc_f32": (ctypes.c_int, [vp, vp, i64, i32, vp]),
             "crnerf_embed_points_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, i32, vp]),
             "crnerf_encoder_workspace_bytes": (ctypes.c_size_t, [i32, i32]),
@@ -146,6 +147,7 @@ def load():
             "crnerf_render_rays_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
             "crnerf_rng_fill_f32": (ctypes.c_int, [vp, i64, i32, ctypes.c_uint64, i32, i64, vp]),
             "crnerf_render_rays_train_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp, vp, vp, vp, vp]),
+            "crnerf_render_rays_train_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp, vp, vp, vp, vp]),
             "crnerf_render_rays_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
             "crnerf_packed_mlp_bf16_bytes": (ctypes.c_size_t, []),
             "crnerf_pack_mlp_weights_bf16": (ctypes.c_int, [pp, vp, vp]),

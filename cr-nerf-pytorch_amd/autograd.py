@@ -68,9 +68,9 @@ _TRAIN_BF16 = [False]
 
 def set_training_precision(precision="f32"):
     """"f32" (default): training through the fp32 twins -- the reference's arithmetic.  "bf16": opt-in mixed precision for NeRF_sigma
-    in grad mode (crnerf_mlp_*_mixed_f32, include/crnerf.h): forward in the arithmetic of the bf16 inference kernels, data and weight
-    gradients from bf16-rounded operands, fp32 accumulation and fp32 storage everywhere.  The renderer then runs un-fused (posenc ->
-    per-layer GEMMs -> compositing): with the matrix work 16x cheaper the MLP passes are bound by their activation traffic."""
+    in grad mode (include/crnerf.h): forward in the arithmetic of the bf16 inference kernels, data and weight gradients from
+    bf16-rounded operands, fp32 accumulation; activations and deltas are kept as bf16 rows.  The forward is the fused bf16 renderer's
+    training twin (crnerf_render_rays_train_bf16); the backward runs per-layer bf16 GEMMs (crnerf_mlp_backward_mixed_ex_f32)."""
     _TRAIN_BF16[0] = ops._is_bf16(precision)
 
 
@@ -228,6 +228,68 @@ class MixedRecomputeRenderFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class MixedFusedRenderFn(torch.autograd.Function):
+    """set_training_precision("bf16"), one chunk of rays as ONE differentiable node: fwd crnerf_render_rays_train_bf16 -- the fused bf16
+    renderer that also keeps, per pass, the bf16 activation rows / relu bits / embedded input (written from the registers they are born
+    in) and the raw MLP outputs; bwd per pass crnerf_composite_backward_f32 -> crnerf_mlp_backward_mixed_ex_f32 (per-layer bf16 GEMMs for
+    the data gradients, weight gradients from the stored rows).  The gradient is taken at exactly the activations the loss saw."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, *params):
+        ctx.set_materialize_grads(False)
+        Nc, Ni = cfg["Nc"], cfg["Ni"]
+        n_models = 2 if Ni > 0 else 1
+        states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(n_models)]
+        for mod in cfg["modules"]:
+            if mod is not None and hasattr(mod, "invalidate_packed"):
+                mod.invalidate_packed()
+        packed = [ops.pack_mlp_weights(st, precision="bf16") for st in states]
+        out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
+                              z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
+                              noise_std=cfg["noise_std"], want_z_fine=True, precision="bf16", train=True)
+        ctx.cfg, ctx.n_models = cfg, n_models
+        keep = [out["z_fine"] if Ni > 0 else rays.new_empty(0), out["acts_coarse"], out["raw_coarse"]]
+        if Ni > 0:
+            keep += [out["acts_fine"], out["raw_fine"]]
+        ctx.n_keep = len(keep)
+        ctx.save_for_backward(*keep, *params)
+        res = (out["weights_coarse"], out["feature_coarse"], out["depth_coarse"])
+        if Ni > 0:
+            res += (out["weights_fine"], out["feature_fine"], out["depth_fine"])
+        return res
+
+    @staticmethod
+    def backward(ctx, *g):
+        cfg = ctx.cfg
+        saved = ctx.saved_tensors
+        keep, params = saved[:ctx.n_keep], saved[ctx.n_keep:]
+        z_fine = keep[0]
+        grads = []
+        for m in range(ctx.n_models):
+            d_w, d_f, d_d = g[3 * m], g[3 * m + 1], g[3 * m + 2]
+            if d_w is None and d_f is None and d_d is None:
+                grads += [None] * 24
+                continue
+            acts, raw = keep[1 + 2 * m], keep[2 + 2 * m]
+            z = z_fine if m == 1 else cfg["z_coarse"]
+            noise = cfg["noise_f"] if m == 1 else cfg["noise_c"]
+            if d_f is None:
+                d_f = torch.zeros(raw.shape[0], 64, device=raw.device)
+            d_raw = ops.composite_backward(raw, z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
+                                           None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
+            packed, tensors = ops.pack_mlp_weights_mixed(dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])))
+            grads += ops.mlp_backward_mixed(packed, tensors, None, raw.view(-1, 65), d_raw.view(-1, 65), acts, fused_acts=True)
+            del d_raw
+        return (None, None) + tuple(grads)
+
+
+def get_training_bf16_fused():
+    """The mixed-precision mode trains through the fused bf16 renderer (MixedFusedRenderFn) unless CRNERF_TRAIN_BF16_UNFUSED=1 asks for the
+    round-2 path (embedded points -> per-layer GEMM twins -> compositing), kept for A/B runs and as the module-level twin."""
+    import os
+    return os.environ.get("CRNERF_TRAIN_BF16_UNFUSED", "") in ("", "0")
+
+
 def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, rng=None):
     """Grad-mode render of `rays` in ray chunks of ~2^20 fine sample points (rays are independent; the chunk bounds the
     backward's scratch -- 10 KB of layer deltas per point -- and, in recompute mode, the live activations)."""
@@ -254,7 +316,9 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
             cfg["z_steps"] = z_steps          # the reference's torch.linspace table (rendering.py:160): the jitter is formed from it in-kernel
             if rng.get("u") and Ni > 0:
                 cfg["u"] = None
-        fn = MixedRecomputeRenderFn if (get_training_bf16() and get_training_recompute()) else FusedRenderFn
+        fn = FusedRenderFn
+        if get_training_bf16():
+            fn = MixedRecomputeRenderFn if get_training_recompute() else MixedFusedRenderFn
         parts.append(fn.apply(cfg, rays[lo:hi].contiguous(), *params))
     keys = ["weights_coarse", "feature_coarse", "depth_coarse"] + (["weights_fine", "feature_fine", "depth_fine"] if Ni > 0 else [])
     return {k: (parts[0][i] if len(parts) == 1 else torch.cat([p[i] for p in parts], 0)) for i, k in enumerate(keys)}

@@ -227,6 +227,7 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   if (bf16) {
     // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
     static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();
+    if (acts_c) return launch_render_rays_bf16p(r, (hipStream_t)stream);   // the bf16 training twin exists on the pair core only
     return core64 ? launch_render_rays_bf16(r, (hipStream_t)stream) : launch_render_rays_bf16p(r, (hipStream_t)stream);
   }
   if (acts_c) return launch_render_rays16(r, (hipStream_t)stream);       // the training twin exists on the 16x16x4 core only
@@ -273,6 +274,26 @@ int crnerf_mlp_backward_mixed_f32(const float* const* tensors, const void* packe
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!tensors[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_mixed: a tensor / gradient pointer is NULL");
   return launch_mlp_backward_mixed(to_tensors(tensors), packed, x, out, d_out, acts, scratch, grads, (long)n, (hipStream_t)stream);
+}
+
+int crnerf_mlp_backward_mixed_ex_f32(const float* const* tensors, const void* packed, const float* out, const float* d_out, const void* acts,
+                                     void* scratch, float* const* grads, int64_t n, int acts_layout, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
+  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  if (acts_layout != CRNERF_MIXED_ACTS_GEMM && acts_layout != CRNERF_MIXED_ACTS_FUSED) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_mixed_ex: unknown acts_layout");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_mixed_ex: a tensor / gradient pointer is NULL");
+  return launch_mlp_backward_mixed(to_tensors(tensors), packed, nullptr, out, d_out, acts, scratch, grads, (long)n, (hipStream_t)stream, acts_layout);
+}
+
+int crnerf_render_rays_train_bf16(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
+                                  void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
+  if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
+  return render_rays_common(a, stream, true, acts_coarse, acts_fine, raw_coarse, raw_fine);
 }
 
 int crnerf_render_rays_train_f32(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,

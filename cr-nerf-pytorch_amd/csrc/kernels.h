@@ -47,7 +47,7 @@ size_t mlp_train_mixed_scratch_bytes(long P);
 int launch_pack_mlp_gemm(const MlpTensors& t, void* packed, hipStream_t st);
 int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, const float* x, float* out, void* acts, long P, hipStream_t st);
 int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const void* acts,
-                              void* scratch, float* const* grads, long P, hipStream_t st);
+                              void* scratch, float* const* grads, long P, hipStream_t st, int acts_layout = 0);
 // dst[m * ldc + n] = sum_c partial[c][m][n] (+ db[m] = sum_c bias_partial[c][m]): the deterministic partial-sum reduction of the wgrad kernels
 int launch_wgrad_reduce(const float* partial, int nchunk, int M, int N, float* dst, int ldc, const float* bias_partial, float* db, hipStream_t st);
 int launch_ray_directions(float fx, float fy, float cx, float cy, int H, int W, float* dirs, hipStream_t stream);

@@ -95,7 +95,9 @@ struct WeightPipeP {
     voff = (F + 1 == STAGESB_PER_PASS) ? lane16 : voff + STAGE_BYTES;
     asm volatile("" : "+v"(voff));
   }
-  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int first_model, int lane, int wave) {
+  // all_landed (training twin): the first tile's barriers use store windows that assume a previous tile; with its first three stages
+  // already in LDS they have nothing left to wait for
+  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int first_model, int lane, int wave, bool all_landed = false) {
     lds = lds_;
     lane16 = (uint32_t)lane * 16u;
     rd_base = LDS_RING + lane16;
@@ -112,7 +114,8 @@ struct WeightPipeP {
       issue_piece(1, F);
       cursor_update(F);
     }
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (all_landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ void begin_tile(int next_model) {
@@ -123,8 +126,20 @@ struct WeightPipeP {
     // positions in 64 VGPRs outside the tile loop instead of using the ds_read offset field
     asm volatile("" : "+v"(rd_base));
   }
-  __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // `stores`: store instructions this wave has issued since its pieces of the stage the barrier opens (training twin; 0 at inference)
+  __device__ __forceinline__ void advance(int stores = 0) {
+    switch (stores) {   // the count must be an immediate; constant after unrolling
+#ifndef CRNERF_EXP_VMSLACK
+#define CRNERF_EXP_VMSLACK 0   // (timing experiments only: > 0 lets weight stages be read before they land)
+#endif
+#define CRNERF_VMW(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + N + (N ? CRNERF_EXP_VMSLACK : 0)) : "memory"); break;
+      CRNERF_VMW(0) CRNERF_VMW(1) CRNERF_VMW(2) CRNERF_VMW(3) CRNERF_VMW(4) CRNERF_VMW(5) CRNERF_VMW(6) CRNERF_VMW(7) CRNERF_VMW(8) CRNERF_VMW(9)
+      CRNERF_VMW(10) CRNERF_VMW(11) CRNERF_VMW(12) CRNERF_VMW(13) CRNERF_VMW(14) CRNERF_VMW(15) CRNERF_VMW(16) CRNERF_VMW(17) CRNERF_VMW(18)
+      CRNERF_VMW(19) CRNERF_VMW(20) CRNERF_VMW(21) CRNERF_VMW(22) CRNERF_VMW(23) CRNERF_VMW(24) CRNERF_VMW(25) CRNERF_VMW(26) CRNERF_VMW(27)
+      CRNERF_VMW(28) CRNERF_VMW(29) CRNERF_VMW(30) CRNERF_VMW(31) CRNERF_VMW(32)
+#undef CRNERF_VMW
+      default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ u32x4 read(int pos) const {
@@ -143,15 +158,198 @@ struct WeightPipeP {
 // kernel 128 VGPR + 128 AGPR (SIRegisterInfo: usesAGPRs => MaxNumVGPRs /= 2), which does not hold the two 64-register
 // activation buffers -- and a VGPR accumulator needs no v_accvgpr_read: a quarter is TWO VALU instructions.  The asm
 // statements pin each quarter to the k-step it was written in (see PackEpi in mlp_core_bf16.h).
-struct NoEpiP {
-  __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void finish(int, int, const f32x16&) {}
+// ---- training twin (crnerf_render_rays_train_bf16): what the backward twins need is written from the registers it is born in.
+// Saved state of a pass with P points (the buffer of crnerf_mlp_train_mixed_acts_bytes(P), mlp_gemm_bf16.hip):
+//   rows  [10][P][256] bf16   the B operands themselves: k-step 2T + j of lane (p, h) is ONE 16-byte piece at byte 64T + 32j + 16h of
+//                             the point's row ("fused" storage order: feature 32T + 8c + 4h + i at position 32T + 16(c>>1) + 8h + 4(c&1) + i;
+//                             the weight-gradient kernel un-permutes when it writes dW, mlp_gemm_bf16.hip perm_fused)
+//   bits  [10][P] x 32 B      relu-activity bits in the layout of linear_bf16_kernel (byte [q4][u], bit 4b + i <-> feature 32u + 16b + 4q4 + i):
+//                             lane (p, h) owns q4 = h and q4 = 2 + h, one dword per four tiles
+//   xb    [P][128] bf16       the embedded input as B operands, SLOT order (layout.h posenc_slot_to_col_b): xyz k-steps 0..5, dir k-steps 6, 7
+// Store pieces ride in the MFMA loop of the NEXT tile (k-steps 9 and 11; the activity bits are formed in k-steps 10 and 12): a store
+// wave-instruction holds the CU's store path ~64 cycles, see ActSaver in mlp_train16.h.
+//
+// Stores and the weight ring share vmcnt (gfx9 has no separate store counter; VMEM operations retire in issue order).  The ring's barrier in
+// stage c must know that this wave's LDS-DMA pieces of stage c + 1 have landed; they were issued in stage c - 2, and everything issued after
+// them may stay in flight: the four pieces of stages c + 2 and c + 3 -- vmcnt(4) at inference -- PLUS every store issued since.  With
+// vmcnt(4) kept as it is each barrier also waited for all but the last few stores to reach L2 (measured: 2.7 ms per 2^20 points = 2.3 TB/s
+// of saved state against 1.17 ms for the inference kernel).  So every store of the training twin is UNCONDITIONAL -- a raw-buffer store whose
+// resource ends at the pass' last row; lanes without a point (tail of a ray, rays past R) carry an out-of-range offset and the hardware
+// drops them -- which makes the number of stores between any two points of the tile's static schedule a compile-time constant, and the
+// barrier waits vmcnt(4 + that number) (p_store_window below).  Stores the model does not know (compositing outputs between tiles) only
+// make the wait stricter.
+constexpr uint32_t SAVE_OOB = 0xF0000000u;     // offset of a lane that stores nothing (>= every resource size; + instruction offsets stays < 2^32)
+constexpr int SAVE_FLAGS = 0x00020000;         // buffer resource word 3 (gfx9: DATA_FORMAT_32), raw buffer: stride 0, range check on the byte offset
+constexpr int SAVE_TILE_BURST = 8 + 9;         // between two tiles: the raw output row (8 x 16 B + sigma) and the embedded input (8 x 16 B)
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+struct NoSaveP {
+  static constexpr bool on = false;
+};
+struct ActSaveP {
+  static constexpr bool on = true;
+  const char* acts;      // scalar: this pass' buffer
+  long slot_bytes;       // scalar: P * 512
+  long P;                // scalar
+  uint32_t voff;         // per lane: point * 512 + 16 h, or SAVE_OOB
+  uint32_t boff;         // per lane: point * 32 + 8 h, or SAVE_OOB
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows(int slot) const {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(acts + slot * slot_bytes), 0, (int)(uint32_t)slot_bytes, SAVE_FLAGS);
+  }
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bits(int slot) const {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(acts + 10 * slot_bytes + (long)slot * P * 32), 0, (int)(uint32_t)(P * 32), SAVE_FLAGS);
+  }
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t xb() const {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(acts + 10 * slot_bytes + 10 * P * 32), 0, (int)(uint32_t)(P * 256), SAVE_FLAGS);
+  }
 };
 
-template <bool RELU>
+// activity byte of four packed post-relu dwords: bit 2d + e <-> half e of dword d is non-zero
+__device__ __forceinline__ uint32_t act_byte(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 one = {1, 1};
+  auto nz = [&](uint32_t d) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, d), one)); };   // v_pk_min_u16
+  uint32_t m = nz(d0) | (nz(d1) << 2);
+  m |= nz(d2) << 4;
+  m |= nz(d3) << 6;
+  return (m | (m >> 15)) & 0xffu;
+}
+
+template <class SV>
+struct SaveSlot {   // per-epilogue state of the training twin; empty at inference
+  __amdgpu_buffer_rsrc_t rows, bitp;
+  uint32_t bA = 0, bB = 0;
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4
+  __amdgpu_buffer_rsrc_t exp_rows0;
+  uint32_t exp_slot;
+#endif
+  template <bool BITS>
+  __device__ __forceinline__ void set(const SV& sv, int slot) {
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4
+    exp_rows0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sv.acts), 0, (int)0xffffff00u, SAVE_FLAGS);
+    exp_slot = slot;
+#endif
+    rows = sv.rows(slot);
+    if (BITS) bitp = sv.bits(slot);
+  }
+  // step 0 / 2: the two row pieces of tile T; step 1 / 3: the activity bytes of q4 = h / q4 = 2 + h (+ the dword stores behind every 4th tile).
+  // The store count per step is mirrored by p_stores_at() below.
+  template <bool BITS>
+  __device__ __forceinline__ void step(const SV& sv, const u32x4 (&dst)[KS_HID], int T, int st) {
+    if (st == 0 || st == 2) {
+      const int j = st >> 1;
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 3   // (timing experiments only; breaks the vmcnt model: results are garbage) no row stores at all
+      return;
+#endif
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4   // (timing experiments only; garbage) point-major addresses: the ten rows of a point adjacent
+      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], exp_rows0, (int)((sv.voff & ~511u) * 10u + (sv.voff & 511u) + 512u * exp_slot + (uint32_t)(64 * T + 32 * j)), 0, 0);
+      return;
+#endif
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 5   // (timing experiments only; garbage) full 128-byte lines per instruction: 8 rows x 128 B
+      {
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const uint32_t base = sv.voff - ((lane & 31u) * 512u + 16u * (lane >> 5));
+        const uint32_t e = 2u * (T & 1) + j;
+        __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)(base + (8u * e + (lane >> 3)) * 512u + 128u * (T >> 1) + 16u * (lane & 7u)), 0, 0);
+        return;
+      }
+#endif
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 2   // (timing experiments only) rows into a 1 MB window per slot
+      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)((sv.voff & 0xfffffu) + (uint32_t)(64 * T + 32 * j)), 0, 0);
+      return;
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)(sv.voff + (uint32_t)(64 * T + 32 * j)), 0, 0);
+    } else if (BITS) {
+      const int e = st == 1 ? 0 : 2;
+      const uint32_t by = act_byte(dst[2 * T][e], dst[2 * T][e + 1], dst[2 * T + 1][e], dst[2 * T + 1][e + 1]);
+      uint32_t& acc = st == 1 ? bA : bB;
+      acc = (T & 3) == 0 ? by : (acc | (by << (8 * (T & 3))));
+      if ((T & 3) == 3) __builtin_amdgcn_raw_buffer_store_b32(acc, bitp, (int)(sv.boff + (uint32_t)((st == 1 ? 0 : 16) + 4 * (T >> 2))), 0, 0);
+    }
+  }
+};
+template <>
+struct SaveSlot<NoSaveP> {
+  template <bool BITS>
+  __device__ __forceinline__ void set(const NoSaveP&, int) {}
+  template <bool BITS>
+  __device__ __forceinline__ void step(const NoSaveP&, const u32x4 (&)[KS_HID], int, int) {}
+};
+
+// ---- the static store schedule of one tile (what SaveSlot::step issues where mma_layer_p calls it), for the ring's vmcnt
+struct PLayerSched { int fbase, nt, ns, prev_kind, epi_kind, pt; };   // kind 0: stores nothing, 1: rows, 2: rows + activity bits
+constexpr PLayerSched P_SCHED[11] = {
+    {OFFB_L1, 8, KS_XYZ, 0, 2, 0},          {OFFB_L2, 8, KS_HID, 2, 2, 7},           {OFFB_L2 + FB_HID, 8, KS_HID, 2, 2, 7},
+    {OFFB_L2 + 2 * FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_L5, 8, KS_XYZ + KS_HID, 2, 2, 7}, {OFFB_L6, 8, KS_HID, 2, 2, 7},
+    {OFFB_L6 + FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_L6 + 2 * FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_FIN, 8, KS_HID, 2, 1, 7},
+    {OFFB_DIR, 4, KS_HID + KS_DIR, 1, 2, 7}, {OFFB_RGB, 2, KS_HALF, 2, 0, 3}};
+constexpr int p_stores_at(int i) {   // store instructions issued in k-step i (pass-relative fragment index)
+  for (int l = 0; l < 11; ++l) {
+    const PLayerSched& L = P_SCHED[l];
+    if (i < L.fbase || i >= L.fbase + L.nt * L.ns) continue;
+    const int T = (i - L.fbase) / L.ns, s = (i - L.fbase) % L.ns;
+    const int kind = T == 0 ? L.prev_kind : L.epi_kind, tile = T == 0 ? L.pt : T - 1;
+    if (kind == 0) return 0;
+    const int bits = (kind == 2 && (tile & 3) == 3) ? 1 : 0;
+    if (L.ns >= 16) return (s == 9 || s == 11) ? 1 : ((s == 10 || s == 12) ? bits : 0);
+    return s == L.ns - 1 ? 2 + 2 * bits : 0;
+  }
+  return 0;
+}
+constexpr int p_second_piece_step(int stage, int stagger) {   // k-step that issues piece 1 of the stage fetched during `stage`
+  return stage * STAGE_FRAGS + (stage == STAGESB_PER_PASS - 1 ? 2 + stagger : 5 + 2 * stagger);
+}
+// stores issued after this wave's pieces of stage c + 1 (issued in stage c - 2, possibly of the previous tile) up to the barrier of stage c
+constexpr int p_store_window(int i_barrier, int stagger) {
+  const int c = i_barrier / STAGE_FRAGS;
+  int n = 0;
+  if (c >= 2) {
+    for (int i = p_second_piece_step(c - 2, stagger); i <= i_barrier; ++i) n += p_stores_at(i);
+  } else {
+    for (int i = p_second_piece_step(c - 2 + STAGESB_PER_PASS, stagger); i < STREAMB_USED; ++i) n += p_stores_at(i);
+    n += SAVE_TILE_BURST;
+    for (int i = 0; i <= i_barrier; ++i) n += p_stores_at(i);
+  }
+  return n;
+}
+constexpr int p_store_total() {
+  int n = 0;
+  for (int i = 0; i < STREAMB_USED; ++i) n += p_stores_at(i);
+  return n;
+}
+static_assert(p_store_total() == 9 * 16 + 8 + 8 * 4 + 2, "store schedule: 9 x 8 tiles x 2 rows + dir 4 x 2, activity dwords 8 x 4 + dir 2");
+constexpr int p_store_window_max() {
+  int m = 0;
+  for (int i = 0; i < STREAMB_USED; ++i)
+    if (b_advance_at(i) && p_store_window(i, P_STAGGER) > m) m = p_store_window(i, P_STAGGER);
+  return m;
+}
+static_assert(4 + p_store_window_max() <= 36, "vmcnt is a 6-bit counter; WeightPipeP::advance spells out the immediates up to 4 + 32");
+struct PWindowTable { int v[STAGESB_PER_PASS]; };
+constexpr PWindowTable p_make_windows() {   // per stage: the store window of its barrier (a table, so that the unrolled tile loop folds it to an immediate)
+  PWindowTable t{};
+  for (int i = 0; i < STREAMB_USED; ++i)
+    if (b_advance_at(i)) t.v[i / STAGE_FRAGS] = p_store_window(i, P_STAGGER);
+  return t;
+}
+constexpr PWindowTable P_WINDOWS = p_make_windows();
+
+struct NoEpiP {
+  static constexpr bool saving = false;
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void finish(int, int, const f32x16&) {}
+  __device__ __forceinline__ void save_step(int, int) {}
+};
+
+template <bool RELU, class SV = NoSaveP>
 struct PackEpiP {
+  static constexpr bool saving = SV::on;
   u32x4 (&dst)[KS_HID];
-  __device__ __forceinline__ explicit PackEpiP(u32x4 (&d)[KS_HID]) : dst(d) {}
+  const SV& sv;
+  SaveSlot<SV> ss;
+  __device__ __forceinline__ PackEpiP(u32x4 (&d)[KS_HID], const SV& s) : dst(d), sv(s) {}
+  __device__ __forceinline__ void slot(int sl) { ss.template set<RELU>(sv, sl); }
+  __device__ __forceinline__ void save_step(int T, int st) { ss.template step<RELU>(sv, dst, T, st); }
   __device__ __forceinline__ void prefetch(int) {}
   __device__ __forceinline__ void finish(int T, int qc, const f32x16& acc) {
     uint32_t pk;
@@ -164,13 +362,19 @@ struct PackEpiP {
 };
 
 // xyz_encoding_8: as PackEpiP<true>, plus static_sigma (256 -> 1) in fp32 on the un-rounded activations
+template <class SV = NoSaveP>
 struct SigmaEpiP {
+  static constexpr bool saving = SV::on;
   u32x4 (&dst)[KS_HID];
   float& sg;
   const lds_float* wsig;
   int h;
+  const SV& sv;
+  SaveSlot<SV> ss;
   f32x4 wv[4];
-  __device__ __forceinline__ SigmaEpiP(u32x4 (&d)[KS_HID], float& s, const lds_float* w, int h_) : dst(d), sg(s), wsig(w), h(h_) {}
+  __device__ __forceinline__ SigmaEpiP(u32x4 (&d)[KS_HID], float& s, const lds_float* w, int h_, const SV& v) : dst(d), sg(s), wsig(w), h(h_), sv(v) {}
+  __device__ __forceinline__ void slot(int sl) { ss.template set<true>(sv, sl); }
+  __device__ __forceinline__ void save_step(int T, int st) { ss.template step<true>(sv, dst, T, st); }
   __device__ __forceinline__ void prefetch(int T) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) wv[c] = lds_f4(wsig + 32 * T + 8 * c + 4 * h);
@@ -187,9 +391,11 @@ struct SigmaEpiP {
 };
 
 struct RgbEpiP {   // static_rgb: sigmoid, fp32 out
+  static constexpr bool saving = false;
   f32x16 (&feat)[2];
   __device__ __forceinline__ explicit RgbEpiP(f32x16 (&f)[2]) : feat(f) {}
   __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void save_step(int, int) {}
   __device__ __forceinline__ void finish(int T, int qc, const f32x16& acc) {
     float x0 = acc[2 * qc], x1 = acc[2 * qc + 1];
     asm volatile("" : "+v"(x0), "+v"(x1));
@@ -258,11 +464,25 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);
       }
+      {   // training twin: the previous tile's row pieces / activity bits, behind its last epilogue quarter (no-ops at inference)
+        const int st = LONG ? s - 9 : -1;
+        if (LONG && st >= 0 && st < 4) {
+          if (T == 0) prev.save_step(PT, st);
+          else epi.save_step(T - 1, st);
+        }
+        if (!LONG && s == NS - 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (T == 0) prev.save_step(PT, u);
+            else epi.save_step(T - 1, u);
+          }
+        }
+      }
       if (s == NS - 2 || s == NS - 1) {   // the next tile's bias, straight into its accumulator (drained by k-step 8 / 4)
         const lds_float* nb = (T + 1 < NT) ? bias : next_bias;
         load_bias_into(accs[cur ^ 1], nb, (T + 1 < NT) ? T + 1 : 0, h, s - (NS - 2));
       }
-      if (b_advance_at(i)) p.advance();
+      if (b_advance_at(i)) p.advance((PREV::saving || EPI::saving) ? P_WINDOWS.v[i / STAGE_FRAGS] : 0);
       if (b_cursor_at(i)) p.cursor_update(i / STAGE_FRAGS + B_RING - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -272,8 +492,9 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
 // One 32-point tile through one model.  pe[s]: the xyz embedding as B operands (posenc_b); dirsrc: this lane half's 2 x 16 bytes
 // of the ray's direction embedding, parked in LDS.  Returns feat[t][r] = rgb feature 32t + 8(r>>2) + 4h + (r&3) of point p, and
 // sigma (valid in both lane halves).
+template <class SV = NoSaveP>
 __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_model, const u32x4 (&pe)[KS_XYZ], const lds_char* dirsrc,
-                                           f32x16 (&feat)[2], float& sigma, int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm) {
+                                           f32x16 (&feat)[2], float& sigma, int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm, const SV& sv = SV()) {
   p.begin_tile(next_model);
   uint32_t c_off = model ? LDS_CONST1 : LDS_CONST0;
   asm volatile("" : "+s"(c_off));     // loop-invariant LDS: launder the address once per tile (LICM would hoist ~1,300 reads)
@@ -286,19 +507,30 @@ __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_m
   load_bias_into(accs[0], B1, 0, h, 1);
   tm.tick(T_PROLOGUE);
 
+  // slot(k): where the training twin keeps the output of the layer this epilogue closes (h1..h8 = 0..7, final = 8, dir act = 9); an epilogue's
+  // last tile is stored from the NEXT layer's first tile, so the slot is switched between that layer and the epilogue's next own layer
   NoEpiP none;
-  PackEpiP<true> eA(actA), eB(actB);
-  PackEpiP<false> efin(actA);
-  SigmaEpiP e8(actB, sg, C + C_WSIG, h);
+  PackEpiP<true, SV> eA(actA, sv), eB(actB, sv);
+  PackEpiP<false, SV> efin(actA, sv);
+  SigmaEpiP<SV> e8(actB, sg, C + C_WSIG, h, sv);
   RgbEpiP ergb(feat);
+  eA.slot(0);
   mma_layer_p<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, B1, B1 + 1 * W_HIDDEN, h, none, eA);                                // xyz_encoding_1
+  eB.slot(1);
   mma_layer_p<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, B1 + 1 * W_HIDDEN, B1 + 2 * W_HIDDEN, h, eA, eB);               // 2
+  eA.slot(2);
   mma_layer_p<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, B1 + 2 * W_HIDDEN, B1 + 3 * W_HIDDEN, h, eB, eA);     // 3
+  eB.slot(3);
   mma_layer_p<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, B1 + 3 * W_HIDDEN, B1 + 4 * W_HIDDEN, h, eA, eB); // 4
+  eA.slot(4);
   mma_layer_p<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, B1 + 4 * W_HIDDEN, B1 + 5 * W_HIDDEN, h, eB, eA);           // 5 = Linear(cat[xyz, h])
+  eB.slot(5);
   mma_layer_p<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, B1 + 5 * W_HIDDEN, B1 + 6 * W_HIDDEN, h, eA, eB);              // 6
+  eA.slot(6);
   mma_layer_p<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, B1 + 6 * W_HIDDEN, B1 + 7 * W_HIDDEN, h, eB, eA);     // 7
+  e8.slot(7);
   mma_layer_p<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, B1 + 7 * W_HIDDEN, C + C_BFIN, h, eA, e8);        // 8 (+ static_sigma)
+  efin.slot(8);
   mma_layer_p<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, C + C_BFIN, C + C_BDIR, h, e8, efin);                         // xyz_encoding_final
   tm.tick(T_MMA);
   sg += __shfl_xor(sg, 32);
@@ -307,6 +539,7 @@ __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_m
 #pragma unroll
   for (int s = 0; s < KS_DIR; ++s) dv[s] = *(const __attribute__((address_space(3))) u32x4*)(dirsrc + 32 * s);
   tm.tick(T_SIGMA);
+  eB.slot(9);
   mma_layer_p<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, C + C_BDIR, C + C_BRGB, h, efin, eB);                      // dir_encoding
   mma_layer_p<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, C + C_BRGB, C + C_BRGB, h, eB, ergb);                         // static_rgb
   tm.tick(T_MMA);

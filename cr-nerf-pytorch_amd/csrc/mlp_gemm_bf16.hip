@@ -39,6 +39,17 @@ typedef unsigned short bf16_t;   // raw storage
 // q4 = lane >> 4: the lane quarter that holds accumulator rows 4 q4 .. 4 q4 + 3)
 __host__ __device__ constexpr int perm32(int f) { return (f & ~31) | (((f >> 2) & 3) << 3) | (((f >> 4) & 1) << 2) | (f & 3); }
 __host__ __device__ constexpr int unperm32(int c) { return (c & ~31) | (((c >> 2) & 1) << 4) | (((c >> 3) & 3) << 2) | (c & 3); }
+// "fused" storage order of the rows the bf16 pair renderer's training twin writes (mlp_core_bf16p.h): feature 32T + 8c + 4h + i sits at
+// position 32T + 16(c>>1) + 8h + 4(c&1) + i, i.e. bits 2 and 3 of the index trade places (an involution that keeps groups of four together)
+__host__ __device__ constexpr int perm_fused(int f) { return (f & ~12) | (((f >> 2) & 1) << 3) | (((f >> 3) & 1) << 2); }
+static_assert(perm_fused(perm_fused(91)) == 91 && perm_fused(32 * 3 + 8 * 2 + 4 * 1 + 3) == 32 * 3 + 16 * 1 + 8 * 1 + 4 * 0 + 3 &&
+              perm_fused(8 * 1 + 4 * 0 + 2) == 4 + 2, "fused storage permutation");
+// column orders of a weight-gradient operand: where column c of the stored row lives in the reference's feature order (-1: padding)
+enum { ORD_REF = 0, ORD_PERM32 = 1, ORD_FUSED = 2, ORD_XYZ_SLOTS = 3, ORD_DIR_SLOTS = 4 };
+__host__ __device__ inline int ord_to_ref(int ord, int c) {
+  return ord == ORD_PERM32 ? unperm32(c) : ord == ORD_FUSED ? perm_fused(c) : ord == ORD_XYZ_SLOTS ? posenc_slot_to_col_b(c, XYZ_FREQS)
+       : ord == ORD_DIR_SLOTS ? posenc_slot_to_col_b(c, DIR_FREQS) : c;
+}
 static_assert(unperm32(perm32(77)) == 77 && perm32(unperm32(200)) == 200 && perm32(16 * 1 + 4 * 2 + 3) == 8 * 2 + 4 + 3 && perm32(16 * 0 + 4 * 3 + 1) == 24 + 1,
               "storage permutation");
 
@@ -572,20 +583,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_b_kernel(WgradBJob j) {
   if (do_bias) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) bsum[t] += __shfl_xor(bsum[t], 32);
-    if (kk == 0 && mc < j.M) *(gb_f32x4*)(j.bias_partial + slot * j.M + (j.permD ? unperm32(mc) : mc)) = bsum;   // M is a multiple of 4
+    if (kk == 0 && mc < j.M) *(gb_f32x4*)(j.bias_partial + slot * j.M + ord_to_ref(j.permD, mc)) = bsum;   // M is a multiple of 4
   }
   float* outp = j.partial + slot * j.M * j.N;
-  const int fn = j.permA ? unperm32(nc) : nc;                   // the permutation keeps groups of four together
-  const bool vec = (j.N & 3) == 0;
+  const bool slots = j.permA >= ORD_XYZ_SLOTS;                  // embedding slots: every column finds its own place (or is padding)
+  const int fn = slots ? 0 : ord_to_ref(j.permA, nc);           // the row permutations keep groups of four together
+  int fs[4] = {0, 0, 0, 0};
+  if (slots) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fs[b] = nc + b < j.Aw ? ord_to_ref(j.permA, nc + b) : -1;
+  }
+  const bool vec = (j.N & 3) == 0 && !slots;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
-      if (m >= j.M || nc >= j.N) continue;
-      float* o = outp + (long)(j.permD ? unperm32(m) : m) * j.N + fn;
+      if (m >= j.M || nc >= (slots ? j.Aw : j.N)) continue;
+      float* o = outp + (long)ord_to_ref(j.permD, m) * j.N + fn;
       if (vec) *(gb_f32x4*)o = gb_f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
-      else {
+      else if (slots) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (fs[b] >= 0) o[fs[b]] = acc[a][b][r];
+      } else {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           if (nc + b < j.N) o[b] = acc[a][b][r];
@@ -634,9 +655,9 @@ __global__ __launch_bounds__(256) void sigma_wgrad_kernel(const bf16_t* __restri
   }
 }
 
-__global__ __launch_bounds__(320) void sigma_wgrad_finish_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db) {
+__global__ __launch_bounds__(320) void sigma_wgrad_finish_kernel(const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db, int fused) {
   const int f = threadIdx.x;
-  if (f < 256) dw[f] = sums[perm32(f)];
+  if (f < 256) dw[f] = sums[fused ? perm_fused(f) : perm32(f)];
   else if (f == 256) db[0] = sums[256];
 }
 
@@ -707,9 +728,14 @@ int launch_mlp_forward_train_mixed(const MlpTensors& t, const void* packed, cons
   return check_launch("mlp_forward_train_mixed");
 }
 
+// acts_layout: 0 = written by launch_mlp_forward_train_mixed (rows in perm32 order, xb in reference column order); 1 = written by the fused
+// renderer's training twin (crnerf_render_rays_train_bf16: rows in "fused" order, xb in embedding-slot order).  The deltas this function
+// produces are perm32 either way; the activity bits have one layout.
 int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const float* x, const float* out, const float* d_out, const void* acts,
-                              void* scratch, float* const* grads, long P, hipStream_t st) {
+                              void* scratch, float* const* grads, long P, hipStream_t st, int acts_layout) {
   if (P <= 0) return 0;
+  const int oA = acts_layout ? ORD_FUSED : ORD_PERM32;
+  const int oX = acts_layout ? ORD_XYZ_SLOTS : ORD_REF, oDir = acts_layout ? ORD_DIR_SLOTS : ORD_REF;
   (void)x;                                   // the bf16 copy the forward left in `acts` is what the weight gradients read
   const GemmLayout& L = layout();
   const bf16_t* abase = (const bf16_t*)acts;
@@ -736,16 +762,16 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
     if (int rc = dg(GM_T8 + (7 - l), GemmSeg{D(l), ACT_W, 256}, bits(l - 1), nullptr, nullptr, D(l - 1))) return rc;
   if (int rc = check_launch("mlp_backward_mixed")) return rc;
   // weight / bias gradients of the eleven nn.Linear (grads in crnerf.h tensor order)
-  if (int rc = wgrad_b(D(0), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[0], XYZ_DIM, grads[1], P, ws, st)) return rc;          // xyz_encoding_1
+  if (int rc = wgrad_b(D(0), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, oX, grads[0], XYZ_DIM, grads[1], P, ws, st)) return rc;          // xyz_encoding_1
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {                                                                                              // xyz_encoding_5: cat([xyz, h4])
-      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, 0, grads[8], XYZ_DIM + 256, grads[9], P, ws, st)) return rc;
-      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, A(3), ACT_W, 256, 256, 1, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, st)) return rc;
+      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, xb, XB_W, XYZ_DIM, 96, oX, grads[8], XYZ_DIM + 256, grads[9], P, ws, st)) return rc;
+      if (int rc = wgrad_b(D(4), ACT_W, 256, 256, 1, A(3), ACT_W, 256, 256, oA, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, st)) return rc;
     } else {
-      if (int rc = wgrad_b(D(l), ACT_W, 256, 256, 1, A(l - 1), ACT_W, 256, 256, 1, grads[2 * l], 256, grads[2 * l + 1], P, ws, st)) return rc;
+      if (int rc = wgrad_b(D(l), ACT_W, 256, 256, 1, A(l - 1), ACT_W, 256, 256, oA, grads[2 * l], 256, grads[2 * l + 1], P, ws, st)) return rc;
     }
   }
-  if (int rc = wgrad_b(D(8), ACT_W, 256, 256, 1, A(7), ACT_W, 256, 256, 1, grads[16], 256, grads[17], P, ws, st)) return rc;             // xyz_encoding_final
+  if (int rc = wgrad_b(D(8), ACT_W, 256, 256, 1, A(7), ACT_W, 256, 256, oA, grads[16], 256, grads[17], P, ws, st)) return rc;             // xyz_encoding_final
   {                                                                                                            // static_sigma
     const long chunk = (P + SIGW_BLOCKS - 1) / SIGW_BLOCKS;
     const int nblk = (int)((P + chunk - 1) / chunk);
@@ -753,11 +779,11 @@ int launch_mlp_backward_mixed(const MlpTensors& t, const void* packed, const flo
     float* sums = ws + (size_t)SIGW_BLOCKS * 257;
     hipLaunchKernelGGL(sigma_wgrad_kernel, dim3(nblk), dim3(256), 0, st, A(7), d_sig, P, chunk, part);
     if (int rc = launch_wgrad_reduce(part, nblk, 1, 257, sums, 257, nullptr, nullptr, st)) return rc;
-    hipLaunchKernelGGL(sigma_wgrad_finish_kernel, dim3(1), dim3(320), 0, st, sums, grads[18], grads[19]);
+    hipLaunchKernelGGL(sigma_wgrad_finish_kernel, dim3(1), dim3(320), 0, st, sums, grads[18], grads[19], acts_layout);
   }
-  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, A(8), ACT_W, 256, 256, 1, grads[20], 256 + DIR_DIM, grads[21], P, ws, st)) return rc;   // dir_encoding: cat([final, dir])
-  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, xb + XB_DIR, XB_W, DIR_DIM, 32, 0, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, st)) return rc;
-  if (int rc = wgrad_b(d_rgb, DRGB_W, FEAT_DIM, DRGB_W, 0, A(9), ACT_W, 128, 128, 1, grads[22], 128, grads[23], P, ws, st)) return rc;   // static_rgb
+  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, A(8), ACT_W, 256, 256, oA, grads[20], 256 + DIR_DIM, grads[21], P, ws, st)) return rc;   // dir_encoding: cat([final, dir])
+  if (int rc = wgrad_b(D(9), ACT_W, 128, 128, 1, xb + XB_DIR, XB_W, DIR_DIM, 32, oDir, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, st)) return rc;
+  if (int rc = wgrad_b(d_rgb, DRGB_W, FEAT_DIM, DRGB_W, 0, A(9), ACT_W, 128, 128, oA, grads[22], 128, grads[23], P, ws, st)) return rc;   // static_rgb
   return check_launch("mlp_backward_mixed wgrad");
 }
 

@@ -27,6 +27,27 @@ struct RenderParamsP {
   float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
 };
 
+// What the training twin adds (crnerf_render_rays_train_bf16): per pass the saved state of mlp_core_bf16p.h "training twin" -- activation rows,
+// activity bits, the embedded input, all written from the registers they are born in -- and the raw MLP output rows [R*N,65] fp32.  The inference
+// kernel instantiates the no-op hook.
+struct NoHookP {
+  static constexpr bool on = false;
+  __device__ __forceinline__ NoSaveP saver(int, long, int, int, bool, int) const { return NoSaveP(); }
+};
+struct TrainHookP {
+  static constexpr bool on = true;
+  char* acts[2];    // crnerf_mlp_train_mixed_acts_bytes(R*N) each, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
+  float* rawo[2];   // [R*N][65]
+  long R;
+  __device__ __forceinline__ ActSaveP saver(int pass, long r, int N, int n, bool ok, int h) const {
+    const long P = R * N, pt = r * N + n;
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1   // (timing experiments only) every row / bit store issued and dropped
+    ok = false;
+#endif
+    return ActSaveP{acts[pass], P * 512, P, ok ? (uint32_t)pt * 512u + 16u * (uint32_t)h : SAVE_OOB, ok ? (uint32_t)pt * 32u + 8u * (uint32_t)h : SAVE_OOB};
+  }
+};
+
 static __device__ unsigned int crnerf_sched_bf16p[SCHED_SLOTS][2];   // kernels.h "Dynamic work distribution"
 #ifdef CRNERF_TIMING
 static __device__ unsigned long long crnerf_wg_times_p[2 * 1024];
@@ -51,7 +72,8 @@ __device__ __forceinline__ float fold32(float (&v)[32], int p) {
   return v[0];
 }
 
-__global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP a) {
+template <class HOOK>
+__device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, const HOOK& hook) {
 #ifdef CRNERF_TIMING
   if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times_p[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -72,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP
   lds_char* dirbuf = lds + LDS_DIR_P + wave * 64;
 
   WeightPipeP pipe;
-  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, 0, lane, wave);
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, 0, lane, wave, HOOK::on);
   u32x4 q[B_AHEAD];
   pipe.prime(q);
   tm.tick(T_RAYLEVEL);
@@ -139,7 +161,31 @@ __global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP
         float sigma;
         // the model of the tile after this one: same pass, the fine pass, or the next ray's coarse pass
         const int next_model = k + 1 < steps ? pass : (pass + 1 < npass ? 1 : 0);
-        mlp_tile_p(pipe, pass, next_model, pe, dirbuf + 16 * h, feat, sigma, h, q, tm);
+        const auto sv = hook.saver(pass, r, N, n, valid && ray_ok, h);
+        if constexpr (HOOK::on) {   // the embedded input as the MLP multiplies it: xyz k-steps 0..5, dir k-steps 6, 7 (32 B per point and k-step);
+          const __amdgpu_buffer_rsrc_t xr = sv.xb();                        // unconditional stores, counted in SAVE_TILE_BURST (mlp_core_bf16p.h)
+          const uint32_t xo = sv.voff == SAVE_OOB ? SAVE_OOB : (sv.voff >> 1) + 8u * (uint32_t)h;   // point * 256 + 16 h
+#pragma unroll
+          for (int s = 0; s < KS_XYZ; ++s) __builtin_amdgcn_raw_buffer_store_b128(pe[s], xr, (int)(xo + 32u * s), 0, 0);
+#pragma unroll
+          for (int s = 0; s < KS_DIR; ++s)
+            __builtin_amdgcn_raw_buffer_store_b128(*(const __attribute__((address_space(3))) u32x4*)(dirbuf + 16 * h + 32 * s), xr, (int)(xo + 32u * (KS_XYZ + s)), 0, 0);
+        }
+        mlp_tile_p(pipe, pass, next_model, pe, dirbuf + 16 * h, feat, sigma, h, q, tm, sv);
+        if constexpr (HOOK::on) {   // raw MLP output row (rgb features after the sigmoid, sigma after the softplus): what compositing consumes.
+          // 8 x 16 B + sigma, unconditional (SAVE_TILE_BURST); rows are 260 B apart: dword-aligned 16-byte stores
+          const long P = hook.R * N;
+          const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(hook.rawo[pass], 0, (int)(uint32_t)(P * (OUT_DIM * 4)), SAVE_FLAGS);
+          const uint32_t ro = sv.voff == SAVE_OOB ? SAVE_OOB : (uint32_t)(r * N + n) * (uint32_t)(OUT_DIM * 4) + 16u * (uint32_t)h;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const u32x4 v = {__float_as_uint(feat[t][4 * c]), __float_as_uint(feat[t][4 * c + 1]), __float_as_uint(feat[t][4 * c + 2]), __float_as_uint(feat[t][4 * c + 3])};
+              __builtin_amdgcn_raw_buffer_store_b128(v, rr, (int)(ro + 4u * (32 * t + 8 * c)), 0, 0);
+            }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sigma), rr, (int)(h == 0 && ro != SAVE_OOB ? ro + 4u * FEAT_DIM : SAVE_OOB), 0, 0);
+        }
 #ifdef CRNERF_EXP_MLP_ONLY
         fsum += feat[0][0] + feat[1][15] + sigma;
         if (valid && h == 0 && pass == 0) scr.wc[n] = znext;
@@ -227,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP
 #endif
 }
 
+__global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP a) { render_rays_bf16p_body(a, NoHookP()); }
+__global__ __launch_bounds__(512, 2) void render_rays_train_bf16p_kernel(RenderParamsP a, TrainHookP hook) { render_rays_bf16p_body(a, hook); }
+
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
   if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays_bf16: N_samples must be in [2, 256] for the fused kernel");
@@ -246,6 +295,16 @@ int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
   const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
   k.iters = (int)((quads + grid - 1) / grid);
   k.sched = k.iters > 1 ? sched_slot((const void*)crnerf_sched_bf16p) : nullptr;
+  if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_bf16)
+    if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train_bf16: fine buffers are NULL");
+    if (!a.train_raw_coarse) return set_error(-1, "render_rays_train_bf16: raw_coarse is NULL");
+    if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 512ull >= (unsigned long long)SAVE_OOB)
+      return set_error(-2, "render_rays_train_bf16: more than 7.8 M sample points per pass and call (the saved rows are addressed with 32-bit offsets)");
+    TrainHookP h{{(char*)a.train_acts_coarse, (char*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
+    if (int rc = ensure_dynamic_lds((const void*)render_rays_train_bf16p_kernel, LDS_TOTAL_P, "render_rays_train_bf16p_kernel")) return rc;
+    hipLaunchKernelGGL(render_rays_train_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k, h);
+    return check_launch("render_rays_train_bf16p_kernel");
+  }
   if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16p_kernel, LDS_TOTAL_P, "render_rays_bf16p_kernel")) return rc;
   hipLaunchKernelGGL(render_rays_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k);
   return check_launch("render_rays_bf16p_kernel");

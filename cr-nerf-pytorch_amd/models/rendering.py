@@ -115,7 +115,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     R = rays.shape[0]
     view_dir = kwargs.get('view_dir', None)
     z_coarse = u = noise_c = noise_f = None
-    from ..autograd import get_training_bf16, get_training_recompute
+    from ..autograd import get_training_bf16, get_training_recompute, get_training_bf16_fused
     fused_train = (train and not get_training_bf16() and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
                    and (N_importance == 0 or N_samples >= 3))
     rng = None
@@ -133,7 +133,8 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         if N_importance > 0:
             noise_f = torch.randn(R, N_samples + N_importance, device=rays.device)
 
-    if (train and (not get_training_bf16() or get_training_recompute()) and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
+    if (train and (not get_training_bf16() or get_training_recompute() or get_training_bf16_fused()) and not jitter
+            and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
             and (N_importance == 0 or N_samples >= 3)):
         # training: the fused renderer's training twin (one launch per ray chunk: posenc + MLPs + activation save + compositing +
         # sample_pdf/merge) as one autograd node whose backward runs the HIP backward twins (autograd.FusedRenderFn)

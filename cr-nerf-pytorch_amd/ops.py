@@ -167,13 +167,20 @@ def mlp_forward_train_mixed(packed_mixed, tensors, x):
     return out, acts
 
 
-def mlp_backward_mixed(packed_mixed, tensors, x, out, d_out, acts):
-    """Gradients of sum(out * d_out) w.r.t. the 24 tensors through the mixed-precision twins (MLP_TENSOR_NAMES order)."""
+def mlp_backward_mixed(packed_mixed, tensors, x, out, d_out, acts, fused_acts=False):
+    """Gradients of sum(out * d_out) w.r.t. the 24 tensors through the mixed-precision twins (MLP_TENSOR_NAMES order).
+    fused_acts: `acts` was written by the fused renderer's training twin (render_rays(..., precision="bf16", train=True)); x is unused then."""
     lib = _lib.load()
-    x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
-    n = x.shape[0]
-    grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
-    scratch = torch.empty(lib.crnerf_mlp_train_mixed_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+    out, d_out = _f32c(out, "out"), _f32c(d_out, "d_out")
+    n = out.shape[0]
+    grads = [torch.empty(s, dtype=torch.float32, device=out.device) for s in MLP_TENSOR_SHAPES]
+    scratch = torch.empty(lib.crnerf_mlp_train_mixed_scratch_bytes(n), dtype=torch.uint8, device=out.device)
+    if fused_acts:
+        _lib.check(lib.crnerf_mlp_backward_mixed_ex_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(out),
+                                                        _lib.dev_ptr(d_out), ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
+                                                        _lib.ptr_array(grads, "grad"), n, 1, _lib.stream_ptr()), "crnerf_mlp_backward_mixed_ex_f32")
+        return grads
+    x = _f32c(x, "x")
     _lib.check(lib.crnerf_mlp_backward_mixed_f32(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(packed_mixed.data_ptr()), _lib.dev_ptr(x),
                                                  _lib.dev_ptr(out), _lib.dev_ptr(d_out), ctypes.c_void_p(acts.data_ptr()),
                                                  ctypes.c_void_p(scratch.data_ptr()), _lib.ptr_array(grads, "grad"), n, _lib.stream_ptr()),
@@ -273,17 +280,17 @@ def sample_pdf_merge(z_coarse, weights_coarse, n_importance, u=None, return_samp
 
 def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
                 noise_coarse=None, noise_fine=None, noise_std=0.0, want_z_fine=False, precision="f32", train=False, launcher=False, rng=None):
-    """Fused renderer.  Returns a dict of freshly allocated tensors.  train=True (fp32 only): the training twin
+    """Fused renderer.  Returns a dict of freshly allocated tensors.  train=True: the training twin
     crnerf_render_rays_train_f32 -- the dict additionally holds what the backward needs: z_coarse (as used), z_fine,
     acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65].
+    train=True with precision="bf16": crnerf_render_rays_train_bf16, the twin of the opt-in mixed-precision mode (acts_* in the layout
+    mlp_backward_mixed(..., fused_acts=True) reads).
     rng (fp32 only): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
     steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
     bf16 = _is_bf16(precision)
-    if train and bf16:
-        raise ValueError("crnerf_amd: the fused training forward is fp32 (precision='f32')")
     want_z_fine = want_z_fine or train
     _check_packed(packed_coarse, bf16)
     _check_packed(packed_fine, bf16)
@@ -340,14 +347,16 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
         return launch, out
     if train:
         Nf = Nc + Ni
-        out["acts_coarse"] = torch.empty(lib.crnerf_mlp_train_acts_bytes(R * Nc), dtype=torch.uint8, device=dev)
+        acts_bytes = lib.crnerf_mlp_train_mixed_acts_bytes if bf16 else lib.crnerf_mlp_train_acts_bytes
+        out["acts_coarse"] = torch.empty(acts_bytes(R * Nc), dtype=torch.uint8, device=dev)
         out["raw_coarse"] = new(R, Nc, 65)
         if Ni > 0:
-            out["acts_fine"] = torch.empty(lib.crnerf_mlp_train_acts_bytes(R * Nf), dtype=torch.uint8, device=dev)
+            out["acts_fine"] = torch.empty(acts_bytes(R * Nf), dtype=torch.uint8, device=dev)
             out["raw_fine"] = new(R, Nf, 65)
         vp = lambda k: ctypes.c_void_p(out[k].data_ptr()) if k in out else None  # noqa: E731
-        _lib.check(lib.crnerf_render_rays_train_f32(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"),
-                                                    _lib.stream_ptr()), "crnerf_render_rays_train_f32")
+        fn = lib.crnerf_render_rays_train_bf16 if bf16 else lib.crnerf_render_rays_train_f32
+        _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()),
+                   "crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32")
         return out
     fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")

@@ -105,6 +105,13 @@ int crnerf_mlp_forward_train_mixed_f32(const float* const* tensors, const void* 
                                        void* stream);
 int crnerf_mlp_backward_mixed_f32(const float* const* tensors, const void* packed_mixed, const float* x, const float* out, const float* d_out,
                                   const void* acts, void* scratch, float* const* grads, int64_t n, void* stream);
+/* The same backward for either producer of `acts`: CRNERF_MIXED_ACTS_GEMM = crnerf_mlp_forward_train_mixed_f32 (as the call above),
+ * CRNERF_MIXED_ACTS_FUSED = crnerf_render_rays_train_bf16 below (the fused renderer's training twin keeps its rows in the order its
+ * registers hold them and the embedded input as the MLP multiplied it; x is not needed -- the embedded input is part of `acts`). */
+#define CRNERF_MIXED_ACTS_GEMM 0
+#define CRNERF_MIXED_ACTS_FUSED 1
+int crnerf_mlp_backward_mixed_ex_f32(const float* const* tensors, const void* packed_mixed, const float* out, const float* d_out, const void* acts,
+                                     void* scratch, float* const* grads, int64_t n, int acts_layout, void* stream);
 
 /* Compositing part of the nested inference(), models/rendering.py:116-143:
  * raw[R,N,65], z[R,N], optional noise[R,N] (scaled by noise_std) -> weights[R,N], feature[R,64], depth[R]. */
@@ -192,6 +199,16 @@ int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed_bf16,
 int crnerf_mlp_forward_bf16(const void* packed_bf16, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 /* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are bf16 packs. */
 int crnerf_render_rays_bf16(const crnerf_render_args* args, void* stream);
+
+/* Training twin of crnerf_render_rays_bf16 for the opt-in mixed-precision training mode (no counterpart in the reference): the same
+ * fused launch on the bf16 matrix cores that additionally keeps, per pass, what crnerf_mlp_backward_mixed_ex_f32(..., CRNERF_MIXED_ACTS_FUSED)
+ * needs -- acts_*: crnerf_mlp_train_mixed_acts_bytes(R*N) bytes (bf16 activation rows, relu-activity bits, the embedded input; point index
+ * = ray*N + sample), raw_*[R*N,65] fp32 MLP outputs -- written from the registers the values are born in: no embedded-input tensor, no
+ * per-layer round trip of the activations.  args->z_fine is REQUIRED when n_importance > 0.  R*(n_samples + n_importance) < 2^23 per call.
+ * Random draws come as tensors (z_coarse / u / noise_*); rng_flags must be 0.  Backward = per pass crnerf_composite_backward_f32 then
+ * crnerf_mlp_backward_mixed_ex_f32. */
+int crnerf_render_rays_train_bf16(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
+                                  void* stream);
 
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.
