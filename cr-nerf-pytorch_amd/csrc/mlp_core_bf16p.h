@@ -92,8 +92,8 @@ struct WeightPipeP {
 #endif
   }
   __device__ __forceinline__ void cursor_update(int F) {
-    voff = (F + 1 == STAGESB_PER_PASS) ? lane16 : voff + STAGE_BYTES;
-    asm volatile("" : "+v"(voff));
+    voff = (F + 1 == STAGESB_PER_PASS) ? rd_base - LDS_RING : voff + STAGE_BYTES;   // = lane16, from the register that is live in every k-step
+    asm volatile("" : "+v"(voff));                                                  // (lane16 itself is spilled in the training twin and came back behind a vmcnt(0))
   }
   // all_landed (training twin): the first tile's barriers use store windows that assume a previous tile; with its first three stages
   // already in LDS they have nothing left to wait for
@@ -152,47 +152,58 @@ struct WeightPipeP {
   }
 };
 
-// ---- epilogues, one point group: quarter qc (0..7) = accumulator registers 2qc, 2qc+1 -> dword qc&3 of k-step
-// 2T + (qc>>2) of the next layer's B operand.  The accumulators live in ARCHITECTURAL registers here (gfx950 MFMA takes
-// VGPRs for C/D): an "a" constraint anywhere in the kernel makes hipcc split the 256-register budget of a two-waves-per-SIMD
-// kernel 128 VGPR + 128 AGPR (SIRegisterInfo: usesAGPRs => MaxNumVGPRs /= 2), which does not hold the two 64-register
-// activation buffers -- and a VGPR accumulator needs no v_accvgpr_read: a quarter is TWO VALU instructions.  The asm
-// statements pin each quarter to the k-step it was written in (see PackEpi in mlp_core_bf16.h).
 // ---- training twin (crnerf_render_rays_train_bf16): what the backward twins need is written from the registers it is born in.
 // Saved state of a pass with P points (the buffer of crnerf_mlp_train_mixed_acts_bytes(P), mlp_gemm_bf16.hip):
-//   rows  [10][P][256] bf16   the B operands themselves: k-step 2T + j of lane (p, h) is ONE 16-byte piece at byte 64T + 32j + 16h of
-//                             the point's row ("fused" storage order: feature 32T + 8c + 4h + i at position 32T + 16(c>>1) + 8h + 4(c&1) + i;
+//   rows  [10][P][256] bf16   the B operands themselves: k-step 2T + j of lane (p, h) is the 16-byte piece at byte 64T + 32j + 16h of the
+//                             point's row ("fused" storage order: feature 32T + 8c + 4h + i at position 32T + 16(c>>1) + 8h + 4(c&1) + i;
 //                             the weight-gradient kernel un-permutes when it writes dW, mlp_gemm_bf16.hip perm_fused)
 //   bits  [10][P] x 32 B      relu-activity bits in the layout of linear_bf16_kernel (byte [q4][u], bit 4b + i <-> feature 32u + 16b + 4q4 + i):
 //                             lane (p, h) owns q4 = h and q4 = 2 + h, one dword per four tiles
 //   xb    [P][128] bf16       the embedded input as B operands, SLOT order (layout.h posenc_slot_to_col_b): xyz k-steps 0..5, dir k-steps 6, 7
-// Store pieces ride in the MFMA loop of the NEXT tile (k-steps 9 and 11; the activity bits are formed in k-steps 10 and 12): a store
-// wave-instruction holds the CU's store path ~64 cycles, see ActSaver in mlp_train16.h.
+//
+// Rows leave through LDS in whole cache lines.  Stored straight from the registers a row piece is 32 contiguous bytes per point and
+// instruction (two lanes per point), a 128-byte line is completed by four instructions of two different tiles, ~1 us apart: 2.76 ms per
+// 2^20 points against 1.17 ms for the inference kernel (2.25 TB/s of saved state), and the same stores aimed at whole lines -- eight points
+// x 128 bytes per instruction -- 2.16 ms (tools/mixed_fwd_bench.py with -DCRNERF_EXP_SAVE=5).  So a wave parks the 64-byte pieces of two
+// consecutive tiles in a private 32 x (128 + 16)-byte LDS block (ds_write_b128, conflict-free with the 16-byte row pad) and reads them back
+// transposed: lane l takes bytes 16(l & 7).. of row 8e + (l >> 3), four instructions e = 0..3 per tile pair, each writing eight full lines.
+// Every piece of that traffic rides in the MFMA loop of the following tiles (mma_layer_p: LDS writes in k-steps 9 / 11, activity bits in
+// 10 / 12, the read -> store chain in k-steps 13, 15, 1, 3, 5): a store wave-instruction holds the CU's store path ~64 cycles, see ActSaver
+// in mlp_train16.h.
 //
 // Stores and the weight ring share vmcnt (gfx9 has no separate store counter; VMEM operations retire in issue order).  The ring's barrier in
 // stage c must know that this wave's LDS-DMA pieces of stage c + 1 have landed; they were issued in stage c - 2, and everything issued after
-// them may stay in flight: the four pieces of stages c + 2 and c + 3 -- vmcnt(4) at inference -- PLUS every store issued since.  With
-// vmcnt(4) kept as it is each barrier also waited for all but the last few stores to reach L2 (measured: 2.7 ms per 2^20 points = 2.3 TB/s
-// of saved state against 1.17 ms for the inference kernel).  So every store of the training twin is UNCONDITIONAL -- a raw-buffer store whose
-// resource ends at the pass' last row; lanes without a point (tail of a ray, rays past R) carry an out-of-range offset and the hardware
-// drops them -- which makes the number of stores between any two points of the tile's static schedule a compile-time constant, and the
-// barrier waits vmcnt(4 + that number) (p_store_window below).  Stores the model does not know (compositing outputs between tiles) only
-// make the wait stricter.
+// them may stay in flight: the four pieces of stages c + 2 and c + 3 -- vmcnt(4) at inference -- PLUS every store issued since.  So every
+// store of the training twin is UNCONDITIONAL -- a raw-buffer store whose resource ends at the pass' last row; lanes without a point (tail
+// of a ray, rays past R) carry an out-of-range offset and the hardware drops them -- which makes the number of stores between any two
+// points of the tile's static schedule a compile-time constant, and the barrier waits vmcnt(4 + that number) (p_store_window below).  Stores
+// the model does not know (compositing outputs between tiles) only make the wait stricter.
 constexpr uint32_t SAVE_OOB = 0xF0000000u;     // offset of a lane that stores nothing (>= every resource size; + instruction offsets stays < 2^32)
 constexpr int SAVE_FLAGS = 0x00020000;         // buffer resource word 3 (gfx9: DATA_FORMAT_32), raw buffer: stride 0, range check on the byte offset
 constexpr int SAVE_TILE_BURST = 8 + 9;         // between two tiles: the raw output row (8 x 16 B + sigma) and the embedded input (8 x 16 B)
-template <class T>
-using gptr = __attribute__((address_space(1))) T*;
+constexpr int SAVE_LDS_ROW = 128 + 16;         // one point's bytes of a tile pair + pad (row stride 36 dwords: eight lanes' ds_write_b128 hit 32 different banks)
+constexpr int SAVE_LDS_WAVE = 32 * SAVE_LDS_ROW;
 struct NoSaveP {
   static constexpr bool on = false;
+  __device__ __forceinline__ void drain() {}
 };
 struct ActSaveP {
   static constexpr bool on = true;
   const char* acts;      // scalar: this pass' buffer
   long slot_bytes;       // scalar: P * 512
   long P;                // scalar
-  uint32_t voff;         // per lane: point * 512 + 16 h, or SAVE_OOB
   uint32_t boff;         // per lane: point * 32 + 8 h, or SAVE_OOB
+  uint32_t toff;         // per lane: (the tile's first point + (lane >> 3)) * 512 + 16 (lane & 7): where the transposed stores go
+  int rowlim;            // per lane: points of the tile - (lane >> 3); row 8e + (lane >> 3) of the tile is a point iff 8e < rowlim
+  lds_char* lds;
+  uint32_t lds_w;        // per lane: this wave's block + p * SAVE_LDS_ROW + 16 h
+  uint32_t lds_r;        // per lane: this wave's block + (lane >> 3) * SAVE_LDS_ROW + 16 (lane & 7)
+  // the tile pair being drained: rows of its slot, its byte column, and where the read -> store chain stands (5 = idle); all of it folds
+  // to constants in the unrolled tile
+  __amdgpu_buffer_rsrc_t pend;
+  int pend_col = 0;
+  int dstep = 5;
+  u32x4 dval;
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows(int slot) const {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(acts + slot * slot_bytes), 0, (int)(uint32_t)slot_bytes, SAVE_FLAGS);
   }
@@ -202,7 +213,19 @@ struct ActSaveP {
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t xb() const {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(acts + 10 * slot_bytes + 10 * P * 32), 0, (int)(uint32_t)(P * 256), SAVE_FLAGS);
   }
+  // one link of the chain (called in the k-steps p_drain_slot names): store the eight rows read last time, read the next eight
+  __device__ __forceinline__ void drain() {
+    if (dstep >= 5) return;
+    if (dstep >= 1) {
+      const int e = dstep - 1;
+      const uint32_t off = 8 * e < rowlim ? toff + (uint32_t)(8 * e * 512 + pend_col) : SAVE_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(dval, pend, (int)off, 0, 0);
+    }
+    if (dstep <= 3) dval = *(const __attribute__((address_space(3))) u32x4*)(lds + lds_r + 8 * dstep * SAVE_LDS_ROW);
+    ++dstep;
+  }
 };
+constexpr bool p_drain_slot(int ns, int s) { return ns >= 16 ? (s == 1 || s == 3 || s == 5 || s == 13 || s == 15) : (s >= 1 && s <= 5); }
 
 // activity byte of four packed post-relu dwords: bit 2d + e <-> half e of dword d is non-zero
 __device__ __forceinline__ uint32_t act_byte(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
@@ -219,46 +242,23 @@ template <class SV>
 struct SaveSlot {   // per-epilogue state of the training twin; empty at inference
   __amdgpu_buffer_rsrc_t rows, bitp;
   uint32_t bA = 0, bB = 0;
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4
-  __amdgpu_buffer_rsrc_t exp_rows0;
-  uint32_t exp_slot;
-#endif
   template <bool BITS>
   __device__ __forceinline__ void set(const SV& sv, int slot) {
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4
-    exp_rows0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sv.acts), 0, (int)0xffffff00u, SAVE_FLAGS);
-    exp_slot = slot;
-#endif
     rows = sv.rows(slot);
     if (BITS) bitp = sv.bits(slot);
   }
-  // step 0 / 2: the two row pieces of tile T; step 1 / 3: the activity bytes of q4 = h / q4 = 2 + h (+ the dword stores behind every 4th tile).
-  // The store count per step is mirrored by p_stores_at() below.
+  // step 0 / 2: the two row pieces of tile T go to the wave's LDS block (the second piece of an odd tile starts the drain chain);
+  // step 1 / 3: the activity bytes of q4 = h / q4 = 2 + h (+ the dword stores behind every 4th tile).  p_make_stores() mirrors this.
   template <bool BITS>
-  __device__ __forceinline__ void step(const SV& sv, const u32x4 (&dst)[KS_HID], int T, int st) {
+  __device__ __forceinline__ void step(SV& sv, const u32x4 (&dst)[KS_HID], int T, int st) {
     if (st == 0 || st == 2) {
       const int j = st >> 1;
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 3   // (timing experiments only; breaks the vmcnt model: results are garbage) no row stores at all
-      return;
-#endif
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 4   // (timing experiments only; garbage) point-major addresses: the ten rows of a point adjacent
-      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], exp_rows0, (int)((sv.voff & ~511u) * 10u + (sv.voff & 511u) + 512u * exp_slot + (uint32_t)(64 * T + 32 * j)), 0, 0);
-      return;
-#endif
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 5   // (timing experiments only; garbage) full 128-byte lines per instruction: 8 rows x 128 B
-      {
-        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const uint32_t base = sv.voff - ((lane & 31u) * 512u + 16u * (lane >> 5));
-        const uint32_t e = 2u * (T & 1) + j;
-        __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)(base + (8u * e + (lane >> 3)) * 512u + 128u * (T >> 1) + 16u * (lane & 7u)), 0, 0);
-        return;
+      *(__attribute__((address_space(3))) u32x4*)(sv.lds + sv.lds_w + (64 * (T & 1) + 32 * j)) = dst[2 * T + j];
+      if ((T & 1) && j == 1) {
+        sv.pend = rows;
+        sv.pend_col = 128 * (T >> 1);
+        sv.dstep = 0;
       }
-#endif
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 2   // (timing experiments only) rows into a 1 MB window per slot
-      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)((sv.voff & 0xfffffu) + (uint32_t)(64 * T + 32 * j)), 0, 0);
-      return;
-#endif
-      __builtin_amdgcn_raw_buffer_store_b128(dst[2 * T + j], rows, (int)(sv.voff + (uint32_t)(64 * T + 32 * j)), 0, 0);
     } else if (BITS) {
       const int e = st == 1 ? 0 : 2;
       const uint32_t by = act_byte(dst[2 * T][e], dst[2 * T][e + 1], dst[2 * T + 1][e], dst[2 * T + 1][e + 1]);
@@ -273,29 +273,47 @@ struct SaveSlot<NoSaveP> {
   template <bool BITS>
   __device__ __forceinline__ void set(const NoSaveP&, int) {}
   template <bool BITS>
-  __device__ __forceinline__ void step(const NoSaveP&, const u32x4 (&)[KS_HID], int, int) {}
+  __device__ __forceinline__ void step(NoSaveP&, const u32x4 (&)[KS_HID], int, int) {}
 };
 
-// ---- the static store schedule of one tile (what SaveSlot::step issues where mma_layer_p calls it), for the ring's vmcnt
+// ---- the static store schedule of one tile (what ActSaveP::drain / SaveSlot::step issue where mma_layer_p calls them), for the ring's vmcnt
 struct PLayerSched { int fbase, nt, ns, prev_kind, epi_kind, pt; };   // kind 0: stores nothing, 1: rows, 2: rows + activity bits
 constexpr PLayerSched P_SCHED[11] = {
     {OFFB_L1, 8, KS_XYZ, 0, 2, 0},          {OFFB_L2, 8, KS_HID, 2, 2, 7},           {OFFB_L2 + FB_HID, 8, KS_HID, 2, 2, 7},
     {OFFB_L2 + 2 * FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_L5, 8, KS_XYZ + KS_HID, 2, 2, 7}, {OFFB_L6, 8, KS_HID, 2, 2, 7},
     {OFFB_L6 + FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_L6 + 2 * FB_HID, 8, KS_HID, 2, 2, 7}, {OFFB_FIN, 8, KS_HID, 2, 1, 7},
     {OFFB_DIR, 4, KS_HID + KS_DIR, 1, 2, 7}, {OFFB_RGB, 2, KS_HALF, 2, 0, 3}};
-constexpr int p_stores_at(int i) {   // store instructions issued in k-step i (pass-relative fragment index)
+struct PStoreTable { int n[STREAMB_USED]; bool ok; };
+constexpr PStoreTable p_make_stores() {   // n[i]: store instructions issued in k-step i (pass-relative fragment index)
+  PStoreTable t{};
+  t.ok = true;
+  int dstep = 5;
   for (int l = 0; l < 11; ++l) {
     const PLayerSched& L = P_SCHED[l];
-    if (i < L.fbase || i >= L.fbase + L.nt * L.ns) continue;
-    const int T = (i - L.fbase) / L.ns, s = (i - L.fbase) % L.ns;
-    const int kind = T == 0 ? L.prev_kind : L.epi_kind, tile = T == 0 ? L.pt : T - 1;
-    if (kind == 0) return 0;
-    const int bits = (kind == 2 && (tile & 3) == 3) ? 1 : 0;
-    if (L.ns >= 16) return (s == 9 || s == 11) ? 1 : ((s == 10 || s == 12) ? bits : 0);
-    return s == L.ns - 1 ? 2 + 2 * bits : 0;
+    for (int T = 0; T < L.nt; ++T)
+      for (int s = 0; s < L.ns; ++s) {
+        const int i = L.fbase + T * L.ns + s;
+        if (p_drain_slot(L.ns, s) && dstep < 5) {   // ActSaveP::drain
+          if (dstep >= 1) ++t.n[i];
+          ++dstep;
+        }
+        const int kind = T == 0 ? L.prev_kind : L.epi_kind, tile = T == 0 ? L.pt : T - 1;
+        if (kind == 0) continue;
+        const int bits = (kind == 2 && (tile & 3) == 3) ? 1 : 0;
+        const bool last_piece = L.ns >= 16 ? s == 11 : s == L.ns - 1;
+        if (L.ns >= 16) t.n[i] += (s == 10 || s == 12) ? bits : 0;
+        else if (s == L.ns - 1) t.n[i] += 2 * bits;
+        if (last_piece && (tile & 1)) {
+          if (dstep != 5) t.ok = false;        // the previous pair must have left the LDS block
+          dstep = 0;
+        }
+      }
   }
-  return 0;
+  if (dstep != 5) t.ok = false;                // nothing pending across tiles
+  return t;
 }
+constexpr PStoreTable P_STORES = p_make_stores();
+constexpr int p_stores_at(int i) { return P_STORES.n[i]; }
 constexpr int p_second_piece_step(int stage, int stagger) {   // k-step that issues piece 1 of the stage fetched during `stage`
   return stage * STAGE_FRAGS + (stage == STAGESB_PER_PASS - 1 ? 2 + stagger : 5 + 2 * stagger);
 }
@@ -317,7 +335,7 @@ constexpr int p_store_total() {
   for (int i = 0; i < STREAMB_USED; ++i) n += p_stores_at(i);
   return n;
 }
-static_assert(p_store_total() == 9 * 16 + 8 + 8 * 4 + 2, "store schedule: 9 x 8 tiles x 2 rows + dir 4 x 2, activity dwords 8 x 4 + dir 2");
+static_assert(P_STORES.ok && p_store_total() == 9 * 16 + 8 + 8 * 4 + 2, "store schedule: 38 tile pairs x 4 line stores, activity dwords 8 x 4 + dir 2");
 constexpr int p_store_window_max() {
   int m = 0;
   for (int i = 0; i < STREAMB_USED; ++i)
@@ -334,6 +352,12 @@ constexpr PWindowTable p_make_windows() {   // per stage: the store window of it
 }
 constexpr PWindowTable P_WINDOWS = p_make_windows();
 
+// ---- epilogues, one point group: quarter qc (0..7) = accumulator registers 2qc, 2qc+1 -> dword qc&3 of k-step
+// 2T + (qc>>2) of the next layer's B operand.  The accumulators live in ARCHITECTURAL registers here (gfx950 MFMA takes
+// VGPRs for C/D): an "a" constraint anywhere in the kernel makes hipcc split the 256-register budget of a two-waves-per-SIMD
+// kernel 128 VGPR + 128 AGPR (SIRegisterInfo: usesAGPRs => MaxNumVGPRs /= 2), which does not hold the two 64-register
+// activation buffers -- and a VGPR accumulator needs no v_accvgpr_read: a quarter is TWO VALU instructions.  The asm
+// statements pin each quarter to the k-step it was written in (see PackEpi in mlp_core_bf16.h).
 struct NoEpiP {
   static constexpr bool saving = false;
   __device__ __forceinline__ void prefetch(int) {}
@@ -345,9 +369,9 @@ template <bool RELU, class SV = NoSaveP>
 struct PackEpiP {
   static constexpr bool saving = SV::on;
   u32x4 (&dst)[KS_HID];
-  const SV& sv;
+  SV& sv;
   SaveSlot<SV> ss;
-  __device__ __forceinline__ PackEpiP(u32x4 (&d)[KS_HID], const SV& s) : dst(d), sv(s) {}
+  __device__ __forceinline__ PackEpiP(u32x4 (&d)[KS_HID], SV& s) : dst(d), sv(s) {}
   __device__ __forceinline__ void slot(int sl) { ss.template set<RELU>(sv, sl); }
   __device__ __forceinline__ void save_step(int T, int st) { ss.template step<RELU>(sv, dst, T, st); }
   __device__ __forceinline__ void prefetch(int) {}
@@ -369,10 +393,10 @@ struct SigmaEpiP {
   float& sg;
   const lds_float* wsig;
   int h;
-  const SV& sv;
+  SV& sv;
   SaveSlot<SV> ss;
   f32x4 wv[4];
-  __device__ __forceinline__ SigmaEpiP(u32x4 (&d)[KS_HID], float& s, const lds_float* w, int h_, const SV& v) : dst(d), sg(s), wsig(w), h(h_), sv(v) {}
+  __device__ __forceinline__ SigmaEpiP(u32x4 (&d)[KS_HID], float& s, const lds_float* w, int h_, SV& v) : dst(d), sg(s), wsig(w), h(h_), sv(v) {}
   __device__ __forceinline__ void slot(int sl) { ss.template set<true>(sv, sl); }
   __device__ __forceinline__ void save_step(int T, int st) { ss.template step<true>(sv, dst, T, st); }
   __device__ __forceinline__ void prefetch(int T) {
@@ -419,10 +443,10 @@ __device__ __forceinline__ void load_bias_into(f32x16& acc, const lds_float* bia
 // in accs[G & 1] --, PT: the previous layer's last tile, whose epilogue `prev` runs behind this layer's first tile).  On entry
 // accs[G0 & 1] holds the bias of tile 0; the bias of each following tile (and of the NEXT layer's tile 0, from next_bias) is
 // read into the other accumulator in the tile's last two k-steps, after the epilogue quarters have drained it.
-template <int NT, int NSA, int NSB, int FBASE, int G0, int PT, int NA, int NB, class PREV, class EPI>
+template <int NT, int NSA, int NSB, int FBASE, int G0, int PT, int NA, int NB, class PREV, class EPI, class SV>
 __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[NA], const u32x4 (&srcB)[NB], u32x4 (&q)[B_AHEAD],
                                             f32x16 (&accs)[2], const lds_float* bias, const lds_float* next_bias, int h, PREV& prev,
-                                            EPI& epi) {
+                                            EPI& epi, SV& sv) {
   static_assert(NSA <= NA && NSB <= NB, "source too small");
   constexpr int NS = NSA + NSB;
   static_assert(NS >= 16 || NS == 6 || NS == 8, "epilogue quarters must finish before the last source tile is read");
@@ -464,6 +488,7 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);
       }
+      if (SV::on && p_drain_slot(NS, s)) sv.drain();   // training twin: a tile pair's lines on their way out (no-op at inference)
       {   // training twin: the previous tile's row pieces / activity bits, behind its last epilogue quarter (no-ops at inference)
         const int st = LONG ? s - 9 : -1;
         if (LONG && st >= 0 && st < 4) {
@@ -482,7 +507,7 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
         const lds_float* nb = (T + 1 < NT) ? bias : next_bias;
         load_bias_into(accs[cur ^ 1], nb, (T + 1 < NT) ? T + 1 : 0, h, s - (NS - 2));
       }
-      if (b_advance_at(i)) p.advance((PREV::saving || EPI::saving) ? P_WINDOWS.v[i / STAGE_FRAGS] : 0);
+      if (b_advance_at(i)) p.advance(SV::on ? P_WINDOWS.v[i / STAGE_FRAGS] : 0);
       if (b_cursor_at(i)) p.cursor_update(i / STAGE_FRAGS + B_RING - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -494,7 +519,7 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
 // sigma (valid in both lane halves).
 template <class SV = NoSaveP>
 __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_model, const u32x4 (&pe)[KS_XYZ], const lds_char* dirsrc,
-                                           f32x16 (&feat)[2], float& sigma, int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm, const SV& sv = SV()) {
+                                           f32x16 (&feat)[2], float& sigma, int h, u32x4 (&q)[B_AHEAD], PhaseTimer& tm, SV& sv) {
   p.begin_tile(next_model);
   uint32_t c_off = model ? LDS_CONST1 : LDS_CONST0;
   asm volatile("" : "+s"(c_off));     // loop-invariant LDS: launder the address once per tile (LICM would hoist ~1,300 reads)
@@ -515,23 +540,23 @@ __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_m
   SigmaEpiP<SV> e8(actB, sg, C + C_WSIG, h, sv);
   RgbEpiP ergb(feat);
   eA.slot(0);
-  mma_layer_p<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, B1, B1 + 1 * W_HIDDEN, h, none, eA);                                // xyz_encoding_1
+  mma_layer_p<8, KS_XYZ, 0, OFFB_L1, 0, 0>(p, pe, pe, q, accs, B1, B1 + 1 * W_HIDDEN, h, none, eA, sv);                                // xyz_encoding_1
   eB.slot(1);
-  mma_layer_p<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, B1 + 1 * W_HIDDEN, B1 + 2 * W_HIDDEN, h, eA, eB);               // 2
+  mma_layer_p<8, KS_HID, 0, OFFB_L2, 8, 7>(p, actA, actA, q, accs, B1 + 1 * W_HIDDEN, B1 + 2 * W_HIDDEN, h, eA, eB, sv);               // 2
   eA.slot(2);
-  mma_layer_p<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, B1 + 2 * W_HIDDEN, B1 + 3 * W_HIDDEN, h, eB, eA);     // 3
+  mma_layer_p<8, KS_HID, 0, OFFB_L2 + FB_HID, 16, 7>(p, actB, actB, q, accs, B1 + 2 * W_HIDDEN, B1 + 3 * W_HIDDEN, h, eB, eA, sv);     // 3
   eB.slot(3);
-  mma_layer_p<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, B1 + 3 * W_HIDDEN, B1 + 4 * W_HIDDEN, h, eA, eB); // 4
+  mma_layer_p<8, KS_HID, 0, OFFB_L2 + 2 * FB_HID, 24, 7>(p, actA, actA, q, accs, B1 + 3 * W_HIDDEN, B1 + 4 * W_HIDDEN, h, eA, eB, sv); // 4
   eA.slot(4);
-  mma_layer_p<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, B1 + 4 * W_HIDDEN, B1 + 5 * W_HIDDEN, h, eB, eA);           // 5 = Linear(cat[xyz, h])
+  mma_layer_p<8, KS_XYZ, KS_HID, OFFB_L5, 32, 7>(p, pe, actB, q, accs, B1 + 4 * W_HIDDEN, B1 + 5 * W_HIDDEN, h, eB, eA, sv);           // 5 = Linear(cat[xyz, h])
   eB.slot(5);
-  mma_layer_p<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, B1 + 5 * W_HIDDEN, B1 + 6 * W_HIDDEN, h, eA, eB);              // 6
+  mma_layer_p<8, KS_HID, 0, OFFB_L6, 40, 7>(p, actA, actA, q, accs, B1 + 5 * W_HIDDEN, B1 + 6 * W_HIDDEN, h, eA, eB, sv);              // 6
   eA.slot(6);
-  mma_layer_p<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, B1 + 6 * W_HIDDEN, B1 + 7 * W_HIDDEN, h, eB, eA);     // 7
+  mma_layer_p<8, KS_HID, 0, OFFB_L6 + FB_HID, 48, 7>(p, actB, actB, q, accs, B1 + 6 * W_HIDDEN, B1 + 7 * W_HIDDEN, h, eB, eA, sv);     // 7
   e8.slot(7);
-  mma_layer_p<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, B1 + 7 * W_HIDDEN, C + C_BFIN, h, eA, e8);        // 8 (+ static_sigma)
+  mma_layer_p<8, KS_HID, 0, OFFB_L6 + 2 * FB_HID, 56, 7>(p, actA, actA, q, accs, B1 + 7 * W_HIDDEN, C + C_BFIN, h, eA, e8, sv);        // 8 (+ static_sigma)
   efin.slot(8);
-  mma_layer_p<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, C + C_BFIN, C + C_BDIR, h, e8, efin);                         // xyz_encoding_final
+  mma_layer_p<8, KS_HID, 0, OFFB_FIN, 64, 7>(p, actB, actB, q, accs, C + C_BFIN, C + C_BDIR, h, e8, efin, sv);                         // xyz_encoding_final
   tm.tick(T_MMA);
   sg += __shfl_xor(sg, 32);
   sigma = softplus_fast(sg + C[C_BSIG]);
@@ -540,8 +565,8 @@ __device__ __forceinline__ void mlp_tile_p(WeightPipeP& p, int model, int next_m
   for (int s = 0; s < KS_DIR; ++s) dv[s] = *(const __attribute__((address_space(3))) u32x4*)(dirsrc + 32 * s);
   tm.tick(T_SIGMA);
   eB.slot(9);
-  mma_layer_p<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, C + C_BDIR, C + C_BRGB, h, efin, eB);                      // dir_encoding
-  mma_layer_p<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, C + C_BRGB, C + C_BRGB, h, eB, ergb);                         // static_rgb
+  mma_layer_p<4, KS_HID, KS_DIR, OFFB_DIR, 72, 7>(p, actA, dv, q, accs, C + C_BDIR, C + C_BRGB, h, efin, eB, sv);                      // dir_encoding
+  mma_layer_p<2, KS_HALF, 0, OFFB_RGB, 76, 3>(p, actB, actB, q, accs, C + C_BRGB, C + C_BRGB, h, eB, ergb, sv);                         // static_rgb
   tm.tick(T_MMA);
 #pragma unroll
   for (int qc = 0; qc < 8; ++qc) {   // rgb's last tile: nothing left to hide it behind

@@ -27,24 +27,54 @@ struct RenderParamsP {
   float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
 };
 
+constexpr int LDS_DIR_P = LDS_SCRATCH_P + 4 * PAIR_BYTES;        // 8 waves x 64 B: the ray's direction embedding as B operands
+constexpr int LDS_QSLOT_P = LDS_DIR_P + P_WAVES * 64;
+constexpr int LDS_TOTAL_P = LDS_QSLOT_P + 16;
+constexpr int LDS_STAGE_P = LDS_TOTAL_P;                         // training twin: 8 waves x SAVE_LDS_WAVE, the tile pairs' rows on their way out
+constexpr int LDS_TOTAL_TRAIN_P = LDS_STAGE_P + P_WAVES * SAVE_LDS_WAVE;
+static_assert(LDS_TOTAL_TRAIN_P <= 160 * 1024 && LDS_STAGE_P % 16 == 0, "LDS budget of the training twin");
+
 // What the training twin adds (crnerf_render_rays_train_bf16): per pass the saved state of mlp_core_bf16p.h "training twin" -- activation rows,
 // activity bits, the embedded input, all written from the registers they are born in -- and the raw MLP output rows [R*N,65] fp32.  The inference
 // kernel instantiates the no-op hook.
 struct NoHookP {
   static constexpr bool on = false;
-  __device__ __forceinline__ NoSaveP saver(int, long, int, int, bool, int) const { return NoSaveP(); }
+  __device__ __forceinline__ NoSaveP saver(int, long, int, int, int, bool, int, int, lds_char*) const { return NoSaveP(); }
 };
 struct TrainHookP {
   static constexpr bool on = true;
   char* acts[2];    // crnerf_mlp_train_mixed_acts_bytes(R*N) each, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
   float* rawo[2];   // [R*N][65]
   long R;
-  __device__ __forceinline__ ActSaveP saver(int pass, long r, int N, int n, bool ok, int h) const {
+  __device__ __forceinline__ bool stores_on() const {
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1
+    return false;
+#else
+    return true;
+#endif
+  }
+  // n0: the tile's first sample, n = n0 + p this lane's; ray_ok: r < R
+  __device__ __forceinline__ ActSaveP saver(int pass, long r, int N, int n0, int n, bool ray_ok, int lane, int wave, lds_char* lds) const {
     const long P = R * N, pt = r * N + n;
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1   // (timing experiments only) every row / bit store issued and dropped
+    const int h = lane >> 5;
+    bool ok = ray_ok && n < N;
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1   // (timing experiments only) every store issued and dropped
     ok = false;
 #endif
-    return ActSaveP{acts[pass], P * 512, P, ok ? (uint32_t)pt * 512u + 16u * (uint32_t)h : SAVE_OOB, ok ? (uint32_t)pt * 32u + 8u * (uint32_t)h : SAVE_OOB};
+    int pts = ray_ok ? (N - n0 < 32 ? N - n0 : 32) : 0;   // points of this tile (<= 0: none)
+#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1
+    pts = 0;
+#endif
+    ActSaveP sv;
+    sv.acts = acts[pass]; sv.slot_bytes = P * 512; sv.P = P;
+    sv.boff = ok ? (uint32_t)pt * 32u + 8u * (uint32_t)h : SAVE_OOB;
+    sv.toff = (uint32_t)(r * N + n0 + (lane >> 3)) * 512u + 16u * (uint32_t)(lane & 7);
+    sv.rowlim = pts - (lane >> 3);
+    sv.lds = lds;
+    const uint32_t blk = LDS_STAGE_P + (uint32_t)wave * SAVE_LDS_WAVE;
+    sv.lds_w = blk + (uint32_t)(lane & 31) * SAVE_LDS_ROW + 16u * (uint32_t)h;
+    sv.lds_r = blk + (uint32_t)(lane >> 3) * SAVE_LDS_ROW + 16u * (uint32_t)(lane & 7);
+    return sv;
   }
 };
 
@@ -53,9 +83,6 @@ static __device__ unsigned int crnerf_sched_bf16p[SCHED_SLOTS][2];   // kernels.
 static __device__ unsigned long long crnerf_wg_times_p[2 * 1024];
 #endif
 
-constexpr int LDS_DIR_P = LDS_SCRATCH_P + 4 * PAIR_BYTES;        // 8 waves x 64 B: the ray's direction embedding as B operands
-constexpr int LDS_QSLOT_P = LDS_DIR_P + P_WAVES * 64;
-constexpr int LDS_TOTAL_P = LDS_QSLOT_P + 16;
 
 // sum over the 32 lanes of this lane's half of v[idx], idx = p: after the five halving steps lane p holds the total of value p
 __device__ __forceinline__ float fold32(float (&v)[32], int p) {
@@ -161,10 +188,10 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
         float sigma;
         // the model of the tile after this one: same pass, the fine pass, or the next ray's coarse pass
         const int next_model = k + 1 < steps ? pass : (pass + 1 < npass ? 1 : 0);
-        const auto sv = hook.saver(pass, r, N, n, valid && ray_ok, h);
+        auto sv = hook.saver(pass, r, N, 64 * k + 32 * half, n, ray_ok, lane, wave, lds);
         if constexpr (HOOK::on) {   // the embedded input as the MLP multiplies it: xyz k-steps 0..5, dir k-steps 6, 7 (32 B per point and k-step);
           const __amdgpu_buffer_rsrc_t xr = sv.xb();                        // unconditional stores, counted in SAVE_TILE_BURST (mlp_core_bf16p.h)
-          const uint32_t xo = sv.voff == SAVE_OOB ? SAVE_OOB : (sv.voff >> 1) + 8u * (uint32_t)h;   // point * 256 + 16 h
+          const uint32_t xo = sv.boff == SAVE_OOB ? SAVE_OOB : (uint32_t)(r * N + n) * 256u + 16u * (uint32_t)h;
 #pragma unroll
           for (int s = 0; s < KS_XYZ; ++s) __builtin_amdgcn_raw_buffer_store_b128(pe[s], xr, (int)(xo + 32u * s), 0, 0);
 #pragma unroll
@@ -176,7 +203,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
           // 8 x 16 B + sigma, unconditional (SAVE_TILE_BURST); rows are 260 B apart: dword-aligned 16-byte stores
           const long P = hook.R * N;
           const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(hook.rawo[pass], 0, (int)(uint32_t)(P * (OUT_DIM * 4)), SAVE_FLAGS);
-          const uint32_t ro = sv.voff == SAVE_OOB ? SAVE_OOB : (uint32_t)(r * N + n) * (uint32_t)(OUT_DIM * 4) + 16u * (uint32_t)h;
+          const uint32_t ro = (valid && ray_ok && hook.stores_on()) ? (uint32_t)(r * N + n) * (uint32_t)(OUT_DIM * 4) + 16u * (uint32_t)h : SAVE_OOB;
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -301,8 +328,8 @@ int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
     if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 512ull >= (unsigned long long)SAVE_OOB)
       return set_error(-2, "render_rays_train_bf16: more than 7.8 M sample points per pass and call (the saved rows are addressed with 32-bit offsets)");
     TrainHookP h{{(char*)a.train_acts_coarse, (char*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
-    if (int rc = ensure_dynamic_lds((const void*)render_rays_train_bf16p_kernel, LDS_TOTAL_P, "render_rays_train_bf16p_kernel")) return rc;
-    hipLaunchKernelGGL(render_rays_train_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k, h);
+    if (int rc = ensure_dynamic_lds((const void*)render_rays_train_bf16p_kernel, LDS_TOTAL_TRAIN_P, "render_rays_train_bf16p_kernel")) return rc;
+    hipLaunchKernelGGL(render_rays_train_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_TRAIN_P, stream, k, h);
     return check_launch("render_rays_train_bf16p_kernel");
   }
   if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16p_kernel, LDS_TOTAL_P, "render_rays_bf16p_kernel")) return rc;
