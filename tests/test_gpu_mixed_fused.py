@@ -173,3 +173,45 @@ def test_bf16_train_fused_autograd_matches_unfused_mixed_path():
         cos = float((g_fu[k] * g_un[k]).sum() / (g_fu[k].norm() * g_un[k].norm() + 1e-30))
         # two bf16 evaluations whose relu masks / hierarchical depths differ in a few places: a few per cent
         assert rel <= 0.15 and cos >= 0.985, (k, rel, cos)
+
+
+@torch.no_grad()
+def test_bf16_train_twin_cold_l2_is_deterministic_and_equals_inference():
+    """Guard for the training twin's weight-ring waits (mlp_core_bf16p.h: the stage barrier waits vmcnt(4 + the stores issued since the pieces
+    it needs) -- a window that is too wide by one store would let a wave read a weight stage before its LDS-DMA has landed, and only a cold L2
+    makes a piece late enough to show it; tests/test_gpu_bf16.py::test_render_cold_l2_is_deterministic is the inference kernel's guard).
+    65,536 rays x (64 + 64) in 5,460-ray chunks (the chunk size of the training step), L2 thrashed by a 1 GiB copy before every chunk, four
+    passes: the outputs must be bit-identical to the INFERENCE renderer's every time, and the saved rows identical between passes."""
+    st_c = {k: C(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()}
+    st_f = {k: C(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()}
+    pc, pf = ops.pack_mlp_weights(st_c, precision="bf16"), ops.pack_mlp_weights(st_f, precision="bf16")
+    R, step = 65536, 5460
+    rays = C(synth.rays(R, seed=0, H=256, W=256))
+    z_steps, u = torch.linspace(0, 1, 64, device=DEV), torch.linspace(0, 1, 64, device=DEV)
+    junk_a, junk_b = torch.empty(1 << 28, device=DEV), torch.zeros(1 << 28, device=DEV)
+    keys = ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine", "z_fine")
+    ref = {k: torch.cat([ops.render_rays(pc, pf, rays[i:i + step], 64, 64, z_steps=z_steps, u=u, want_z_fine=True, precision="bf16")[k]
+                         for i in range(0, R, step)]) for k in keys}
+    first = None
+    for it in range(4):
+        sums = []
+        for i in range(0, R, step):
+            junk_a.copy_(junk_b)
+            out = ops.render_rays(pc, pf, rays[i:i + step], 64, 64, z_steps=z_steps, u=u, precision="bf16", train=True)
+            for k in keys:
+                assert torch.equal(out[k], ref[k][i:i + step]), (it, i, k)
+            # the saved state, folded to a few numbers per chunk (exact integer sums over the regions the kernel writes)
+            for tag in ("coarse", "fine"):
+                raw = out["raw_" + tag]
+                P = raw.shape[0] * raw.shape[1]
+                buf = out["acts_" + tag]
+                rows = buf[:10 * P * 512].view(10, P, 512)
+                bits = buf[10 * P * 512:10 * P * 544].view(10, P, 32)
+                xb = buf[10 * P * 544:10 * P * 544 + P * 256]
+                isum = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum())  # noqa: E731
+                # (slot 9 holds 128 features = the first 256 bytes of a row; slot 8 is linear: no bits; the rest of the buffer is never written)
+                sums += [isum(rows[:9]), isum(rows[9, :, :256]), isum(bits[:8]), isum(xb), float(raw.double().sum())]
+            del out
+        if first is None:
+            first = sums
+        assert sums == first, it
