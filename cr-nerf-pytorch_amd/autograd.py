@@ -176,11 +176,10 @@ class FusedRenderFn(torch.autograd.Function):
 
 class MixedRecomputeRenderFn(torch.autograd.Function):
     """set_training_precision("bf16") + set_training_recompute(True), one chunk of rays: the forward IS the fused bf16 inference
-    renderer (crnerf_render_rays_bf16: ~0.22 ms per 1,024 rays, nothing kept but rays / depths / noise); backward rebuilds each
-    pass from the embedded points with the mixed-precision training twins (crnerf_mlp_forward_train_mixed_f32 -> composite backward
-    -> crnerf_mlp_backward_mixed_f32) at the forward's own depths.  The two forwards implement the same arithmetic (bf16-rounded
-    operands, fp32 accumulation) with different summation orders and sin/cos routines, so the gradient is taken at outputs that
-    differ from the ones the loss saw by the bf16 kernels' mutual tolerance (mean 3e-5, tests/test_gpu_bf16.py)."""
+    renderer (crnerf_render_rays_bf16: ~0.22 ms per 1,024 rays, nothing kept but rays / depths / noise); backward re-runs the chunk through
+    the renderer's training twin (crnerf_render_rays_train_bf16 -- bit-identical outputs, so the gradient is taken at exactly the activations
+    the loss saw) and then runs MixedFusedRenderFn's backward.  CRNERF_TRAIN_BF16_UNFUSED=1: the round-2 rebuild (embedded points -> per-layer
+    GEMM twins), whose outputs differ from the forward's by the bf16 kernels' mutual tolerance (mean 3e-5, tests/test_gpu_bf16.py)."""
 
     @staticmethod
     def forward(ctx, cfg, rays, *params):
@@ -205,7 +204,16 @@ class MixedRecomputeRenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         cfg = ctx.cfg
+        Nc, Ni = cfg["Nc"], cfg["Ni"]
         rays, z_fine, *params = ctx.saved_tensors
+        states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(ctx.n_models)]
+        fused = get_training_bf16_fused()
+        if fused:
+            packed_b = [ops.pack_mlp_weights(st, precision="bf16") for st in states]
+            trn = ops.render_rays(packed_b[0], packed_b[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
+                                  z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
+                                  noise_std=cfg["noise_std"], precision="bf16", train=True)
+            z_fine = trn["z_fine"] if Ni > 0 else z_fine
         grads = []
         for m in range(ctx.n_models):
             d_w, d_f, d_d = g[3 * m], g[3 * m + 1], g[3 * m + 2]
@@ -214,16 +222,19 @@ class MixedRecomputeRenderFn(torch.autograd.Function):
                 continue
             z = z_fine if m == 1 else cfg["z_coarse"]
             noise = cfg["noise_f"] if m == 1 else cfg["noise_c"]
-            state = dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24]))
-            packed, tensors = ops.pack_mlp_weights_mixed(state)
-            x = _embed_points(rays, z, cfg["view_dir"])
-            raw, acts = ops.mlp_forward_train_mixed(packed, tensors, x)
+            packed, tensors = ops.pack_mlp_weights_mixed(states[m])
             R, N = z.shape
+            if fused:
+                tag = "fine" if m == 1 else "coarse"
+                raw, acts, x = trn["raw_" + tag].view(-1, 65), trn["acts_" + tag], None
+            else:
+                x = _embed_points(rays, z, cfg["view_dir"])
+                raw, acts = ops.mlp_forward_train_mixed(packed, tensors, x)
             if d_f is None:
                 d_f = torch.zeros(R, 64, device=raw.device)
             d_raw = ops.composite_backward(raw.view(R, N, 65), z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
                                            None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
-            grads += ops.mlp_backward_mixed(packed, tensors, x, raw, d_raw.view(-1, 65), acts)
+            grads += ops.mlp_backward_mixed(packed, tensors, x, raw, d_raw.view(-1, 65), acts, fused_acts=fused)
             del x, raw, acts, d_raw
         return (None, None) + tuple(grads)
 

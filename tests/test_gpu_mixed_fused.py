@@ -215,3 +215,27 @@ def test_bf16_train_twin_cold_l2_is_deterministic_and_equals_inference():
         if first is None:
             first = sums
         assert sums == first, it
+
+
+def test_bf16_recompute_mode_gradients_are_bit_identical_to_the_stored_mode():
+    """set_training_recompute(True) in the mixed-precision mode: forward = the bf16 inference renderer, backward re-runs the chunk through the
+    training twin -- whose outputs and saved rows are bit-identical to what the stored mode kept, so the two modes' gradients are EQUAL."""
+    from test_gpu_train_fused import _grads, _modules
+    models, emb, args = _modules(gain=2.45, sigma_bias=-1.0, band_limit=4)
+    R = 96
+    rays, z, u, nc, nf = _inputs(R, 64, 64, seed=9)
+    gw = torch.randn(R, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run():
+        out = AG.fused_render_with_grad(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0)
+        return (out["feature_fine"] * gw).sum() + 0.5 * (out["feature_coarse"] * gw).sum() + 0.1 * (out["weights_fine"] ** 2).sum()
+    AG.set_training_precision("bf16")
+    try:
+        g_st = _grads(models, run)
+        AG.set_training_recompute(True)
+        g_rc = _grads(models, run)
+    finally:
+        AG.set_training_recompute(False)
+        AG.set_training_precision("f32")
+    for k in g_st:
+        assert torch.equal(g_st[k], g_rc[k]), k
