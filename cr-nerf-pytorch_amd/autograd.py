@@ -51,7 +51,7 @@ def mlp_forward_with_grad(module, x):
 
 
 _RECOMPUTE = [False]
-_WGRAD_BF16 = [False]
+_WGRAD_BF16 = [0]
 
 
 def set_wgrad_precision(precision="f32"):
@@ -59,8 +59,11 @@ def set_wgrad_precision(precision="f32"):
     gradients of every nn.Linear except static_sigma (CRNERF_BWD_WGRAD_BF16, include/crnerf.h: the full 256x256 blocks AND the
     narrow edge blocks of the 93/349/283-wide layers): same fp32 operands, rounded to bf16 in registers, bf16 MFMA with fp32
     accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
-    Forward, loss, data gradients, biases and all other tensors are unchanged."""
-    _WGRAD_BF16[0] = ops._is_bf16(precision)
+    "bf16x3": fp32-ACCURATE weight gradients on the bf16 matrix cores (CRNERF_BWD_WGRAD_BF16X3, include/crnerf.h): every fp32 operand of
+    the 256 x 256 blocks is split into three bf16 pieces in registers and a product is the sum of the six leading piece products (fp32
+    accumulation; the dropped terms are one fp32 rounding), so that third of the MLP work runs at the rate of its operand reads with none
+    of the bf16 mode's rounding noise.  Forward, loss, data gradients, biases and all other tensors are unchanged."""
+    _WGRAD_BF16[0] = 2 if str(precision).lower() in ("bf16x3", "x3") else (1 if ops._is_bf16(precision) else 0)
 
 
 _TRAIN_BF16 = [False]
@@ -80,8 +83,13 @@ def get_training_bf16():
 
 
 def get_wgrad_bf16():
+    """0: exact fp32 MFMA; 1: bf16-rounded operands; 2: three-piece bf16 split (fp32-accurate)."""
     import os
-    return _WGRAD_BF16[0] or os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0")
+    if _WGRAD_BF16[0]:
+        return int(_WGRAD_BF16[0])
+    if os.environ.get("CRNERF_WGRAD_BF16X3", "") not in ("", "0"):
+        return 2
+    return 1 if os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0") else 0
 
 
 def set_training_recompute(flag=True):

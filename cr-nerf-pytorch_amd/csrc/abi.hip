@@ -140,7 +140,8 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
-  if (flags & ~CRNERF_BWD_WGRAD_BF16) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: unknown flag bits");
+  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: unknown flag bits");
+  if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: the two weight-gradient modes are exclusive");
   REQUIRE(packed_t, "packed_t"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
   REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)

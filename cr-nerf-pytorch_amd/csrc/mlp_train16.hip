@@ -203,7 +203,13 @@ struct WgradJob {
   int bf16;                            // != 0: the full 256 x 256 tiles multiply bf16-rounded operands (fp32 accumulate), see wgrad_kernel
 };
 
-template <int MT, int NT>
+__device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32: a -> low half, b -> high half
+  typedef __bf16 pkbf16x2 __attribute__((ext_vector_type(2)));
+  const pkbf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <int MT, int NT, bool X3 = false>
 __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
                                                     bool bias_wave, int bx, int bz) {
   // k-steps (2 points each) per iteration = prefetch depth: the small blocks are bandwidth-bound, keep more rows in flight
@@ -215,7 +221,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
   for (int t = 0; t < NT; ++t) { const int c = n0 + 32 * t + i; acol[t] = c < j.N ? c : j.N - 1; amask[t] = c < j.N ? 1.0f : 0.0f; }
   const long plast = p1 - 1;
-  if (j.bf16) {
+  if (j.bf16 || X3) {
     // opt-in mixed precision (CRNERF_BWD_WGRAD_BF16), narrow blocks: the same dword-per-lane operand loads, eight points per lane
     // and k-step of 16 points, rounded to bf16 in registers and multiplied on v_mfma_f32_32x32x16_bf16 (see the full-tile path in
     // wgrad_kernel); bias sums from the un-rounded deltas
@@ -243,6 +249,56 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
     fetch16(p0, dcu, acu);
     for (long pb = p0; pb < p1; pb += 16) {
       fetch16(pb + 16, dnx, anx);
+      if constexpr (X3) {   // CRNERF_BWD_WGRAD_BF16X3 on the narrow blocks: three-piece splits, six MFMAs per tile (see the full-block path)
+        auto split3 = [&](float x0, float x1, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+          w1 = pk_bf16_rne(x0, x1);
+          const float r0 = x0 - __uint_as_float(w1 << 16), r1 = x1 - __uint_as_float(w1 & 0xffff0000u);
+          w2 = pk_bf16_rne(r0, r1);
+          const float s0 = r0 - __uint_as_float(w2 << 16), s1 = r1 - __uint_as_float(w2 & 0xffff0000u);
+          w3 = pk_bf16_rne(s0, s1);
+        };
+        pbf16x8 a1[NT], a2[NT], a3[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split3(acu[2 * q][t], acu[2 * q + 1][t], w1[q], w2[q], w3[q]);
+          a1[t] = __builtin_bit_cast(pbf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+          a2[t] = __builtin_bit_cast(pbf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+          a3[t] = __builtin_bit_cast(pbf16x8, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split3(dcu[2 * q][a], dcu[2 * q + 1][a], w1[q], w2[q], w3[q]);
+          const pbf16x8 d1 = __builtin_bit_cast(pbf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+          const pbf16x8 d2 = __builtin_bit_cast(pbf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+          const pbf16x8 d3 = __builtin_bit_cast(pbf16x8, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+          if (do_bias16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs16[a] += dcu[e][a];
+          }
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d3, a1[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a3[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a2[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a1[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a2[b], c, 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a1[b], c, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) dcu[e][t] = dnx[e][t];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acu[e][t] = anx[e][t];
+        }
+        continue;
+      }
       pbf16x8 df[MT], af[NT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -360,6 +416,9 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 // iteration's operands are in flight while the current MFMAs run.  Tiles beyond M or N are skipped.
 // (bx, by, bz): the workgroup's chunk / row-block / column-block inside job j -- blockIdx for a single-job launch, decoded from a flat
 // block index by the batched launch below.
+
+// X3: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3) -- see the full-tile branch below
+template <bool X3 = false>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
@@ -405,6 +464,105 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
     const float* dbase = j.D + m0 + 4 * i;
     const float* abase = j.A + n0 + 4 * i;
     const long plast = p1 - 1;
+    if constexpr (X3) {
+      // ---- opt-in "bf16x3" (CRNERF_BWD_WGRAD_BF16X3): fp32-ACCURATE products on the bf16 matrix cores.  Every fp32 operand is split in
+      // registers into three bf16 pieces, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (8 + 8 + 8 mantissa
+      // bits: the split is exact up to the last bit or two), and a product d * a is the sum of the SIX leading piece products
+      // d1 a1 + (d1 a2 + d2 a1) + (d2 a2 + d1 a3 + d3 a1); the three that are dropped are <= 3 x 2^-24 of it -- the size of one fp32 rounding.
+      // Piece products are exact in fp32 (8 x 8 bits) and accumulate in the MFMA's fp32 accumulator like the products of the fp32 MFMA do.
+      // Why: the fp32 MFMA peaks at 157 TFLOP/s, the bf16 MFMA at 2.5 PFLOP/s -- six bf16 MFMAs per k-step of 16 points are 96 x 32 cycles
+      // against 128 x 64 for the same points in fp32, so the kernel runs at the rate of its operand reads (2 KB per point and layer) like
+      // the single-piece path below, with none of its rounding noise.  The small terms are added first.
+      typedef __bf16 xbf16x8_t __attribute__((ext_vector_type(8)));
+      f32x4 dcur[8], acur[8], dnxt[8], anxt[8];
+      auto fetch16 = [&](long pb, f32x4 (&d)[8], f32x4 (&a)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const long pt = pb + 8 * kk + e;
+          const long pc = pt < plast ? pt : plast;
+          const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
+          const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
+          const float keep = pt < p1 ? 1.0f : 0.0f;
+          d[e] = dv * keep;
+          a[e] = av;
+        }
+      };
+      // column t of eight points -> the three piece fragments (dword q = points 2q, 2q + 1)
+      auto split3 = [&](const f32x4 (&v)[8], int t, xbf16x8_t& f1, xbf16x8_t& f2, xbf16x8_t& f3) {
+        uint32_t w1[4], w2[4], w3[4];
+#ifdef CRNERF_EXP_X3_NOSPLIT   // (timing experiments only; garbage) the cost of everything but the split
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w1[q] = __float_as_uint(v[2 * q][t]); w2[q] = __float_as_uint(v[2 * q + 1][t]); w3[q] = w1[q] ^ w2[q]; }
+        f1 = __builtin_bit_cast(xbf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+        f2 = __builtin_bit_cast(xbf16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+        f3 = __builtin_bit_cast(xbf16x8_t, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x0 = v[2 * q][t], x1 = v[2 * q + 1][t];
+          w1[q] = pk_bf16_rne(x0, x1);
+          const float r0 = x0 - __uint_as_float(w1[q] << 16), r1 = x1 - __uint_as_float(w1[q] & 0xffff0000u);
+          w2[q] = pk_bf16_rne(r0, r1);
+          const float s0 = r0 - __uint_as_float(w2[q] << 16), s1 = r1 - __uint_as_float(w2[q] & 0xffff0000u);
+          w3[q] = pk_bf16_rne(s0, s1);
+        }
+        f1 = __builtin_bit_cast(xbf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+        f2 = __builtin_bit_cast(xbf16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+        f3 = __builtin_bit_cast(xbf16x8_t, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+      };
+      const bool do_bias3 = j.bias_partial && bz == 0 && bias_wave;
+      f32x4 bsum3 = {0.0f, 0.0f, 0.0f, 0.0f};
+      fetch16(p0, dcur, acur);
+      for (long pb = p0; pb < p1; pb += 16) {
+        fetch16(pb + 16, dnxt, anxt);
+        if (do_bias3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum3 += dcur[e];
+        }
+        xbf16x8_t a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split3(acur, t, a1[t], a2[t], a3[t]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          xbf16x8_t d1, d2, d3;
+          split3(dcur, a, d1, d2, d3);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d3, a1[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a3[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a2[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a1[b], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a2[b], c, 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a1[b], c, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+        // ask the scheduler to thread the splits' VALU work between the MFMAs (three behind each; measured 18.29 -> 17.85 ms per 2^20-point backward;
+#pragma unroll            // without the hint hipcc emits the MFMAs of a column back to back and the splits in clumps)
+        for (int g = 0; g < 96; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+      if (do_bias3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bsum3[t] += __shfl_xor(bsum3[t], 32);
+        if (kk == 0) *(f32x4*)(j.bias_partial + (long)bx * j.M + m0 + 4 * i) = bsum3;
+      }
+      float* outp3 = j.partial + (long)bx * j.M * j.N;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
+          const f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+          *(f32x4*)(outp3 + (long)m * j.N + n0 + 4 * i) = v;
+        }
+      return;
+    }
     if (j.bf16) {
       // ---- opt-in mixed precision (crnerf_mlp_backward_ex_f32, CRNERF_BWD_WGRAD_BF16): the SAME fp32 operands from HBM, rounded to
       // bf16 (RNE) in registers and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  k-step = 16 points; lane
@@ -519,7 +677,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
   // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
   const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, X3>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
   CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
   CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
@@ -527,6 +685,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 
 
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(WgradJob j) { wgrad_body<true>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Every weight gradient of one NeRF_sigma backward in ONE launch: at the reference's 1,024-ray batches a per-layer launch is
 // ~256 workgroups of 256 points each -- fourteen ramp-ups and drains per model, and a [256 chunks][256][256] partial-sum slab
@@ -540,15 +699,18 @@ struct WgradBatch {
   int my[WG_MAX_JOBS];          // row blocks (ceil(M / 256))
   int njobs;
 };
-__global__ __launch_bounds__(256, 1) void wgrad_batch_kernel(WgradBatch b) {
+template <bool X3>
+__device__ __forceinline__ void wgrad_batch_body(const WgradBatch& b) {
   int k = 0;
 #pragma unroll 1
   while (k + 1 < b.njobs && (int)blockIdx.x >= b.first[k + 1]) ++k;
   k = __builtin_amdgcn_readfirstlane(k);
   const int local = (int)blockIdx.x - b.first[k];
   const int bx = local % b.nchunk[k], rest = local / b.nchunk[k];
-  wgrad_body(b.job[k], bx, rest % b.my[k], rest / b.my[k]);
+  wgrad_body<X3>(b.job[k], bx, rest % b.my[k], rest / b.my[k]);
 }
+__global__ __launch_bounds__(256, 1) void wgrad_batch_kernel(WgradBatch b) { wgrad_batch_body<false>(b); }
+__global__ __launch_bounds__(256, 1) void wgrad_x3_batch_kernel(WgradBatch b) { wgrad_batch_body<true>(b); }
 
 struct ReduceJob { const float* partial; const float* bias_partial; float* dst; float* db; int nchunk, M, N, ldc; };
 struct ReduceBatch { ReduceJob job[WG_MAX_JOBS]; int first[WG_MAX_JOBS + 1]; int njobs; };
@@ -611,8 +773,9 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
   const int chunk = wg_chunk(P);
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
-  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16};
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 == 2 ? 0 : bf16};   // bf16x3: its own kernel (wgrad_body<true>)
+  if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  else hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);
   return 0;
 }
@@ -689,11 +852,13 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
   b.njobs = r.njobs = n;
   int blocks = 0, rblocks = 0;
   float* w = ws;
+  bool x3 = false;
   for (int q = 0; q < n; ++q) {
     const WgradSpec& sp = specs[order[q]];
     const int nc = nchunk[order[q]];
     float* bws = w + (size_t)nc * sp.M * sp.N;
-    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16};
+    x3 = x3 || sp.bf16 == 2;
+    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16 == 2 ? 0 : sp.bf16};
     b.first[q] = blocks;
     b.nchunk[q] = nc;
     b.my[q] = (sp.M + 255) / 256;
@@ -706,7 +871,8 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
   b.first[n] = blocks;
   r.first[n] = rblocks;
   if ((size_t)(w - ws) > ws_floats) return set_error(-3, "wgrad batch: workspace too small");
-  hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+  if (x3) hipLaunchKernelGGL(wgrad_x3_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+  else hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblocks), dim3(256), 0, st, r);
   return 0;
 }
@@ -769,7 +935,7 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
 // grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags) {
-  const int wb = flags & 1;
+  const int wb = (flags & 2) ? 2 : (flags & 1);   // CRNERF_BWD_WGRAD_BF16X3 / CRNERF_BWD_WGRAD_BF16
   if (P <= 0) return 0;
   float* deltas = (float*)scratch;
   float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;

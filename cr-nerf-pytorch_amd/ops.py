@@ -128,9 +128,10 @@ def mlp_forward_train(packed, x):
 
 
 def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
-    """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: CRNERF_BWD_WGRAD_BF16
-    (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; data gradients,
-    biases and everything else exact fp32."""
+    """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
+    (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
+    CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
+    cores.  Data gradients, biases and everything else exact fp32."""
     lib = _lib.load()
     x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
     n = x.shape[0]
@@ -138,7 +139,8 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
     scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
     _lib.check(lib.crnerf_mlp_backward_ex_f32(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
                                               ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
-                                              _lib.ptr_array(grads, "grad"), n, 1 if wgrad_bf16 else 0, _lib.stream_ptr()),
+                                              _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
+                                              _lib.stream_ptr()),
                "crnerf_mlp_backward_ex_f32")
     return grads
 

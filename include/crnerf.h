@@ -85,6 +85,12 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
  * precision with no counterpart in the reference (its autograd is fp32): data gradients, biases, every other tensor and the loss
  * stay exact fp32; each affected dW entry carries an unbiased rounding noise of ~2^-8 / sqrt(points) relative to its terms. */
 #define CRNERF_BWD_WGRAD_BF16 1
+/* CRNERF_BWD_WGRAD_BF16X3: fp32-ACCURATE weight gradients on the bf16 matrix cores.  Each fp32 operand of the 256 x 256 blocks is split in
+ * registers into three bf16 pieces (x = x1 + x2 + x3, 24 mantissa bits) and every product is the sum of the six leading piece products, exact
+ * in fp32 and accumulated in fp32; what is dropped is <= 3 x 2^-24 of a product -- one fp32 rounding.  Applies to every weight-gradient
+ * block of the eleven nn.Linear (static_sigma: only when the jobs share one batched launch, n <= 2^18); bias gradients, data gradients
+ * and everything else: the exact fp32 path.  Exclusive with CRNERF_BWD_WGRAD_BF16. */
+#define CRNERF_BWD_WGRAD_BF16X3 2
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream);
 

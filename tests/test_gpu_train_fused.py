@@ -299,3 +299,35 @@ def test_embed_points_equals_the_torch_composition_bitwise(R, N):
         want = torch.cat([ops.posenc(pts, 15), demb[:, None, :].expand(R, N, 27).reshape(R * N, 27)], 1)
         got = AG._embed_points(rays, z, view_dir)
         assert got.shape == (R * N, 120) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n", [50000, 300000])      # batched launch (<= 2^18 points) / per-layer launches
+def test_wgrad_bf16x3_is_as_accurate_as_the_fp32_matrix_cores(n):
+    """CRNERF_BWD_WGRAD_BF16X3 (opt-in): the 256 x 256 weight-gradient blocks from three-piece bf16 splits of the fp32 operands, six bf16
+    MFMAs per product.  Held against (i) the exact fp32-MFMA path on the same deltas / activations -- the two may differ by fp32 summation
+    noise only -- and (ii) a float64 evaluation of the same sums through torch autograd on the GPU (the oracle's MLP in float64 on the
+    kernel's own inputs): the split path must not be further from it than the fp32 matrix cores are."""
+    from oracle import cpu_ref as O
+    st = synth.mlp_state(23, 1.0, 0.5)
+    g = torch.Generator().manual_seed(n)
+    x = torch.cat([O.posenc(torch.rand(n, 3, generator=g) * 4 - 2, 15), O.posenc(torch.rand(n, 3, generator=g) * 2 - 1, 4)], 1).to(DEV)
+    d_out = torch.randn(n, 65, generator=g).to(DEV)
+    dev = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev), x)
+        pt = ops.pack_mlp_weights_t(dev)
+        exact = ops.mlp_backward(pt, x, out, d_out, acts)
+        split = ops.mlp_backward(pt, x, out, d_out, acts, wgrad_bf16="x3")
+    w64 = {k: v.double().clone().requires_grad_(True) for k, v in dev.items()}
+    (O.mlp_forward(w64, x.double()) * d_out.double()).sum().backward()
+    worst = 0.0
+    for name, ge, gs in zip(ops.MLP_TENSOR_NAMES, exact, split):
+        ref = w64[name].grad
+        scale = float(ref.abs().max())
+        e_exact, e_split = float((ge.double() - ref).abs().max()) / scale, float((gs.double() - ref).abs().max()) / scale
+        diff = float((gs - ge).abs().max()) / scale
+        worst = max(worst, diff)
+        print("%-28s vs float64: fp32 MFMA %.2e  bf16x3 %.2e   |bf16x3 - fp32 MFMA| %.2e" % (name, e_exact, e_split, diff))
+        # weights: fp32 summation noise; biases: fp32 column sums in a different order
+        assert diff <= 5e-6 and e_split <= 1.5 * e_exact + 2e-7, (name, e_exact, e_split, diff)
+    assert worst > 0.0                                             # the split path did run

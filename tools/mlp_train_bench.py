@@ -39,6 +39,10 @@ print("flags: %s   P = %d" % (flags, P))
 print("forward (inference kernel)  %7.2f ms  %6.1f TFLOP/s" % (t_f * 1e3, flop / t_f / 1e12))
 print("forward with saved acts     %7.2f ms  %6.1f TFLOP/s" % (t_s * 1e3, flop / t_s / 1e12))
 print("backward (dgrad + wgrad)    %7.2f ms  %6.1f TFLOP/s" % (t_b * 1e3, 2 * flop / t_b / 1e12))
+t_b1, _ = timed(lambda: ops.mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=1))
+t_b3, _ = timed(lambda: ops.mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=2))
+print("backward, bf16 weight gradients     %7.2f ms" % (t_b1 * 1e3))
+print("backward, bf16x3 weight gradients   %7.2f ms   (fp32-accurate: three-piece split, six bf16 MFMAs per product)" % (t_b3 * 1e3))
 if flags and not os.environ.get("CRNERF_KEEP_BUILD"):
     env = {k: v for k, v in os.environ.items() if k != "CRNERF_EXTRA_FLAGS"}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL, env=env)
