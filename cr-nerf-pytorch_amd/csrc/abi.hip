@@ -306,6 +306,22 @@ int crnerf_render_rays_train_f32(const crnerf_render_args* a, void* acts_coarse,
   return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine);
 }
 
+size_t crnerf_packed_mlp_x3_bytes(void) { return PACKEDX_BYTES; }
+
+int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_x3: a tensor pointer is NULL");
+  return launch_pack_mlp_x3(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_f32x3(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32x3: negative n");
+  return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+}
+
 size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }
 
 int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed, void* stream) {

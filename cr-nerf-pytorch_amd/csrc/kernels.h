@@ -115,6 +115,9 @@ int launch_render_rays(const RenderArgs& a, hipStream_t stream);
 int launch_render_rays16(const RenderArgs& a, hipStream_t stream);
 int launch_mlp_forward16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
+int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream);
 int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);    // one ray per wave, 64-point tiles, one wave per SIMD (render_fused_bf16.hip)
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);

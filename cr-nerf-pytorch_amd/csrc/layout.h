@@ -164,4 +164,33 @@ __host__ __device__ inline int posenc_slot_to_col_b(int k, int F) {
   return -1;
 }
 
+// ---- "x3" stream for the fp32-accurate core on the bf16 matrix cores (mlp_core_x3.h): every weight is THREE bf16 pieces,
+// w = w1 + w2 + w3 with w1 = bf16(w), w2 = bf16(w - w1), w3 = bf16(w - w1 - w2); a fragment is the A operand of one
+// v_mfma_f32_32x32x16_bf16 as in fragB, and the stream is ordered layer-major, K-STEP-major, tile-minor, piece-minor -- the core keeps
+// the accumulators of all output tiles of a layer and walks the contraction once, splitting each fp32 activation once:
+//     fragX(layer, k-step s, tile T, piece w)[lane = 32*hh + i][e] = piece_w(W[32T + i][col(16s + 8(e>>2) + 4hh + (e&3))])
+// col(k): k is a hidden feature index (exactly the feature lane-half hh holds in registers 8(s%2) + e of source tile s/2 in the 32x32
+// C/D layout) or, for the two embeddings, a padded slot in the fp32 order of posenc_slot_to_col -- the registers posenc_regs fills.
+// dir_encoding (216 fragments) is padded to 240: whole 16-fragment stages AND whole 6-fragment turns of the core's read-ahead queue, whose
+// phase must be the same at every layer entry; consts block: the fp32 one.
+constexpr int FX_L1 = KS_XYZ * 8 * 3;                //  144
+constexpr int FX_HID = KS_HID * 8 * 3;               //  384
+constexpr int FX_L5 = (KS_XYZ + KS_HID) * 8 * 3;     //  528
+constexpr int FX_DIR_USED = (KS_HID + KS_DIR) * 4 * 3;   // 216
+constexpr int FX_DIR = (FX_DIR_USED + 47) / 48 * 48;   // 240
+constexpr int FX_RGB = KS_HALF * 2 * 3;              //   48
+constexpr int OFFX_L1 = 0;
+constexpr int OFFX_L2 = OFFX_L1 + FX_L1;             // L2, L3, L4 contiguous
+constexpr int OFFX_L5 = OFFX_L2 + 3 * FX_HID;
+constexpr int OFFX_L6 = OFFX_L5 + FX_L5;             // L6, L7, L8 contiguous
+constexpr int OFFX_FIN = OFFX_L6 + 3 * FX_HID;
+constexpr int OFFX_DIR = OFFX_FIN + FX_HID;
+constexpr int OFFX_RGB = OFFX_DIR + FX_DIR;
+constexpr int STREAMX_FRAGS = OFFX_RGB + FX_RGB;                 // 3648
+constexpr int STAGESX_PER_PASS = STREAMX_FRAGS / STAGE_FRAGS;    // 228
+static_assert(STREAMX_FRAGS % STAGE_FRAGS == 0 && FX_L1 % STAGE_FRAGS == 0 && FX_HID % STAGE_FRAGS == 0 && FX_L5 % STAGE_FRAGS == 0 &&
+              FX_RGB % STAGE_FRAGS == 0 && FX_DIR % STAGE_FRAGS == 0, "x3 layers must be whole stages");
+static_assert(FX_L1 % 6 == 0 && FX_HID % 6 == 0 && FX_L5 % 6 == 0 && FX_DIR % 6 == 0 && FX_RGB % 6 == 0, "x3 layers must be whole queue turns");
+constexpr size_t PACKEDX_BYTES = (size_t)CONST_BYTES + (size_t)STREAMX_FRAGS * FRAG_BYTES;   // 3,746,816
+
 }  // namespace crnerf

@@ -1,0 +1,247 @@
+// NeRF_sigma forward, fp32-ACCURATE on the bf16 matrix cores ("x3" core): one 32-point tile per wavefront, four wavefronts per
+// workgroup (one per SIMD, 512 registers), activations register-resident in fp32.
+//
+// Reference semantics: NeRF_sigma.forward, models/nerf.py:157-182, in fp32 -- the arithmetic of mlp_core.h / mlp_core16.h, evaluated
+// differently: the fp32 MFMA of this part peaks at 157 TFLOP/s, the bf16 MFMA at 2.5 PFLOP/s, so every product w * a of a Linear layer is
+// formed from THREE-PIECE bf16 splits of both fp32 operands,
+//     w = w1 + w2 + w3,  w1 = bf16(w), w2 = bf16(w - w1), w3 = bf16(w - w1 - w2)          (8 + 8 + 8 mantissa bits; exact to the last bit or two)
+//     w * a ~= w3 a1 + w1 a3 + w2 a2 + w2 a1 + w1 a2 + w1 a1                                (the six leading piece products, small terms first)
+// each piece product exact in fp32 and accumulated in the MFMA's fp32 accumulator; the three dropped terms are <= 3 x 2^-24 of the product --
+// one fp32 rounding.  Weights are split once, at pack time (layout.h "fragX", three fragments per (k-step, tile)); an activation is split
+// once per layer, in registers, when its k-step comes up (44 VALU instructions per 16 k-values, beside 6 x NT MFMAs).  Biases, relu, the
+// sigma head (fp32 VALU), softplus / sigmoid and the embeddings (accurate sincosf) are the fp32 code of mlp_core.h.
+//
+// Structure (that of mlp_core.h, the round-1 fp32 core): lane (p = lane&31, h = lane>>5) owns point p; the 32x32 C/D layout leaves it with
+// features 32t + 8q + 4h + j in register 4q+j of tile t, and registers 8(s%2) .. +7 of tile s/2 ARE the lane's eight k-values of k-step s of
+// the next layer.  K-outer: the accumulators of all output tiles of a layer are live (128 registers), the contraction is walked once.
+// Weights: the 6-slot x 16 KiB LDS ring of mlp_core.h (dynamic slot counters; LDS-DMA as inline asm, see glds16), four pieces per wave and
+// stage; fragments are consumed in stream order through an X_AHEAD-deep register queue, so the stage boundaries (16 fragments) need not
+// line up with the k-steps (3 NT fragments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.h"
+#include "mlp_core.h"
+
+namespace crnerf {
+
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X_AHEAD = 6;   // fragments read ahead of the one being multiplied (two (tile, k-step) triples)
+static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
+
+// WeightPipe of mlp_core.h for the x3 stream: STAGESX_PER_PASS stages per pass, LDS-DMA as asm.  Protocol as there: stages c and c + 1 may be
+// read; advance() -- after the last read of stage c has been issued -- waits until this wave's pieces of stage c + 2 have landed (counted
+// vmcnt) and barriers; the slot of stage c - 1 is then refilled with stage c + 5 by four issue_piece() calls during stage c + 1.
+struct WeightPipeX {
+  lds_char* lds;
+  const char* base[2];   // scalar: packed streams + this wave's 4 KiB column
+  const char* pf_ptr;
+  int pf_left, pf_pass, passes0, passes;
+  uint32_t pf_slot, rd_slot, rd_addr, lane16, lds_ring;
+
+  __device__ __forceinline__ void issue_piece(int i) {
+    const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    switch (i) {   // the instruction offset must be an immediate
+      case 0: glds16(dst, pf_ptr, lane16, 0); break;
+      case 1: glds16(dst, pf_ptr, lane16, FRAG_BYTES); break;
+      case 2: glds16(dst, pf_ptr, lane16, 2 * FRAG_BYTES); break;
+      default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
+    }
+    if (i == 3) {
+      pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
+      pf_ptr += STAGE_BYTES;
+      if (--pf_left == 0) {
+        pf_left = STAGESX_PER_PASS;
+        pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
+        pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
+      }
+    }
+  }
+  // Call once, all waves.  On return stages 0 and 1 are readable.
+  __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_, int lane, int wave) {
+    lds = lds_;
+    lane16 = (uint32_t)lane * 16u;
+    const uint32_t wave4k = (uint32_t)wave * 4096u;
+    lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + wave4k;
+    base[0] = stream0 + wave4k;
+    base[1] = stream1 + wave4k;
+    passes0 = passes0_;
+    passes = passes_;
+    pf_pass = 0;
+    pf_left = STAGESX_PER_PASS;
+    pf_ptr = (passes0 > 0) ? base[0] : base[1];
+    pf_slot = 0;
+    rd_slot = 0;
+    rd_addr = LDS_RING + lane16;
+#pragma unroll
+    for (int s = 0; s < RING_SLOTS - 1; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issue_piece(i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  __device__ __forceinline__ uint32_t next_addr() const {
+    const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    return LDS_RING + n * STAGE_BYTES + lane16;
+  }
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
+  }
+  // fragment at slot s of the stage being consumed; s >= 16 reads ahead into the next stage
+  __device__ __forceinline__ xu32x4 read_slot(int s) const {
+    const uint32_t a = (s < STAGE_FRAGS) ? rd_addr + s * FRAG_BYTES : next_addr() + (s - STAGE_FRAGS) * FRAG_BYTES;
+    return *(const __attribute__((address_space(3))) xu32x4*)(lds + a);
+  }
+  __device__ __forceinline__ void prime(xu32x4 (&q)[X_AHEAD]) const {
+#pragma unroll
+    for (int i = 0; i < X_AHEAD; ++i) q[i] = read_slot(i);
+  }
+};
+
+// eight fp32 k-values of a lane -> the three piece operands (dword d = values 2d, 2d + 1; v_cvt_pk_bf16_f32 rounds to nearest even)
+__device__ __forceinline__ uint32_t x3_pk(float a, float b) {
+  typedef __bf16 pk2 __attribute__((ext_vector_type(2)));
+  const pk2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void x3_split(const float (&v)[8], xbf16x8& b1, xbf16x8& b2, xbf16x8& b3) {
+  xu32x4 w1, w2, w3;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float x0 = v[2 * d], x1 = v[2 * d + 1];
+    w1[d] = x3_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(w1[d] << 16), r1 = x1 - __uint_as_float(w1[d] & 0xffff0000u);
+    w2[d] = x3_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(w2[d] << 16), s1 = r1 - __uint_as_float(w2[d] & 0xffff0000u);
+    w3[d] = x3_pk(s0, s1);
+  }
+  b1 = __builtin_bit_cast(xbf16x8, w1);
+  b2 = __builtin_bit_cast(xbf16x8, w2);
+  b3 = __builtin_bit_cast(xbf16x8, w3);
+}
+
+#define CRNERF_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, (a)), (b), (c), 0, 0, 0)
+
+// One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2).. of tile s/2), the following NSB from
+// srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
+// layer (dir_encoding), skipped through the queue without being multiplied.  q always holds the next X_AHEAD fragments of the STREAM.
+template <int NT, int NSA, int NSB, int PAD, int NA, int NB>
+__device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA)[NA], const f32x16 (&srcB)[NB], f32x16 (&acc)[NT],
+                                             xu32x4 (&q)[X_AHEAD]) {
+  static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
+  constexpr int NS = NSA + NSB;
+  static_assert(((NS * NT * 3 + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * 3 + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
+                "layer (+ padding) must be whole stages and whole queue turns; tiles go in pairs");
+  // consume one fragment of the stream: returns it, refills the queue, keeps the ring going (f = the fragment's index in the layer)
+  auto take = [&](int f) {
+    const int slot = f % STAGE_FRAGS;
+    const xu32x4 w = q[f % X_AHEAD];
+    if (slot % 4 == 0) p.issue_piece(slot / 4);
+    q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
+    if (slot == STAGE_FRAGS - 1) p.advance();
+    return w;
+  };
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ss = s < NSA ? s : s - NSA;
+      v[e] = s < NSA ? srcA[s < NSA ? ss >> 1 : 0][8 * (ss & 1) + e] : srcB[s < NSA ? 0 : ss >> 1][8 * (ss & 1) + e];
+    }
+    xbf16x8 b1, b2, b3;
+    x3_split(v, b1, b2, b3);
+#pragma unroll
+    for (int T = 0; T < NT; T += 2) {   // two tiles at a time: consecutive MFMAs belong to different accumulators
+      const int f = (s * NT + T) * 3;
+      const xu32x4 u1 = take(f), u2 = take(f + 1), u3 = take(f + 2);
+      const xu32x4 w1 = take(f + 3), w2 = take(f + 4), w3 = take(f + 5);
+      acc[T] = CRNERF_MFMA_X(u3, b1, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w3, b1, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u1, b3, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w1, b3, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u2, b2, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w2, b2, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u2, b1, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w2, b1, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u1, b2, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w1, b2, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u1, b1, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w1, b1, acc[T + 1]);
+    }
+  }
+#pragma unroll
+  for (int f = NS * NT * 3; f < NS * NT * 3 + PAD; ++f) (void)take(f);
+}
+
+// One 32-point tile through one model.  pe / dv: the positional embeddings in the register order of posenc_regs (posenc.h), exactly as
+// mlp_core.h's mlp_tile takes them.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both lane halves).
+__device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1], f32x16 (&feat)[2], float& sigma,
+                                            int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm) {
+  const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
+  const float NEG_INF = -__builtin_huge_valf();
+  f32x16 act[8], acc[8];
+  tm.tick(T_PROLOGUE);
+
+  init_acc<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
+  mma_layer_x3<8, KS_XYZ, 0, 0>(p, pe, pe, acc, q);
+  store_act<8>(acc, act, 0.0f);
+#pragma unroll 1
+  for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4
+    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
+    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+    store_act<8>(acc, act, 0.0f);
+  }
+  init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
+  mma_layer_x3<8, KS_XYZ, KS_HID, 0>(p, pe, act, acc, q);
+  store_act<8>(acc, act, 0.0f);
+#pragma unroll 1
+  for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
+    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
+    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+    store_act<8>(acc, act, 0.0f);
+  }
+  tm.tick(T_MMA);
+  {                                                      // static_sigma: 256 -> 1 on the VALU (fp32, as mlp_core.h)
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 w = *(const __attribute__((address_space(3))) f32x4*)(C + C_WSIG + 32 * t + 8 * qq + 4 * h);
+        s = fmaf(w[0], act[t][4 * qq + 0], s);
+        s = fmaf(w[1], act[t][4 * qq + 1], s);
+        s = fmaf(w[2], act[t][4 * qq + 2], s);
+        s = fmaf(w[3], act[t][4 * qq + 3], s);
+      }
+    s += __shfl_xor(s, 32);
+    sigma = softplus_ref(s + C[C_BSIG]);
+    tm.tick(T_SIGMA);
+  }
+  init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation)
+  mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+  store_act<8>(acc, act, NEG_INF);
+  {
+    f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir]))
+    init_acc<4>(acc4, C + C_BDIR, h);
+    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED>(p, act, dv, acc4, q);
+    store_act<4>(acc4, act, 0.0f);
+  }
+  {
+    f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear)
+    init_acc<2>(acc2, C + C_BRGB, h);
+    mma_layer_x3<2, KS_HALF, 0, 0>(p, act, act, acc2, q);
+    tm.tick(T_MMA);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(acc2[t][r]);
+    tm.tick(T_EPILOGUE);
+  }
+}
+
+}  // namespace crnerf

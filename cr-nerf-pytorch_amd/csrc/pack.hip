@@ -147,6 +147,57 @@ int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream) 
   return check_launch("pack_mlp_bf16");
 }
 
+// x3 stream (layout.h "fragX"): one thread per bf16 element; the three pieces of a weight by repeated round-to-nearest-even
+__global__ void pack_stream_x3_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMX_FRAGS * 512) return;
+  const int frag = (int)(idx / 512);
+  const int lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+  const int i = lane & 31, hh = lane >> 5;
+  const float* W;
+  int in_dim, nt, phi, kind;   // kind: 0 hidden, 1 L1, 2 L5 (skip), 3 dir
+  if (frag < OFFX_L2) { W = t.w[0]; in_dim = XYZ_DIM; nt = 8; phi = frag - OFFX_L1; kind = 1; }
+  else if (frag < OFFX_L5) { const int l = (frag - OFFX_L2) / FX_HID; W = t.w[1 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFFX_L2) % FX_HID; kind = 0; }
+  else if (frag < OFFX_L6) { W = t.w[4]; in_dim = XYZ_DIM + W_HIDDEN; nt = 8; phi = frag - OFFX_L5; kind = 2; }
+  else if (frag < OFFX_FIN) { const int l = (frag - OFFX_L6) / FX_HID; W = t.w[5 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFFX_L6) % FX_HID; kind = 0; }
+  else if (frag < OFFX_DIR) { W = t.w_final; in_dim = W_HIDDEN; nt = 8; phi = frag - OFFX_FIN; kind = 0; }
+  else if (frag < OFFX_RGB) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; nt = 4; phi = frag - OFFX_DIR; kind = 3; }
+  else { W = t.w_rgb; in_dim = 128; nt = 2; phi = frag - OFFX_RGB; kind = 0; }
+  if (kind == 3 && phi >= FX_DIR_USED) { stream[idx] = 0; return; }      // stage padding behind dir_encoding
+  const int piece = phi % 3, st = phi / 3;
+  const int s = st / nt, T = st % nt;
+  const int row = 32 * T + i;
+  auto kidx = [&](int sl) { return 16 * sl + 8 * (e >> 2) + 4 * hh + (e & 3); };
+  int col;
+  switch (kind) {
+    case 1: col = posenc_slot_to_col(kidx(s), XYZ_FREQS); break;
+    case 2: col = s < KS_XYZ ? posenc_slot_to_col(kidx(s), XYZ_FREQS) : XYZ_DIM + kidx(s - KS_XYZ); break;      // nerf.py:169 cat([xyz, h])
+    case 3: {
+      if (s < KS_HID) col = kidx(s);
+      else { const int dc = posenc_slot_to_col(kidx(s - KS_HID), DIR_FREQS); col = dc < 0 ? -1 : W_HIDDEN + dc; }   // nerf.py:177 cat([final, dir])
+      break;
+    }
+    default: col = kidx(s); break;
+  }
+  if (col < 0) { stream[idx] = 0; return; }
+  const float w = W[(long)row * in_dim + col];
+  const unsigned short p1 = f32_to_bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = f32_to_bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p2 << 16);
+  const unsigned short p3 = f32_to_bf16_rne(r2);
+  stream[idx] = piece == 0 ? p1 : (piece == 1 ? p2 : p3);
+}
+
+int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAMX_FRAGS * 512;
+  hipLaunchKernelGGL(pack_stream_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlp_x3");
+}
+
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);

@@ -105,6 +105,31 @@ def _mlp_tensor_list(state):
     return tensors
 
 
+def pack_mlp_weights_x3(state):
+    """Packed weights for the "f32x3" entry points (include/crnerf.h): every weight as three bf16 pieces, k-step-major fragment stream."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_x3_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_x3(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_x3")
+    return out
+
+
+def mlp_forward_x3(packed_x3, x, sigma_only=False):
+    """NeRF_sigma.forward in fp32 on the bf16 matrix cores (three-piece splits, six MFMAs per product; crnerf_mlp_forward_f32x3)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    want = 93 if sigma_only else 120
+    if x.dim() != 2 or x.shape[1] != want:
+        raise ValueError("mlp_forward_x3 expects [n,%d], got %s" % (want, tuple(x.shape)))
+    if packed_x3.numel() != lib.crnerf_packed_mlp_x3_bytes():
+        raise ValueError("crnerf_amd: packed weights are not an x3 pack (pack_mlp_weights_x3)")
+    out = torch.empty(x.shape[0], 1 if sigma_only else 65, dtype=torch.float32, device=x.device)
+    _lib.check(lib.crnerf_mlp_forward_f32x3(ctypes.c_void_p(packed_x3.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], int(bool(sigma_only)),
+                                            _lib.stream_ptr()), "crnerf_mlp_forward_f32x3")
+    return out
+
+
 def pack_mlp_weights_t(state):
     """Transposed fragment stream for the backward-data kernel."""
     lib = _lib.load()

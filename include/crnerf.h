@@ -216,6 +216,16 @@ int crnerf_render_rays_bf16(const crnerf_render_args* args, void* stream);
 int crnerf_render_rays_train_bf16(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
                                   void* stream);
 
+/* ---- "f32x3": the fp32 entry points evaluated on the bf16 matrix cores (no counterpart in the reference; opt-in).  Same functions, same
+ * fp32 inputs / outputs / biases / activations / sigma head / embeddings as crnerf_mlp_forward_f32 and crnerf_render_rays_f32; only the
+ * products of the eleven nn.Linear are formed differently: each fp32 operand is split into three bf16 pieces (w = w1 + w2 + w3, 24 mantissa
+ * bits; weights at pack time, activations in registers) and a product is the sum of the six leading piece products, each exact in fp32 and
+ * accumulated in fp32 -- the dropped terms are <= 3 x 2^-24 of a product, one fp32 rounding.  The results meet the fp32 entry points'
+ * tolerances against the oracle (tests/test_gpu_x3.py); they are not bit-identical to the fp32 MFMA's.  packed = crnerf_pack_mlp_weights_x3. */
+size_t crnerf_packed_mlp_x3_bytes(void);
+int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed_x3, void* stream);
+int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, int64_t n, int sigma_only, void* stream);
+
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.
  * weights = HOST array of 14 device pointers: conv1.weight, conv1.bias, ..., conv7.weight, conv7.bias (reference layouts). */
