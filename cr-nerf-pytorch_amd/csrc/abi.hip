@@ -199,7 +199,7 @@ int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coar
 }
 
 static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16, void* acts_c = nullptr, void* acts_f = nullptr,
-                              float* raw_c = nullptr, float* raw_f = nullptr) {
+                              float* raw_c = nullptr, float* raw_f = nullptr, bool x3 = false) {
   REQUIRE(a, "args");
   if (a->n_rays == 0) return 0;
   if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays: negative n_rays");
@@ -218,13 +218,14 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
   if (a->rng_flags) {
     if (a->rng_flags & ~(CRNERF_RNG_JITTER | CRNERF_RNG_U | CRNERF_RNG_NOISE)) return set_error(CRNERF_ERR_CONFIG, "render_rays: unknown rng_flags bits");
-    if (bf16 || !(acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 kernels only");
+    if (bf16 || x3 || !(acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 kernels only");
     if ((a->rng_flags & CRNERF_RNG_JITTER) && a->z_coarse) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_JITTER and z_coarse are exclusive");
     if ((a->rng_flags & CRNERF_RNG_U) && a->u) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_U and u are exclusive");
     if ((a->rng_flags & CRNERF_RNG_NOISE) && (a->noise_coarse || a->noise_fine)) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_NOISE and noise_* are exclusive");
     r.rng_seed = a->rng_seed; r.rng_ray_offset = (long)a->rng_ray_offset; r.rng_flags = a->rng_flags; r.perturb = a->perturb;
   }
   r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
+  if (x3) return launch_render_rays_x3(r, (hipStream_t)stream);
   if (bf16) {
     // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
     static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();
@@ -321,6 +322,8 @@ int crnerf_mlp_forward_f32x3(const void* packed, const float* x, float* out, int
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32x3: negative n");
   return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
+
+int crnerf_render_rays_f32x3(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, true); }
 
 size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }
 

@@ -1,0 +1,165 @@
+// "f32x3" fused volumetric renderer: render_fused.hip's kernel on the x3 core (mlp_core_x3.h: fp32-accurate products from three-piece bf16
+// splits on the bf16 matrix cores); everything around the MLP is the same fp32 code.
+// Fused volumetric renderer: the whole of render_rays_cross_ray (models/rendering.py:50-196) for
+// one ray per wavefront in ONE launch -- coarse depths, positional encoding, coarse NeRF_sigma,
+// compositing, sample_pdf, z merge, fine NeRF_sigma, compositing.  Per ray the kernel reads 32 B
+// (rays[r,0:8]) and writes weights/feature/depth; the [P,93] embeddings, the [P,256] activations
+// and the [P,65] raw MLP output never exist in HBM (the reference materialises all three).
+//
+// Work decomposition: workgroup = 4 waves = 4 rays in lockstep on the shared LDS weight ring
+// (mlp_core.h); a ray's N samples are walked in 32-sample tiles by its wave, carrying the running
+// transmittance, so compositing needs no cross-wave traffic.  Grid-stride over ray quads.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "mlp_core_x3.h"
+#include "posenc.h"
+#include "ray_ops.h"
+
+namespace crnerf {
+
+struct RenderParamsX {
+  const char* packed0;
+  const char* packed1;
+  const float* rays;
+  const float* view_dir;
+  const float* z_coarse;
+  const float* z_steps;
+  const float* u;
+  long u_stride;
+  const float* noise_c;
+  const float* noise_f;
+  float noise_std;
+  int use_disp;
+  long R;
+  int Nc, Ni;
+  int iters;
+  float* weights_c;
+  float* feature_c;
+  float* depth_c;
+  float* weights_f;
+  float* feature_f;
+  float* depth_f;
+  float* z_fine;
+};
+
+__global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* lds = (lds_char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int Nc = a.Nc, Ni = a.Ni, Nf = Nc + Ni;
+
+  load_consts(lds, a.packed0, a.packed1);
+  RayScratch scr;
+  scr.bind(lds + LDS_SCRATCH + wave * SCRATCH_BYTES);
+
+  const int tiles_c = (Nc + 31) >> 5, tiles_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
+  WeightPipeX pipe;
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, tiles_c, tiles_c + tiles_f, lane, wave);
+  xu32x4 cur[X_AHEAD];
+  pipe.prime(cur);
+  PhaseTimer tm;
+  tm.start(blockIdx.x == 0 && threadIdx.x == 0);
+
+#pragma unroll 1
+  for (int it = 0; it < a.iters; ++it) {
+    const long rr = ((long)it * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool ray_ok = rr < a.R;
+    const long r = ray_ok ? rr : a.R - 1;
+    const float* ray = a.rays + r * 8;
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float near = ray[6], far = ray[7];
+    f32x16 dv[1];
+    {
+      // rendering.py:155  dir_embedded = embedding_dir(kwargs.get('view_dir', rays_d))
+      const float* vd = a.view_dir ? a.view_dir + r * 3 : ray + 3;
+      float tmp[16];
+      posenc_regs<DIR_FREQS, 8>(vd[0], vd[1], vd[2], h, tmp);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dv[0][i] = tmp[i];
+    }
+    for (int n = lane; n < Nc; n += 64)
+      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    wave_lds_fence();
+
+    // pass 0 = coarse model on zc, pass 1 = fine model on the merged zs; ONE copy of the MLP code
+    const int npass = Ni > 0 ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      const int N = pass ? Nf : Nc;
+      const lds_float* zsrc = pass ? scr.zs : scr.zc;
+      const float* noise_row = pass ? (a.noise_f ? a.noise_f + r * Nf : nullptr) : (a.noise_c ? a.noise_c + r * Nc : nullptr);
+      float* weights_row = pass ? a.weights_f + r * Nf : a.weights_c + r * Nc;
+      CompositeState st;
+      st.reset();
+      const int tiles = (N + 31) >> 5;
+#pragma unroll 1
+      for (int tile = 0; tile < tiles; ++tile) {
+        const int n = tile * 32 + p;
+        const bool valid = n < N;
+        const int nc = valid ? n : N - 1;
+        const float zn = zsrc[nc];
+        const float znext = zsrc[nc + 1 < N ? nc + 1 : N - 1];
+        // rendering.py:178 / :188  xyz = rays_o + rays_d * z  (separate mul and add)
+        const float x = ox + dx * zn, y = oy + dy * zn, z = oz + dz * zn;
+        f32x16 pe[3], feat[2];
+        {
+          float tmp[48];
+          posenc_regs<XYZ_FREQS, 24>(x, y, z, h, tmp);
+#pragma unroll
+          for (int i = 0; i < 48; ++i) pe[i / 16][i % 16] = tmp[i];
+        }
+        float sigma;
+        mlp_tile_x3(pipe, pass, pe, dv, feat, sigma, h, cur, tm);
+        const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        const float w = composite_tile(st, feat, sigma, noise, zn, znext, n == N - 1, valid, p);
+        if (valid && h == 0) {
+          if (ray_ok) weights_row[n] = w;
+          if (pass == 0) scr.wc[n] = w;
+        }
+        tm.tick(T_COMPOSITE);
+      }
+      composite_finish(st);
+      if (ray_ok)
+        store_ray_feature(st, (pass ? a.feature_f : a.feature_c) + r * FEAT_DIM, (pass ? a.depth_f : a.depth_c) + r, p, h);
+      if (pass == 0 && Ni > 0) {
+        wave_lds_fence();
+        sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane);
+        merge_sort_wave(scr, Nc, Ni, lane);
+        if (a.z_fine && ray_ok)
+          for (int n = lane; n < Nf; n += 64) a.z_fine[r * Nf + n] = scr.zs[n];
+      }
+      tm.tick(T_RAYLEVEL);
+    }
+  }
+  tm.flush();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
+  if (a.R <= 0) return 0;
+  if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays_f32x3: N_samples must be in [2, 256] for the fused kernel");
+  if (a.Ni < 0 || a.Ni > MAX_NI) return set_error(-2, "render_rays_f32x3: N_importance must be in [0, 256] for the fused kernel");
+  if (a.Ni > 0 && a.Nc < 3) return set_error(-2, "render_rays_f32x3: hierarchical sampling needs N_samples >= 3");
+  if (a.Ni > 0 && !a.packed_fine) return set_error(-3, "render_rays_f32x3: N_importance > 0 but no fine model");
+  RenderParamsX k;
+  k.packed0 = (const char*)a.packed_coarse;
+  k.packed1 = (const char*)(a.packed_fine ? a.packed_fine : a.packed_coarse);
+  k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.z_steps = a.z_steps; k.u = a.u; k.u_stride = a.u_stride;
+  k.noise_c = a.noise_coarse; k.noise_f = a.noise_fine; k.noise_std = a.noise_std; k.use_disp = a.use_disp;
+  k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
+  k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
+  k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
+  const long quads = (a.R + 3) / 4;
+  const int cus = num_cus();
+  const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
+  k.iters = (int)((quads + grid - 1) / grid);
+  const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES;
+  if (int rc = ensure_dynamic_lds((const void*)render_rays_x3_kernel, shmem, "render_rays_x3_kernel")) return rc;
+  hipLaunchKernelGGL(render_rays_x3_kernel, dim3(grid), dim3(256), shmem, stream, k);
+  return check_launch("render_rays_x3_kernel");
+}
+
+
+}  // namespace crnerf

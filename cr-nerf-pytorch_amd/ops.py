@@ -130,6 +130,11 @@ def mlp_forward_x3(packed_x3, x, sigma_only=False):
     return out
 
 
+def render_rays_x3(packed_coarse, packed_fine, rays, n_samples, n_importance, **kw):
+    """render_rays(..., precision="f32x3")."""
+    return render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, precision="f32x3", **kw)
+
+
 def pack_mlp_weights_t(state):
     """Transposed fragment stream for the backward-data kernel."""
     lib = _lib.load()
@@ -317,10 +322,18 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
-    bf16 = _is_bf16(precision)
+    x3 = precision in ("f32x3", "x3")            # fp32 on the bf16 matrix cores (crnerf_render_rays_f32x3; packs from pack_mlp_weights_x3)
+    bf16 = False if x3 else _is_bf16(precision)
     want_z_fine = want_z_fine or train
-    _check_packed(packed_coarse, bf16)
-    _check_packed(packed_fine, bf16)
+    if x3:
+        if train or rng is not None:
+            raise ValueError("crnerf_amd: precision='f32x3' is an inference entry point (no training twin, no in-kernel random draws)")
+        for pk in (packed_coarse, packed_fine):
+            if pk is not None and pk.numel() != lib.crnerf_packed_mlp_x3_bytes():
+                raise ValueError("crnerf_amd: precision='f32x3' needs packs from pack_mlp_weights_x3")
+    else:
+        _check_packed(packed_coarse, bf16)
+        _check_packed(packed_fine, bf16)
     rays = _f32c(rays, "rays")
     if rays.dim() != 2 or rays.shape[1] != 8:
         raise ValueError("rays must be [R,8], got %s" % (tuple(rays.shape),))
@@ -364,8 +377,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     if launcher:      # measurement helper: re-launch the same call on the same buffers with nothing but the C call on the host side
         if train:
             raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
-        fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
-        name = "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"
+        fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
+        name = "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
         held = (keep, rays, packed_coarse, packed_fine, out)  # the argument struct holds raw pointers: keep EVERY tensor behind them alive
         # (the outputs too: a caller that drops `out` must not hand their memory back to the caching allocator while launch() can still write it)
 
@@ -385,8 +398,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
         _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()),
                    "crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32")
         return out
-    fn = lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32
-    _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
+    fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
+    _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))
     return out
 
 

@@ -225,6 +225,8 @@ int crnerf_render_rays_train_bf16(const crnerf_render_args* args, void* acts_coa
 size_t crnerf_packed_mlp_x3_bytes(void);
 int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed_x3, void* stream);
 int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, int64_t n, int sigma_only, void* stream);
+/* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are x3 packs; rng_flags must be 0. */
+int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
 
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.

@@ -66,3 +66,61 @@ def test_mlp_x3_is_as_accurate_as_the_fp32_matrix_cores(gain):
     print("gain %.1f: fp32 MFMA max %.3e mean %.3e | x3 max %.3e mean %.3e | x3 vs fp32 MFMA max %.3e" %
           (gain, float(e32.max()), float(e32.mean()), float(ex3.max()), float(ex3.mean()), float((ox3 - o32).abs().max())))
     assert float(ex3.mean()) <= 1.5 * float(e32.mean()) + 1e-9 and float(ex3.max()) <= 2.0 * float(e32.max()) + 1e-7
+
+
+# ------------------------------------------------------------------ the fused renderer on the x3 core (crnerf_render_rays_f32x3)
+def _packx(st):
+    return ops.pack_mlp_weights_x3({k: C(v) for k, v in st.items()})
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("tag,ni,disp", [("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)])
+def test_render_x3_golden(golden, tag, ni, disp):
+    """tests/test_gpu_parity.py::test_render_golden, assertion for assertion, on the f32x3 renderer."""
+    from test_gpu_parity import _models, assert_depths
+    g = golden("g5_render")
+    st_c, st_f = _models(g)
+    out = ops.render_rays(_packx(st_c), _packx(st_f) if ni else None, C(g["rays"]), 64, ni, use_disp=disp, z_steps=C(g["z_steps_64"]),
+                          u=C(g["u_steps_%d" % ni]) if ni else None, want_z_fine=True, precision="f32x3")
+    close(out["weights_coarse"], g[tag + "__weights_coarse"], atol=3e-6)
+    close(out["feature_coarse"], g[tag + "__feature_coarse"], atol=1e-5)
+    close(out["depth_coarse"], g[tag + "__depth_coarse"], atol=1e-5)
+    if not ni:
+        return
+    z_coarse = O.coarse_depths(torch.from_numpy(g["rays"]), 64, disp, torch.from_numpy(g["z_steps_64"]))
+    assert_depths(out["z_fine"], g[tag + "__z_fine"], z_coarse, g[tag + "__weights_coarse"])
+    rays = torch.from_numpy(g["rays"])
+    zf = out["z_fine"].cpu()
+    raw = O._run_model(O.to_torch(st_f), rays, zf, O.posenc(rays[:, 3:6], 4), 32768)
+    w2, f2, d2 = O.composite(raw, zf)
+    close(out["weights_fine"], w2, atol=3e-6)
+    close(out["feature_fine"], f2, atol=1e-5)
+    close(out["depth_fine"], d2, atol=2e-5)
+    close(out["feature_fine"], g[tag + "__feature_fine"], atol=0.15)
+    ref = torch.from_numpy(g[tag + "__feature_fine"])
+    assert float((out["feature_fine"].cpu() - ref).norm() / ref.norm()) < 3e-2
+    assert float((out["weights_fine"].sum(-1).cpu() - 1).abs().max()) < 1e-5
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("net", ["band", "gain1"])
+@pytest.mark.parametrize("tag,disp", [("c64_f128", False), ("c64_f128_disp", True)])
+def test_x3_end_to_end_meets_the_stated_fp32_tolerance(golden, net, tag, disp):
+    """tests/test_gpu_e2e_parity.py::test_fp32_end_to_end_meets_stated_tolerance on the f32x3 renderer: SURVEY 8d's fp32 bars, END TO END
+    against the reference's own outputs, through the high-contrast decoder."""
+    import test_gpu_e2e_parity as E
+    g = golden("g14_render_smooth")
+    key = "%s__%s__" % (net, tag)
+    st_c, st_f = synth.mlp_state(41, **E.SMOOTH_NETS[net]), synth.mlp_state(42, **E.SMOOTH_NETS[net])
+    out = ops.render_rays(_packx(st_c), _packx(st_f), C(g["rays"]), 64, 128, use_disp=disp, z_steps=C(g["z_steps_64"]), u=C(g["u_steps_128"]),
+                          want_z_fine=True, precision="f32x3")
+    H, W = int(g["H"]), int(g["W"])
+    rgb = E._decoder(g)(out["feature_fine"].t().reshape(1, 64, H, W), C(g["style"])).reshape(3, H * W).t()
+    m = E._metrics(out, g, key, rgb)
+    E.record("f32x3 %s %s" % (net, tag), m)
+    far = float(g["rays"][:, 7].max())
+    assert m["rgb"]["max_abs"] <= 2e-5, m
+    assert m["feature_fine"]["rel_l2"] <= 1e-5 and m["feature_coarse"]["rel_l2"] <= 1e-5, m
+    assert m["z_fine"]["max_abs"] <= 1e-5 * far, m
+    assert m["feature_fine"]["max_abs"] <= 1e-5 and m["weights_fine"]["max_abs"] <= 1e-5 and m["depth_fine"]["max_abs"] <= 2e-5, m
+    assert m["weights_coarse"]["max_abs"] <= 3e-6 and m["depth_coarse"]["max_abs"] <= 1e-5, m
