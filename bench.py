@@ -307,6 +307,43 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
                             "parity_smooth_nets": {"vs_fp32_oracle_end_to_end": bf["end_to_end"], "vs_bf16_oracle_identical_depths": bf["identical_depths"],
                                                    "image_high_contrast_vs_fp32_oracle": bf["image_high_contrast"]}}
 
+    # ---- "f32x3": the same fp32 path evaluated on the bf16 matrix cores (three-piece splits of every fp32 operand, six bf16 MFMAs per product, fp32
+    # accumulation; include/crnerf.h) on the timed ray batch.  NOT the headline: the timed step above is the fp32-MFMA kernel.
+    with torch.no_grad():
+        pcx, pfx = ops.pack_mlp_weights_x3(to_dev(st_c)), ops.pack_mlp_weights_x3(to_dev(st_f))
+        launchx, _ = ops.render_rays(pcx, pfx, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="f32x3", launcher=True)
+        for _ in range(5):
+            launchx()
+        e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e4.record()
+        for _ in range(n):
+            launchx()
+        e5.record()
+        torch.cuda.synchronize()
+        msx = e4.elapsed_time(e5) / n
+
+        def gpu_render_x3(sc, sf):
+            out = ops.render_rays(ops.pack_mlp_weights_x3(to_dev(sc)), ops.pack_mlp_weights_x3(to_dev(sf)), rays, NC, NI, z_steps=z_steps, u=u_steps,
+                                  want_z_fine=True, precision="f32x3")
+            out["rgb_hi"] = net_hi(out["feature_fine"].t().reshape(1, 64, *grid_hw), style)
+            return out
+        px3 = parity_block(O, gpu_render_x3(sm_c, sm_f), rays_cpu, O.to_torch(sm_c), O.to_torch(sm_f), args_hi, grid_hw, style_cpu, zt, ut)[0]
+    extra["f32x3_kernel"] = {"kernel": "render_rays_x3_kernel", "kernel_ms": msx, "rays_per_s_kernel_only": R / (msx * 1e-3),
+                             "fp32_work_tflops": flops / (msx * 1e-3) / 1e12, "bf16_mfma_tflops": 6 * (7296.0 / 7248.0) * flops / (msx * 1e-3) / 1e12,
+                             "frac_nominal_2500_of_issued_bf16_mfma": 6 * (7296.0 / 7248.0) * flops / (msx * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                             "speedup_vs_fp32_mfma_kernel": None,
+                             "note": "fp32 inputs / outputs / biases / activations / embeddings; each product of the eleven nn.Linear = the six leading products of "
+                                     "three-piece bf16 splits of both fp32 operands (w = w1 + w2 + w3, 24 mantissa bits), exact in fp32, accumulated in fp32; dropped "
+                                     "terms <= 3 x 2^-24 of a product.  Meets the fp32 entry points' goldens and SURVEY 8d's fp32 bars (tests/test_gpu_x3.py) and sits at "
+                                     "the fp32 MFMA's distance from a float64 evaluation.  fp32_work_tflops counts the ALGORITHMIC fp32 FLOPs (it exceeds the fp32 "
+                                     "MFMA peak of 157.3: the work runs on the bf16 pipe); the issued bf16 MFMA work is 6x that, at the power-limited rate the bf16 "
+                                     "renderer reaches (extra.bf16_kernel)",
+                             "parity_smooth_nets": {"end_to_end": px3["end_to_end"], "identical_depths": px3["identical_depths"],
+                                                    "image_high_contrast": px3["image_high_contrast"],
+                                                    "meets_stated_fp32_tolerance": bool(px3["image_high_contrast"]["max_abs_rgb"] <= 2e-5 and
+                                                                                        px3["end_to_end"]["feature_fine"]["rel_l2"] <= 1e-5 and
+                                                                                        px3["end_to_end"]["z_fine"]["max_abs"] <= 1e-5 * px3["end_to_end"]["z_fine"]["far"])}}
+
     def timed(fn, reps):
         fn()
         torch.cuda.synchronize()
@@ -669,6 +706,8 @@ def main():
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
+                if not bf16 and "f32x3_kernel" in line["extra"]:
+                    line["extra"]["f32x3_kernel"]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"]["f32x3_kernel"]["kernel_ms"]
             except Exception as e:   # noqa: BLE001
                 line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rgb_sums is not None:
