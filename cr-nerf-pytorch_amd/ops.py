@@ -87,6 +87,10 @@ def pack_mlp_weights(state, out=None, precision="f32"):
     return out
 
 
+def _is_x3(precision):
+    return precision in ("f32x3", "x3")
+
+
 def _is_bf16(precision):
     if precision in ("bf16", "bfloat16", torch.bfloat16):
         return True
@@ -322,7 +326,7 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
-    x3 = precision in ("f32x3", "x3")            # fp32 on the bf16 matrix cores (crnerf_render_rays_f32x3; packs from pack_mlp_weights_x3)
+    x3 = _is_x3(precision)                       # fp32 on the bf16 matrix cores (crnerf_render_rays_f32x3; packs from pack_mlp_weights_x3)
     bf16 = False if x3 else _is_bf16(precision)
     want_z_fine = want_z_fine or train
     if x3:

@@ -96,15 +96,16 @@ def record(name, values):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])      # f32x3: the same fp32 bars on the bf16 matrix cores (three-piece splits, include/crnerf.h)
 @pytest.mark.parametrize("tag,nc,ni", [("64_128", 64, 128), ("256_256", 256, 256)])
-def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni):
+def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni, precision):
     g = golden("g15_trained")
     hp, models, emb, enc_a, side = _load(g, tmp_path)
     rays, style_img = T(g["rays"]).to(DEV), (T(g["style_rgbs"]).t().reshape(1, 3, side, side)).contiguous().to(DEV)   # enc_a input in [0, 1]
     a = enc_a(style_img)
     m = {"a_embedded": _diff(a, T(g["ref__a_embedded"]))}
     assert m["a_embedded"]["max_abs"] <= 1e-5, m
-    res = pipeline.batched_inference(models, emb, rays, None, nc, ni, False, 2048, False, args=hp, a_embedded_from_img=a, precision="f32")
+    res = pipeline.batched_inference(models, emb, rays, None, nc, ni, False, 2048, False, args=hp, a_embedded_from_img=a, precision=precision)
     rgb_f = pipeline.decode_image(models, res, side, side, a)
     rgb_c = pipeline.decode_image(models, res, side, side, a, key="feature_coarse")
     cond = lambda k: float(g["cond__%s__%s" % (tag, k)][0])   # noqa: E731  the reference's own fp64 - fp32 max-abs on this output
@@ -116,7 +117,7 @@ def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni):
     gt = T(g["gt"])
     m["psnr_vs_gt_reference"], m["psnr_vs_gt_hip"] = _psnr(T(g["ref__%s__rgb_fine" % tag]), gt), _psnr(rgb_f.cpu(), gt)
     m["psnr_hip_vs_reference"] = _psnr(rgb_f.cpu(), T(g["ref__%s__rgb_fine" % tag]))
-    record("fp32 %s" % tag, m)
+    record("%s %s" % ("fp32" if precision == "f32" else precision, tag), m)
     # SURVEY 8d's fp32 bars, as stated, END TO END against the reference's outputs on its own trained checkpoint
     assert m["rgb_fine"]["max_abs"] <= 2e-5 and m["rgb_coarse"]["max_abs"] <= 2e-5, m
     assert m["feature_fine"]["rel_l2"] <= 1e-5 and m["feature_coarse"]["rel_l2"] <= 1e-5, m
