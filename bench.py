@@ -374,7 +374,7 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
     K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]])
     c2w = np.array([[1, 0, 0, 0.05], [0, -1, 0, 0.02], [0, 0, -1, 0.1]], dtype=np.float32)
     photo = torch.rand(1, 3, 100, 100, device=dev)
-    for prec, reps in (("bf16", 3), ("f32", 1)):
+    for prec, reps in (("bf16", 3), ("f32x3", 2), ("f32", 1)):
         t = timed(lambda: pipeline.render_frame(m, emb, enc, photo, 800, 800, K, c2w, hp, chunk=32768, precision=prec), reps)
         extra["configs2_full_image_%s" % prec] = {"rays_per_s": 640000 / t, "ms_per_frame": t * 1e3, "tflops": FLOP_PER_POINT * (NC + NC + NI) * 640000 / t / 1e12,
                                                   "workload": "800x800 rays in 32,768-ray chunks x (64+128), appearance encoder + on-device rays + "
