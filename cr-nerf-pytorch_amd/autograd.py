@@ -67,6 +67,19 @@ def set_wgrad_precision(precision="f32"):
 
 
 _TRAIN_BF16 = [False]
+_TRAIN_FWD_X3 = [False]
+
+
+def set_training_forward_precision(precision="f32"):
+    """"f32" (default): the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
+    fp32 forward on the bf16 matrix cores (crnerf_render_rays_train_f32x3: three-piece bf16 splits of every fp32 operand, six MFMAs per
+    product -- include/crnerf.h "f32x3"): same saved state, same fp32 backward twins; the stochastic draws then come as tensors."""
+    _TRAIN_FWD_X3[0] = ops._is_x3(precision)
+
+
+def get_training_forward_x3():
+    import os
+    return _TRAIN_FWD_X3[0] or os.environ.get("CRNERF_TRAIN_FWD_X3", "") not in ("", "0")
 
 
 def set_training_precision(precision="f32"):
@@ -126,11 +139,14 @@ class FusedRenderFn(torch.autograd.Function):
         for mod in cfg["modules"]:
             if mod is not None and hasattr(mod, "invalidate_packed"):
                 mod.invalidate_packed()      # an optimiser step follows (see MlpFn)
-        packed = [ops.pack_mlp_weights(st) for st in states]
+        x3 = get_training_forward_x3() and cfg.get("rng") is None
+        packed = [ops.pack_mlp_weights_x3(st) if x3 else ops.pack_mlp_weights(st) for st in states]
         recompute = get_training_recompute()
+        ctx.x3 = x3
         out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                               z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
-                              noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"))
+                              noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"),
+                              precision="f32x3" if x3 else "f32")
         if cfg.get("rng") is not None:       # what the kernel drew is what the backward composites with (a few KB per ray chunk)
             cfg = dict(cfg, z_coarse_bwd=out["z_coarse_used"], noise_c_bwd=out.get("noise_coarse_used", cfg["noise_c"]),
                        noise_f_bwd=out.get("noise_fine_used", cfg["noise_f"]))
@@ -154,10 +170,11 @@ class FusedRenderFn(torch.autograd.Function):
         rays, z_fine = keep[0], keep[1]
         states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(ctx.n_models)]
         if ctx.recompute:
-            packed = [ops.pack_mlp_weights(st) for st in states]
+            packed = [ops.pack_mlp_weights_x3(st) if ctx.x3 else ops.pack_mlp_weights(st) for st in states]
             out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                                   z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
-                                  noise_std=cfg["noise_std"], train=True, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"))   # same (seed, ray, sample) -> same draws
+                                  noise_std=cfg["noise_std"], train=True, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"),
+                                  precision="f32x3" if ctx.x3 else "f32")   # same (seed, ray, sample) -> same draws
             per_pass = [(out["acts_coarse"], out["raw_coarse"])] + ([(out["acts_fine"], out["raw_fine"])] if Ni > 0 else [])
             z_fine = out["z_fine"] if Ni > 0 else z_fine
             del out

@@ -325,6 +325,14 @@ int crnerf_mlp_forward_f32x3(const void* packed, const float* x, float* out, int
 
 int crnerf_render_rays_f32x3(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, true); }
 
+int crnerf_render_rays_train_f32x3(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine, void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
+  if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
+  return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine, true);
+}
+
 size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }
 
 int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed, void* stream) {

@@ -124,14 +124,50 @@ __device__ __forceinline__ void x3_split(const float (&v)[8], xbf16x8& b1, xbf16
   b3 = __builtin_bit_cast(xbf16x8, w3);
 }
 
+// ---- training twin (crnerf_render_rays_train_f32x3): the saved state of the fp32 training twins (mlp_train16.h: acts[10][P][256] fp32 in reference
+// feature order, then the relu-activity bits masks[10][P][4] x 64 bit, bit 4T + r <-> feature 16T + 4g + r), written from this core's registers so
+// that the fp32 backward twins (mlp_backward16_kernel, the weight-gradient kernels) read it unchanged.  A layer's output is stored when the NEXT
+// layer walks it as its B operand -- the eight values of k-step s are two 16-byte pieces (64 contiguous bytes per point with the other lane half),
+// two stores per k-step, spread evenly through that layer's MFMAs; the activity bits are formed right after the relu.
+struct NoSaveX {
+  static constexpr bool on = false;
+  __device__ __forceinline__ float* row(int) const { return nullptr; }
+  template <int NT>
+  __device__ __forceinline__ void masks(int, const f32x16 (&)[NT]) const {}
+};
+struct ActSaveX {
+  static constexpr bool on = true;
+  float* base; long P; long n; bool valid; int h;
+  __device__ __forceinline__ float* row(int slot) const { return base + ((long)slot * P + n) * 256 + 4 * h; }
+  // lane (p, h) owns the mask words g = h and g = h + 2: bit 4T + r <-> register 4q + r of tile T >> 1, q = 2 (T & 1) + (g >> 1)
+  template <int NT>
+  __device__ __forceinline__ void masks(int slot, const f32x16 (&a)[NT]) const {
+    unsigned long long* m = (unsigned long long*)(base + (size_t)10 * P * 256) + ((size_t)slot * P + n) * 4;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int T = 0; T < 2 * NT; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t bit = a[T >> 1][4 * (2 * (T & 1) + gg) + r] > 0.0f ? 1u : 0u;   // post-relu values: > 0 <=> pre-activation > 0
+          const int k = 4 * T + r;
+          if (k < 32) lo |= bit << k; else hi |= bit << (k - 32);
+        }
+      if (valid) m[h + 2 * gg] = ((unsigned long long)hi << 32) | lo;
+    }
+  }
+};
+
 #define CRNERF_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, (a)), (b), (c), 0, 0, 0)
 
 // One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2).. of tile s/2), the following NSB from
 // srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
 // layer (dir_encoding), skipped through the queue without being multiplied.  q always holds the next X_AHEAD fragments of the STREAM.
+// rowA / rowB (training twin): where source A / B is saved -- this lane's row pointer of the slot, or null (embeddings; inference).
 template <int NT, int NSA, int NSB, int PAD, int NA, int NB>
 __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA)[NA], const f32x16 (&srcB)[NB], f32x16 (&acc)[NT],
-                                             xu32x4 (&q)[X_AHEAD]) {
+                                             xu32x4 (&q)[X_AHEAD], float* rowA = nullptr, float* rowB = nullptr, bool save_ok = false) {
   static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
   constexpr int NS = NSA + NSB;
   static_assert(((NS * NT * 3 + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * 3 + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
@@ -152,6 +188,14 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
     for (int e = 0; e < 8; ++e) {
       const int ss = s < NSA ? s : s - NSA;
       v[e] = s < NSA ? srcA[s < NSA ? ss >> 1 : 0][8 * (ss & 1) + e] : srcB[s < NSA ? 0 : ss >> 1][8 * (ss & 1) + e];
+    }
+    {   // training twin: this k-step's sixteen features of the source leave for HBM (two 16-byte pieces per lane)
+      float* row = s < NSA ? rowA : rowB;
+      const int ss = s < NSA ? s : s - NSA;
+      if (row && save_ok) {
+        *(f32x4*)(row + 16 * ss) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(row + 16 * ss + 8) = f32x4{v[4], v[5], v[6], v[7]};
+      }
     }
     xbf16x8 b1, b2, b3;
     x3_split(v, b1, b2, b3);
@@ -180,30 +224,37 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
 
 // One 32-point tile through one model.  pe / dv: the positional embeddings in the register order of posenc_regs (posenc.h), exactly as
 // mlp_core.h's mlp_tile takes them.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both lane halves).
+template <class SV = NoSaveX>
 __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1], f32x16 (&feat)[2], float& sigma,
-                                            int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm) {
+                                            int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm, const SV& sv = SV()) {
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
   const float NEG_INF = -__builtin_huge_valf();
   f32x16 act[8], acc[8];
+  bool ok = false;
+  if constexpr (SV::on) ok = sv.valid;
   tm.tick(T_PROLOGUE);
 
   init_acc<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
   mma_layer_x3<8, KS_XYZ, 0, 0>(p, pe, pe, acc, q);
   store_act<8>(acc, act, 0.0f);
+  sv.template masks<8>(0, act);
 #pragma unroll 1
-  for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4
+  for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4 (their input h_l is saved in slot l - 1 on the way)
     init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(l - 1), nullptr, ok);
     store_act<8>(acc, act, 0.0f);
+    sv.template masks<8>(l, act);
   }
   init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
-  mma_layer_x3<8, KS_XYZ, KS_HID, 0>(p, pe, act, acc, q);
+  mma_layer_x3<8, KS_XYZ, KS_HID, 0>(p, pe, act, acc, q, nullptr, sv.row(3), ok);
   store_act<8>(acc, act, 0.0f);
+  sv.template masks<8>(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
     init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(l - 1), nullptr, ok);
     store_act<8>(acc, act, 0.0f);
+    sv.template masks<8>(l, act);
   }
   tm.tick(T_MMA);
   {                                                      // static_sigma: 256 -> 1 on the VALU (fp32, as mlp_core.h)
@@ -222,19 +273,25 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
     sigma = softplus_ref(s + C[C_BSIG]);
     tm.tick(T_SIGMA);
   }
-  init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation)
-  mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q);
+  init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation); h8 -> slot 7
+  mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(7), nullptr, ok);
   store_act<8>(acc, act, NEG_INF);
   {
-    f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir]))
+    f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir])); final -> slot 8
     init_acc<4>(acc4, C + C_BDIR, h);
-    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED>(p, act, dv, acc4, q);
+    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED>(p, act, dv, acc4, q, sv.row(8), nullptr, ok);
     store_act<4>(acc4, act, 0.0f);
+    {
+      f32x16 a4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a4[t] = act[t];
+      sv.template masks<4>(9, a4);
+    }
   }
   {
-    f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear)
+    f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear); the dir activation -> slot 9
     init_acc<2>(acc2, C + C_BRGB, h);
-    mma_layer_x3<2, KS_HALF, 0, 0>(p, act, act, acc2, q);
+    mma_layer_x3<2, KS_HALF, 0, 0>(p, act, act, acc2, q, sv.row(9), nullptr, ok);
     tm.tick(T_MMA);
 #pragma unroll
     for (int t = 0; t < 2; ++t)

@@ -42,7 +42,32 @@ struct RenderParamsX {
   float* z_fine;
 };
 
-__global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) {
+// What the training twin adds (crnerf_render_rays_train_f32x3): every tile's layer activations + relu bits in the layout of the fp32 training
+// twins (ActSaveX, mlp_core_x3.h) and its raw MLP output row, per pass -- the fp32 backward twins read them unchanged.
+struct NoHookX {
+  __device__ __forceinline__ NoSaveX saver(int, long, int, int, bool, int) const { return NoSaveX(); }
+  __device__ __forceinline__ void raw(int, long, int, int, bool, int, const f32x16 (&)[2], float) const {}
+};
+struct TrainHookX {
+  float* acts[2];   // [10][R*N][256] + masks, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
+  float* rawo[2];   // [R*N][65]
+  long R;
+  __device__ __forceinline__ ActSaveX saver(int pass, long r, int N, int n, bool ok, int h) const { return ActSaveX{acts[pass], R * N, r * N + n, ok, h}; }
+  __device__ __forceinline__ void raw(int pass, long r, int N, int n, bool ok, int h, const f32x16 (&feat)[2], float sigma) const {
+    if (!ok) return;
+    float* o = rawo[pass] + (r * N + n) * OUT_DIM;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[32 * t + 8 * q + 4 * h + j] = feat[t][4 * q + j];
+    if (h == 0) o[FEAT_DIM] = sigma;
+  }
+};
+
+template <class HOOK>
+__device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const HOOK hook) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
   const int lane = threadIdx.x & 63;
@@ -111,7 +136,9 @@ __global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a)
           for (int i = 0; i < 48; ++i) pe[i / 16][i % 16] = tmp[i];
         }
         float sigma;
-        mlp_tile_x3(pipe, pass, pe, dv, feat, sigma, h, cur, tm);
+        const auto sv = hook.saver(pass, r, N, n, valid && ray_ok, h);
+        mlp_tile_x3(pipe, pass, pe, dv, feat, sigma, h, cur, tm, sv);
+        hook.raw(pass, r, N, n, valid && ray_ok, h, feat, sigma);
         const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
         const float w = composite_tile(st, feat, sigma, noise, zn, znext, n == N - 1, valid, p);
         if (valid && h == 0) {
@@ -137,6 +164,9 @@ __global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+__global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) { render_rays_x3_body(a, NoHookX()); }
+__global__ __launch_bounds__(256, 1) void render_rays_train_x3_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body(a, hook); }
+
 int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
   if (a.Nc < 2 || a.Nc > MAX_NC) return set_error(-2, "render_rays_f32x3: N_samples must be in [2, 256] for the fused kernel");
@@ -156,6 +186,14 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES;
+  if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_f32x3)
+    if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train_f32x3: fine buffers are NULL");
+    if (!a.train_raw_coarse) return set_error(-1, "render_rays_train_f32x3: raw_coarse is NULL");
+    TrainHookX h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
+    if (int rc = ensure_dynamic_lds((const void*)render_rays_train_x3_kernel, shmem, "render_rays_train_x3_kernel")) return rc;
+    hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
+    return check_launch("render_rays_train_x3_kernel");
+  }
   if (int rc = ensure_dynamic_lds((const void*)render_rays_x3_kernel, shmem, "render_rays_x3_kernel")) return rc;
   hipLaunchKernelGGL(render_rays_x3_kernel, dim3(grid), dim3(256), shmem, stream, k);
   return check_launch("render_rays_x3_kernel");

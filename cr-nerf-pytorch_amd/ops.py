@@ -330,8 +330,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     bf16 = False if x3 else _is_bf16(precision)
     want_z_fine = want_z_fine or train
     if x3:
-        if train or rng is not None:
-            raise ValueError("crnerf_amd: precision='f32x3' is an inference entry point (no training twin, no in-kernel random draws)")
+        if rng is not None:
+            raise ValueError("crnerf_amd: precision='f32x3' takes its random draws as tensors (no in-kernel draws)")
         for pk in (packed_coarse, packed_fine):
             if pk is not None and pk.numel() != lib.crnerf_packed_mlp_x3_bytes():
                 raise ValueError("crnerf_amd: precision='f32x3' needs packs from pack_mlp_weights_x3")
@@ -398,9 +398,9 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
             out["acts_fine"] = torch.empty(acts_bytes(R * Nf), dtype=torch.uint8, device=dev)
             out["raw_fine"] = new(R, Nf, 65)
         vp = lambda k: ctypes.c_void_p(out[k].data_ptr()) if k in out else None  # noqa: E731
-        fn = lib.crnerf_render_rays_train_bf16 if bf16 else lib.crnerf_render_rays_train_f32
+        fn = lib.crnerf_render_rays_train_f32x3 if x3 else (lib.crnerf_render_rays_train_bf16 if bf16 else lib.crnerf_render_rays_train_f32)
         _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()),
-                   "crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32")
+                   "crnerf_render_rays_train_f32x3" if x3 else ("crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32"))
         return out
     fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))

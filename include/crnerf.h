@@ -227,6 +227,11 @@ int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed_x3, voi
 int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 /* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are x3 packs; rng_flags must be 0. */
 int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
+/* Training twin: crnerf_render_rays_train_f32 on the x3 core -- the same saved state (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes in the
+ * layout of crnerf_mlp_forward_train_f32, raw_*[R*N,65]), so the fp32 backward twins (crnerf_composite_backward_f32 ->
+ * crnerf_mlp_backward[_ex]_f32) follow unchanged.  args->packed_* are x3 packs; rng_flags must be 0 (random draws come as tensors). */
+int crnerf_render_rays_train_f32x3(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
+                                   void* stream);
 
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.
