@@ -85,8 +85,14 @@ struct WeightPipeX {
     const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
     return LDS_RING + n * STAGE_BYTES + lane16;
   }
-  __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory");
+  // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twin; they share vmcnt with the LDS-DMA and retire in
+  // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
+  __device__ __forceinline__ void advance(int stores = 0) {
+    switch (stores) {
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4) + 2) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4) + 4) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory"); break;
+    }
     __builtin_amdgcn_s_barrier();
     rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
@@ -129,16 +135,26 @@ __device__ __forceinline__ void x3_split(const float (&v)[8], xbf16x8& b1, xbf16
 // that the fp32 backward twins (mlp_backward16_kernel, the weight-gradient kernels) read it unchanged.  A layer's output is stored when the NEXT
 // layer walks it as its B operand -- the eight values of k-step s are two 16-byte pieces (64 contiguous bytes per point with the other lane half),
 // two stores per k-step, spread evenly through that layer's MFMAs; the activity bits are formed right after the relu.
+constexpr uint32_t SAVEX_OOB = 0xF0000000u;   // offset of a lane that stores nothing (beyond every buffer resource: the hardware drops the store)
+struct SaveRowX { __amdgpu_buffer_rsrc_t rs; };   // the rows of one slot
 struct NoSaveX {
   static constexpr bool on = false;
-  __device__ __forceinline__ float* row(int) const { return nullptr; }
+  __device__ __forceinline__ SaveRowX row(int) const { return SaveRowX{}; }
+  __device__ __forceinline__ uint32_t offset() const { return 0; }
   template <int NT>
   __device__ __forceinline__ void masks(int, const f32x16 (&)[NT]) const {}
 };
 struct ActSaveX {
   static constexpr bool on = true;
   float* base; long P; long n; bool valid; int h;
-  __device__ __forceinline__ float* row(int slot) const { return base + ((long)slot * P + n) * 256 + 4 * h; }
+  // row stores are UNCONDITIONAL raw-buffer stores (lanes without a point carry an out-of-range offset), so that their number between two
+  // points of a layer's code is a compile-time constant the ring's vmcnt can allow for (mma_layer_x3).  (Measured: the allowance changes
+  // nothing -- 11.70 vs 11.75 ms per 16,384-ray chunk; the twin's time is the inference kernel's plus the time of its 10.5 KB per point of
+  // stores, 5.4 + 2.4 ms per 2^20 points, as for the bf16 twin)
+  __device__ __forceinline__ SaveRowX row(int slot) const {
+    return SaveRowX{__builtin_amdgcn_make_buffer_rsrc(base + (long)slot * P * 256, 0, (int)(uint32_t)(P * 1024), 0x00020000)};
+  }
+  __device__ __forceinline__ uint32_t offset() const { return valid ? (uint32_t)n * 1024u + 16u * (uint32_t)h : SAVEX_OOB; }
   // lane (p, h) owns the mask words g = h and g = h + 2: bit 4T + r <-> register 4q + r of tile T >> 1, q = 2 (T & 1) + (g >> 1)
   template <int NT>
   __device__ __forceinline__ void masks(int slot, const f32x16 (&a)[NT]) const {
@@ -164,10 +180,10 @@ struct ActSaveX {
 // One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2).. of tile s/2), the following NSB from
 // srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
 // layer (dir_encoding), skipped through the queue without being multiplied.  q always holds the next X_AHEAD fragments of the STREAM.
-// rowA / rowB (training twin): where source A / B is saved -- this lane's row pointer of the slot, or null (embeddings; inference).
-template <int NT, int NSA, int NSB, int PAD, int NA, int NB>
+// SAVEA / SAVEB (training twin): source A / B is saved while it is walked -- rowA / rowB = the slot's rows, voff = this lane's byte offset.
+template <int NT, int NSA, int NSB, int PAD, bool SAVEA = false, bool SAVEB = false, int NA, int NB>
 __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA)[NA], const f32x16 (&srcB)[NB], f32x16 (&acc)[NT],
-                                             xu32x4 (&q)[X_AHEAD], float* rowA = nullptr, float* rowB = nullptr, bool save_ok = false) {
+                                             xu32x4 (&q)[X_AHEAD], SaveRowX rowA = SaveRowX{}, SaveRowX rowB = SaveRowX{}, uint32_t voff = 0) {
   static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
   constexpr int NS = NSA + NSB;
   static_assert(((NS * NT * 3 + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * 3 + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
@@ -178,7 +194,14 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
     const xu32x4 w = q[f % X_AHEAD];
     if (slot % 4 == 0) p.issue_piece(slot / 4);
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
-    if (slot == STAGE_FRAGS - 1) p.advance();
+    if (slot == STAGE_FRAGS - 1) {
+      // row stores issued since this wave's pieces of the stage the barrier certifies (stage c + 2, issued in the take() of fragment
+      // 16 (c - 2) + 12): the k-steps of THIS layer that start in (16 (c - 2) + 12, f] -- a lower bound (the previous layer's are ignored)
+      int st = 0;
+      for (int ks = 0; ks < NSA + NSB; ++ks)
+        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - 35 && ks * NT * 3 <= f) st += 2;
+      p.advance(st);
+    }
     return w;
   };
 #pragma unroll
@@ -189,13 +212,13 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       const int ss = s < NSA ? s : s - NSA;
       v[e] = s < NSA ? srcA[s < NSA ? ss >> 1 : 0][8 * (ss & 1) + e] : srcB[s < NSA ? 0 : ss >> 1][8 * (ss & 1) + e];
     }
-    {   // training twin: this k-step's sixteen features of the source leave for HBM (two 16-byte pieces per lane)
-      float* row = s < NSA ? rowA : rowB;
+    if (s < NSA ? SAVEA : SAVEB) {   // training twin: this k-step's sixteen features of the source leave for HBM (two 16-byte pieces per lane)
+      const SaveRowX& row = s < NSA ? rowA : rowB;
       const int ss = s < NSA ? s : s - NSA;
-      if (row && save_ok) {
-        *(f32x4*)(row + 16 * ss) = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(row + 16 * ss + 8) = f32x4{v[4], v[5], v[6], v[7]};
-      }
+      const xu32x4 lo = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+      const xu32x4 hi = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+      __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * ss), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * ss + 32u), 0, 0);
     }
     xbf16x8 b1, b2, b3;
     x3_split(v, b1, b2, b3);
@@ -230,8 +253,8 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
   const float NEG_INF = -__builtin_huge_valf();
   f32x16 act[8], acc[8];
-  bool ok = false;
-  if constexpr (SV::on) ok = sv.valid;
+  constexpr bool SAVE = SV::on;
+  const uint32_t vo = sv.offset();
   tm.tick(T_PROLOGUE);
 
   init_acc<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
@@ -241,18 +264,18 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4 (their input h_l is saved in slot l - 1 on the way)
     init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(l - 1), nullptr, ok);
+    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
     store_act<8>(acc, act, 0.0f);
     sv.template masks<8>(l, act);
   }
   init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
-  mma_layer_x3<8, KS_XYZ, KS_HID, 0>(p, pe, act, acc, q, nullptr, sv.row(3), ok);
+  mma_layer_x3<8, KS_XYZ, KS_HID, 0, false, SAVE>(p, pe, act, acc, q, SaveRowX{}, sv.row(3), vo);
   store_act<8>(acc, act, 0.0f);
   sv.template masks<8>(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
     init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(l - 1), nullptr, ok);
+    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
     store_act<8>(acc, act, 0.0f);
     sv.template masks<8>(l, act);
   }
@@ -274,12 +297,12 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
     tm.tick(T_SIGMA);
   }
   init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation); h8 -> slot 7
-  mma_layer_x3<8, KS_HID, 0, 0>(p, act, act, acc, q, sv.row(7), nullptr, ok);
+  mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(7), SaveRowX{}, vo);
   store_act<8>(acc, act, NEG_INF);
   {
     f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir])); final -> slot 8
     init_acc<4>(acc4, C + C_BDIR, h);
-    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED>(p, act, dv, acc4, q, sv.row(8), nullptr, ok);
+    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED, SAVE, false>(p, act, dv, acc4, q, sv.row(8), SaveRowX{}, vo);
     store_act<4>(acc4, act, 0.0f);
     {
       f32x16 a4[4];
@@ -291,7 +314,7 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   {
     f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear); the dir activation -> slot 9
     init_acc<2>(acc2, C + C_BRGB, h);
-    mma_layer_x3<2, KS_HALF, 0, 0>(p, act, act, acc2, q, sv.row(9), nullptr, ok);
+    mma_layer_x3<2, KS_HALF, 0, 0, SAVE, false>(p, act, act, acc2, q, sv.row(9), SaveRowX{}, vo);
     tm.tick(T_MMA);
 #pragma unroll
     for (int t = 0; t < 2; ++t)

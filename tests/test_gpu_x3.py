@@ -187,3 +187,35 @@ def test_x3_training_forward_gradients_match_the_fp32_forward():
     for k in g32:
         rel = float((gx3[k] - g32[k]).norm() / (g32[k].norm() + 1e-30))
         assert rel <= 2e-3, (k, rel)     # measured 6e-4 on xyz_encoding_1 (a handful of relu masks flip with the forwards' fp32-level difference)
+
+
+@torch.no_grad()
+def test_x3_render_cold_l2_is_deterministic():
+    """Guard for the x3 core's weight ring (mlp_core_x3.h WeightPipeX: six slots, fragments read through a six-deep queue that runs ahead into the
+    next stage) with the weight stream evicted from L2 before every launch: 131,072 rays in 32,768-ray chunks, a 1 GiB copy before each chunk, four
+    passes, every output bit-identical to the first pass (tests/test_gpu_bf16.py::test_render_cold_l2_is_deterministic is the same guard for the
+    other cores); the training twin rides along on the last chunk."""
+    st_c = {k: C(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()}
+    st_f = {k: C(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()}
+    pc, pf = ops.pack_mlp_weights_x3(st_c), ops.pack_mlp_weights_x3(st_f)
+    R = 131072
+    rays = C(synth.rays(R, seed=0, H=512, W=256))
+    z_steps, u = torch.linspace(0, 1, 64, device=DEV), torch.linspace(0, 1, 128, device=DEV)
+    junk_a, junk_b = torch.empty(1 << 28, device=DEV), torch.zeros(1 << 28, device=DEV)
+
+    def run():
+        outs = []
+        for i in range(0, R, 32768):
+            junk_a.copy_(junk_b)
+            outs.append(ops.render_rays(pc, pf, rays[i:i + 32768], 64, 128, z_steps=z_steps, u=u, precision="f32x3"))
+        junk_a.copy_(junk_b)
+        trn = ops.render_rays(pc, pf, rays[R - 4096:], 64, 128, z_steps=z_steps, u=u, precision="f32x3", train=True)
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}, trn
+    ref, trn0 = run()
+    for k in ("feature_fine", "weights_fine", "feature_coarse"):
+        assert torch.equal(trn0[k], ref[k][R - 4096:]), k
+    for it in range(3):
+        out, trn = run()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (it, k)
+        assert torch.equal(trn["raw_fine"], trn0["raw_fine"]) and torch.equal(trn["raw_coarse"], trn0["raw_coarse"]), it
