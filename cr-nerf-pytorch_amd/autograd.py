@@ -73,7 +73,8 @@ _TRAIN_FWD_X3 = [False]
 def set_training_forward_precision(precision="f32"):
     """"f32" (default): the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
     fp32 forward on the bf16 matrix cores (crnerf_render_rays_train_f32x3: three-piece bf16 splits of every fp32 operand, six MFMAs per
-    product -- include/crnerf.h "f32x3"): same saved state, same fp32 backward twins; the stochastic draws then come as tensors."""
+    product -- include/crnerf.h "f32x3"), and with it the data gradient on the same core (crnerf_mlp_backward_x3_f32): same saved state and
+    scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws then come as tensors."""
     _TRAIN_FWD_X3[0] = ops._is_x3(precision)
 
 
@@ -193,8 +194,9 @@ class FusedRenderFn(torch.autograd.Function):
             d_raw = ops.composite_backward(raw, z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
                                            None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
             x = _embed_points(rays, z, cfg["view_dir"])
-            grads += ops.mlp_backward(ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65), d_raw.view(-1, 65), acts,
-                                      wgrad_bf16=get_wgrad_bf16())
+            x3 = getattr(ctx, "x3", False)       # the f32x3 forward brings the x3 data gradient with it (set_training_forward_precision)
+            grads += ops.mlp_backward(ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65),
+                                      d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3)
             del x, d_raw
         return (None, None) + tuple(grads)
 

@@ -193,4 +193,21 @@ static_assert(STREAMX_FRAGS % STAGE_FRAGS == 0 && FX_L1 % STAGE_FRAGS == 0 && FX
 static_assert(FX_L1 % 6 == 0 && FX_HID % 6 == 0 && FX_L5 % 6 == 0 && FX_DIR % 6 == 0 && FX_RGB % 6 == 0, "x3 layers must be whole queue turns");
 constexpr size_t PACKEDX_BYTES = (size_t)CONST_BYTES + (size_t)STREAMX_FRAGS * FRAG_BYTES;   // 3,746,816
 
+// ---- transposed x3 stream for the backward-data pass on the x3 core (mlp_backward_x3.hip): fragX of M = (W restricted to the hidden inputs)^T,
+//     fragXT(layer, k-step s, tile T, piece w)[lane = 32*hh + i][e] = piece_w(W[16s + 8(e>>2) + 4hh + (e&3)][in_off + 32T + i])
+// (the contraction runs over the layer's OUTPUT features -- the delta registers, in the 32x32 C/D order -- the tiles over its inputs); layers in
+// backward order, as the fp32 transposed stream (OFFT_*).
+constexpr int FXT_RGB = (FEAT_DIM / 16) * 4 * 3;     //  48: static_rgb^T      64 -> 128
+constexpr int FXT_DIR = (128 / 16) * 8 * 3;          // 192: dir_encoding^T   128 -> 256 (columns 0..255 of the [128,283] weight)
+constexpr int FXT_HID = KS_HID * 8 * 3;              // 384: xyz_encoding_final^T and xyz_encoding_{8..2}^T (layer 5: columns 93..348)
+constexpr int OFFXT_RGB = 0;
+constexpr int OFFXT_DIR = OFFXT_RGB + FXT_RGB;
+constexpr int OFFXT_FIN = OFFXT_DIR + FXT_DIR;
+constexpr int OFFXT_L8 = OFFXT_FIN + FXT_HID;        // L8, L7, ..., L2 contiguous
+constexpr int STREAMXT_FRAGS = OFFXT_L8 + 7 * FXT_HID;               // 3312
+constexpr int STAGESXT_PER_PASS = STREAMXT_FRAGS / STAGE_FRAGS;      // 207
+static_assert(STREAMXT_FRAGS % STAGE_FRAGS == 0 && FXT_RGB % STAGE_FRAGS == 0 && FXT_DIR % STAGE_FRAGS == 0 && FXT_RGB % 6 == 0 && FXT_DIR % 6 == 0,
+              "transposed x3 layers must be whole stages and whole queue turns");
+constexpr size_t PACKEDXT_BYTES = (size_t)CONST_BYTES + (size_t)STREAMXT_FRAGS * FRAG_BYTES;
+
 }  // namespace crnerf

@@ -38,6 +38,7 @@ struct WeightPipeX {
   const char* base[2];   // scalar: packed streams + this wave's 4 KiB column
   const char* pf_ptr;
   int pf_left, pf_pass, passes0, passes;
+  int stages_per_pass = STAGESX_PER_PASS;   // 228 forward stream, 207 transposed (backward-data) stream; set before start()
   uint32_t pf_slot, rd_slot, rd_addr, lane16, lds_ring;
 
   __device__ __forceinline__ void issue_piece(int i) {
@@ -52,7 +53,7 @@ struct WeightPipeX {
       pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
       pf_ptr += STAGE_BYTES;
       if (--pf_left == 0) {
-        pf_left = STAGESX_PER_PASS;
+        pf_left = stages_per_pass;
         pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
         pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
       }
@@ -69,7 +70,7 @@ struct WeightPipeX {
     passes0 = passes0_;
     passes = passes_;
     pf_pass = 0;
-    pf_left = STAGESX_PER_PASS;
+    pf_left = stages_per_pass;
     pf_ptr = (passes0 > 0) ? base[0] : base[1];
     pf_slot = 0;
     rd_slot = 0;

@@ -198,6 +198,45 @@ int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream) {
   return check_launch("pack_mlp_x3");
 }
 
+// transposed x3 stream (layout.h "fragXT")
+__global__ void pack_stream_x3t_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMXT_FRAGS * 512) return;
+  const int frag = (int)(idx / 512);
+  const int lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+  const int i = lane & 31, hh = lane >> 5;
+  const float* W;
+  int in_dim, col0, nt, phi;   // W[k][col0 + r]: k = the layer's output feature (contraction), r = its hidden input (tile row)
+  if (frag < OFFXT_DIR) { W = t.w_rgb; in_dim = 128; col0 = 0; nt = 4; phi = frag - OFFXT_RGB; }
+  else if (frag < OFFXT_FIN) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; col0 = 0; nt = 8; phi = frag - OFFXT_DIR; }
+  else if (frag < OFFXT_L8) { W = t.w_final; in_dim = W_HIDDEN; col0 = 0; nt = 8; phi = frag - OFFXT_FIN; }
+  else {
+    const int j = (frag - OFFXT_L8) / FXT_HID;          // 0..6 <-> xyz_encoding_{8 - j}
+    const int l = 7 - j;                                 // index into t.w
+    W = t.w[l]; in_dim = l == 4 ? XYZ_DIM + W_HIDDEN : W_HIDDEN; col0 = l == 4 ? XYZ_DIM : 0; nt = 8; phi = (frag - OFFXT_L8) % FXT_HID;
+  }
+  const int piece = phi % 3, st = phi / 3;
+  const int s = st / nt, T = st % nt;
+  const int k = 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
+  const int r = 32 * T + i;
+  const float w = W[(long)k * in_dim + col0 + r];
+  const unsigned short p1 = f32_to_bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = f32_to_bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p2 << 16);
+  const unsigned short p3 = f32_to_bf16_rne(r2);
+  stream[idx] = piece == 0 ? p1 : (piece == 1 ? p2 : p3);
+}
+
+int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAMXT_FRAGS * 512;
+  hipLaunchKernelGGL(pack_stream_x3t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlp_x3t");
+}
+
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);

@@ -161,7 +161,17 @@ def mlp_forward_train(packed, x):
     return out, acts
 
 
-def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
+def pack_mlp_weights_t_x3(state):
+    """Transposed x3 fragment stream for the backward-data kernel on the x3 core (crnerf_mlp_backward_x3_f32)."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_t_x3_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_t_x3(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_t_x3")
+    return out
+
+
+def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False):
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
     (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
     CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
@@ -171,11 +181,15 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False):
     n = x.shape[0]
     grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
     scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
-    _lib.check(lib.crnerf_mlp_backward_ex_f32(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
-                                              ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
-                                              _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
-                                              _lib.stream_ptr()),
-               "crnerf_mlp_backward_ex_f32")
+    fn = lib.crnerf_mlp_backward_x3_f32 if dgrad_x3 else lib.crnerf_mlp_backward_ex_f32     # dgrad_x3: packed_t is a pack_mlp_weights_t_x3 pack
+    want = lib.crnerf_packed_mlp_t_x3_bytes() if dgrad_x3 else lib.crnerf_packed_mlp_t_bytes()
+    if packed_t.numel() != want:
+        raise ValueError("crnerf_amd: mlp_backward(dgrad_x3=%s) needs a %d-byte transposed pack, got %d" % (dgrad_x3, want, packed_t.numel()))
+    _lib.check(fn(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
+                  ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
+                  _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
+                  _lib.stream_ptr()),
+               "crnerf_mlp_backward_x3_f32" if dgrad_x3 else "crnerf_mlp_backward_ex_f32")
     return grads
 
 

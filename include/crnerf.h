@@ -232,6 +232,13 @@ int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
  * crnerf_mlp_backward[_ex]_f32) follow unchanged.  args->packed_* are x3 packs; rng_flags must be 0 (random draws come as tensors). */
 int crnerf_render_rays_train_f32x3(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
                                    void* stream);
+/* crnerf_mlp_backward_ex_f32 with the DATA gradient on the x3 core (the layer deltas from three-piece splits of the transposed weights and of the
+ * deltas; six bf16 MFMAs per product, fp32 accumulation): same acts / scratch buffers and layouts, same flags for the weight gradients.
+ * packed_t_x3 = crnerf_pack_mlp_weights_t_x3 (crnerf_packed_mlp_t_x3_bytes). */
+size_t crnerf_packed_mlp_t_x3_bytes(void);
+int crnerf_pack_mlp_weights_t_x3(const float* const* tensors, void* packed_t_x3, void* stream);
+int crnerf_mlp_backward_x3_f32(const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
+                               float* const* grads, int64_t n, int flags, void* stream);
 
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.

@@ -219,3 +219,30 @@ def test_x3_render_cold_l2_is_deterministic():
         for k in ref:
             assert torch.equal(out[k], ref[k]), (it, k)
         assert torch.equal(trn["raw_fine"], trn0["raw_fine"]) and torch.equal(trn["raw_coarse"], trn0["raw_coarse"]), it
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("n", [1, 33, 4099, 70000])
+def test_mlp_backward_x3_matches_the_fp32_data_gradient(n):
+    """crnerf_mlp_backward_x3_f32: the data gradient on the x3 core writes the same deltas the fp32 kernel writes (seen through every weight /
+    bias gradient, computed by the SAME exact weight-gradient kernels from them) -- equal up to fp32 summation noise; and against torch autograd
+    through the oracle at the fp32 twin's own tolerance (tests/test_gpu_parity.py::test_mlp_backward_vs_autograd_oracle)."""
+    st = synth.mlp_state(13, 2.0 if n > 100 else 1.0, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32))
+    dev = {k: C(v) for k, v in st.items()}
+    out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev), x.to(DEV))
+    g32 = ops.mlp_backward(ops.pack_mlp_weights_t(dev), x.to(DEV), out, d_out.to(DEV), acts)
+    gx3 = ops.mlp_backward(ops.pack_mlp_weights_t_x3(dev), x.to(DEV), out, d_out.to(DEV), acts, dgrad_x3=True)
+    for name, a, b in zip(ops.MLP_TENSOR_NAMES, gx3, g32):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (name, float((a - b).abs().max()), scale)
+    if n <= 100:
+        with torch.enable_grad():
+            w = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+            (O.mlp_forward(w, x) * d_out).sum().backward()
+        for name, gq in zip(ops.MLP_TENSOR_NAMES, gx3):
+            ref = w[name].grad
+            assert float((gq.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-5, name

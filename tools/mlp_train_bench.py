@@ -43,6 +43,12 @@ t_b1, _ = timed(lambda: ops.mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf
 t_b3, _ = timed(lambda: ops.mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=2))
 print("backward, bf16 weight gradients     %7.2f ms" % (t_b1 * 1e3))
 print("backward, bf16x3 weight gradients   %7.2f ms   (fp32-accurate: three-piece split, six bf16 MFMAs per product)" % (t_b3 * 1e3))
+packed_tx = ops.pack_mlp_weights_t_x3(st)
+t_bx, _ = timed(lambda: ops.mlp_backward(packed_tx, x, out, d_out, acts, wgrad_bf16=2, dgrad_x3=True))
+print("backward, x3 data gradient + bf16x3 weight gradients   %7.2f ms" % (t_bx * 1e3))
+px = ops.pack_mlp_weights_x3(st)
+t_fx, _ = timed(lambda: ops.mlp_forward_x3(px, x))
+print("forward, f32x3 (inference kernel)  %7.2f ms" % (t_fx * 1e3))
 if flags and not os.environ.get("CRNERF_KEEP_BUILD"):
     env = {k: v for k, v in os.environ.items() if k != "CRNERF_EXTRA_FLAGS"}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL, env=env)
