@@ -1,7 +1,7 @@
 set -x
 O=$PWD/gpurun_out
 : > $O/train_config3_steps.txt
-for mode in "" "CRNERF_WGRAD_BF16X3=1" "CRNERF_WGRAD_BF16=1" "CRNERF_TRAIN_BF16=1" "CRNERF_TRAIN_BF16=1 CRNERF_TRAIN_RECOMPUTE=1"; do
+for mode in "" "CRNERF_TRAIN_FWD_X3=1 CRNERF_WGRAD_BF16X3=1" "CRNERF_WGRAD_BF16X3=1" "CRNERF_WGRAD_BF16=1" "CRNERF_TRAIN_BF16=1" "CRNERF_TRAIN_BF16=1 CRNERF_TRAIN_RECOMPUTE=1"; do
   for r in 1024 16384 65536; do
     echo -n "[$mode] " >> $O/train_config3_steps.txt
     env $mode python tools/train_config4_bench.py $r 2>&1 | tail -1 >> $O/train_config3_steps.txt
