@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
-                    help="f32 = BASELINE configs[1] (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]")
+    ap.add_argument("--precision", choices=["f32", "bf16", "f32x3"], default="f32",
+                    help="f32 = BASELINE configs[1] on the fp32 MFMA (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]; "
+                         "f32x3 = configs[1] in fp32 on the bf16 matrix cores (three-piece splits, six MFMAs per product; DESIGN 3.4b)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank renders its own --rays batch.  strong: ONE unit of --workload is "
                          "split over the ranks (the configs BASELINE.json names for 8 GPUs)")
@@ -624,7 +625,10 @@ def main():
         nerf_out_dim, img_wh = 64, [grid_hw[1], grid_hw[0]]
 
     with torch.no_grad():
-        pc, pf = ops.pack_mlp_weights(to_dev(st_c), precision=a.precision), ops.pack_mlp_weights(to_dev(st_f), precision=a.precision)
+        if a.precision == "f32x3":
+            pc, pf = ops.pack_mlp_weights_x3(to_dev(st_c)), ops.pack_mlp_weights_x3(to_dev(st_f))
+        else:
+            pc, pf = ops.pack_mlp_weights(to_dev(st_c), precision=a.precision), ops.pack_mlp_weights(to_dev(st_f), precision=a.precision)
         net = style_net(Args()).to(dev)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in dst.items()})
         rays = torch.from_numpy(rays_np).to(dev)
@@ -674,8 +678,13 @@ def main():
         flops = FLOP_PER_POINT * (NC + NC + NI) * R
         achieved = flops / (kern_ms * 1e-3) / 1e12
         bf16 = a.precision == "bf16"
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        x3 = a.precision == "f32x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or x3) else PEAK_F32_MFMA_TFLOPS
         kernel = ("render_rays_bf16_kernel" if os.environ.get("CRNERF_BF16_CORE") == "64" else "render_rays_bf16p_kernel") if bf16 else ("render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel")
+        if x3:   # the roofline of this mode is the bf16 pipe, priced with the bf16 MFMA work the kernel ISSUES: six piece products per fp32 product
+            kernel = "render_rays_x3_kernel"
+            flops = 6.0 * (7296.0 / 7248.0) * flops
+            achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "render_rays_hbm_bytes.json")   # written from a rocprofv3 --pmc pass (profiles/README.md)
         if os.path.exists(pmc):
@@ -687,7 +696,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]%s: %d rays x (%d coarse + %d fine) per GPU, NeRF_sigma 8x256 coarse+fine, "
                                    "fused render_rays + cross-ray decode of the %dx%d feature grid"
-                                   % (2 if bf16 else 1, " arithmetic (bf16 MFMA operands, fp32 accumulate) on the configs[1] ray batch" if bf16 else "",
+                                   % (2 if bf16 else 1, " arithmetic (bf16 MFMA operands, fp32 accumulate) on the configs[1] ray batch" if bf16 else
+                                      (" in fp32 on the bf16 matrix cores (three-piece bf16 splits of every fp32 operand, six MFMAs per product, fp32 accumulation; "
+                                       "roofline.achieved counts the ISSUED bf16 MFMA work = 6.04 x the algorithmic fp32 FLOPs)" if x3 else ""),
                                       R, NC, NI, grid_hw[0], grid_hw[1]),
                        "rays_per_gpu": R, "n_samples": NC, "n_importance": NI,
                        "parallelism": "rays sharded %d-way, weights replicated" % world,

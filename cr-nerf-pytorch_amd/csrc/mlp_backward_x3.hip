@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_x3_kernel(const char* __r
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream) {
   if (P <= 0) return 0;
+  if ((unsigned long long)P * 1024ull >= (unsigned long long)SAVEX_OOB)
+    return set_error(-2, "mlp_backward_x3: more than 3.9 M points per call (the delta rows are addressed with 32-bit offsets)");
   const long groups = (P + 127) / 128;
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);

@@ -189,6 +189,8 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_f32x3)
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train_f32x3: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train_f32x3: raw_coarse is NULL");
+    if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 1024ull >= (unsigned long long)SAVEX_OOB)
+      return set_error(-2, "render_rays_train_f32x3: more than 3.9 M sample points per pass and call (the saved rows are addressed with 32-bit offsets)");
     TrainHookX h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
     if (int rc = ensure_dynamic_lds((const void*)render_rays_train_x3_kernel, shmem, "render_rays_train_x3_kernel")) return rc;
     hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);

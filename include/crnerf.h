@@ -229,12 +229,13 @@ int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, 
 int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
 /* Training twin: crnerf_render_rays_train_f32 on the x3 core -- the same saved state (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes in the
  * layout of crnerf_mlp_forward_train_f32, raw_*[R*N,65]), so the fp32 backward twins (crnerf_composite_backward_f32 ->
- * crnerf_mlp_backward[_ex]_f32) follow unchanged.  args->packed_* are x3 packs; rng_flags must be 0 (random draws come as tensors). */
+ * crnerf_mlp_backward[_ex]_f32, or crnerf_mlp_backward_x3_f32) follow unchanged.  args->packed_* are x3 packs; rng_flags must be 0 (random draws
+ * come as tensors); R * (n_samples + n_importance) < 3.9 M per call. */
 int crnerf_render_rays_train_f32x3(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
                                    void* stream);
 /* crnerf_mlp_backward_ex_f32 with the DATA gradient on the x3 core (the layer deltas from three-piece splits of the transposed weights and of the
  * deltas; six bf16 MFMAs per product, fp32 accumulation): same acts / scratch buffers and layouts, same flags for the weight gradients.
- * packed_t_x3 = crnerf_pack_mlp_weights_t_x3 (crnerf_packed_mlp_t_x3_bytes). */
+ * packed_t_x3 = crnerf_pack_mlp_weights_t_x3 (crnerf_packed_mlp_t_x3_bytes).  n < 3.9 M points per call (CRNERF_ERR_SHAPE-class error beyond). */
 size_t crnerf_packed_mlp_t_x3_bytes(void);
 int crnerf_pack_mlp_weights_t_x3(const float* const* tensors, void* packed_t_x3, void* stream);
 int crnerf_mlp_backward_x3_f32(const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
