@@ -246,3 +246,23 @@ def test_mlp_backward_x3_matches_the_fp32_data_gradient(n):
         for name, gq in zip(ops.MLP_TENSOR_NAMES, gx3):
             ref = w[name].grad
             assert float((gq.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-5, name
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("log2c", [40, -40, 100])
+def test_mlp_x3_keeps_fp32_accuracy_across_the_exponent_range(log2c):
+    """bf16 has fp32's exponent range, so the three-piece split is scale-free: xyz_encoding_1 scaled by c = 2^log2c and xyz_encoding_2's weights by
+    1/c (relu is positively homogeneous: the same function) must give the outputs of the unscaled net to fp32 accuracy -- activations of 1e12 or
+    1e-12 (1e30 for 2^100) in between are split as exactly as values near 1."""
+    st = synth.mlp_state(31, 1.0, 0.5)
+    c = float(2.0 ** log2c)
+    st2 = dict(st)
+    st2["xyz_encoding_1.0.weight"] = (st["xyz_encoding_1.0.weight"] * c).astype(np.float32)
+    st2["xyz_encoding_1.0.bias"] = (st["xyz_encoding_1.0.bias"] * c).astype(np.float32)
+    st2["xyz_encoding_2.0.weight"] = (st["xyz_encoding_2.0.weight"] / c).astype(np.float32)
+    rng = np.random.default_rng(3)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (2000, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (2000, 3)).astype(np.float32)), 4)], 1).to(DEV)
+    a = ops.mlp_forward_x3(ops.pack_mlp_weights_x3({k: C(v) for k, v in st.items()}), x)
+    b = ops.mlp_forward_x3(ops.pack_mlp_weights_x3({k: C(v) for k, v in st2.items()}), x)
+    assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 1e-6, float((a - b).abs().max())
