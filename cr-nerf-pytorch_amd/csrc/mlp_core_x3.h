@@ -155,7 +155,12 @@ struct ActSaveX {
   __device__ __forceinline__ SaveRowX row(int slot) const {
     return SaveRowX{__builtin_amdgcn_make_buffer_rsrc(base + (long)slot * P * 256, 0, (int)(uint32_t)(P * 1024), 0x00020000)};
   }
-  __device__ __forceinline__ uint32_t offset() const { return valid ? (uint32_t)n * 1024u + 16u * (uint32_t)h : SAVEX_OOB; }
+  __device__ __forceinline__ uint32_t offset() const {
+#ifdef CRNERF_EXP_X3_NOSAVE   // (timing experiments only) every row store issued and dropped
+    return SAVEX_OOB;
+#endif
+    return valid ? (uint32_t)n * 1024u + 16u * (uint32_t)h : SAVEX_OOB;
+  }
   // lane (p, h) owns the mask words g = h and g = h + 2: bit 4T + r <-> register 4q + r of tile T >> 1, q = 2 (T & 1) + (g >> 1)
   template <int NT>
   __device__ __forceinline__ void masks(int slot, const f32x16 (&a)[NT]) const {
