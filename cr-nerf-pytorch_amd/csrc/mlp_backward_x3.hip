@@ -143,8 +143,8 @@ int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d
   const long groups = (P + 127) / 128;
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
-  if (int rc = ensure_dynamic_lds((const void*)mlp_backward_x3_kernel, LDS_SCRATCH, "mlp_backward_x3_kernel")) return rc;
-  hipLaunchKernelGGL(mlp_backward_x3_kernel, dim3(grid), dim3(256), LDS_SCRATCH, stream, (const char*)packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
+  if (int rc = ensure_dynamic_lds((const void*)mlp_backward_x3_kernel, LDS_SCRATCH_X, "mlp_backward_x3_kernel")) return rc;
+  hipLaunchKernelGGL(mlp_backward_x3_kernel, dim3(grid), dim3(256), LDS_SCRATCH_X, stream, (const char*)packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
   return check_launch("mlp_backward_x3_kernel");
 }
 

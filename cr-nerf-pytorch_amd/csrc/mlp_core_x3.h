@@ -27,12 +27,19 @@ namespace crnerf {
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CRNERF_X_RING
+#define CRNERF_X_RING 7
+#endif
+constexpr int X_RING = CRNERF_X_RING;   // LDS ring slots of the x3 kernels (mlp_core.h's protocol with one more stage in flight: the 3.75 MB stream of a
+                                        // model does not stay in an XCD's 4 MB L2, so a piece's latency is the memory side's, not L2's)
+constexpr int LDS_SCRATCH_X = LDS_RING + X_RING * STAGE_BYTES;
+static_assert(X_RING >= 5 && LDS_SCRATCH_X + 4 * 5120 <= 160 * 1024, "x3 ring: protocol depth and LDS budget (ring + four waves of ray scratch)");
 constexpr int X_AHEAD = 6;   // fragments read ahead of the one being multiplied (two (tile, k-step) triples)
 static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
 
 // WeightPipe of mlp_core.h for the x3 stream: STAGESX_PER_PASS stages per pass, LDS-DMA as asm.  Protocol as there: stages c and c + 1 may be
 // read; advance() -- after the last read of stage c has been issued -- waits until this wave's pieces of stage c + 2 have landed (counted
-// vmcnt) and barriers; the slot of stage c - 1 is then refilled with stage c + 5 by four issue_piece() calls during stage c + 1.
+// vmcnt) and barriers; the slot of stage c - 1 is then refilled with stage c + X_RING - 1 by four issue_piece() calls during stage c + 1.
 struct WeightPipeX {
   lds_char* lds;
   const char* base[2];   // scalar: packed streams + this wave's 4 KiB column
@@ -43,14 +50,16 @@ struct WeightPipeX {
 
   __device__ __forceinline__ void issue_piece(int i) {
     const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+#ifndef CRNERF_EXP_NOGLDS   // (timing experiments only: results are garbage without the loads)
     switch (i) {   // the instruction offset must be an immediate
       case 0: glds16(dst, pf_ptr, lane16, 0); break;
       case 1: glds16(dst, pf_ptr, lane16, FRAG_BYTES); break;
       case 2: glds16(dst, pf_ptr, lane16, 2 * FRAG_BYTES); break;
       default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
     }
+#endif
     if (i == 3) {
-      pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
+      pf_slot = (pf_slot + 1 == X_RING) ? 0u : pf_slot + 1;
       pf_ptr += STAGE_BYTES;
       if (--pf_left == 0) {
         pf_left = stages_per_pass;
@@ -76,26 +85,27 @@ struct WeightPipeX {
     rd_slot = 0;
     rd_addr = LDS_RING + lane16;
 #pragma unroll
-    for (int s = 0; s < RING_SLOTS - 1; ++s)
+    for (int s = 0; s < X_RING - 1; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_piece(i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ uint32_t next_addr() const {
-    const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    const uint32_t n = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     return LDS_RING + n * STAGE_BYTES + lane16;
   }
   // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twin; they share vmcnt with the LDS-DMA and retire in
   // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
   __device__ __forceinline__ void advance(int stores = 0) {
     switch (stores) {
-      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4) + 2) : "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4) + 4) : "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 2) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 4) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 6) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4)) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
-    rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
+    rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
   }
   // fragment at slot s of the stage being consumed; s >= 16 reads ahead into the next stage
@@ -202,10 +212,10 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
     if (slot == STAGE_FRAGS - 1) {
       // row stores issued since this wave's pieces of the stage the barrier certifies (stage c + 2, issued in the take() of fragment
-      // 16 (c - 2) + 12): the k-steps of THIS layer that start in (16 (c - 2) + 12, f] -- a lower bound (the previous layer's are ignored)
+      // 16 (c - X_RING + 4) + 12): the k-steps of THIS layer that start in (16 (c - X_RING + 4) + 12, f] -- a lower bound (the previous layer's are ignored)
       int st = 0;
       for (int ks = 0; ks < NSA + NSB; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - 35 && ks * NT * 3 <= f) st += 2;
+        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - (STAGE_FRAGS * (X_RING - 4) + 3) && ks * NT * 3 <= f) st += 2;
       p.advance(st);
     }
     return w;

@@ -76,7 +76,7 @@ int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus);
   const int iters = (int)((groups + grid - 1) / grid);
-  const size_t shmem = LDS_SCRATCH;
+  const size_t shmem = LDS_SCRATCH_X;
   if (int rc = ensure_dynamic_lds((const void*)mlp_forward_x3_kernel, shmem, "mlp_forward_x3_kernel")) return rc;
   hipLaunchKernelGGL(mlp_forward_x3_kernel, dim3(grid), dim3(256), shmem, stream, (const char*)packed, x, out, sigma_only, P, iters);
   return check_launch("mlp_forward_x3_kernel");

@@ -77,7 +77,7 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
 
   load_consts(lds, a.packed0, a.packed1);
   RayScratch scr;
-  scr.bind(lds + LDS_SCRATCH + wave * SCRATCH_BYTES);
+  scr.bind(lds + LDS_SCRATCH_X + wave * SCRATCH_BYTES);
 
   const int tiles_c = (Nc + 31) >> 5, tiles_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
   WeightPipeX pipe;
@@ -185,7 +185,7 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   const int cus = num_cus();
   const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
   k.iters = (int)((quads + grid - 1) / grid);
-  const size_t shmem = LDS_SCRATCH + 4 * SCRATCH_BYTES;
+  const size_t shmem = LDS_SCRATCH_X + 4 * SCRATCH_BYTES;
   if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_f32x3)
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train_f32x3: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train_f32x3: raw_coarse is NULL");
