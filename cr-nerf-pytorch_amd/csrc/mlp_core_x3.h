@@ -32,8 +32,13 @@ typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int X_RING = CRNERF_X_RING;   // LDS ring slots of the x3 kernels (mlp_core.h's protocol with one more stage in flight: the 3.75 MB stream of a
                                         // model does not stay in an XCD's 4 MB L2, so a piece's latency is the memory side's, not L2's)
-constexpr int LDS_SCRATCH_X = LDS_RING + X_RING * STAGE_BYTES;
+constexpr int LDS_TOUCH_X = LDS_RING + X_RING * STAGE_BYTES;   // 4 x 256 B: where the L2-prefetch touches land (never read)
+constexpr int LDS_SCRATCH_X = LDS_TOUCH_X + 1024;
 static_assert(X_RING >= 5 && LDS_SCRATCH_X + 4 * 5120 <= 160 * 1024, "x3 ring: protocol depth and LDS budget (ring + four waves of ray scratch)");
+#ifndef CRNERF_X_TOUCH
+#define CRNERF_X_TOUCH 0
+#endif
+constexpr int X_TOUCH = CRNERF_X_TOUCH;   // stages between an L2-prefetch touch of a stage and its LDS-DMA; 0 = no touches (the default: they did not pay)
 constexpr int X_AHEAD = 6;   // fragments read ahead of the one being multiplied (two (tile, k-step) triples)
 static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
 
@@ -47,9 +52,35 @@ struct WeightPipeX {
   int pf_left, pf_pass, passes0, passes;
   int stages_per_pass = STAGESX_PER_PASS;   // 228 forward stream, 207 transposed (backward-data) stream; set before start()
   uint32_t pf_slot, rd_slot, rd_addr, lane16, lds_ring;
+  // L2 prefetch (experiment, off): a model's 3.75 MB stream is the size of an XCD's L2 and does not stay there, so whichever CU of the XCD reaches a stage first
+  // pays the memory side's latency inside its LDS-DMA -- 19 % of the kernel (with the DMA removed: 1.12 vs 1.38 ms per 1,024 rays).  Each wave
+  // therefore TOUCHES the stage X_TOUCH stages further down the stream once per stage: one global_load_lds_dword whose 64 lanes hit 64 cache
+  // lines (8 KiB; even waves the first half of the stage, odd waves the second) and whose data lands in a dummy LDS row nobody reads -- an
+  // LDS-DMA because a load into a VGPR would write that register at an unknown later time.  Touches are unconditional, one per stage and wave,
+  // so the vmcnt bookkeeping of start() / advance() counts them exactly.  MEASURED (-DCRNERF_X_TOUCH=6): SLOWER, 1.34 -> 1.45 ms per 1,024 rays and
+  // 5.21 -> 5.77 ms per 2^20 points -- VMEM operations retire in order, so a touch that misses to memory holds back the count of every piece
+  // issued behind it.  Off by default; kept for the record.
+  const char* tbase[2];  // scalar: packed streams + this wave's half stage
+  const char* tp_ptr;
+  int tp_left, tp_pass;
+  uint32_t touch_lds;
+  __device__ __forceinline__ void touch() {
+    if (X_TOUCH > 0) {
+#ifndef CRNERF_EXP_NOGLDS
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:0" ::"s"(touch_lds), "v"(lane16 << 3), "s"(tp_ptr) : "memory");
+#endif
+      tp_ptr += STAGE_BYTES;
+      if (--tp_left == 0) {
+        tp_left = stages_per_pass;
+        tp_pass = (tp_pass + 1 == passes) ? 0 : tp_pass + 1;
+        tp_ptr = (tp_pass < passes0) ? tbase[0] : tbase[1];
+      }
+    }
+  }
 
   __device__ __forceinline__ void issue_piece(int i) {
     const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    if (i == 0) touch();
 #ifndef CRNERF_EXP_NOGLDS   // (timing experiments only: results are garbage without the loads)
     switch (i) {   // the instruction offset must be an immediate
       case 0: glds16(dst, pf_ptr, lane16, 0); break;
@@ -84,11 +115,17 @@ struct WeightPipeX {
     pf_slot = 0;
     rd_slot = 0;
     rd_addr = LDS_RING + lane16;
+    tbase[0] = stream0 + (wave & 1) * 8192;
+    tbase[1] = stream1 + (wave & 1) * 8192;
+    touch_lds = (uint32_t)(uintptr_t)lds_ + LDS_TOUCH_X + (uint32_t)wave * 256u;
+    tp_pass = 0;
+    tp_left = stages_per_pass - X_TOUCH;            // the touch cursor starts X_TOUCH stages into the first pass (a pass is >= 200 stages)
+    tp_ptr = ((passes0 > 0) ? tbase[0] : tbase[1]) + X_TOUCH * STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < X_RING - 1; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_piece(i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 3)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((4 + (X_TOUCH > 0 ? 1 : 0)) * (X_RING - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ uint32_t next_addr() const {
@@ -98,11 +135,12 @@ struct WeightPipeX {
   // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twin; they share vmcnt with the LDS-DMA and retire in
   // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
   __device__ __forceinline__ void advance(int stores = 0) {
+    constexpr int PER_STAGE = 4 + (X_TOUCH > 0 ? 1 : 0);   // VMEM operations of the ring per stage and wave: four pieces (+ one touch, issued before piece 0)
     switch (stores) {
-      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 2) : "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 4) : "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4) + 6) : "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (X_RING - 4)) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 2) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 4) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 6) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4)) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
     rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
