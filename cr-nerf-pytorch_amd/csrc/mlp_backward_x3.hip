@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_x3_kernel(const char* __r
   load_consts(lds, packedT, packedT);   // the consts block carries the sigma-head weights
   const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
   WeightPipeX pipe;
-  pipe.stages_per_pass = STAGESXT_PER_PASS;
+  pipe.set_stream_frags(STREAMXT_FRAGS);
   pipe.start(lds, packedT + CONST_BYTES, packedT + CONST_BYTES, 1, 1, lane, wave);
   xu32x4 q[X_AHEAD];
   pipe.prime(q);

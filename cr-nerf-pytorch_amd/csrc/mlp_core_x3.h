@@ -27,20 +27,30 @@ namespace crnerf {
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
 
+// The x3 ring: mlp_core.h's protocol with SEVEN 16-KiB slots.  The 3.75 MB stream of a model does not stay in an XCD's 4 MB L2, so a piece's
+// latency is the memory side's, not L2's, and what hides it is the number of stages in flight (the protocol keeps four out of flight: c - 1
+// being refilled, c and c + 1 readable, c + 2 certified).  Measured per 1,024 rays: 6 x 16 KiB 1.38 ms, 7 x 16 KiB 1.34 ms, 14 x 8 KiB
+// (-DCRNERF_X_RING=14 -DCRNERF_X_STAGE_FRAGS=8: ten stages in flight in the same LDS, twice the barriers) 1.36 ms; without the DMA at all 1.12 ms.
 #ifndef CRNERF_X_RING
 #define CRNERF_X_RING 7
 #endif
-constexpr int X_RING = CRNERF_X_RING;   // LDS ring slots of the x3 kernels (mlp_core.h's protocol with one more stage in flight: the 3.75 MB stream of a
-                                        // model does not stay in an XCD's 4 MB L2, so a piece's latency is the memory side's, not L2's)
-constexpr int LDS_TOUCH_X = LDS_RING + X_RING * STAGE_BYTES;   // 4 x 256 B: where the L2-prefetch touches land (never read)
+#ifndef CRNERF_X_STAGE_FRAGS
+#define CRNERF_X_STAGE_FRAGS 16
+#endif
+constexpr int X_RING = CRNERF_X_RING;
+constexpr int X_STAGE_FRAGS = CRNERF_X_STAGE_FRAGS;
+constexpr int X_STAGE_BYTES = X_STAGE_FRAGS * FRAG_BYTES;
+constexpr int X_PIECES = X_STAGE_FRAGS / 4;        // 1 KiB pieces per wave and stage (four waves)
+static_assert(STAGE_FRAGS % X_STAGE_FRAGS == 0 && X_PIECES >= 1 && X_PIECES <= 4, "x3 stages divide the stream's 16-fragment alignment");
+constexpr int LDS_TOUCH_X = LDS_RING + X_RING * X_STAGE_BYTES;   // 4 x 256 B: where the L2-prefetch touches land (never read)
 constexpr int LDS_SCRATCH_X = LDS_TOUCH_X + 1024;
-static_assert(X_RING >= 5 && LDS_SCRATCH_X + 4 * 5120 <= 160 * 1024, "x3 ring: protocol depth and LDS budget (ring + four waves of ray scratch)");
+static_assert(X_RING >= 5 && (X_PIECES + 1) * (X_RING - 3) + 8 <= 63 && LDS_SCRATCH_X + 4 * 5120 <= 160 * 1024, "x3 ring: protocol depth and LDS budget (ring + four waves of ray scratch)");
 #ifndef CRNERF_X_TOUCH
 #define CRNERF_X_TOUCH 0
 #endif
 constexpr int X_TOUCH = CRNERF_X_TOUCH;   // stages between an L2-prefetch touch of a stage and its LDS-DMA; 0 = no touches (the default: they did not pay)
 constexpr int X_AHEAD = 6;   // fragments read ahead of the one being multiplied (two (tile, k-step) triples)
-static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
+static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= X_STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
 
 // WeightPipe of mlp_core.h for the x3 stream: STAGESX_PER_PASS stages per pass, LDS-DMA as asm.  Protocol as there: stages c and c + 1 may be
 // read; advance() -- after the last read of stage c has been issued -- waits until this wave's pieces of stage c + 2 have landed (counted
@@ -50,8 +60,9 @@ struct WeightPipeX {
   const char* base[2];   // scalar: packed streams + this wave's 4 KiB column
   const char* pf_ptr;
   int pf_left, pf_pass, passes0, passes;
-  int stages_per_pass = STAGESX_PER_PASS;   // 228 forward stream, 207 transposed (backward-data) stream; set before start()
+  int stages_per_pass = STAGESX_PER_PASS * (STAGE_FRAGS / X_STAGE_FRAGS);   // x3 stages per pass: forward stream (set_stream_frags() for another)
   uint32_t pf_slot, rd_slot, rd_addr, lane16, lds_ring;
+  __device__ __forceinline__ void set_stream_frags(int frags) { stages_per_pass = frags / X_STAGE_FRAGS; }   // before start()
   // L2 prefetch (experiment, off): a model's 3.75 MB stream is the size of an XCD's L2 and does not stay there, so whichever CU of the XCD reaches a stage first
   // pays the memory side's latency inside its LDS-DMA -- 19 % of the kernel (with the DMA removed: 1.12 vs 1.38 ms per 1,024 rays).  Each wave
   // therefore TOUCHES the stage X_TOUCH stages further down the stream once per stage: one global_load_lds_dword whose 64 lanes hit 64 cache
@@ -69,7 +80,7 @@ struct WeightPipeX {
 #ifndef CRNERF_EXP_NOGLDS
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:0" ::"s"(touch_lds), "v"(lane16 << 3), "s"(tp_ptr) : "memory");
 #endif
-      tp_ptr += STAGE_BYTES;
+      tp_ptr += X_STAGE_BYTES;
       if (--tp_left == 0) {
         tp_left = stages_per_pass;
         tp_pass = (tp_pass + 1 == passes) ? 0 : tp_pass + 1;
@@ -78,8 +89,9 @@ struct WeightPipeX {
     }
   }
 
+  // piece i (0 .. X_PIECES - 1) of the stage being fetched: this wave's fragments X_PIECES * wave + i
   __device__ __forceinline__ void issue_piece(int i) {
-    const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
+    const uint32_t dst = lds_ring + pf_slot * X_STAGE_BYTES;
     if (i == 0) touch();
 #ifndef CRNERF_EXP_NOGLDS   // (timing experiments only: results are garbage without the loads)
     switch (i) {   // the instruction offset must be an immediate
@@ -89,9 +101,9 @@ struct WeightPipeX {
       default: glds16(dst, pf_ptr, lane16, 3 * FRAG_BYTES); break;
     }
 #endif
-    if (i == 3) {
+    if (i == X_PIECES - 1) {
       pf_slot = (pf_slot + 1 == X_RING) ? 0u : pf_slot + 1;
-      pf_ptr += STAGE_BYTES;
+      pf_ptr += X_STAGE_BYTES;
       if (--pf_left == 0) {
         pf_left = stages_per_pass;
         pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
@@ -103,7 +115,7 @@ struct WeightPipeX {
   __device__ __forceinline__ void start(lds_char* lds_, const char* stream0, const char* stream1, int passes0_, int passes_, int lane, int wave) {
     lds = lds_;
     lane16 = (uint32_t)lane * 16u;
-    const uint32_t wave4k = (uint32_t)wave * 4096u;
+    const uint32_t wave4k = (uint32_t)wave * (X_PIECES * FRAG_BYTES);   // this wave's column of a stage
     lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + wave4k;
     base[0] = stream0 + wave4k;
     base[1] = stream1 + wave4k;
@@ -115,40 +127,41 @@ struct WeightPipeX {
     pf_slot = 0;
     rd_slot = 0;
     rd_addr = LDS_RING + lane16;
-    tbase[0] = stream0 + (wave & 1) * 8192;
-    tbase[1] = stream1 + (wave & 1) * 8192;
+    tbase[0] = stream0;   // (touch experiment: one 8 KiB stage per instruction)
+    tbase[1] = stream1;
     touch_lds = (uint32_t)(uintptr_t)lds_ + LDS_TOUCH_X + (uint32_t)wave * 256u;
     tp_pass = 0;
     tp_left = stages_per_pass - X_TOUCH;            // the touch cursor starts X_TOUCH stages into the first pass (a pass is >= 200 stages)
-    tp_ptr = ((passes0 > 0) ? tbase[0] : tbase[1]) + X_TOUCH * STAGE_BYTES;
+    tp_ptr = ((passes0 > 0) ? tbase[0] : tbase[1]) + X_TOUCH * X_STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < X_RING - 1; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) issue_piece(i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((4 + (X_TOUCH > 0 ? 1 : 0)) * (X_RING - 3)) : "memory");
+      for (int i = 0; i < X_PIECES; ++i) issue_piece(i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((X_PIECES + (X_TOUCH > 0 ? 1 : 0)) * (X_RING - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ uint32_t next_addr() const {
     const uint32_t n = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
-    return LDS_RING + n * STAGE_BYTES + lane16;
+    return LDS_RING + n * X_STAGE_BYTES + lane16;
   }
   // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twin; they share vmcnt with the LDS-DMA and retire in
   // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
   __device__ __forceinline__ void advance(int stores = 0) {
-    constexpr int PER_STAGE = 4 + (X_TOUCH > 0 ? 1 : 0);   // VMEM operations of the ring per stage and wave: four pieces (+ one touch, issued before piece 0)
+    constexpr int PER_STAGE = X_PIECES + (X_TOUCH > 0 ? 1 : 0);   // VMEM operations of the ring per stage and wave: the pieces (+ one touch, issued before piece 0)
     switch (stores) {
       case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 2) : "memory"); break;
       case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 4) : "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 6) : "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 8) : "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4)) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
     rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
-    rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
+    rd_addr = LDS_RING + rd_slot * X_STAGE_BYTES + lane16;
   }
   // fragment at slot s of the stage being consumed; s >= 16 reads ahead into the next stage
   __device__ __forceinline__ xu32x4 read_slot(int s) const {
-    const uint32_t a = (s < STAGE_FRAGS) ? rd_addr + s * FRAG_BYTES : next_addr() + (s - STAGE_FRAGS) * FRAG_BYTES;
+    const uint32_t a = (s < X_STAGE_FRAGS) ? rd_addr + s * FRAG_BYTES : next_addr() + (s - X_STAGE_FRAGS) * FRAG_BYTES;
     return *(const __attribute__((address_space(3))) xu32x4*)(lds + a);
   }
   __device__ __forceinline__ void prime(xu32x4 (&q)[X_AHEAD]) const {
@@ -244,16 +257,18 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
                 "layer (+ padding) must be whole stages and whole queue turns; tiles go in pairs");
   // consume one fragment of the stream: returns it, refills the queue, keeps the ring going (f = the fragment's index in the layer)
   auto take = [&](int f) {
-    const int slot = f % STAGE_FRAGS;
+    const int slot = f % X_STAGE_FRAGS;
     const xu32x4 w = q[f % X_AHEAD];
-    if (slot % 4 == 0) p.issue_piece(slot / 4);
+    if (slot % (X_STAGE_FRAGS / X_PIECES) == 0) p.issue_piece(slot / (X_STAGE_FRAGS / X_PIECES));
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
-    if (slot == STAGE_FRAGS - 1) {
-      // row stores issued since this wave's pieces of the stage the barrier certifies (stage c + 2, issued in the take() of fragment
-      // 16 (c - X_RING + 4) + 12): the k-steps of THIS layer that start in (16 (c - X_RING + 4) + 12, f] -- a lower bound (the previous layer's are ignored)
+    if (slot == X_STAGE_FRAGS - 1) {
+      // row stores issued since this wave's pieces of the stage the barrier certifies (stage c + 2, whose last piece went out in the take() of
+      // fragment X_STAGE_FRAGS (c - X_RING + 4) + last piece slot): the k-steps of THIS layer that start behind it, up to f -- a lower bound
+      // (the previous layer's are ignored)
+      constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
       int st = 0;
       for (int ks = 0; ks < NSA + NSB; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - (STAGE_FRAGS * (X_RING - 4) + 3) && ks * NT * 3 <= f) st += 2;
+        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP) && ks * NT * 3 <= f) st += 2;
       p.advance(st);
     }
     return w;
