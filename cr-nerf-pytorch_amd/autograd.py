@@ -74,7 +74,7 @@ def set_training_forward_precision(precision="f32"):
     """"f32" (default): the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
     fp32 forward on the bf16 matrix cores (crnerf_render_rays_train_f32x3: three-piece bf16 splits of every fp32 operand, six MFMAs per
     product -- include/crnerf.h "f32x3"), and with it the data gradient on the same core (crnerf_mlp_backward_x3_f32): same saved state and
-    scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws then come as tensors."""
+    scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws in-kernel from the same Philox counters as the fp32 twin."""
     _TRAIN_FWD_X3[0] = ops._is_x3(precision)
 
 
@@ -140,7 +140,7 @@ class FusedRenderFn(torch.autograd.Function):
         for mod in cfg["modules"]:
             if mod is not None and hasattr(mod, "invalidate_packed"):
                 mod.invalidate_packed()      # an optimiser step follows (see MlpFn)
-        x3 = get_training_forward_x3() and cfg.get("rng") is None
+        x3 = get_training_forward_x3()
         packed = [ops.pack_mlp_weights_x3(st) if x3 else ops.pack_mlp_weights(st) for st in states]
         recompute = get_training_recompute()
         ctx.x3 = x3

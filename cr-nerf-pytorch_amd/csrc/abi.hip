@@ -218,7 +218,7 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
   if (a->rng_flags) {
     if (a->rng_flags & ~(CRNERF_RNG_JITTER | CRNERF_RNG_U | CRNERF_RNG_NOISE)) return set_error(CRNERF_ERR_CONFIG, "render_rays: unknown rng_flags bits");
-    if (bf16 || x3 || !(acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 kernels only");
+    if (bf16 || !(x3 || acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 and f32x3 kernels only");
     if ((a->rng_flags & CRNERF_RNG_JITTER) && a->z_coarse) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_JITTER and z_coarse are exclusive");
     if ((a->rng_flags & CRNERF_RNG_U) && a->u) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_U and u are exclusive");
     if ((a->rng_flags & CRNERF_RNG_NOISE) && (a->noise_coarse || a->noise_fine)) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_NOISE and noise_* are exclusive");

@@ -14,7 +14,7 @@
 // Structure (that of mlp_core.h, the round-1 fp32 core): lane (p = lane&31, h = lane>>5) owns point p; the 32x32 C/D layout leaves it with
 // features 32t + 8q + 4h + j in register 4q+j of tile t, and registers 8(s%2) .. +7 of tile s/2 ARE the lane's eight k-values of k-step s of
 // the next layer.  K-outer: the accumulators of all output tiles of a layer are live (128 registers), the contraction is walked once.
-// Weights: the 6-slot x 16 KiB LDS ring of mlp_core.h (dynamic slot counters; LDS-DMA as inline asm, see glds16), four pieces per wave and
+// Weights: the 16 KiB-stage LDS ring of mlp_core.h, X_RING = 7 slots here (dynamic slot counters; LDS-DMA as inline asm, see glds16), four pieces per wave and
 // stage; fragments are consumed in stream order through an X_AHEAD-deep register queue, so the stage boundaries (16 fragments) need not
 // line up with the k-steps (3 NT fragments).
 #pragma once

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "mlp_core.h"
+#include "philox.h"
 
 namespace crnerf {
 
@@ -199,7 +200,9 @@ __device__ __forceinline__ void store_ray_feature(const CompositeState& st, floa
 
 // sample_pdf(bins = z_mid, weights = w[1:-1], Ni, det) -- rendering.py:7-46, called at :183-184.
 // In: s.zc[Nc], s.wc[Nc] (coarse weights).  Out: s.zf[Ni].  u_row: per-ray uniforms or null (det).
-__device__ __forceinline__ void sample_pdf_wave(RayScratch& s, int Nc, int Ni, const float* u_row, int lane) {
+// rng != null: the uniforms are drawn in-kernel (philox.h, stream RNG_STREAM_U, ray index rng_ray) instead of read from u_row.
+__device__ __forceinline__ void sample_pdf_wave(RayScratch& s, int Nc, int Ni, const float* u_row, int lane, const RayRng* rng = nullptr,
+                                                long rng_ray = 0) {
   const int n_ = Nc - 2;       // number of pdf bins
   const float eps = 1e-5f;
   // sum of (w + eps) over the interior weights
@@ -228,7 +231,7 @@ __device__ __forceinline__ void sample_pdf_wave(RayScratch& s, int Nc, int Ni, c
   wave_lds_fence();
   const lds_float* cdf = s.wc;  // [n_ + 1]
   for (int k = lane; k < Ni; k += 64) {
-    const float u = u_row ? u_row[k] : linspace01(k, Ni);
+    const float u = rng ? rng->uniform(RNG_STREAM_U, rng_ray, k) : (u_row ? u_row[k] : linspace01(k, Ni));
     // searchsorted(cdf, u, right=True): number of entries <= u
     int lo = 0, hi = n_ + 1;
     while (lo < hi) {

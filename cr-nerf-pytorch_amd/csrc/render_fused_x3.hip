@@ -40,6 +40,10 @@ struct RenderParamsX {
   float* feature_f;
   float* depth_f;
   float* z_fine;
+  // in-kernel random draws (include/crnerf.h, philox.h: the same counters as the fp32 16x16x4 kernels, so one seed gives one set of draws
+  // whichever kernel renders); rng_flags == 0: none
+  unsigned long long rng_seed; long rng_ray_offset; int rng_flags; float perturb;
+  float* z_coarse_out; float* noise_c_out; float* noise_f_out;
 };
 
 // What the training twin adds (crnerf_render_rays_train_f32x3): every tile's layer activations + relu bits in the layout of the fp32 training
@@ -66,7 +70,9 @@ struct TrainHookX {
   }
 };
 
-template <class HOOK>
+// RNG: the instantiation with the in-kernel draws -- a template parameter like render_fused16.hip's, so the kernels without draws carry no
+// Philox registers through the MLP loop
+template <bool RNG, class HOOK>
 __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const HOOK hook) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
@@ -104,8 +110,22 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
 #pragma unroll
       for (int i = 0; i < 16; ++i) dv[0][i] = tmp[i];
     }
-    for (int n = lane; n < Nc; n += 64)
-      scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    const RayRng rng{(uint32_t)(a.rng_seed & 0xffffffffu), (uint32_t)(a.rng_seed >> 32)};
+    const long rng_ray = a.rng_ray_offset + r;
+    for (int n = lane; n < Nc; n += 64) {
+      auto zlin = [&](int k) { return coarse_depth(near, far, a.z_steps ? a.z_steps[k] : linspace01(k, Nc), a.use_disp); };
+      float zv;
+      if (a.z_coarse) zv = a.z_coarse[r * Nc + n];
+      else if (RNG && (a.rng_flags & 1)) {
+        // rendering.py:169-176: mid-points, lower / upper interval ends, z = lower + (upper - lower) * (perturb * U[0,1))
+        const float z0 = zlin(n);
+        const float lower = n == 0 ? z0 : 0.5f * (zlin(n - 1) + z0);
+        const float upper = n == Nc - 1 ? z0 : 0.5f * (z0 + zlin(n + 1));
+        zv = lower + (upper - lower) * (a.perturb * rng.uniform(RNG_STREAM_JITTER, rng_ray, n));
+      } else zv = zlin(n);
+      scr.zc[n] = zv;
+      if (RNG && a.z_coarse_out && ray_ok) a.z_coarse_out[r * Nc + n] = zv;
+    }
     wave_lds_fence();
 
     // pass 0 = coarse model on zc, pass 1 = fine model on the merged zs; ONE copy of the MLP code
@@ -139,7 +159,13 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
         const auto sv = hook.saver(pass, r, N, n, valid && ray_ok, h);
         mlp_tile_x3(pipe, pass, pe, dv, feat, sigma, h, cur, tm, sv);
         hook.raw(pass, r, N, n, valid && ray_ok, h, feat, sigma);
-        const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
+        if (RNG && (a.rng_flags & 4) && valid) {          // rendering.py:125  noise = randn_like(sigma) * noise_std
+          const float draw = rng.normal(pass ? RNG_STREAM_NOISE_FINE : RNG_STREAM_NOISE_COARSE, rng_ray, n);
+          noise = draw * a.noise_std;
+          float* no = pass ? a.noise_f_out : a.noise_c_out;
+          if (no && ray_ok && h == 0) no[r * N + n] = draw;
+        }
         const float w = composite_tile(st, feat, sigma, noise, zn, znext, n == N - 1, valid, p);
         if (valid && h == 0) {
           if (ray_ok) weights_row[n] = w;
@@ -152,7 +178,7 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
         store_ray_feature(st, (pass ? a.feature_f : a.feature_c) + r * FEAT_DIM, (pass ? a.depth_f : a.depth_c) + r, p, h);
       if (pass == 0 && Ni > 0) {
         wave_lds_fence();
-        sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane);
+        sample_pdf_wave(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, (RNG && (a.rng_flags & 2)) ? &rng : nullptr, rng_ray);
         merge_sort_wave(scr, Nc, Ni, lane);
         if (a.z_fine && ray_ok)
           for (int n = lane; n < Nf; n += 64) a.z_fine[r * Nf + n] = scr.zs[n];
@@ -164,8 +190,10 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) { render_rays_x3_body(a, NoHookX()); }
-__global__ __launch_bounds__(256, 1) void render_rays_train_x3_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body(a, hook); }
+__global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) { render_rays_x3_body<false>(a, NoHookX()); }
+__global__ __launch_bounds__(256, 1) void render_rays_x3_rng_kernel(RenderParamsX a) { render_rays_x3_body<true>(a, NoHookX()); }
+__global__ __launch_bounds__(256, 1) void render_rays_train_x3_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body<false>(a, hook); }
+__global__ __launch_bounds__(256, 1) void render_rays_train_x3_rng_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body<true>(a, hook); }
 
 int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
@@ -179,6 +207,9 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   k.rays = a.rays; k.view_dir = a.view_dir; k.z_coarse = a.z_coarse; k.z_steps = a.z_steps; k.u = a.u; k.u_stride = a.u_stride;
   k.noise_c = a.noise_coarse; k.noise_f = a.noise_fine; k.noise_std = a.noise_std; k.use_disp = a.use_disp;
   k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
+  k.rng_seed = a.rng_seed; k.rng_ray_offset = a.rng_ray_offset; k.rng_flags = a.rng_flags; k.perturb = a.perturb;
+  k.z_coarse_out = a.z_coarse_out; k.noise_c_out = a.noise_coarse_out; k.noise_f_out = a.noise_fine_out;
+  const bool rngk = a.rng_flags != 0 || a.z_coarse_out;
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
   const long quads = (a.R + 3) / 4;
@@ -192,12 +223,16 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
     if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 1024ull >= (unsigned long long)SAVEX_OOB)
       return set_error(-2, "render_rays_train_f32x3: more than 3.9 M sample points per pass and call (the saved rows are addressed with 32-bit offsets)");
     TrainHookX h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
-    if (int rc = ensure_dynamic_lds((const void*)render_rays_train_x3_kernel, shmem, "render_rays_train_x3_kernel")) return rc;
-    hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
+    const void* fn = rngk ? (const void*)render_rays_train_x3_rng_kernel : (const void*)render_rays_train_x3_kernel;
+    if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_train_x3_kernel")) return rc;
+    if (rngk) hipLaunchKernelGGL(render_rays_train_x3_rng_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
+    else hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
     return check_launch("render_rays_train_x3_kernel");
   }
-  if (int rc = ensure_dynamic_lds((const void*)render_rays_x3_kernel, shmem, "render_rays_x3_kernel")) return rc;
-  hipLaunchKernelGGL(render_rays_x3_kernel, dim3(grid), dim3(256), shmem, stream, k);
+  const void* fn = rngk ? (const void*)render_rays_x3_rng_kernel : (const void*)render_rays_x3_kernel;
+  if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_x3_kernel")) return rc;
+  if (rngk) hipLaunchKernelGGL(render_rays_x3_rng_kernel, dim3(grid), dim3(256), shmem, stream, k);
+  else hipLaunchKernelGGL(render_rays_x3_kernel, dim3(grid), dim3(256), shmem, stream, k);
   return check_launch("render_rays_x3_kernel");
 }
 

@@ -120,7 +120,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     fused_train = (train and not get_training_bf16() and not jitter and N_samples <= _FUSED_MAX and N_importance <= _FUSED_MAX
                    and (N_importance == 0 or N_samples >= 3))
     rng = None
-    if fused_train and (perturb > 0 or noise_std != 0) and ops.in_kernel_rng() and not get_training_forward_x3():
+    if fused_train and (perturb > 0 or noise_std != 0) and ops.in_kernel_rng():
         # the fused fp32 training kernel draws the jitter / sample_pdf uniforms / density noise itself (csrc/philox.h): no [R,N] random
         # tensors, no launches for them.  The seed comes from torch's CPU generator, so torch.manual_seed() governs the run.
         rng = {"seed": int(torch.randint(0, 2 ** 62, (1,), device="cpu")), "perturb": float(perturb), "jitter": perturb > 0, "u": perturb > 0,

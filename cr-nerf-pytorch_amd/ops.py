@@ -335,7 +335,7 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65].
     train=True with precision="bf16": crnerf_render_rays_train_bf16, the twin of the opt-in mixed-precision mode (acts_* in the layout
     mlp_backward_mixed(..., fused_acts=True) reads).
-    rng (fp32 only): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
+    rng (fp32 and f32x3): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
     steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
@@ -344,8 +344,6 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     bf16 = False if x3 else _is_bf16(precision)
     want_z_fine = want_z_fine or train
     if x3:
-        if rng is not None:
-            raise ValueError("crnerf_amd: precision='f32x3' takes its random draws as tensors (no in-kernel draws)")
         for pk in (packed_coarse, packed_fine):
             if pk is not None and pk.numel() != lib.crnerf_packed_mlp_x3_bytes():
                 raise ValueError("crnerf_amd: precision='f32x3' needs packs from pack_mlp_weights_x3")

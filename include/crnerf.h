@@ -162,7 +162,7 @@ typedef struct crnerf_render_args {
   float* feature_fine;          /* [R,64] */
   float* depth_fine;            /* [R] */
   float* z_fine;                /* [R,Nc+Ni] optional debug/test output, NULL to skip */
-  /* ---- in-kernel random draws (ABI 2; crnerf_render_rays_f32 and crnerf_render_rays_train_f32 only).  rng_flags == 0: everything
+  /* ---- in-kernel random draws (ABI 2; crnerf_render_rays_f32 / _train_f32 and crnerf_render_rays_f32x3 / _train_f32x3).  rng_flags == 0: everything
    * above is used as given.  Draws are Philox4x32-10 keyed on rng_seed, counter = (sample, stream, rng_ray_offset + ray): a pure
    * function of the GLOBAL ray index, so ray chunks and the backward's recomputation see the same numbers.  The same draws as
    * tensors: crnerf_rng_fill_f32 (feeding them through z_coarse / u / noise_* gives bit-identical results). */
@@ -226,12 +226,13 @@ int crnerf_render_rays_train_bf16(const crnerf_render_args* args, void* acts_coa
 size_t crnerf_packed_mlp_x3_bytes(void);
 int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed_x3, void* stream);
 int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, int64_t n, int sigma_only, void* stream);
-/* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are x3 packs; rng_flags must be 0. */
+/* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are x3 packs; rng_flags as in
+ * crnerf_render_rays_f32 (the same counters: one seed, one set of draws, whichever kernel renders). */
 int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
 /* Training twin: crnerf_render_rays_train_f32 on the x3 core -- the same saved state (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes in the
  * layout of crnerf_mlp_forward_train_f32, raw_*[R*N,65]), so the fp32 backward twins (crnerf_composite_backward_f32 ->
- * crnerf_mlp_backward[_ex]_f32, or crnerf_mlp_backward_x3_f32) follow unchanged.  args->packed_* are x3 packs; rng_flags must be 0 (random draws
- * come as tensors); R * (n_samples + n_importance) < 3.9 M per call. */
+ * crnerf_mlp_backward[_ex]_f32, or crnerf_mlp_backward_x3_f32) follow unchanged.  args->packed_* are x3 packs; random draws as tensors or
+ * in-kernel (rng_flags); R * (n_samples + n_importance) < 3.9 M per call. */
 int crnerf_render_rays_train_f32x3(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
                                    void* stream);
 /* crnerf_mlp_backward_ex_f32 with the DATA gradient on the x3 core (the layer deltas from three-piece splits of the transposed weights and of the

@@ -44,8 +44,9 @@ def test_draw_statistics_and_keying():
     assert torch.equal(ops.rng_fill(R, N, seed, 0).double(), u)                   # and it is a pure function of its arguments
 
 
-def _nets():
-    pk = lambda st: ops.pack_mlp_weights({k: C(v) for k, v in st.items()})  # noqa: E731
+def _nets(precision="f32"):
+    pack = ops.pack_mlp_weights_x3 if precision == "f32x3" else ops.pack_mlp_weights
+    pk = lambda st: pack({k: C(v) for k, v in st.items()})  # noqa: E731
     return pk(synth.mlp_state(11, 2.0, 0.5)), pk(synth.mlp_state(12, 2.0, 0.5))
 
 
@@ -64,15 +65,19 @@ def _tensor_path_inputs(rays, Nc, Ni, seed, perturb, use_disp=False, ray_offset=
 @torch.no_grad()
 @pytest.mark.parametrize("use_disp", [False, True])
 @pytest.mark.parametrize("Nc,Ni", [(64, 128), (64, 64), (33, 0)])
-def test_in_kernel_draws_equal_the_tensor_path_bit_for_bit(Nc, Ni, use_disp):
-    pc, pf = _nets()
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_in_kernel_draws_equal_the_tensor_path_bit_for_bit(Nc, Ni, use_disp, precision):
+    """precision = f32x3: the same counters in render_rays_x3 / render_rays_train_x3 (csrc/render_fused_x3.hip) -- one seed, one set of draws."""
+    import functools
+    pc, pf = _nets(precision)
+    render = functools.partial(ops.render_rays, precision=precision)
     rays = C(synth.rays(257, seed=5))
     seed, perturb, nstd = 987654321012, 1.0, 1.0
     z_j, lower, upper, u, n_c, n_f = _tensor_path_inputs(rays, Nc, Ni, seed, perturb, use_disp)
     z_steps = torch.linspace(0, 1, Nc, device=DEV)
-    ref = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_coarse=z_j, u=u if Ni else None, noise_coarse=n_c,
+    ref = render(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_coarse=z_j, u=u if Ni else None, noise_coarse=n_c,
                           noise_fine=n_f if Ni else None, noise_std=nstd, want_z_fine=True)
-    got = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, noise_std=nstd, want_z_fine=True,
+    got = render(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, noise_std=nstd, want_z_fine=True,
                           rng={"seed": seed, "perturb": perturb, "jitter": True, "u": True, "noise": True})
     assert torch.equal(got["z_coarse_used"], z_j)                                 # the reference's jitter expression, same rounding
     assert bool((got["z_coarse_used"] >= lower).all()) and bool((got["z_coarse_used"] <= upper).all())      # stratum bounds
@@ -80,14 +85,14 @@ def test_in_kernel_draws_equal_the_tensor_path_bit_for_bit(Nc, Ni, use_disp):
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
     # chunking: the second half of the batch rendered on its own, with its offset, is the second half of the batch
-    half = ops.render_rays(pc, pf if Ni else None, rays[128:].contiguous(), Nc, Ni, use_disp=use_disp, z_steps=z_steps, noise_std=nstd,
+    half = render(pc, pf if Ni else None, rays[128:].contiguous(), Nc, Ni, use_disp=use_disp, z_steps=z_steps, noise_std=nstd,
                            rng={"seed": seed, "perturb": perturb, "jitter": True, "u": True, "noise": True, "ray_offset": 128})
     for k in ("weights_coarse", "feature_coarse") + (("weights_fine", "feature_fine") if Ni else ()):
         assert torch.equal(half[k], got[k][128:]), k
     # noise only (perturb == 0): deterministic depths, in-kernel noise
-    ref0 = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, u=torch.linspace(0, 1, Ni, device=DEV) if Ni else None,
+    ref0 = render(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, u=torch.linspace(0, 1, Ni, device=DEV) if Ni else None,
                            noise_coarse=n_c, noise_fine=n_f if Ni else None, noise_std=0.5)
-    got0 = ops.render_rays(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, u=torch.linspace(0, 1, Ni, device=DEV) if Ni else None,
+    got0 = render(pc, pf if Ni else None, rays, Nc, Ni, use_disp=use_disp, z_steps=z_steps, u=torch.linspace(0, 1, Ni, device=DEV) if Ni else None,
                            noise_std=0.5, rng={"seed": seed, "noise": True})
     for k in ref0:
         assert torch.equal(got0[k], ref0[k]), k
@@ -107,7 +112,8 @@ def _models():
 
 
 @pytest.mark.parametrize("recompute", [False, True])
-def test_training_through_the_shim_in_kernel_vs_tensor_draws(recompute):
+@pytest.mark.parametrize("forward", ["f32", "f32x3"])
+def test_training_through_the_shim_in_kernel_vs_tensor_draws(recompute, forward):
     """render_rays_cross_ray in grad mode (perturb = 1, noise_std = 1, command/train.sh): the in-kernel path and the tensor path
     fed with the same draws give identical outputs and identical parameter gradients; the recomputing backward re-draws the same
     numbers."""
@@ -118,6 +124,7 @@ def test_training_through_the_shim_in_kernel_vs_tensor_draws(recompute):
     tgt = torch.rand(128, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
     params = [p for k in ("coarse", "fine") for p in m[k].parameters()]
     ag.set_training_recompute(recompute)
+    ag.set_training_forward_precision(forward)      # f32x3: the x3 training twin draws from the same counters
     try:
         def run(in_kernel):
             ops.set_in_kernel_rng(in_kernel)
@@ -138,6 +145,7 @@ def test_training_through_the_shim_in_kernel_vs_tensor_draws(recompute):
     finally:
         ops.set_in_kernel_rng(True)
         ag.set_training_recompute(False)
+        ag.set_training_forward_precision("f32")
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine"):
         assert torch.equal(out_k[k], out_t[k]), k
     for a, b in zip(g_k, g_t):
