@@ -479,7 +479,11 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const long pt = pb + 8 * kk + e;
+#ifdef CRNERF_EXP_WGRAD_L2      // (timing experiments only; garbage) every chunk re-reads 1,024 rows: operands from L2, not HBM
+          const long pc = (pt < plast ? pt : plast) & 1023;
+#else
           const long pc = pt < plast ? pt : plast;
+#endif
           const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
           const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
           const float keep = pt < p1 ? 1.0f : 0.0f;
