@@ -198,8 +198,9 @@ int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coar
   return launch_sample_pdf_merge(z_coarse, weights_coarse, u, (long)u_stride, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
 }
 
+// x3: 0 = no, 1 = the x3 core (three bf16 pieces), 2 = the h2 core (two fp16 pieces)
 static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16, void* acts_c = nullptr, void* acts_f = nullptr,
-                              float* raw_c = nullptr, float* raw_f = nullptr, bool x3 = false) {
+                              float* raw_c = nullptr, float* raw_f = nullptr, int x3 = 0) {
   REQUIRE(a, "args");
   if (a->n_rays == 0) return 0;
   if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays: negative n_rays");
@@ -225,6 +226,7 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
     r.rng_seed = a->rng_seed; r.rng_ray_offset = (long)a->rng_ray_offset; r.rng_flags = a->rng_flags; r.perturb = a->perturb;
   }
   r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
+  if (x3 == 2) return launch_render_rays_h2(r, (hipStream_t)stream);
   if (x3) return launch_render_rays_x3(r, (hipStream_t)stream);
   if (bf16) {
     // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
@@ -344,7 +346,25 @@ int crnerf_mlp_forward_f32x3(const void* packed, const float* x, float* out, int
   return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
-int crnerf_render_rays_f32x3(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, true); }
+int crnerf_render_rays_f32x3(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, 1); }
+
+size_t crnerf_packed_mlp_h2_bytes(void) { return PACKEDH_BYTES; }
+
+int crnerf_pack_mlp_weights_h2(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_h2: a tensor pointer is NULL");
+  return launch_pack_mlp_h2(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_mlp_forward_f32h2(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32h2: negative n");
+  return launch_mlp_forward_h2(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+}
+
+int crnerf_render_rays_f32h2(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, 2); }
 
 int crnerf_render_rays_train_f32x3(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine, void* stream) {
   REQUIRE(a, "args");

@@ -193,6 +193,30 @@ static_assert(STREAMX_FRAGS % STAGE_FRAGS == 0 && FX_L1 % STAGE_FRAGS == 0 && FX
 static_assert(FX_L1 % 6 == 0 && FX_HID % 6 == 0 && FX_L5 % 6 == 0 && FX_DIR % 6 == 0 && FX_RGB % 6 == 0, "x3 layers must be whole queue turns");
 constexpr size_t PACKEDX_BYTES = (size_t)CONST_BYTES + (size_t)STREAMX_FRAGS * FRAG_BYTES;   // 3,746,816
 
+// ---- "fragH": the x3 stream with TWO fp16 pieces per weight ("h2" core: mlp_core_x3.h built with CRNERF_X_NP = 2).  An fp32 value is
+// h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) to 2^-24 of it (11 + 11 mantissa bits + the sign of h2: one fp32 rounding), as long as h2 stays
+// a normal fp16 number; below that its absolute error is <= 2^-25 (fp16 subnormals are honoured by the matrix cores, tools/ubench/
+// mfma_f16_denorm.hip).  Weights are therefore stored SCALED by H2_WSCALE = 2^8 (|w| >= 2^-10 keeps full precision, |w| < 255 stays in range;
+// the core scales the bias up and the layer output down, both exact): piece 0 = fp16(256 w), piece 1 = fp16(256 w - piece 0).  Same
+// fragment geometry and order as fragX with two pieces per (k-step, tile); dir_encoding needs no padding (144 = 9 stages = 36 queue turns).
+constexpr float H2_WSCALE = 256.0f;
+constexpr int FH_L1 = KS_XYZ * 8 * 2;                //   96
+constexpr int FH_HID = KS_HID * 8 * 2;               //  256
+constexpr int FH_L5 = (KS_XYZ + KS_HID) * 8 * 2;     //  352
+constexpr int FH_DIR = (KS_HID + KS_DIR) * 4 * 2;    //  144
+constexpr int FH_RGB = KS_HALF * 2 * 2;              //   32
+constexpr int OFFH_L1 = 0;
+constexpr int OFFH_L2 = OFFH_L1 + FH_L1;
+constexpr int OFFH_L5 = OFFH_L2 + 3 * FH_HID;
+constexpr int OFFH_L6 = OFFH_L5 + FH_L5;
+constexpr int OFFH_FIN = OFFH_L6 + 3 * FH_HID;
+constexpr int OFFH_DIR = OFFH_FIN + FH_HID;
+constexpr int OFFH_RGB = OFFH_DIR + FH_DIR;
+constexpr int STREAMH_FRAGS = OFFH_RGB + FH_RGB;                 // 2416
+static_assert(STREAMH_FRAGS % STAGE_FRAGS == 0 && FH_L1 % STAGE_FRAGS == 0 && FH_HID % STAGE_FRAGS == 0 && FH_L5 % STAGE_FRAGS == 0 &&
+              FH_RGB % STAGE_FRAGS == 0 && FH_DIR % STAGE_FRAGS == 0, "h2 layers must be whole stages (and with them whole 4-fragment queue turns)");
+constexpr size_t PACKEDH_BYTES = (size_t)CONST_BYTES + (size_t)STREAMH_FRAGS * FRAG_BYTES;   // 2,485,248
+
 // ---- transposed x3 stream for the backward-data pass on the x3 core (mlp_backward_x3.hip): fragX of M = (W restricted to the hidden inputs)^T,
 //     fragXT(layer, k-step s, tile T, piece w)[lane = 32*hh + i][e] = piece_w(W[16s + 8(e>>2) + 4hh + (e&3)][in_off + 32T + i])
 // (the contraction runs over the layer's OUTPUT features -- the delta registers, in the 32x32 C/D order -- the tiles over its inputs); layers in

@@ -22,9 +22,34 @@
 #include "layout.h"
 #include "mlp_core.h"
 
-namespace crnerf {
+// CRNERF_X_NP: pieces per operand.  3 (default) = the bf16 x3 core described above.  2 = the "h2" core (mlp_forward_h2.hip, render_fused_h2.hip):
+// TWO fp16 pieces per operand, x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) (11 + 11 mantissa bits and the sign of h2 -- again one fp32
+// rounding, as long as h2 is a normal fp16 number; fp16 subnormals are honoured by the matrix cores, so below that the ABSOLUTE error is <= 2^-25),
+// and a product is the THREE leading piece products w2 a1 + w1 a2 + w1 a1 (the dropped w2 a2 is <= 2^-24 of it): half the MFMAs of the x3 core
+// and two thirds of its weight stream (layout.h "fragH": weights scaled by 2^8 at pack time so that their second pieces stay normal; the bias
+// is scaled up and the layer output down in registers, both exact).  Range: |activation| < 65,504 and |weight| < 255, else inf / nan come out.
+// Everything else -- ring, queue, layer walk -- is the same code; the variant lives in its own inline namespace.
+#ifndef CRNERF_X_NP
+#define CRNERF_X_NP 3
+#endif
 
+namespace crnerf {
+#if CRNERF_X_NP == 2
+inline namespace xcore_h2 {
+#else
+inline namespace xcore_x3 {
+#endif
+constexpr int XNP = CRNERF_X_NP;
+static_assert(XNP == 2 || XNP == 3, "x core: two fp16 pieces or three bf16 pieces");
+constexpr int XSTREAM_FRAGS = XNP == 2 ? STREAMH_FRAGS : STREAMX_FRAGS;       // forward stream of a model
+constexpr int XPAD_DIR = XNP == 2 ? 0 : FX_DIR - FX_DIR_USED;                 // stage / queue padding behind dir_encoding
+constexpr float XWSCALE = XNP == 2 ? H2_WSCALE : 1.0f;                        // the packed weights carry this factor
+
+#if CRNERF_X_NP == 2
+typedef _Float16 xbf16x8 __attribute__((ext_vector_type(8)));    // (the operand vector of the variant's MFMA)
+#else
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+#endif
 typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
 
 // The x3 ring: mlp_core.h's protocol with SEVEN 16-KiB slots.  The 3.75 MB stream of a model does not stay in an XCD's 4 MB L2, so a piece's
@@ -49,8 +74,8 @@ static_assert(X_RING >= 5 && (X_PIECES + 1) * (X_RING - 3) + 8 <= 63 && LDS_SCRA
 #define CRNERF_X_TOUCH 0
 #endif
 constexpr int X_TOUCH = CRNERF_X_TOUCH;   // stages between an L2-prefetch touch of a stage and its LDS-DMA; 0 = no touches (the default: they did not pay)
-constexpr int X_AHEAD = 6;   // fragments read ahead of the one being multiplied (two (tile, k-step) triples)
-static_assert(X_AHEAD % 3 == 0 && X_AHEAD <= X_STAGE_FRAGS, "the queue holds whole triples and never reaches past the next stage");
+constexpr int X_AHEAD = 2 * XNP;   // fragments read ahead of the one being multiplied (the piece groups of two (tile, k-step) pairs)
+static_assert(X_AHEAD % XNP == 0 && X_AHEAD <= X_STAGE_FRAGS, "the queue holds whole piece groups and never reaches past the next stage");
 
 // WeightPipe of mlp_core.h for the x3 stream: STAGESX_PER_PASS stages per pass, LDS-DMA as asm.  Protocol as there: stages c and c + 1 may be
 // read; advance() -- after the last read of stage c has been issued -- waits until this wave's pieces of stage c + 2 have landed (counted
@@ -60,7 +85,7 @@ struct WeightPipeX {
   const char* base[2];   // scalar: packed streams + this wave's 4 KiB column
   const char* pf_ptr;
   int pf_left, pf_pass, passes0, passes;
-  int stages_per_pass = STAGESX_PER_PASS * (STAGE_FRAGS / X_STAGE_FRAGS);   // x3 stages per pass: forward stream (set_stream_frags() for another)
+  int stages_per_pass = XSTREAM_FRAGS / X_STAGE_FRAGS;   // stages per pass: forward stream (set_stream_frags() for another)
   uint32_t pf_slot, rd_slot, rd_addr, lane16, lds_ring;
   __device__ __forceinline__ void set_stream_frags(int frags) { stages_per_pass = frags / X_STAGE_FRAGS; }   // before start()
   // L2 prefetch (experiment, off): a model's 3.75 MB stream is the size of an XCD's L2 and does not stay there, so whichever CU of the XCD reaches a stage first
@@ -177,6 +202,17 @@ __device__ __forceinline__ uint32_t x3_pk(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ void x3_split(const float (&v)[8], xbf16x8& b1, xbf16x8& b2, xbf16x8& b3) {
+#if CRNERF_X_NP == 2
+  // two fp16 pieces (v_cvt_f16_f32 rounds to nearest even and keeps subnormals); b3 is not used by this variant
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h1 = (_Float16)v[e];
+    b1[e] = h1;
+    b2[e] = (_Float16)(v[e] - (float)h1);
+  }
+  b3 = b2;
+  return;
+#else
   xu32x4 w1, w2, w3;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -190,6 +226,7 @@ __device__ __forceinline__ void x3_split(const float (&v)[8], xbf16x8& b1, xbf16
   b1 = __builtin_bit_cast(xbf16x8, w1);
   b2 = __builtin_bit_cast(xbf16x8, w2);
   b3 = __builtin_bit_cast(xbf16x8, w3);
+#endif
 }
 
 // ---- training twin (crnerf_render_rays_train_f32x3): the saved state of the fp32 training twins (mlp_train16.h: acts[10][P][256] fp32 in reference
@@ -242,7 +279,12 @@ struct ActSaveX {
   }
 };
 
+#undef CRNERF_MFMA_X
+#if CRNERF_X_NP == 2
+#define CRNERF_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(xbf16x8, (a)), (b), (c), 0, 0, 0)
+#else
 #define CRNERF_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, (a)), (b), (c), 0, 0, 0)
+#endif
 
 // One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2).. of tile s/2), the following NSB from
 // srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
@@ -253,7 +295,7 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
                                              xu32x4 (&q)[X_AHEAD], SaveRowX rowA = SaveRowX{}, SaveRowX rowB = SaveRowX{}, uint32_t voff = 0) {
   static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
   constexpr int NS = NSA + NSB;
-  static_assert(((NS * NT * 3 + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * 3 + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
+  static_assert(((NS * NT * XNP + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * XNP + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
                 "layer (+ padding) must be whole stages and whole queue turns; tiles go in pairs");
   // consume one fragment of the stream: returns it, refills the queue, keeps the ring going (f = the fragment's index in the layer)
   auto take = [&](int f) {
@@ -268,7 +310,7 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
       int st = 0;
       for (int ks = 0; ks < NSA + NSB; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 3 > f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP) && ks * NT * 3 <= f) st += 2;
+        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * XNP > f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP) && ks * NT * XNP <= f) st += 2;
       p.advance(st);
     }
     return w;
@@ -304,6 +346,17 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
 #endif
 #pragma unroll
     for (int T = 0; T < NT; T += 2) {   // two tiles at a time: consecutive MFMAs belong to different accumulators
+#if CRNERF_X_NP == 2
+      const int f = (s * NT + T) * 2;
+      const xu32x4 u1 = take(f), u2 = take(f + 1);
+      const xu32x4 w1 = take(f + 2), w2 = take(f + 3);
+      acc[T] = CRNERF_MFMA_X(u2, b1, acc[T]);          // small terms first
+      acc[T + 1] = CRNERF_MFMA_X(w2, b1, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u1, b2, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w1, b2, acc[T + 1]);
+      acc[T] = CRNERF_MFMA_X(u1, b1, acc[T]);
+      acc[T + 1] = CRNERF_MFMA_X(w1, b1, acc[T + 1]);
+#else
       const int f = (s * NT + T) * 3;
       const xu32x4 u1 = take(f), u2 = take(f + 1), u3 = take(f + 2);
       const xu32x4 w1 = take(f + 3), w2 = take(f + 4), w3 = take(f + 5);
@@ -319,6 +372,7 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       acc[T + 1] = CRNERF_MFMA_X(w1, b2, acc[T + 1]);
       acc[T] = CRNERF_MFMA_X(u1, b1, acc[T]);
       acc[T + 1] = CRNERF_MFMA_X(w1, b1, acc[T + 1]);
+#endif
     }
 #ifdef CRNERF_X3_NOPIPE
     if (s + 1 < NS) prepare(s + 1, n1, n2, n3);
@@ -326,8 +380,38 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
     b1 = n1; b2 = n2; b3 = n3;
   }
 #pragma unroll
-  for (int f = NS * NT * 3; f < NS * NT * 3 + PAD; ++f) (void)take(f);
+  for (int f = NS * NT * XNP; f < NS * NT * XNP + PAD; ++f) (void)take(f);
 }
+
+// the packed weights carry XWSCALE (h2 core): the bias goes into the accumulator scaled up, the layer output comes out scaled down (powers of two)
+template <int NT>
+__device__ __forceinline__ void xscale(f32x16 (&acc)[NT], float f) {
+  if (XWSCALE != 1.0f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void init_acc_x(f32x16 (&acc)[NT], const lds_float* bias, int h) {
+  init_acc<NT>(acc, bias, h);
+  xscale<NT>(acc, XWSCALE);
+}
+// amax (h2 core): running max |activation| of this lane.  An activation beyond fp16's range would split into (inf, -inf) pieces, turn into NaN in
+// the next layer and be clamped to 0 by its relu -- a finite, wrong result.  mlp_tile_x3 therefore POISONS the outputs of such a point with NaN.
+template <int NT, int NDST>
+__device__ __forceinline__ void store_act_x(f32x16 (&acc)[NT], f32x16 (&act)[NDST], float floor_, float& amax) {
+  xscale<NT>(acc, 1.0f / XWSCALE);
+  store_act<NT>(acc, act, floor_);
+  if (XNP == 2) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(act[t][r])), fabsf(act[t][r + 1]));
+  }
+}
+constexpr float H2_ACT_LIMIT = 65504.0f;   // largest finite fp16
 
 // One 32-point tile through one model.  pe / dv: the positional embeddings in the register order of posenc_regs (posenc.h), exactly as
 // mlp_core.h's mlp_tile takes them.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both lane halves).
@@ -339,28 +423,37 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   f32x16 act[8], acc[8];
   constexpr bool SAVE = SV::on;
   const uint32_t vo = sv.offset();
+  float amax = 0.0f;
+  if (XNP == 2) {   // the embeddings are MMA operands too
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(pe[t][r]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(dv[0][r]));
+  }
   tm.tick(T_PROLOGUE);
 
-  init_acc<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
+  init_acc_x<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
   mma_layer_x3<8, KS_XYZ, 0, 0>(p, pe, pe, acc, q);
-  store_act<8>(acc, act, 0.0f);
+  store_act_x<8>(acc, act, 0.0f, amax);
   sv.template masks<8>(0, act);
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4 (their input h_l is saved in slot l - 1 on the way)
-    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
+    init_acc_x<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
     mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
-    store_act<8>(acc, act, 0.0f);
+    store_act_x<8>(acc, act, 0.0f, amax);
     sv.template masks<8>(l, act);
   }
-  init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
+  init_acc_x<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
   mma_layer_x3<8, KS_XYZ, KS_HID, 0, false, SAVE>(p, pe, act, acc, q, SaveRowX{}, sv.row(3), vo);
-  store_act<8>(acc, act, 0.0f);
+  store_act_x<8>(acc, act, 0.0f, amax);
   sv.template masks<8>(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
-    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
+    init_acc_x<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
     mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
-    store_act<8>(acc, act, 0.0f);
+    store_act_x<8>(acc, act, 0.0f, amax);
     sv.template masks<8>(l, act);
   }
   tm.tick(T_MMA);
@@ -380,14 +473,14 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
     sigma = softplus_ref(s + C[C_BSIG]);
     tm.tick(T_SIGMA);
   }
-  init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation); h8 -> slot 7
+  init_acc_x<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation); h8 -> slot 7
   mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(7), SaveRowX{}, vo);
-  store_act<8>(acc, act, NEG_INF);
+  store_act_x<8>(acc, act, NEG_INF, amax);
   {
     f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir])); final -> slot 8
-    init_acc<4>(acc4, C + C_BDIR, h);
-    mma_layer_x3<4, KS_HID, KS_DIR, FX_DIR - FX_DIR_USED, SAVE, false>(p, act, dv, acc4, q, sv.row(8), SaveRowX{}, vo);
-    store_act<4>(acc4, act, 0.0f);
+    init_acc_x<4>(acc4, C + C_BDIR, h);
+    mma_layer_x3<4, KS_HID, KS_DIR, XPAD_DIR, SAVE, false>(p, act, dv, acc4, q, sv.row(8), SaveRowX{}, vo);
+    store_act_x<4>(acc4, act, 0.0f, amax);
     {
       f32x16 a4[4];
 #pragma unroll
@@ -397,15 +490,28 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   }
   {
     f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear); the dir activation -> slot 9
-    init_acc<2>(acc2, C + C_BRGB, h);
+    init_acc_x<2>(acc2, C + C_BRGB, h);
     mma_layer_x3<2, KS_HALF, 0, 0, SAVE, false>(p, act, act, acc2, q, sv.row(9), SaveRowX{}, vo);
     tm.tick(T_MMA);
+    xscale<2>(acc2, 1.0f / XWSCALE);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(acc2[t][r]);
+    if (XNP == 2) {   // an operand left fp16's range somewhere in this point's MLP: NaN out, not a finite wrong answer
+      amax = fmaxf(amax, __shfl_xor(amax, 32));
+      if (!(amax < H2_ACT_LIMIT)) {
+        const float poison = __builtin_nanf("");
+        sigma = poison;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) feat[t][r] = poison;
+      }
+    }
     tm.tick(T_EPILOGUE);
   }
 }
 
+}  // inline namespace xcore_*
 }  // namespace crnerf

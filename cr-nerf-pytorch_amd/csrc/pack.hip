@@ -189,6 +189,66 @@ __global__ void pack_stream_x3_kernel(MlpTensors t, unsigned short* __restrict__
   stream[idx] = piece == 0 ? p1 : (piece == 1 ? p2 : p3);
 }
 
+// h2 stream (layout.h "fragH"): one thread per fp16 element; weights scaled by H2_WSCALE, two pieces by repeated round-to-nearest-even.
+// A weight whose scaled value leaves the fp16 range becomes inf: the outputs are then inf / nan, not silently wrong.
+__device__ int g_h2_range_flag;   // set by pack_stream_h2_kernel when a scaled weight is not a finite fp16 number
+__global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMH_FRAGS * 512) return;
+  const int frag = (int)(idx / 512);
+  const int lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+  const int i = lane & 31, hh = lane >> 5;
+  const float* W;
+  int in_dim, nt, phi, kind;   // kind: 0 hidden, 1 L1, 2 L5 (skip), 3 dir
+  if (frag < OFFH_L2) { W = t.w[0]; in_dim = XYZ_DIM; nt = 8; phi = frag - OFFH_L1; kind = 1; }
+  else if (frag < OFFH_L5) { const int l = (frag - OFFH_L2) / FH_HID; W = t.w[1 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFFH_L2) % FH_HID; kind = 0; }
+  else if (frag < OFFH_L6) { W = t.w[4]; in_dim = XYZ_DIM + W_HIDDEN; nt = 8; phi = frag - OFFH_L5; kind = 2; }
+  else if (frag < OFFH_FIN) { const int l = (frag - OFFH_L6) / FH_HID; W = t.w[5 + l]; in_dim = W_HIDDEN; nt = 8; phi = (frag - OFFH_L6) % FH_HID; kind = 0; }
+  else if (frag < OFFH_DIR) { W = t.w_final; in_dim = W_HIDDEN; nt = 8; phi = frag - OFFH_FIN; kind = 0; }
+  else if (frag < OFFH_RGB) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; nt = 4; phi = frag - OFFH_DIR; kind = 3; }
+  else { W = t.w_rgb; in_dim = 128; nt = 2; phi = frag - OFFH_RGB; kind = 0; }
+  const int piece = phi % 2, st = phi / 2;
+  const int s = st / nt, T = st % nt;
+  const int row = 32 * T + i;
+  auto kidx = [&](int sl) { return 16 * sl + 8 * (e >> 2) + 4 * hh + (e & 3); };
+  int col;
+  switch (kind) {
+    case 1: col = posenc_slot_to_col(kidx(s), XYZ_FREQS); break;
+    case 2: col = s < KS_XYZ ? posenc_slot_to_col(kidx(s), XYZ_FREQS) : XYZ_DIM + kidx(s - KS_XYZ); break;      // nerf.py:169 cat([xyz, h])
+    case 3: {
+      if (s < KS_HID) col = kidx(s);
+      else { const int dc = posenc_slot_to_col(kidx(s - KS_HID), DIR_FREQS); col = dc < 0 ? -1 : W_HIDDEN + dc; }   // nerf.py:177 cat([final, dir])
+      break;
+    }
+    default: col = kidx(s); break;
+  }
+  if (col < 0) { stream[idx] = 0; return; }
+  const float w = W[(long)row * in_dim + col] * H2_WSCALE;
+  if ((__float_as_uint(w) & 0x7fffffffu) >= 0x477fe000u && piece == 0) atomicOr(&g_h2_range_flag, 1);   // |w| >= 65,504, inf or NaN (bit test: this unit is built with -fno-honor-nans)
+  const _Float16 p1 = (_Float16)w;                       // round to nearest even; subnormals kept
+  const _Float16 p2 = (_Float16)(w - (float)p1);
+  stream[idx] = __builtin_bit_cast(unsigned short, piece == 0 ? p1 : p2);
+}
+
+int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  const long n = (long)STREAMH_FRAGS * 512;
+  // range check: the ONE place this library waits for the stream -- packing happens once per set of weights, and a weight beyond fp16's range
+  // would otherwise surface as a finite, wrong output (inf - inf = NaN in a hidden layer is clamped to 0 by the relu)
+  int flag = 0;
+  if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_h2_range_flag), &flag, sizeof(int), 0, hipMemcpyHostToDevice, stream) != hipSuccess)
+    return set_error(-10, "pack_mlp_h2: clearing the range flag failed");
+  hipLaunchKernelGGL(pack_stream_h2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  if (int rc = check_launch("pack_mlp_h2")) return rc;
+  if (hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_h2_range_flag), sizeof(int), 0, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return set_error(-10, "pack_mlp_h2: reading the range flag failed");
+  if (flag) return set_error(-3, "pack_mlp_weights_h2: a weight is outside the h2 core's range (|w| < 255, finite); use the f32x3 or fp32 entry points");
+  return 0;
+}
+
 int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);

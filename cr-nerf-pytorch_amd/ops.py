@@ -91,6 +91,10 @@ def _is_x3(precision):
     return precision in ("f32x3", "x3")
 
 
+def _is_h2(precision):
+    return precision in ("f32h2", "h2")
+
+
 def _is_bf16(precision):
     if precision in ("bf16", "bfloat16", torch.bfloat16):
         return True
@@ -131,6 +135,31 @@ def mlp_forward_x3(packed_x3, x, sigma_only=False):
     out = torch.empty(x.shape[0], 1 if sigma_only else 65, dtype=torch.float32, device=x.device)
     _lib.check(lib.crnerf_mlp_forward_f32x3(ctypes.c_void_p(packed_x3.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], int(bool(sigma_only)),
                                             _lib.stream_ptr()), "crnerf_mlp_forward_f32x3")
+    return out
+
+
+def pack_mlp_weights_h2(state):
+    """Packed weights for the "f32h2" entry points (include/crnerf.h): every weight, scaled by 2^8, as two fp16 pieces."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_h2_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_h2(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_h2")
+    return out
+
+
+def mlp_forward_h2(packed_h2, x, sigma_only=False):
+    """NeRF_sigma.forward in fp32 on the fp16 matrix cores (two-piece splits, three MFMAs per product; crnerf_mlp_forward_f32h2)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    want = 93 if sigma_only else 120
+    if x.dim() != 2 or x.shape[1] != want:
+        raise ValueError("mlp_forward_h2 expects [n,%d], got %s" % (want, tuple(x.shape)))
+    if packed_h2.numel() != lib.crnerf_packed_mlp_h2_bytes():
+        raise ValueError("crnerf_amd: packed weights are not an h2 pack (pack_mlp_weights_h2)")
+    out = torch.empty(x.shape[0], 1 if sigma_only else 65, dtype=torch.float32, device=x.device)
+    _lib.check(lib.crnerf_mlp_forward_f32h2(ctypes.c_void_p(packed_h2.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], int(bool(sigma_only)),
+                                            _lib.stream_ptr()), "crnerf_mlp_forward_f32h2")
     return out
 
 
@@ -340,10 +369,17 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
+    h2 = _is_h2(precision)                       # fp32 on the fp16 matrix cores (crnerf_render_rays_f32h2; packs from pack_mlp_weights_h2)
     x3 = _is_x3(precision)                       # fp32 on the bf16 matrix cores (crnerf_render_rays_f32x3; packs from pack_mlp_weights_x3)
-    bf16 = False if x3 else _is_bf16(precision)
+    bf16 = False if (x3 or h2) else _is_bf16(precision)
     want_z_fine = want_z_fine or train
-    if x3:
+    if h2:
+        if train:
+            raise ValueError("crnerf_amd: precision='f32h2' has no training twin")
+        for pk in (packed_coarse, packed_fine):
+            if pk is not None and pk.numel() != lib.crnerf_packed_mlp_h2_bytes():
+                raise ValueError("crnerf_amd: precision='f32h2' needs packs from pack_mlp_weights_h2")
+    elif x3:
         for pk in (packed_coarse, packed_fine):
             if pk is not None and pk.numel() != lib.crnerf_packed_mlp_x3_bytes():
                 raise ValueError("crnerf_amd: precision='f32x3' needs packs from pack_mlp_weights_x3")
@@ -393,8 +429,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     if launcher:      # measurement helper: re-launch the same call on the same buffers with nothing but the C call on the host side
         if train:
             raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
-        fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
-        name = "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32")
+        fn = lib.crnerf_render_rays_f32h2 if h2 else (lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32))
+        name = "crnerf_render_rays_f32h2" if h2 else ("crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))
         held = (keep, rays, packed_coarse, packed_fine, out)  # the argument struct holds raw pointers: keep EVERY tensor behind them alive
         # (the outputs too: a caller that drops `out` must not hand their memory back to the caching allocator while launch() can still write it)
 
@@ -413,6 +449,9 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
         fn = lib.crnerf_render_rays_train_f32x3 if x3 else (lib.crnerf_render_rays_train_bf16 if bf16 else lib.crnerf_render_rays_train_f32)
         _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()),
                    "crnerf_render_rays_train_f32x3" if x3 else ("crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32"))
+        return out
+    if h2:
+        _lib.check(lib.crnerf_render_rays_f32h2(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32h2")
         return out
     fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))

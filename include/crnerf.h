@@ -229,6 +229,16 @@ int crnerf_mlp_forward_f32x3(const void* packed_x3, const float* x, float* out, 
 /* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are x3 packs; rng_flags as in
  * crnerf_render_rays_f32 (the same counters: one seed, one set of draws, whichever kernel renders). */
 int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
+/* ---- "f32h2": the same idea with TWO fp16 pieces per operand and THREE piece products (w2 a1 + w1 a2 + w1 a1; the dropped w2 a2 is <= 2^-24 of the
+ * product): x = h1 + h2, h1 = fp16(x), h2 = fp16(x - h1) -- 11 + 11 mantissa bits and the sign of h2, one fp32 rounding while h2 is a normal fp16
+ * number, an absolute error <= 2^-25 below that (the matrix cores honour fp16 subnormals).  Half the MFMAs and two thirds of the weight stream of
+ * f32x3.  NOT scale-free: the packed weights are scaled by 2^8 (exactly undone in registers) so that their second pieces stay normal, and the
+ * operands must fit fp16's range -- |weight| < 255, |activation| < 65,504 -- or the outputs are inf / nan (loud, not silently wrong).  Inference
+ * entry points only; held to the fp32 entry points' goldens and tolerances (tests/test_gpu_h2.py).  packed = crnerf_pack_mlp_weights_h2. */
+size_t crnerf_packed_mlp_h2_bytes(void);
+int crnerf_pack_mlp_weights_h2(const float* const* tensors, void* packed_h2, void* stream);
+int crnerf_mlp_forward_f32h2(const void* packed_h2, const float* x, float* out, int64_t n, int sigma_only, void* stream);
+int crnerf_render_rays_f32h2(const crnerf_render_args* args, void* stream);   /* args->packed_* are h2 packs; rng_flags as in crnerf_render_rays_f32 */
 /* Training twin: crnerf_render_rays_train_f32 on the x3 core -- the same saved state (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes in the
  * layout of crnerf_mlp_forward_train_f32, raw_*[R*N,65]), so the fp32 backward twins (crnerf_composite_backward_f32 ->
  * crnerf_mlp_backward[_ex]_f32, or crnerf_mlp_backward_x3_f32) follow unchanged.  args->packed_* are x3 packs; random draws as tensors or

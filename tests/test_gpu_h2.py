@@ -1,0 +1,220 @@
+"""The "f32h2" entry points (include/crnerf.h): NeRF_sigma.forward (models/nerf.py:157-182) in fp32 on the fp16 matrix cores -- every fp32
+operand of the eleven nn.Linear split into TWO fp16 pieces (weights scaled by 2^8 at pack time), a product = the three leading piece products,
+fp32 accumulation.  Held to the SAME goldens and tolerances as the fp32 entry points (tests/test_gpu_parity.py; tests/test_gpu_x3.py is the
+same file for the three-piece bf16 core), and against a float64 evaluation: the split path must sit where the fp32 matrix cores sit.  Unlike
+f32x3 the split is not scale-free -- the range tests pin what happens at fp16's edges."""
+import numpy as np
+import pytest
+import torch
+
+import crnerf_amd.synth as synth
+from crnerf_amd import ops
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def C(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, want, atol, rtol=0.0):
+    torch.testing.assert_close(got.detach().float().cpu(), torch.as_tensor(want).float(), atol=atol, rtol=rtol)
+
+
+def _packh(st):
+    return ops.pack_mlp_weights_h2({k: C(v) for k, v in st.items()})
+
+
+def test_mlp_h2_golden(golden):
+    g = golden("g2_mlp")
+    x = C(g["x"])
+    for tag, atol, rtol in (("default", 1e-6, 0.0), ("peaky", 3e-5, 1e-5)):      # the fp32 entry point's bars (test_mlp_golden)
+        pk = _packh(synth.mlp_state(int(g["seed_" + tag]), float(g["gain_" + tag])))
+        close(ops.mlp_forward_h2(pk, x), g["out_" + tag], atol=atol, rtol=rtol)
+        close(ops.mlp_forward_h2(pk, x[:, :93].contiguous(), sigma_only=True), g["sigma_" + tag], atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 127, 129, 4099])
+def test_mlp_h2_vs_oracle_ragged_sizes(n):
+    st = synth.mlp_state(11, 2.0, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-3, 3, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    w = {k: torch.from_numpy(v) for k, v in st.items()}
+    close(ops.mlp_forward_h2(_packh(st), x.to(DEV)), O.mlp_forward(w, x), atol=2e-5, rtol=1e-5)
+
+
+def test_mlp_h2_detects_transposed_or_permuted_packing():
+    """One-hot input rows reproduce single columns of W1 / of the dir layer: catches any row / column / slot / piece-order error in fragH."""
+    st = synth.mlp_state(3, 1.0)
+    w = {k: torch.from_numpy(v) for k, v in st.items()}
+    x = torch.zeros(120, 120)
+    x[torch.arange(120), torch.arange(120)] = 1.0
+    close(ops.mlp_forward_h2(_packh(st), x.to(DEV)), O.mlp_forward(w, x), atol=1e-6)
+
+
+@pytest.mark.parametrize("gain", [1.0, 2.0, 3.0])
+def test_mlp_h2_is_as_accurate_as_the_fp32_matrix_cores(gain):
+    """Against the oracle's MLP in float64 on the same fp32 inputs and weights: max / mean error of the h2 path vs the fp32-MFMA path."""
+    n = 20000
+    st = synth.mlp_state(29, gain, 0.5)
+    g = torch.Generator().manual_seed(int(gain * 10))
+    x = torch.cat([O.posenc(torch.rand(n, 3, generator=g) * 4 - 2, 15), O.posenc(torch.rand(n, 3, generator=g) * 2 - 1, 4)], 1).to(DEV)
+    dev = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        ref = O.mlp_forward({k: v.double() for k, v in dev.items()}, x.double())
+        o32 = ops.mlp_forward(ops.pack_mlp_weights(dev), x).double()
+        oh2 = ops.mlp_forward_h2(ops.pack_mlp_weights_h2(dev), x).double()
+    e32, eh2 = (o32 - ref).abs(), (oh2 - ref).abs()
+    print("gain %.1f: fp32 MFMA max %.3e mean %.3e | h2 max %.3e mean %.3e | h2 vs fp32 MFMA max %.3e" %
+          (gain, float(e32.max()), float(e32.mean()), float(eh2.max()), float(eh2.mean()), float((oh2 - o32).abs().max())))
+    assert float(eh2.mean()) <= 1.5 * float(e32.mean()) + 1e-9 and float(eh2.max()) <= 2.0 * float(e32.max()) + 1e-7
+
+
+def test_mlp_h2_range_edges_are_loud_or_exact():
+    """fp16's range is the price of three MFMAs per product.  (a) Tiny weights (|w| ~ 2^-14: second pieces subnormal even after the 2^8 pack scale)
+    still come out within fp32 noise -- the matrix cores honour fp16 subnormals.  (b) A weight beyond the documented bound (|w| >= 255 after which
+    256 w leaves fp16), or a non-finite one, is REFUSED at pack time (crnerf_pack_mlp_weights_h2 checks and reports), never packed into a
+    silently wrong stream."""
+    st = synth.mlp_state(5, 1.0)
+    tiny = dict(st)
+    tiny["xyz_encoding_2.0.weight"] = (st["xyz_encoding_2.0.weight"] * 2.0 ** -10).astype(np.float32)
+    tiny["xyz_encoding_3.0.weight"] = (st["xyz_encoding_3.0.weight"] * 2.0 ** 10).astype(np.float32)     # keeps the later activations at scale
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([O.posenc(torch.rand(512, 3, generator=g) * 4 - 2, 15), O.posenc(torch.rand(512, 3, generator=g) * 2 - 1, 4)], 1)
+    ref = O.mlp_forward({k: torch.from_numpy(v).double() for k, v in tiny.items()}, x.double())
+    o32 = ops.mlp_forward(ops.pack_mlp_weights({k: C(v) for k, v in tiny.items()}), x.to(DEV)).double().cpu()
+    oh2 = ops.mlp_forward_h2(_packh(tiny), x.to(DEV)).double().cpu()
+    e32, eh2 = float((o32 - ref).abs().max()), float((oh2 - ref).abs().max())
+    print("tiny weights: fp32 MFMA max err %.3e, h2 max err %.3e" % (e32, eh2))
+    assert eh2 <= 4.0 * e32 + 2e-7
+    big = dict(st)
+    wbig = st["xyz_encoding_4.0.weight"].copy()
+    wbig[7, 9] = 300.0
+    big["xyz_encoding_4.0.weight"] = wbig
+    with pytest.raises(RuntimeError, match="h2 core's range"):
+        _packh(big)
+    nanw = dict(st)
+    wn = st["static_rgb.0.weight"].copy()
+    wn[0, 0] = np.nan
+    nanw["static_rgb.0.weight"] = wn
+    with pytest.raises(RuntimeError, match="h2 core's range"):
+        _packh(nanw)
+
+
+def test_mlp_h2_activation_overflow_poisons_the_point():
+    """(c) Activations beyond fp16's range (|a| >= 65,504; weights in range): every point is either right -- within the fp32 path's tolerance --
+    or NaN in all 65 outputs; never finite and wrong.  (Without the guard the (inf, -inf) pieces of such an activation become NaN in the next
+    layer and its relu clamps that to 0.)"""
+    st = dict(synth.mlp_state(5, 1.0))
+    for l in (1, 2, 3):
+        st["xyz_encoding_%d.0.weight" % l] = (st["xyz_encoding_%d.0.weight" % l] * 200.0).astype(np.float32)
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([O.posenc(torch.rand(2048, 3, generator=g) * 4 - 2, 15), O.posenc(torch.rand(2048, 3, generator=g) * 2 - 1, 4)], 1)
+    x[::2] *= 1e-3                                          # half of the points stay small enough
+    dev = {k: C(v) for k, v in st.items()}
+    assert max(float(v.abs().max()) for v in dev.values()) < 255
+    o32 = ops.mlp_forward(ops.pack_mlp_weights(dev), x.to(DEV))
+    oh2 = ops.mlp_forward_h2(ops.pack_mlp_weights_h2(dev), x.to(DEV))
+    bad = torch.isnan(oh2).any(1)
+    assert bool((torch.isnan(oh2).all(1) == bad).all())    # poisoned points are NaN in every output
+    assert 0 < int(bad.sum()) < 2048, int(bad.sum())
+    ok = ~bad
+    torch.testing.assert_close(oh2[ok], o32[ok], atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ the fused renderer on the h2 core (crnerf_render_rays_f32h2)
+@torch.no_grad()
+@pytest.mark.parametrize("tag,ni,disp", [("c64", 0, False), ("c64_f128", 128, False), ("c64_f128_disp", 128, True), ("c64_f64", 64, False)])
+def test_render_h2_golden(golden, tag, ni, disp):
+    """tests/test_gpu_parity.py::test_render_golden, assertion for assertion, on the f32h2 renderer."""
+    from test_gpu_parity import _models, assert_depths
+    g = golden("g5_render")
+    st_c, st_f = _models(g)
+    out = ops.render_rays(_packh(st_c), _packh(st_f) if ni else None, C(g["rays"]), 64, ni, use_disp=disp, z_steps=C(g["z_steps_64"]),
+                          u=C(g["u_steps_%d" % ni]) if ni else None, want_z_fine=True, precision="f32h2")
+    close(out["weights_coarse"], g[tag + "__weights_coarse"], atol=3e-6)
+    close(out["feature_coarse"], g[tag + "__feature_coarse"], atol=1e-5)
+    close(out["depth_coarse"], g[tag + "__depth_coarse"], atol=1e-5)
+    if not ni:
+        return
+    z_coarse = O.coarse_depths(torch.from_numpy(g["rays"]), 64, disp, torch.from_numpy(g["z_steps_64"]))
+    assert_depths(out["z_fine"], g[tag + "__z_fine"], z_coarse, g[tag + "__weights_coarse"])
+    rays = torch.from_numpy(g["rays"])
+    zf = out["z_fine"].cpu()
+    raw = O._run_model(O.to_torch(st_f), rays, zf, O.posenc(rays[:, 3:6], 4), 32768)
+    w2, f2, d2 = O.composite(raw, zf)
+    close(out["weights_fine"], w2, atol=3e-6)
+    close(out["feature_fine"], f2, atol=1e-5)
+    close(out["depth_fine"], d2, atol=2e-5)
+    close(out["feature_fine"], g[tag + "__feature_fine"], atol=0.15)
+    ref = torch.from_numpy(g[tag + "__feature_fine"])
+    assert float((out["feature_fine"].cpu() - ref).norm() / ref.norm()) < 3e-2
+    assert float((out["weights_fine"].sum(-1).cpu() - 1).abs().max()) < 1e-5
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("net", ["band", "gain1"])
+@pytest.mark.parametrize("tag,disp", [("c64_f128", False), ("c64_f128_disp", True)])
+def test_h2_end_to_end_meets_the_stated_fp32_tolerance(golden, net, tag, disp):
+    """tests/test_gpu_e2e_parity.py::test_fp32_end_to_end_meets_stated_tolerance on the f32h2 renderer: SURVEY 8d's fp32 bars, END TO END
+    against the reference's own outputs, through the high-contrast decoder."""
+    import test_gpu_e2e_parity as E
+    g = golden("g14_render_smooth")
+    key = "%s__%s__" % (net, tag)
+    st_c, st_f = synth.mlp_state(41, **E.SMOOTH_NETS[net]), synth.mlp_state(42, **E.SMOOTH_NETS[net])
+    out = ops.render_rays(_packh(st_c), _packh(st_f), C(g["rays"]), 64, 128, use_disp=disp, z_steps=C(g["z_steps_64"]), u=C(g["u_steps_128"]),
+                          want_z_fine=True, precision="f32h2")
+    H, W = int(g["H"]), int(g["W"])
+    rgb = E._decoder(g)(out["feature_fine"].t().reshape(1, 64, H, W), C(g["style"])).reshape(3, H * W).t()
+    m = E._metrics(out, g, key, rgb)
+    E.record("f32h2 %s %s" % (net, tag), m)
+    far = float(g["rays"][:, 7].max())
+    assert m["rgb"]["max_abs"] <= 2e-5, m
+    assert m["feature_fine"]["rel_l2"] <= 1e-5 and m["feature_coarse"]["rel_l2"] <= 1e-5, m
+    assert m["z_fine"]["max_abs"] <= 1e-5 * far, m
+    assert m["feature_fine"]["max_abs"] <= 1e-5 and m["weights_fine"]["max_abs"] <= 1e-5 and m["depth_fine"]["max_abs"] <= 2e-5, m
+    assert m["weights_coarse"]["max_abs"] <= 3e-6 and m["depth_coarse"]["max_abs"] <= 1e-5, m
+
+
+@torch.no_grad()
+def test_h2_in_kernel_draws_equal_the_tensor_path():
+    """The renderer's in-kernel Philox draws (include/crnerf.h CRNERF_RNG_*) on the h2 core: the same draws through the tensor arguments give
+    bit-identical outputs (tests/test_gpu_rng.py holds the fp32 and f32x3 kernels to the same)."""
+    from test_gpu_rng import _tensor_path_inputs
+    pc, pf = _packh(synth.mlp_state(11, 2.0, 0.5)), _packh(synth.mlp_state(12, 2.0, 0.5))
+    rays = C(synth.rays(257, seed=5))
+    seed = 987654321012
+    z_j, lower, upper, u, n_c, n_f = _tensor_path_inputs(rays, 64, 128, seed, 1.0, False)
+    ref = ops.render_rays(pc, pf, rays, 64, 128, z_coarse=z_j, u=u, noise_coarse=n_c, noise_fine=n_f, noise_std=1.0, want_z_fine=True, precision="f32h2")
+    got = ops.render_rays(pc, pf, rays, 64, 128, z_steps=torch.linspace(0, 1, 64, device=DEV), noise_std=1.0, want_z_fine=True, precision="f32h2",
+                          rng={"seed": seed, "perturb": 1.0, "jitter": True, "u": True, "noise": True})
+    assert torch.equal(got["z_coarse_used"], z_j)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_h2_render_cold_l2_is_deterministic():
+    """Guard for the weight ring under the h2 core's geometry (two-fragment groups, four-deep queue, 151 stages per pass) with the weight stream
+    evicted from L2 before every launch: 131,072 rays in 32,768-ray chunks, a 1 GiB copy before each chunk, four passes, every output
+    bit-identical to the first pass."""
+    pc, pf = _packh(synth.mlp_state(1, 2.0, 0.5)), _packh(synth.mlp_state(2, 2.0, 0.5))
+    R = 131072
+    rays = C(synth.rays(R, seed=0, H=512, W=256))
+    z_steps, u = torch.linspace(0, 1, 64, device=DEV), torch.linspace(0, 1, 128, device=DEV)
+    junk_a, junk_b = torch.empty(1 << 28, device=DEV), torch.zeros(1 << 28, device=DEV)
+
+    def run():
+        outs = []
+        for i in range(0, R, 32768):
+            junk_a.copy_(junk_b)
+            outs.append(ops.render_rays(pc, pf, rays[i:i + 32768], 64, 128, z_steps=z_steps, u=u, precision="f32h2"))
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+    ref = run()
+    assert bool(torch.isfinite(ref["feature_fine"]).all())
+    for it in range(3):
+        out = run()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (it, k)
