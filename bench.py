@@ -48,9 +48,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16", "f32x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16", "f32x3", "f32h2"], default="f32",
                     help="f32 = BASELINE configs[1] on the fp32 MFMA (the headline, default); bf16 = the bf16 matrix-core kernel of configs[2]; "
-                         "f32x3 = configs[1] in fp32 on the bf16 matrix cores (three-piece splits, six MFMAs per product; DESIGN 3.4b)")
+                         "f32x3 = configs[1] in fp32 on the bf16 matrix cores (three-piece splits, six MFMAs per product; DESIGN 3.4b); "
+                         "f32h2 = the same on the fp16 matrix cores (two-piece splits, three MFMAs per product; DESIGN 3.4c)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank renders its own --rays batch.  strong: ONE unit of --workload is "
                          "split over the ranks (the configs BASELINE.json names for 8 GPUs)")
@@ -308,42 +309,50 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
                             "parity_smooth_nets": {"vs_fp32_oracle_end_to_end": bf["end_to_end"], "vs_bf16_oracle_identical_depths": bf["identical_depths"],
                                                    "image_high_contrast_vs_fp32_oracle": bf["image_high_contrast"]}}
 
-    # ---- "f32x3": the same fp32 path evaluated on the bf16 matrix cores (three-piece splits of every fp32 operand, six bf16 MFMAs per product, fp32
-    # accumulation; include/crnerf.h) on the timed ray batch.  NOT the headline: the timed step above is the fp32-MFMA kernel.
-    with torch.no_grad():
-        pcx, pfx = ops.pack_mlp_weights_x3(to_dev(st_c)), ops.pack_mlp_weights_x3(to_dev(st_f))
-        launchx, _ = ops.render_rays(pcx, pfx, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="f32x3", launcher=True)
-        for _ in range(5):
-            launchx()
-        e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e4.record()
-        for _ in range(n):
-            launchx()
-        e5.record()
-        torch.cuda.synchronize()
-        msx = e4.elapsed_time(e5) / n
+    # ---- "f32x3" / "f32h2": the same fp32 path evaluated on the bf16 / fp16 matrix cores (three-piece bf16 splits, six MFMAs per product; two-piece
+    # fp16 splits, three MFMAs per product; fp32 accumulation; include/crnerf.h) on the timed ray batch.  NOT the headline: the
+    # timed step above is the fp32-MFMA kernel.
+    def split_kernel(prec, pack, pieces_products):
+        with torch.no_grad():
+            pcx, pfx = pack(to_dev(st_c)), pack(to_dev(st_f))
+            launchx, _ = ops.render_rays(pcx, pfx, rays, NC, NI, z_steps=z_steps, u=u_steps, precision=prec, launcher=True)
+            for _ in range(5):
+                launchx()
+            e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e4.record()
+            for _ in range(n):
+                launchx()
+            e5.record()
+            torch.cuda.synchronize()
+            msx = e4.elapsed_time(e5) / n
 
-        def gpu_render_x3(sc, sf):
-            out = ops.render_rays(ops.pack_mlp_weights_x3(to_dev(sc)), ops.pack_mlp_weights_x3(to_dev(sf)), rays, NC, NI, z_steps=z_steps, u=u_steps,
-                                  want_z_fine=True, precision="f32x3")
-            out["rgb_hi"] = net_hi(out["feature_fine"].t().reshape(1, 64, *grid_hw), style)
-            return out
-        px3 = parity_block(O, gpu_render_x3(sm_c, sm_f), rays_cpu, O.to_torch(sm_c), O.to_torch(sm_f), args_hi, grid_hw, style_cpu, zt, ut)[0]
-    extra["f32x3_kernel"] = {"kernel": "render_rays_x3_kernel", "kernel_ms": msx, "rays_per_s_kernel_only": R / (msx * 1e-3),
-                             "fp32_work_tflops": flops / (msx * 1e-3) / 1e12, "bf16_mfma_tflops": 6 * (7296.0 / 7248.0) * flops / (msx * 1e-3) / 1e12,
-                             "frac_nominal_2500_of_issued_bf16_mfma": 6 * (7296.0 / 7248.0) * flops / (msx * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                             "speedup_vs_fp32_mfma_kernel": None,
-                             "note": "fp32 inputs / outputs / biases / activations / embeddings; each product of the eleven nn.Linear = the six leading products of "
-                                     "three-piece bf16 splits of both fp32 operands (w = w1 + w2 + w3, 24 mantissa bits), exact in fp32, accumulated in fp32; dropped "
-                                     "terms <= 3 x 2^-24 of a product.  Meets the fp32 entry points' goldens and SURVEY 8d's fp32 bars (tests/test_gpu_x3.py) and sits at "
-                                     "the fp32 MFMA's distance from a float64 evaluation.  fp32_work_tflops counts the ALGORITHMIC fp32 FLOPs (it exceeds the fp32 "
-                                     "MFMA peak of 157.3: the work runs on the bf16 pipe); the issued bf16 MFMA work is 6x that, at the power-limited rate the bf16 "
-                                     "renderer reaches (extra.bf16_kernel)",
-                             "parity_smooth_nets": {"end_to_end": px3["end_to_end"], "identical_depths": px3["identical_depths"],
-                                                    "image_high_contrast": px3["image_high_contrast"],
-                                                    "meets_stated_fp32_tolerance": bool(px3["image_high_contrast"]["max_abs_rgb"] <= 2e-5 and
-                                                                                        px3["end_to_end"]["feature_fine"]["rel_l2"] <= 1e-5 and
-                                                                                        px3["end_to_end"]["z_fine"]["max_abs"] <= 1e-5 * px3["end_to_end"]["z_fine"]["far"])}}
+            def gpu_render_split(sc, sf):
+                out = ops.render_rays(pack(to_dev(sc)), pack(to_dev(sf)), rays, NC, NI, z_steps=z_steps, u=u_steps, want_z_fine=True, precision=prec)
+                out["rgb_hi"] = net_hi(out["feature_fine"].t().reshape(1, 64, *grid_hw), style)
+                return out
+            px3 = parity_block(O, gpu_render_split(sm_c, sm_f), rays_cpu, O.to_torch(sm_c), O.to_torch(sm_f), args_hi, grid_hw, style_cpu, zt, ut)[0]
+        issued = pieces_products * (7296.0 / 7248.0) * flops / (msx * 1e-3) / 1e12
+        return {"kernel_ms": msx, "rays_per_s_kernel_only": R / (msx * 1e-3), "fp32_work_tflops": flops / (msx * 1e-3) / 1e12,
+                "issued_mfma_tflops": issued, "frac_nominal_2500_of_issued_mfma": issued / PEAK_BF16_MFMA_TFLOPS, "speedup_vs_fp32_mfma_kernel": None,
+                "parity_smooth_nets": {"end_to_end": px3["end_to_end"], "identical_depths": px3["identical_depths"],
+                                       "image_high_contrast": px3["image_high_contrast"],
+                                       "meets_stated_fp32_tolerance": bool(px3["image_high_contrast"]["max_abs_rgb"] <= 2e-5 and
+                                                                           px3["end_to_end"]["feature_fine"]["rel_l2"] <= 1e-5 and
+                                                                           px3["end_to_end"]["z_fine"]["max_abs"] <= 1e-5 * px3["end_to_end"]["z_fine"]["far"])}}
+    extra["f32x3_kernel"] = dict(split_kernel("f32x3", ops.pack_mlp_weights_x3, 6), kernel="render_rays_x3_kernel",
+                                 note="fp32 inputs / outputs / biases / activations / embeddings; each product of the eleven nn.Linear = the six leading products of "
+                                      "three-piece bf16 splits of both fp32 operands (w = w1 + w2 + w3, 24 mantissa bits), exact in fp32, accumulated in fp32; dropped "
+                                      "terms <= 3 x 2^-24 of a product.  Meets the fp32 entry points' goldens and SURVEY 8d's fp32 bars (tests/test_gpu_x3.py) and sits at "
+                                      "the fp32 MFMA's distance from a float64 evaluation.  fp32_work_tflops counts the ALGORITHMIC fp32 FLOPs (it exceeds the fp32 "
+                                      "MFMA peak of 157.3: the work runs on the bf16 pipe); the issued bf16 MFMA work is 6x that, at the power-limited rate the bf16 "
+                                      "renderer reaches (extra.bf16_kernel)")
+    extra["f32x3_kernel"]["bf16_mfma_tflops"] = extra["f32x3_kernel"]["issued_mfma_tflops"]
+    extra["f32h2_kernel"] = dict(split_kernel("f32h2", ops.pack_mlp_weights_h2, 3), kernel="render_rays_h2_kernel",
+                                 note="as f32x3 with TWO fp16 pieces per operand (x = h1 + h2: 11 + 11 mantissa bits and the sign of h2) and the THREE leading piece "
+                                      "products per product (dropped: h2 h2 <= 2^-24): half the MFMAs, two thirds of the weight stream.  Weights are scaled by 2^8 at "
+                                      "pack time (undone exactly in registers) so that their second pieces stay normal fp16 numbers; the matrix cores honour fp16 "
+                                      "subnormals.  NOT scale-free: |w| < 255 is checked when packing, an activation >= 65,504 turns its point's outputs into NaN "
+                                      "(tests/test_gpu_h2.py).  Meets the same fp32 goldens / SURVEY 8d bars and sits at the fp32 MFMA's distance from float64")
 
     def timed(fn, reps):
         fn()
@@ -375,7 +384,7 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
     K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]])
     c2w = np.array([[1, 0, 0, 0.05], [0, -1, 0, 0.02], [0, 0, -1, 0.1]], dtype=np.float32)
     photo = torch.rand(1, 3, 100, 100, device=dev)
-    for prec, reps in (("bf16", 3), ("f32x3", 2), ("f32", 1)):
+    for prec, reps in (("bf16", 3), ("f32h2", 2), ("f32x3", 2), ("f32", 1)):
         t = timed(lambda: pipeline.render_frame(m, emb, enc, photo, 800, 800, K, c2w, hp, chunk=32768, precision=prec), reps)
         extra["configs2_full_image_%s" % prec] = {"rays_per_s": 640000 / t, "ms_per_frame": t * 1e3, "tflops": FLOP_PER_POINT * (NC + NC + NI) * 640000 / t / 1e12,
                                                   "workload": "800x800 rays in 32,768-ray chunks x (64+128), appearance encoder + on-device rays + "
@@ -627,6 +636,8 @@ def main():
     with torch.no_grad():
         if a.precision == "f32x3":
             pc, pf = ops.pack_mlp_weights_x3(to_dev(st_c)), ops.pack_mlp_weights_x3(to_dev(st_f))
+        elif a.precision == "f32h2":
+            pc, pf = ops.pack_mlp_weights_h2(to_dev(st_c)), ops.pack_mlp_weights_h2(to_dev(st_f))
         else:
             pc, pf = ops.pack_mlp_weights(to_dev(st_c), precision=a.precision), ops.pack_mlp_weights(to_dev(st_f), precision=a.precision)
         net = style_net(Args()).to(dev)
@@ -678,12 +689,13 @@ def main():
         flops = FLOP_PER_POINT * (NC + NC + NI) * R
         achieved = flops / (kern_ms * 1e-3) / 1e12
         bf16 = a.precision == "bf16"
-        x3 = a.precision == "f32x3"
+        x3 = a.precision in ("f32x3", "f32h2")
+        h2 = a.precision == "f32h2"
         peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or x3) else PEAK_F32_MFMA_TFLOPS
         kernel = ("render_rays_bf16_kernel" if os.environ.get("CRNERF_BF16_CORE") == "64" else "render_rays_bf16p_kernel") if bf16 else ("render_rays_kernel" if os.environ.get("CRNERF_CORE") == "32" else "render_rays16_kernel")
         if x3:   # the roofline of this mode is the bf16 pipe, priced with the bf16 MFMA work the kernel ISSUES: six piece products per fp32 product
-            kernel = "render_rays_x3_kernel"
-            flops = 6.0 * (7296.0 / 7248.0) * flops
+            kernel = "render_rays_h2_kernel" if h2 else "render_rays_x3_kernel"
+            flops = (3.0 if h2 else 6.0) * (7296.0 / 7248.0) * flops      # (the fp16 MFMA's dense peak is the bf16 MFMA's)
             achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "render_rays_hbm_bytes.json")   # written from a rocprofv3 --pmc pass (profiles/README.md)
@@ -697,7 +709,9 @@ def main():
             "config": {"workload": "BASELINE configs[%d]%s: %d rays x (%d coarse + %d fine) per GPU, NeRF_sigma 8x256 coarse+fine, "
                                    "fused render_rays + cross-ray decode of the %dx%d feature grid"
                                    % (2 if bf16 else 1, " arithmetic (bf16 MFMA operands, fp32 accumulate) on the configs[1] ray batch" if bf16 else
-                                      (" in fp32 on the bf16 matrix cores (three-piece bf16 splits of every fp32 operand, six MFMAs per product, fp32 accumulation; "
+                                      (" in fp32 on the fp16 matrix cores (two-piece fp16 splits of every fp32 operand, three MFMAs per product, fp32 accumulation; "
+                                       "roofline.achieved counts the ISSUED fp16 MFMA work = 3.02 x the algorithmic fp32 FLOPs)" if h2 else
+                                       " in fp32 on the bf16 matrix cores (three-piece bf16 splits of every fp32 operand, six MFMAs per product, fp32 accumulation; "
                                        "roofline.achieved counts the ISSUED bf16 MFMA work = 6.04 x the algorithmic fp32 FLOPs)" if x3 else ""),
                                       R, NC, NI, grid_hw[0], grid_hw[1]),
                        "rays_per_gpu": R, "n_samples": NC, "n_importance": NI,
@@ -717,8 +731,9 @@ def main():
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
-                if not bf16 and "f32x3_kernel" in line["extra"]:
-                    line["extra"]["f32x3_kernel"]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"]["f32x3_kernel"]["kernel_ms"]
+                for kx in ("f32x3_kernel", "f32h2_kernel"):
+                    if not bf16 and kx in line["extra"]:
+                        line["extra"][kx]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"][kx]["kernel_ms"]
             except Exception as e:   # noqa: BLE001
                 line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rgb_sums is not None:
