@@ -26,8 +26,8 @@
 // TWO fp16 pieces per operand, x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) (11 + 11 mantissa bits and the sign of h2 -- again one fp32
 // rounding, as long as h2 is a normal fp16 number; fp16 subnormals are honoured by the matrix cores, so below that the ABSOLUTE error is <= 2^-25),
 // and a product is the THREE leading piece products w2 a1 + w1 a2 + w1 a1 (the dropped w2 a2 is <= 2^-24 of it): half the MFMAs of the x3 core
-// and two thirds of its weight stream (layout.h "fragH": weights scaled by 2^8 at pack time so that their second pieces stay normal; the bias
-// is scaled up and the layer output down in registers, both exact).  Range: |activation| < 65,504 and |weight| < 255, else inf / nan come out.
+// and two thirds of its weight stream (layout.h "fragH": weights AND biases scaled by 2^8 at pack time so that the weights' second pieces stay
+// normal; the layer output is scaled down in registers -- exact).  Range: |activation| < 65,504 and |weight| < 255, else inf / nan come out.
 // Everything else -- ring, queue, layer walk -- is the same code; the variant lives in its own inline namespace.
 #ifndef CRNERF_X_NP
 #define CRNERF_X_NP 3
@@ -74,7 +74,13 @@ static_assert(X_RING >= 5 && (X_PIECES + 1) * (X_RING - 3) + 8 <= 63 && LDS_SCRA
 #define CRNERF_X_TOUCH 0
 #endif
 constexpr int X_TOUCH = CRNERF_X_TOUCH;   // stages between an L2-prefetch touch of a stage and its LDS-DMA; 0 = no touches (the default: they did not pay)
-constexpr int X_AHEAD = 2 * XNP;   // fragments read ahead of the one being multiplied (the piece groups of two (tile, k-step) pairs)
+#ifndef CRNERF_X_AHEAD_PAIRS
+#define CRNERF_X_AHEAD_PAIRS 1
+#endif
+// fragments read ahead of the one being multiplied: the piece groups of one tile PAIR (12 MFMAs = 384 matrix-pipe cycles on the x3 core, 6 = 192 on
+// the h2 core).  Two pairs on the h2 core (-DCRNERF_X_AHEAD_PAIRS=2) measured the same -- 0.824 vs 0.82 ms per 1,024 rays -- at twice the spills:
+// the ds_read_b128 latency is not what that core waits for
+constexpr int X_AHEAD = 2 * XNP * CRNERF_X_AHEAD_PAIRS;
 static_assert(X_AHEAD % XNP == 0 && X_AHEAD <= X_STAGE_FRAGS, "the queue holds whole piece groups and never reaches past the next stage");
 
 // WeightPipe of mlp_core.h for the x3 stream: STAGESX_PER_PASS stages per pass, LDS-DMA as asm.  Protocol as there: stages c and c + 1 may be
@@ -286,6 +292,22 @@ struct ActSaveX {
 #define CRNERF_MFMA_X(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, (a)), (b), (c), 0, 0, 0)
 #endif
 
+// Scheduling fence between a tile pair's queue refills (the ds_read_b128 of the fragments X_AHEAD further down the stream) and its MFMAs: VALU and
+// SALU instructions may cross it, LDS reads and MFMAs may not.  Without it hipcc sinks every look-ahead read to just in front of the MFMA that
+// consumes it (one live fragment register instead of the queue: ds_read, s_waitcnt lgkmcnt(0), v_mfma -- the LDS latency exposed once per MFMA).
+// MEASURED on the h2 core (-DCRNERF_X_FENCE_ON=1): the ISA then shows the intended pattern (four reads, six MFMAs, lgkmcnt(6) / (4)) and the time
+// does not move -- 0.816 vs 0.82 ms per 1,024 rays, 3.43 vs 3.39 ms per 2^20 points: what the h2 core waits for is the layer boundary (the
+// accumulators' way out of the AGPRs: v_accvgpr_read, scale, relu, range max -- ~0.4 k VALU instructions per layer with no MFMA in flight) and
+// the weight DMA (11-13 %, -DCRNERF_EXP_NOGLDS), not the LDS latency.  Off by default.
+#ifndef CRNERF_X_FENCE_ON
+#define CRNERF_X_FENCE_ON 0
+#endif
+#if CRNERF_X_FENCE_ON
+#define CRNERF_X_FENCE() __builtin_amdgcn_sched_barrier(0x6)
+#else
+#define CRNERF_X_FENCE() ((void)0)
+#endif
+
 // One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2).. of tile s/2), the following NSB from
 // srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
 // layer (dir_encoding), skipped through the queue without being multiplied.  q always holds the next X_AHEAD fragments of the STREAM.
@@ -350,12 +372,14 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       const int f = (s * NT + T) * 2;
       const xu32x4 u1 = take(f), u2 = take(f + 1);
       const xu32x4 w1 = take(f + 2), w2 = take(f + 3);
+      CRNERF_X_FENCE();
       acc[T] = CRNERF_MFMA_X(u2, b1, acc[T]);          // small terms first
       acc[T + 1] = CRNERF_MFMA_X(w2, b1, acc[T + 1]);
       acc[T] = CRNERF_MFMA_X(u1, b2, acc[T]);
       acc[T + 1] = CRNERF_MFMA_X(w1, b2, acc[T + 1]);
       acc[T] = CRNERF_MFMA_X(u1, b1, acc[T]);
       acc[T + 1] = CRNERF_MFMA_X(w1, b1, acc[T + 1]);
+      CRNERF_X_FENCE();
 #else
       const int f = (s * NT + T) * 3;
       const xu32x4 u1 = take(f), u2 = take(f + 1), u3 = take(f + 2);
@@ -386,6 +410,9 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
 // the packed weights carry XWSCALE (h2 core): the bias goes into the accumulator scaled up, the layer output comes out scaled down (powers of two)
 template <int NT>
 __device__ __forceinline__ void xscale(f32x16 (&acc)[NT], float f) {
+#ifdef CRNERF_EXP_H2_NOEPI   // (timing experiments only; garbage) the h2 core without its scale multiplications and range tracking
+  return;
+#endif
   if (XWSCALE != 1.0f) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -395,8 +422,7 @@ __device__ __forceinline__ void xscale(f32x16 (&acc)[NT], float f) {
 }
 template <int NT>
 __device__ __forceinline__ void init_acc_x(f32x16 (&acc)[NT], const lds_float* bias, int h) {
-  init_acc<NT>(acc, bias, h);
-  xscale<NT>(acc, XWSCALE);
+  init_acc<NT>(acc, bias, h);   // h2 packs carry their biases scaled by XWSCALE (pack_consts_kernel): a plain LDS read, straight into the accumulator
 }
 // amax (h2 core): running max |activation| of this lane.  An activation beyond fp16's range would split into (inf, -inf) pieces, turn into NaN in
 // the next layer and be clamped to 0 by its relu -- a finite, wrong result.  mlp_tile_x3 therefore POISONS the outputs of such a point with NaN.
@@ -404,6 +430,9 @@ template <int NT, int NDST>
 __device__ __forceinline__ void store_act_x(f32x16 (&acc)[NT], f32x16 (&act)[NDST], float floor_, float& amax) {
   xscale<NT>(acc, 1.0f / XWSCALE);
   store_act<NT>(acc, act, floor_);
+#ifdef CRNERF_EXP_H2_NOEPI
+  return;
+#endif
   if (XNP == 2) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)

@@ -43,17 +43,19 @@ __global__ void pack_stream_kernel(MlpTensors t, float* __restrict__ stream, int
   stream[idx] = col >= 0 ? W[(long)row * in_dim + col] : 0.0f;
 }
 
-__global__ void pack_consts_kernel(MlpTensors t, float* __restrict__ c) {
+// bias_scale: factor on the biases of the ten matrix-core layers (h2 packs: H2_WSCALE, the factor their weights carry -- the accumulator is then
+// initialised with a plain LDS read); the sigma head (fp32 VALU) is never scaled
+__global__ void pack_consts_kernel(MlpTensors t, float* __restrict__ c, float bias_scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= CONST_BYTES / 4) return;
   float v = 0.0f;
-  if (i < C_BFIN) v = t.b[i / W_HIDDEN][i % W_HIDDEN];
-  else if (i < C_WSIG) v = t.b_final[i - C_BFIN];
+  if (i < C_BFIN) v = t.b[i / W_HIDDEN][i % W_HIDDEN] * bias_scale;
+  else if (i < C_WSIG) v = t.b_final[i - C_BFIN] * bias_scale;
   else if (i < C_BSIG) v = t.w_sigma[i - C_WSIG];
   else if (i == C_BSIG) v = t.b_sigma[0];
   else if (i < C_BDIR) v = 0.0f;
-  else if (i < C_BRGB) v = t.b_dir[i - C_BDIR];
-  else if (i < CONST_FLOATS) v = t.b_rgb[i - C_BRGB];
+  else if (i < C_BRGB) v = t.b_dir[i - C_BDIR] * bias_scale;
+  else if (i < CONST_FLOATS) v = t.b_rgb[i - C_BRGB] * bias_scale;
   c[i] = v;
 }
 
@@ -83,7 +85,7 @@ __global__ void pack_streamT_kernel(MlpTensors t, float* __restrict__ stream) {
 int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAMT_FRAGS * FRAG_FLOATS;
   hipLaunchKernelGGL(pack_streamT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
   return check_launch("pack_mlpT");
@@ -141,7 +143,7 @@ __global__ void pack_stream_bf16_kernel(MlpTensors t, unsigned short* __restrict
 int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAMB_FRAGS * 512;
   hipLaunchKernelGGL(pack_stream_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
   return check_launch("pack_mlp_bf16");
@@ -233,7 +235,7 @@ __global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__
 int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, H2_WSCALE);
   const long n = (long)STREAMH_FRAGS * 512;
   // range check: the ONE place this library waits for the stream -- packing happens once per set of weights, and a weight beyond fp16's range
   // would otherwise surface as a finite, wrong output (inf - inf = NaN in a hidden layer is clamped to 0 by the relu)
@@ -252,7 +254,7 @@ int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
 int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAMX_FRAGS * 512;
   hipLaunchKernelGGL(pack_stream_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
   return check_launch("pack_mlp_x3");
@@ -291,7 +293,7 @@ __global__ void pack_stream_x3t_kernel(MlpTensors t, unsigned short* __restrict_
 int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAMXT_FRAGS * 512;
   hipLaunchKernelGGL(pack_stream_x3t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
   return check_launch("pack_mlp_x3t");
@@ -300,7 +302,7 @@ int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream) {
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);
-  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAM_FRAGS * FRAG_FLOATS;
   hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream, v16);
   return check_launch("pack_mlp");
