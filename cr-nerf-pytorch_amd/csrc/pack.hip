@@ -193,8 +193,11 @@ __global__ void pack_stream_x3_kernel(MlpTensors t, unsigned short* __restrict__
 
 // h2 stream (layout.h "fragH"): one thread per fp16 element; weights scaled by H2_WSCALE, two pieces by repeated round-to-nearest-even.
 // A weight whose scaled value leaves the fp16 range becomes inf: the outputs are then inf / nan, not silently wrong.
-__device__ int g_h2_range_flag;   // set by pack_stream_h2_kernel when a scaled weight is not a finite fp16 number
-__global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+// range_flag: one word of the pack's own consts block (behind CONST_FLOATS, zeroed by pack_consts_kernel; no kernel reads it), set when a scaled
+// weight is not a finite fp16 number -- per pack, so concurrent packs on different streams / threads do not share state
+constexpr int H2_FLAG_WORD = CONST_FLOATS;
+static_assert((H2_FLAG_WORD + 1) * 4 <= CONST_BYTES, "no spare word in the consts block");
+__global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__ stream, int* __restrict__ range_flag) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)STREAMH_FRAGS * 512) return;
   const int frag = (int)(idx / 512);
@@ -226,7 +229,7 @@ __global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__
   }
   if (col < 0) { stream[idx] = 0; return; }
   const float w = W[(long)row * in_dim + col] * H2_WSCALE;
-  if ((__float_as_uint(w) & 0x7fffffffu) >= 0x477fe000u && piece == 0) atomicOr(&g_h2_range_flag, 1);   // |w| >= 65,504, inf or NaN (bit test: this unit is built with -fno-honor-nans)
+  if ((__float_as_uint(w) & 0x7fffffffu) >= 0x477fe000u && piece == 0) atomicOr(range_flag, 1);   // |w| >= 65,504, inf or NaN (bit test: this unit is built with -fno-honor-nans)
   const _Float16 p1 = (_Float16)w;                       // round to nearest even; subnormals kept
   const _Float16 p2 = (_Float16)(w - (float)p1);
   stream[idx] = __builtin_bit_cast(unsigned short, piece == 0 ? p1 : p2);
@@ -240,12 +243,10 @@ int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
   // range check: the ONE place this library waits for the stream -- packing happens once per set of weights, and a weight beyond fp16's range
   // would otherwise surface as a finite, wrong output (inf - inf = NaN in a hidden layer is clamped to 0 by the relu)
   int flag = 0;
-  if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_h2_range_flag), &flag, sizeof(int), 0, hipMemcpyHostToDevice, stream) != hipSuccess)
-    return set_error(-10, "pack_mlp_h2: clearing the range flag failed");
-  hipLaunchKernelGGL(pack_stream_h2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  int* dflag = (int*)consts + H2_FLAG_WORD;
+  hipLaunchKernelGGL(pack_stream_h2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream, dflag);
   if (int rc = check_launch("pack_mlp_h2")) return rc;
-  if (hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_h2_range_flag), sizeof(int), 0, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipStreamSynchronize(stream) != hipSuccess)
+  if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
     return set_error(-10, "pack_mlp_h2: reading the range flag failed");
   if (flag) return set_error(-3, "pack_mlp_weights_h2: a weight is outside the h2 core's range (|w| < 255, finite); use the f32x3 or fp32 entry points");
   return 0;
