@@ -312,9 +312,14 @@ struct ActSaveX {
 // srcB.  FOFF: the layer's first fragment modulo the stage (0: every layer is whole stages); PAD: stage-padding fragments behind the
 // layer (dir_encoding), skipped through the queue without being multiplied.  q always holds the next X_AHEAD fragments of the STREAM.
 // SAVEA / SAVEB (training twin): source A / B is saved while it is walked -- rowA / rowB = the slot's rows, voff = this lane's byte offset.
-template <int NT, int NSA, int NSB, int PAD, bool SAVEA = false, bool SAVEB = false, int NA, int NB>
+// FINA / FINB (h2 core, "lazy epilogue"): the source holds the RAW accumulator values of the layer that produced it (scaled by XWSCALE, before
+// the activation) and is finished here, eight values at a time, when its k-step comes up -- 1: scale down + relu, 2: scale down only (a linear
+// layer's output) -- with the running max |activation| of the range guard kept in *amax.  Every activation is a B operand exactly once per layer,
+// so this is the same work as an epilogue between the layers, moved from a stretch with no MFMA in flight into the shadow of this layer's MFMAs.
+template <int NT, int NSA, int NSB, int PAD, bool SAVEA = false, bool SAVEB = false, int FINA = 0, int FINB = 0, int NA, int NB>
 __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA)[NA], const f32x16 (&srcB)[NB], f32x16 (&acc)[NT],
-                                             xu32x4 (&q)[X_AHEAD], SaveRowX rowA = SaveRowX{}, SaveRowX rowB = SaveRowX{}, uint32_t voff = 0) {
+                                             xu32x4 (&q)[X_AHEAD], SaveRowX rowA = SaveRowX{}, SaveRowX rowB = SaveRowX{}, uint32_t voff = 0,
+                                             float* amax = nullptr) {
   static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
   constexpr int NS = NSA + NSB;
   static_assert(((NS * NT * XNP + PAD) % STAGE_FRAGS) == 0 && ((NS * NT * XNP + PAD) % X_AHEAD) == 0 && NT % 2 == 0,
@@ -355,6 +360,18 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       const xu32x4 hi = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
       __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * ss), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * ss + 32u), 0, 0);
+    }
+    const int fin = s < NSA ? FINA : FINB;
+    if (fin) {
+      float m = *amax;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        v[e] *= 1.0f / XWSCALE;
+        v[e + 1] *= 1.0f / XWSCALE;
+        if (fin == 1) { v[e] = fmaxf(v[e], 0.0f); v[e + 1] = fmaxf(v[e + 1], 0.0f); }
+        m = fmaxf(fmaxf(m, fabsf(v[e])), fabsf(v[e + 1]));
+      }
+      *amax = m;
     }
     x3_split(v, b1, b2, b3);
   };
@@ -441,6 +458,32 @@ __device__ __forceinline__ void store_act_x(f32x16 (&acc)[NT], f32x16 (&act)[NDS
   }
 }
 constexpr float H2_ACT_LIMIT = 65504.0f;   // largest finite fp16
+// -DCRNERF_X_LAZY=1 (h2 core only): finish a layer's output inside the NEXT layer's walk (mma_layer_x3 FINA / FINB) instead of between the layers.
+// MEASURED: correct (tests/test_gpu_h2.py green) and not faster -- 0.824 vs 0.78-0.82 ms per 1,024 rays, 3.39 vs 3.36 ms per 2^20 points: holding the
+// raw rows across the layer costs registers (28 -> 105 spilled VGPRs) and the spill traffic eats what the overlap gives.  Off by default.
+#ifndef CRNERF_X_LAZY
+#define CRNERF_X_LAZY 0
+#endif
+constexpr bool XLAZY = CRNERF_X_LAZY != 0;
+static_assert(!XLAZY || XNP == 2, "the lazy epilogue is the h2 core's");
+// lazy variant of store_act_x: the raw accumulators leave the AGPRs, nothing else
+template <int NT, int NDST>
+__device__ __forceinline__ void store_raw_x(const f32x16 (&acc)[NT], f32x16 (&act)[NDST]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) act[t] = acc[t];
+}
+// eager finish in place (the sigma head reads h8 on the VALU)
+template <int NT, int NDST>
+__device__ __forceinline__ void finish_act_x(f32x16 (&act)[NDST], float floor_, float& amax) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      act[t][r] = fmaxf(act[t][r] * (1.0f / XWSCALE), floor_);
+      act[t][r + 1] = fmaxf(act[t][r + 1] * (1.0f / XWSCALE), floor_);
+      amax = fmaxf(fmaxf(amax, fabsf(act[t][r])), fabsf(act[t][r + 1]));
+    }
+}
 
 // One 32-point tile through one model.  pe / dv: the positional embeddings in the register order of posenc_regs (posenc.h), exactly as
 // mlp_core.h's mlp_tile takes them.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both lane halves).
@@ -465,26 +508,27 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
 
   init_acc_x<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
   mma_layer_x3<8, KS_XYZ, 0, 0>(p, pe, pe, acc, q);
-  store_act_x<8>(acc, act, 0.0f, amax);
+  if (XLAZY) store_raw_x<8>(acc, act); else store_act_x<8>(acc, act, 0.0f, amax);
   sv.template masks<8>(0, act);
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4 (their input h_l is saved in slot l - 1 on the way)
     init_acc_x<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
-    store_act_x<8>(acc, act, 0.0f, amax);
+    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false, XLAZY ? 1 : 0, 0>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo, &amax);
+    if (XLAZY) store_raw_x<8>(acc, act); else store_act_x<8>(acc, act, 0.0f, amax);
     sv.template masks<8>(l, act);
   }
   init_acc_x<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
-  mma_layer_x3<8, KS_XYZ, KS_HID, 0, false, SAVE>(p, pe, act, acc, q, SaveRowX{}, sv.row(3), vo);
-  store_act_x<8>(acc, act, 0.0f, amax);
+  mma_layer_x3<8, KS_XYZ, KS_HID, 0, false, SAVE, 0, XLAZY ? 1 : 0>(p, pe, act, acc, q, SaveRowX{}, sv.row(3), vo, &amax);
+  if (XLAZY) store_raw_x<8>(acc, act); else store_act_x<8>(acc, act, 0.0f, amax);
   sv.template masks<8>(4, act);
 #pragma unroll 1
   for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
     init_acc_x<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo);
-    store_act_x<8>(acc, act, 0.0f, amax);
+    mma_layer_x3<8, KS_HID, 0, 0, SAVE, false, XLAZY ? 1 : 0, 0>(p, act, act, acc, q, sv.row(l - 1), SaveRowX{}, vo, &amax);
+    if (XLAZY) store_raw_x<8>(acc, act); else store_act_x<8>(acc, act, 0.0f, amax);
     sv.template masks<8>(l, act);
   }
+  if (XLAZY) finish_act_x<8>(act, 0.0f, amax);           // h8 is finished eagerly: the sigma head reads it on the VALU
   tm.tick(T_MMA);
   {                                                      // static_sigma: 256 -> 1 on the VALU (fp32, as mlp_core.h)
     float s = 0.0f;
@@ -504,12 +548,12 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   }
   init_acc_x<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation); h8 -> slot 7
   mma_layer_x3<8, KS_HID, 0, 0, SAVE, false>(p, act, act, acc, q, sv.row(7), SaveRowX{}, vo);
-  store_act_x<8>(acc, act, NEG_INF, amax);
+  if (XLAZY) store_raw_x<8>(acc, act); else store_act_x<8>(acc, act, NEG_INF, amax);
   {
     f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir])); final -> slot 8
     init_acc_x<4>(acc4, C + C_BDIR, h);
-    mma_layer_x3<4, KS_HID, KS_DIR, XPAD_DIR, SAVE, false>(p, act, dv, acc4, q, sv.row(8), SaveRowX{}, vo);
-    store_act_x<4>(acc4, act, 0.0f, amax);
+    mma_layer_x3<4, KS_HID, KS_DIR, XPAD_DIR, SAVE, false, XLAZY ? 2 : 0, 0>(p, act, dv, acc4, q, sv.row(8), SaveRowX{}, vo, &amax);
+    if (XLAZY) store_raw_x<4>(acc4, act); else store_act_x<4>(acc4, act, 0.0f, amax);
     {
       f32x16 a4[4];
 #pragma unroll
@@ -520,7 +564,7 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   {
     f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear); the dir activation -> slot 9
     init_acc_x<2>(acc2, C + C_BRGB, h);
-    mma_layer_x3<2, KS_HALF, 0, 0, SAVE, false>(p, act, act, acc2, q, sv.row(9), SaveRowX{}, vo);
+    mma_layer_x3<2, KS_HALF, 0, 0, SAVE, false, XLAZY ? 1 : 0, 0>(p, act, act, acc2, q, sv.row(9), SaveRowX{}, vo, &amax);
     tm.tick(T_MMA);
     xscale<2>(acc2, 1.0f / XWSCALE);
 #pragma unroll
