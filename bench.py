@@ -475,8 +475,10 @@ def strong_configs2(a, dev, world, rank, use_dist, dist, exchange):
         torch.cuda.synchronize()
         render_ms = sum(s.elapsed_time(e) for s, e in ev[-a.steps:]) / a.steps
     flops_local = FLOP_PER_POINT * (NC + NC + NI) * (hi - lo)
-    peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
-    achieved = flops_local / (render_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if prec in ("bf16", "f32x3", "f32h2") else PEAK_F32_MFMA_TFLOPS
+    issued = {"f32x3": 6.0 * 7296.0 / 7248.0, "f32h2": 3.0 * 7296.0 / 7248.0}.get(prec, 1.0)   # split modes: the piece MFMAs the kernel ISSUES
+    achieved = issued * flops_local / (render_ms * 1e-3) / 1e12
+    kernel = {"bf16": "render_rays_bf16p_kernel", "f32x3": "render_rays_x3_kernel", "f32h2": "render_rays_h2_kernel"}.get(prec, "render_rays16_kernel")
     return {"metric": "rays/sec (64+128 samples, 8-layer W=256 MLP)", "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": prec,
             "data": "synthetic",
@@ -485,9 +487,9 @@ def strong_configs2(a, dev, world, rank, use_dist, dist, exchange):
                        "rays_total": R, "rays_this_rank": hi - lo, "n_samples": NC, "n_importance": NI,
                        "parallelism": "one frame's rays sharded %d-way, weights replicated" % world,
                        "reductions": "none" if world == 1 else ("peer windows (HIP IPC)" if exchange is not None else "RCCL all-reduce")},
-            "roofline": {"bound": "mfma", "kernel": "render_rays_bf16p_kernel" if prec == "bf16" else "render_rays16_kernel", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "traffic_source": None, "kernel_ms": render_ms,
-                         "flops_per_launch": flops_local, "note": "rank 0's render chunks of one frame (HIP events around the chunk loop)"},
+                         "flops_per_launch": issued * flops_local, "note": "rank 0's render chunks of one frame (HIP events around the chunk loop)"},
             "image_checksum": float(last.double().sum())}
 
 

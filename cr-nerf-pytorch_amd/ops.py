@@ -68,7 +68,12 @@ def _f32c(t, name):
 
 def pack_mlp_weights(state, out=None, precision="f32"):
     """state: mapping name -> device tensor with the 24 NeRF_sigma tensors (models/nerf.py:137-154).
-    precision "f32" -> buffer for the *_f32 entry points, "bf16" -> for the *_bf16 ones (different layouts)."""
+    precision "f32" -> buffer for the *_f32 entry points, "bf16" -> for the *_bf16 ones, "f32x3" / "f32h2" -> for the *_f32x3 / *_f32h2 ones
+    (pack_mlp_weights_x3 / pack_mlp_weights_h2; different layouts each)."""
+    if _is_h2(precision) or _is_x3(precision):
+        if out is not None:
+            raise ValueError("crnerf_amd: out= is for the f32 / bf16 packs")
+        return pack_mlp_weights_h2(state) if _is_h2(precision) else pack_mlp_weights_x3(state)
     lib = _lib.load()
     tensors = []
     for name, shape in zip(MLP_TENSOR_NAMES, MLP_TENSOR_SHAPES):
@@ -291,6 +296,10 @@ def embed_points(rays, z, dir_emb):
 
 
 def mlp_forward(packed, x, sigma_only=False, precision="f32"):
+    if _is_h2(precision):
+        return mlp_forward_h2(packed, x, sigma_only=sigma_only)
+    if _is_x3(precision):
+        return mlp_forward_x3(packed, x, sigma_only=sigma_only)
     lib = _lib.load()
     x = _f32c(x, "x")
     want = 93 if sigma_only else 120
