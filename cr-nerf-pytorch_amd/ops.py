@@ -103,9 +103,9 @@ def _is_h2(precision):
 def _is_bf16(precision):
     if precision in ("bf16", "bfloat16", torch.bfloat16):
         return True
-    if precision in ("f32", "fp32", "float32", torch.float32, None):
+    if precision in ("f32", "fp32", "float32", torch.float32, None) or _is_x3(precision) or _is_h2(precision):
         return False
-    raise ValueError("crnerf_amd: precision must be 'f32' or 'bf16', got %r" % (precision,))
+    raise ValueError("crnerf_amd: precision must be 'f32', 'bf16', 'f32x3' or 'f32h2', got %r" % (precision,))
 
 
 def _mlp_tensor_list(state):
