@@ -39,6 +39,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.crnerf_abi_version() == 2
     lib.crnerf_packed_mlp_bytes.restype = ctypes.c_size_t
     assert lib.crnerf_packed_mlp_bytes() == 11264 + 2416 * 1024
+    # the split-precision packs: three bf16 pieces per weight (f32x3; dir_encoding padded to whole stages and queue turns), two fp16 pieces (f32h2)
+    for fn, frags in (("crnerf_packed_mlp_x3_bytes", 3648), ("crnerf_packed_mlp_h2_bytes", 2416), ("crnerf_packed_mlp_t_x3_bytes", 3312)):
+        getattr(lib, fn).restype = ctypes.c_size_t
+        assert getattr(lib, fn)() == 11264 + frags * 1024, fn
+    # NULL arguments of the split-precision entry points are rejected before any device work
+    for fn in ("crnerf_mlp_forward_f32x3", "crnerf_mlp_forward_f32h2"):
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+        assert f(None, None, None, 4, 0, None) == -1, fn
+        assert f(None, None, None, 0, 0, None) == 0, fn
+    for fn in ("crnerf_pack_mlp_weights_x3", "crnerf_pack_mlp_weights_h2"):
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        assert f(None, None, None) == -1, fn
     # error path without touching a device: NULL arguments are rejected with a message
     lib.crnerf_posenc_f32.restype = ctypes.c_int
     lib.crnerf_posenc_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
