@@ -186,7 +186,9 @@ struct WeightPipeX {
       case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4) + 8) : "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (X_RING - 4)) : "memory"); break;
     }
+#ifndef CRNERF_EXP_NOBARRIER   // (timing experiments only: racy without it) what the per-stage rendezvous of the four waves costs
     __builtin_amdgcn_s_barrier();
+#endif
     rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * X_STAGE_BYTES + lane16;
   }
