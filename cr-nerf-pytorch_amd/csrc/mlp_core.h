@@ -81,6 +81,12 @@ struct PhaseTimer {
 // the compiler (M0 is a reserved register, clang rejects it as a clobber): kernels that contain it must not index
 // register arrays dynamically (s_set_gpr_idx / v_movrel keep their index in M0) -- checked by grepping the ISA.
 __device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
+#ifdef CRNERF_EXP_GLOADONLY   // (timing experiments only; garbage) the same VMEM request into a dummy register: issue + L2 traffic, no LDS write
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  u4 dummy;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dummy) : "v"(voff), "s"(base), "n"(imm) : "memory");
+  return;
+#endif
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
                : "memory");
 }

@@ -2,7 +2,11 @@
 // on the bf16 matrix cores.  Module-level entry (NeRF_sigma.__call__, models/nerf.py:157-182) and the unit under test for that core.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#if defined(CRNERF_X_NP) && CRNERF_X_NP == 2
+#include "mlp_core_h2.h"
+#else
 #include "mlp_core_x3.h"
+#endif
 
 namespace crnerf {
 

@@ -11,7 +11,11 @@
 // transmittance, so compositing needs no cross-wave traffic.  Grid-stride over ray quads.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#if defined(CRNERF_X_NP) && CRNERF_X_NP == 2
+#include "mlp_core_h2.h"
+#else
 #include "mlp_core_x3.h"
+#endif
 #include "posenc.h"
 #include "ray_ops.h"
 
@@ -249,5 +253,14 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   return check_launch("render_rays_x3_kernel");
 }
 
+#ifdef CRNERF_TIMING
+#if CRNERF_X_NP == 2
+extern "C" int crnerf_debug_read_timing_h2(unsigned long long* host_out) {
+#else
+extern "C" int crnerf_debug_read_timing_x3(unsigned long long* host_out) {
+#endif
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crnerf_timing), sizeof(unsigned long long) * T_COUNT);
+}
+#endif
 
 }  // namespace crnerf

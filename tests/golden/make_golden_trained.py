@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--ckpt", default="/tmp/crnerf_trained/last.ckpt")
     ap.add_argument("--eval-only", action="store_true")
+    ap.add_argument("--out", default="g15_trained.npz", help="fixture file name under tests/golden/ (g16_trained.npz: the long run, --steps 8000)")
+    ap.add_argument("--eval-modules-only", action="store_true",
+                    help="keep only the state_dict prefixes eval.py loads (nerf_coarse / nerf_fine / decoder / enc_a): a smaller fixture")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     torch.manual_seed(7)
@@ -197,12 +200,13 @@ def main():
     psnr = float(-10 * torch.log10(((ref32["64_128__rgb_fine"] - test["rgbs"]) ** 2).mean()))
     print("held-out PSNR of the reference's render vs the scene (own appearance not applied): %.2f dB" % psnr)
     ck = torch.load(a.ckpt, map_location="cpu", weights_only=False)
-    arrays = {"sd__" + k: v.numpy() for k, v in ck["state_dict"].items()}
+    keep = ("nerf_coarse.", "nerf_fine.", "decoder.", "enc_a.") if a.eval_modules_only else ("",)
+    arrays = {"sd__" + k: v.numpy() for k, v in ck["state_dict"].items() if k.startswith(keep)}
     arrays.update({"ref__" + k: v.numpy() for k, v in ref32.items()})
     arrays.update({"cond__" + k: np.array(v) for k, v in cond.items()})
     arrays.update(rays=test["rays"].numpy(), ts=test["ts"].numpy(), gt=test["rgbs"].numpy(), style_rgbs=style.numpy(),
                   global_step=ck["global_step"], train_log=np.array(log, dtype=np.float32), side=SIDE)
-    path = os.path.join(OUT, "g15_trained.npz")
+    path = os.path.join(OUT, a.out)
     np.savez_compressed(path, **arrays)
     print("wrote %s  %.1f MiB" % (path, os.path.getsize(path) / 2 ** 20))
 

@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
-fn = ((lib.crnerf_debug_read_timing_bf16 if os.environ.get("CRNERF_BF16_CORE") == "64" else lib.crnerf_debug_read_timing_bf16p) if PREC == "bf16" else
+fn = lib.crnerf_debug_read_timing_h2 if PREC == "f32h2" else lib.crnerf_debug_read_timing_x3 if PREC == "f32x3" else ((lib.crnerf_debug_read_timing_bf16 if os.environ.get("CRNERF_BF16_CORE") == "64" else lib.crnerf_debug_read_timing_bf16p) if PREC == "bf16" else
       lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16)
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
@@ -29,7 +29,9 @@ for n, v in zip(names, buf):
     print("%-18s %12d cycles  %6.2f %%" % (n, v, 100.0 * v / tot))
 if buf[15]:
     print("wave lifetime %.1f us -> shader clock %.3f GHz" % (buf[15] / 100.0, tot / (buf[15] * 10.0)))
-if PREC == "bf16":
+if PREC == "f32h2":
+    print("x0..x6 = xyz_encoding_1 | 2-4 | 5 | 6-8 | final | dir | rgb; ideal matrix-pipe cycles per tile: 4608 | 36864 | 16896 | 36864 | 12288 | 6912 | 1536 = 115968; x 8 tiles per ray = %d" % (8 * 115968))
+elif PREC == "bf16":
     print("ideal matrix-pipe cycles per SIMD: %d (9664 MFMA x 32 cycles; pair core: two waves of 4 x 1208 each)" % (4 * 2416 * 32))
 else:
     print("ideal matrix-pipe cycles per SIMD: %d (8 steps x 9664 MFMA x 64 cycles-equivalent)" % (8 * 9664 * 64))
