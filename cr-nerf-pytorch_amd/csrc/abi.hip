@@ -198,7 +198,7 @@ int crnerf_sample_pdf_merge_f32(const float* z_coarse, const float* weights_coar
   return launch_sample_pdf_merge(z_coarse, weights_coarse, u, (long)u_stride, z_sorted, z_samples, (long)R, Nc, Ni, (hipStream_t)stream);
 }
 
-// x3: 0 = no, 1 = the x3 core (three bf16 pieces), 2 = the h2 core (two fp16 pieces)
+// x3: 0 = no, 1 = the x3 core (three bf16 pieces), 2 = the h2 core (two fp16 pieces), 3 = the x3 core repairing NaN ray quads
 static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf16, void* acts_c = nullptr, void* acts_f = nullptr,
                               float* raw_c = nullptr, float* raw_f = nullptr, int x3 = 0) {
   REQUIRE(a, "args");
@@ -227,6 +227,7 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   }
   r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
   if (x3 == 2) return launch_render_rays_h2(r, (hipStream_t)stream);
+  if (x3 == 3) r.repair = 1;
   if (x3) return launch_render_rays_x3(r, (hipStream_t)stream);
   if (bf16) {
     // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
@@ -343,7 +344,7 @@ int crnerf_mlp_forward_f32x3(const void* packed, const float* x, float* out, int
   if (n == 0) return 0;
   REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32x3: negative n");
-  return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream, 0);
 }
 
 int crnerf_render_rays_f32x3(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, 1); }
@@ -361,9 +362,16 @@ int crnerf_mlp_forward_f32h2(const void* packed, const float* x, float* out, int
   if (n == 0) return 0;
   REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32h2: negative n");
-  return launch_mlp_forward_h2(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  return launch_mlp_forward_h2(packed, x, out, (long)n, sigma_only, (hipStream_t)stream, 0);
 }
 
+int crnerf_render_rays_f32x3_repair(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, 3); }
+int crnerf_mlp_forward_f32x3_repair(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {
+  if (n == 0) return 0;
+  REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
+  if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_f32x3_repair: negative n");
+  return launch_mlp_forward_x3(packed, x, out, (long)n, sigma_only, (hipStream_t)stream, 1);
+}
 int crnerf_render_rays_f32h2(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false, nullptr, nullptr, nullptr, nullptr, 2); }
 
 int crnerf_render_rays_train_f32x3(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine, void* stream) {

@@ -105,6 +105,8 @@ struct RenderArgs {
   float* z_coarse_out = nullptr;
   float* noise_coarse_out = nullptr;
   float* noise_fine_out = nullptr;
+  // crnerf_render_rays_f32x3_repair: only ray quads whose feature_coarse / feature_fine hold a NaN are rendered (again)
+  int repair = 0;
   // training twin (crnerf_render_rays_train_f32; all null for inference): saved activations + raw MLP outputs per pass
   void* train_acts_coarse = nullptr;   // crnerf_mlp_train_acts_bytes(R*Nc)
   void* train_acts_fine = nullptr;     // crnerf_mlp_train_acts_bytes(R*(Nc+Ni))
@@ -116,12 +118,12 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream);
 int launch_mlp_forward16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_pack_mlp_x3(const MlpTensors& t, void* packed, hipStream_t stream);
-int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
+int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream);
 int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream);
 // "h2" core (mlp_core_x3.h built with two fp16 pieces per operand): packs, module forward, fused renderer (inference)
 int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream);
-int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
+int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_h2(const RenderArgs& a, hipStream_t stream);
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream);

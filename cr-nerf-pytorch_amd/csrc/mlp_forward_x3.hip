@@ -23,13 +23,18 @@ __device__ __forceinline__ void gather_embedded_x3(const float* __restrict__ row
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_forward_x3_kernel(const char* __restrict__ packed, const float* __restrict__ x, float* __restrict__ out,
-                                                                int sigma_only, long P, int iters) {
+                                                                int sigma_only, long P, int iters, int repair) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 31, h = lane >> 5;
 
+  if (repair) {   // crnerf_mlp_forward_f32x3_repair: one workgroup per 128 points; it leaves at once unless a previous call left a NaN sigma among them
+    const long n = ((long)blockIdx.x * 4 + wave) * 32 + p;
+    const bool bad = n < P && (__float_as_uint(sigma_only ? out[n] : out[n * OUT_DIM + FEAT_DIM]) & 0x7fffffffu) > 0x7f800000u;
+    if (!__syncthreads_or(bad)) return;
+  }
   load_consts(lds, packed, packed);
   WeightPipeX pipe;
   pipe.start(lds, packed + CONST_BYTES, packed + CONST_BYTES, 1, 1, lane, wave);
@@ -74,15 +79,16 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_x3_kernel(const char* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the prefetches still in flight before the workgroup (and its LDS) goes away
 }
 
-int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream) {
+int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair) {
   if (P <= 0) return 0;
   const long groups = (P + 127) / 128;   // 128 points per workgroup-iteration
   const int cus = num_cus();
-  const int grid = (int)(groups < cus ? groups : cus);
+  if (repair && groups > 0x7fffffffL) return set_error(-2, "mlp_forward_f32x3_repair: too many points");
+  const int grid = repair ? (int)groups : (int)(groups < cus ? groups : cus);
   const int iters = (int)((groups + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH_X;
   if (int rc = ensure_dynamic_lds((const void*)mlp_forward_x3_kernel, shmem, "mlp_forward_x3_kernel")) return rc;
-  hipLaunchKernelGGL(mlp_forward_x3_kernel, dim3(grid), dim3(256), shmem, stream, (const char*)packed, x, out, sigma_only, P, iters);
+  hipLaunchKernelGGL(mlp_forward_x3_kernel, dim3(grid), dim3(256), shmem, stream, (const char*)packed, x, out, sigma_only, P, iters, repair);
   return check_launch("mlp_forward_x3_kernel");
 }
 

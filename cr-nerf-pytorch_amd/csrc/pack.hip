@@ -248,7 +248,7 @@ int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
   if (int rc = check_launch("pack_mlp_h2")) return rc;
   if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
     return set_error(-10, "pack_mlp_h2: reading the range flag failed");
-  if (flag) return set_error(-3, "pack_mlp_weights_h2: a weight is outside the h2 core's range (|w| < 255, finite); use the f32x3 or fp32 entry points");
+  if (flag) return set_error(-4, "pack_mlp_weights_h2: a weight is outside the h2 core's range (|w| < 255, finite); use the f32x3 or fp32 entry points");
   return 0;
 }
 

@@ -48,6 +48,7 @@ struct RenderParamsX {
   // whichever kernel renders); rng_flags == 0: none
   unsigned long long rng_seed; long rng_ray_offset; int rng_flags; float perturb;
   float* z_coarse_out; float* noise_c_out; float* noise_f_out;
+  int repair;   // crnerf_render_rays_f32x3_repair: one workgroup per ray quad; it leaves at once unless one of its rays came out of a previous render as NaN
 };
 
 // What the training twin adds (crnerf_render_rays_train_f32x3): every tile's layer activations + relu bits in the layout of the fp32 training
@@ -87,6 +88,12 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
   const int p = lane & 31, h = lane >> 5;
   const int Nc = a.Nc, Ni = a.Ni, Nf = Nc + Ni;
 
+  if (a.repair) {   // (bit test: this unit is built with -fno-honor-nans)
+    const long rr = (long)blockIdx.x * 4 + wave;
+    auto is_nan = [](float v) { return (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u; };
+    const bool bad = rr < a.R && (is_nan(a.feature_c[rr * FEAT_DIM]) || (Ni > 0 && is_nan(a.feature_f[rr * FEAT_DIM])));
+    if (!__syncthreads_or(bad)) return;
+  }
   load_consts(lds, a.packed0, a.packed1);
   RayScratch scr;
   scr.bind(lds + LDS_SCRATCH_X + wave * SCRATCH_BYTES);
@@ -227,7 +234,9 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
   const long quads = (a.R + 3) / 4;
   const int cus = num_cus();
-  const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
+  if (a.repair && (a.train_acts_coarse || quads > 0x7fffffffL)) return set_error(-3, "render_rays_f32x3_repair: inference renders of < 2^33 rays only");
+  k.repair = a.repair;
+  const int grid = a.repair ? (int)quads : (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads (repair: one per quad)
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH_X + 4 * SCRATCH_BYTES;
 #if CRNERF_X_NP != 3

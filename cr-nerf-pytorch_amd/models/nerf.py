@@ -78,15 +78,16 @@ class NeRF_sigma(nn.Module):
         return super()._load_from_state_dict(*args, **kwargs)
 
     def packed_weights(self, precision="f32"):
-        """Packed buffer for the crnerf_*_f32 (default), crnerf_*_bf16, crnerf_*_f32x3 or crnerf_*_f32h2 entry points; re-packed when a parameter changes."""
-        bf16 = "h2" if ops._is_h2(precision) else ("x3" if ops._is_x3(precision) else ops._is_bf16(precision))
+        """Packed buffer for the crnerf_*_f32 (default), crnerf_*_bf16, crnerf_*_f32x3 or crnerf_*_f32h2 entry points ("auto": an ops.AutoPack holding the
+        h2 and the x3 pack); re-packed when a parameter changes."""
+        bf16 = "auto" if ops._is_auto(precision) else "h2" if ops._is_h2(precision) else ("x3" if ops._is_x3(precision) else ops._is_bf16(precision))
         params = dict(zip(ops.MLP_TENSOR_NAMES, ops.mlp_params(self)))
         key = tuple((p.data_ptr(), p._version, p.device) for p in params.values())
         if self._packed is None or key != self._packed_key:
             self._packed = {}
             self._packed_key = key
         if bf16 not in self._packed:
-            self._packed[bf16] = (ops.pack_mlp_weights_h2(params) if bf16 == "h2" else ops.pack_mlp_weights_x3(params) if bf16 == "x3"
+            self._packed[bf16] = (ops.pack_mlp_weights_auto(params) if bf16 == "auto" else ops.pack_mlp_weights_h2(params) if bf16 == "h2" else ops.pack_mlp_weights_x3(params) if bf16 == "x3"
                                   else ops.pack_mlp_weights(params, out=None, precision="bf16" if bf16 else "f32"))
         return self._packed[bf16]
 
@@ -100,6 +101,8 @@ class NeRF_sigma(nn.Module):
         if precision is None:
             from .. import get_precision
             precision = get_precision()
+        if ops._is_auto(precision):
+            return ops.mlp_forward_auto(self.packed_weights(precision), x, sigma_only=sigma_only)
         if ops._is_h2(precision):
             return ops.mlp_forward_h2(self.packed_weights(precision), x, sigma_only=sigma_only)
         if ops._is_x3(precision):

@@ -65,9 +65,7 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
             from ..autograd import CompositeFn, mlp_forward_with_grad
             raw = torch.cat([mlp_forward_with_grad(model, x) for x in xs], 0)
             return CompositeFn.apply(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
-        fwd = ((lambda pk, x: ops.mlp_forward_h2(pk, x)) if ops._is_h2(precision) else (lambda pk, x: ops.mlp_forward_x3(pk, x)) if ops._is_x3(precision)
-               else (lambda pk, x: ops.mlp_forward(pk, x, precision=precision)))
-        raw = torch.cat([fwd(model.packed_weights(precision), x) for x in xs], 0)   # point chunks, rendering.py:110-114
+        raw = torch.cat([ops.mlp_forward(model.packed_weights(precision), x, precision=precision) for x in xs], 0)   # point chunks, rendering.py:110-114
         return ops.composite(raw.view(R, N, 65), z.contiguous(), noise, noise_std)
 
     out = {}
@@ -91,7 +89,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     N_importance > 0, 'fine' (+ 'feature_fine_random', the SAME tensor object as 'feature_fine',
     models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
     reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible).
-    One keyword beyond the reference's: precision="f32"|"bf16"|"f32x3"|"f32h2" (default crnerf_amd.get_precision()) selects the
+    One keyword beyond the reference's: precision="f32"|"bf16"|"f32x3"|"f32h2"|"auto" (default crnerf_amd.get_precision()) selects the
     matrix-core arithmetic of NeRF_sigma at inference (include/crnerf.h).  Grad mode trains through the exact-fp32 twins unless
     the caller opted into mixed precision (autograd.set_training_precision("bf16") / CRNERF_TRAIN_BF16=1: bf16-operand GEMM twins,
     fp32 accumulation; autograd.set_wgrad_precision("bf16"): weight gradients only) -- neither has a counterpart in the reference."""
@@ -111,7 +109,8 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     if precision is None:
         from .. import get_precision
         precision = get_precision()
-    precision = "f32" if train else ("f32h2" if ops._is_h2(precision) else "f32x3" if ops._is_x3(precision) else ("bf16" if ops._is_bf16(precision) else "f32"))
+    precision = "f32" if train else ("auto" if ops._is_auto(precision) else "f32h2" if ops._is_h2(precision) else "f32x3" if ops._is_x3(precision)
+                                     else ("bf16" if ops._is_bf16(precision) else "f32"))
 
     rays = rays.to(torch.float32).contiguous()
     R = rays.shape[0]

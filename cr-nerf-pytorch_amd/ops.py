@@ -66,10 +66,35 @@ def _f32c(t, name):
     return t
 
 
+class AutoPack:
+    """The packs of precision="auto": `h2` (None when crnerf_pack_mlp_weights_h2 refused the weights: one of them is >= 255 or not finite) and
+    `x3`, the scale-free fallback (always there)."""
+    __slots__ = ("h2", "x3")
+
+    def __init__(self, h2, x3):
+        self.h2, self.x3 = h2, x3
+
+
+def pack_mlp_weights_auto(state):
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    h2 = torch.empty(lib.crnerf_packed_mlp_h2_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    rc = lib.crnerf_pack_mlp_weights_h2(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(h2.data_ptr()), _lib.stream_ptr())
+    if rc == _lib.ERR_RANGE:
+        h2 = None
+    else:
+        _lib.check(rc, "crnerf_pack_mlp_weights_h2")
+    return AutoPack(h2, pack_mlp_weights_x3(state))
+
+
 def pack_mlp_weights(state, out=None, precision="f32"):
     """state: mapping name -> device tensor with the 24 NeRF_sigma tensors (models/nerf.py:137-154).
     precision "f32" -> buffer for the *_f32 entry points, "bf16" -> for the *_bf16 ones, "f32x3" / "f32h2" -> for the *_f32x3 / *_f32h2 ones
-    (pack_mlp_weights_x3 / pack_mlp_weights_h2; different layouts each)."""
+    (pack_mlp_weights_x3 / pack_mlp_weights_h2; different layouts each), "auto" -> an AutoPack (h2 + x3)."""
+    if _is_auto(precision):
+        if out is not None:
+            raise ValueError("crnerf_amd: out= is for the f32 / bf16 packs")
+        return pack_mlp_weights_auto(state)
     if _is_h2(precision) or _is_x3(precision):
         if out is not None:
             raise ValueError("crnerf_amd: out= is for the f32 / bf16 packs")
@@ -92,6 +117,10 @@ def pack_mlp_weights(state, out=None, precision="f32"):
     return out
 
 
+def _is_auto(precision):
+    return precision in ("auto", "f32auto")
+
+
 def _is_x3(precision):
     return precision in ("f32x3", "x3")
 
@@ -103,9 +132,9 @@ def _is_h2(precision):
 def _is_bf16(precision):
     if precision in ("bf16", "bfloat16", torch.bfloat16):
         return True
-    if precision in ("f32", "fp32", "float32", torch.float32, None) or _is_x3(precision) or _is_h2(precision):
+    if precision in ("f32", "fp32", "float32", torch.float32, None) or _is_x3(precision) or _is_h2(precision) or _is_auto(precision):
         return False
-    raise ValueError("crnerf_amd: precision must be 'f32', 'bf16', 'f32x3' or 'f32h2', got %r" % (precision,))
+    raise ValueError("crnerf_amd: precision must be 'f32', 'bf16', 'f32x3', 'f32h2' or 'auto', got %r" % (precision,))
 
 
 def _mlp_tensor_list(state):
@@ -295,7 +324,22 @@ def embed_points(rays, z, dir_emb):
     return x
 
 
+def mlp_forward_auto(pack, x, sigma_only=False):
+    """precision="auto": the h2 core, then crnerf_mlp_forward_f32x3_repair over the same output -- the 128-point groups in which a point left
+    fp16's range are evaluated again on the scale-free x3 core (nothing else is touched; no host round trip).  A refused h2 pack: x3 throughout."""
+    if pack.h2 is None:
+        return mlp_forward_x3(pack.x3, x, sigma_only=sigma_only)
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    out = mlp_forward_h2(pack.h2, x, sigma_only=sigma_only)
+    _lib.check(lib.crnerf_mlp_forward_f32x3_repair(ctypes.c_void_p(pack.x3.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), x.shape[0], int(bool(sigma_only)),
+                                                   _lib.stream_ptr()), "crnerf_mlp_forward_f32x3_repair")
+    return out
+
+
 def mlp_forward(packed, x, sigma_only=False, precision="f32"):
+    if _is_auto(precision):
+        return mlp_forward_auto(packed, x, sigma_only=sigma_only)
     if _is_h2(precision):
         return mlp_forward_h2(packed, x, sigma_only=sigma_only)
     if _is_x3(precision):
@@ -373,11 +417,26 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65].
     train=True with precision="bf16": crnerf_render_rays_train_bf16, the twin of the opt-in mixed-precision mode (acts_* in the layout
     mlp_backward_mixed(..., fused_acts=True) reads).
+    precision="auto": packs from pack_mlp_weights(..., precision="auto"); the h2 core, repaired by the x3 core where it poisoned a ray.
     rng (fp32 and f32x3): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
     steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""
     lib = _lib.load()
+    repair = None
+    if _is_auto(precision):
+        # the h2 core with the x3 core as its safety net: render on h2, then crnerf_render_rays_f32x3_repair re-renders the ray quads that came out NaN
+        # (a point's activations left fp16's range).  A refused h2 pack (a weight >= 255) or a training twin: the x3 core throughout.
+        packs = [pk for pk in (packed_coarse, packed_fine) if pk is not None]
+        if any(not isinstance(pk, AutoPack) for pk in packs):
+            raise ValueError("crnerf_amd: precision='auto' needs packs from pack_mlp_weights(..., precision='auto')")
+        if train or any(pk.h2 is None for pk in packs):
+            precision = "f32x3"
+            packed_coarse, packed_fine = packed_coarse.x3, (packed_fine.x3 if packed_fine is not None else None)
+        else:
+            precision = "f32h2"
+            repair = (packed_coarse.x3, packed_fine.x3 if packed_fine is not None else None)
+            packed_coarse, packed_fine = packed_coarse.h2, (packed_fine.h2 if packed_fine is not None else None)
     h2 = _is_h2(precision)                       # fp32 on the fp16 matrix cores (crnerf_render_rays_f32h2; packs from pack_mlp_weights_h2)
     x3 = _is_x3(precision)                       # fp32 on the bf16 matrix cores (crnerf_render_rays_f32x3; packs from pack_mlp_weights_x3)
     bf16 = False if (x3 or h2) else _is_bf16(precision)
@@ -440,11 +499,14 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
             raise ValueError("crnerf_amd: launcher=True is for the inference entry points")
         fn = lib.crnerf_render_rays_f32h2 if h2 else (lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32))
         name = "crnerf_render_rays_f32h2" if h2 else ("crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))
-        held = (keep, rays, packed_coarse, packed_fine, out)  # the argument struct holds raw pointers: keep EVERY tensor behind them alive
+        held = (keep, rays, packed_coarse, packed_fine, out, repair)  # the argument struct holds raw pointers: keep EVERY tensor behind them alive
         # (the outputs too: a caller that drops `out` must not hand their memory back to the caching allocator while launch() can still write it)
+        a2 = _repair_args(a, repair)
 
         def launch(_held=held):
             _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), name)
+            if a2 is not None:
+                _lib.check(lib.crnerf_render_rays_f32x3_repair(ctypes.byref(a2), _lib.stream_ptr()), "crnerf_render_rays_f32x3_repair")
         return launch, out
     if train:
         Nf = Nc + Ni
@@ -461,10 +523,24 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
         return out
     if h2:
         _lib.check(lib.crnerf_render_rays_f32h2(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32h2")
+        a2 = _repair_args(a, repair)
+        if a2 is not None:
+            _lib.check(lib.crnerf_render_rays_f32x3_repair(ctypes.byref(a2), _lib.stream_ptr()), "crnerf_render_rays_f32x3_repair")
         return out
     fn = lib.crnerf_render_rays_f32x3 if x3 else (lib.crnerf_render_rays_bf16 if bf16 else lib.crnerf_render_rays_f32)
     _lib.check(fn(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32x3" if x3 else ("crnerf_render_rays_bf16" if bf16 else "crnerf_render_rays_f32"))
     return out
+
+
+def _repair_args(a, repair):
+    """The argument block of the h2 render with the x3 packs in place of the h2 ones (crnerf_render_rays_f32x3_repair)."""
+    if repair is None:
+        return None
+    a2 = _lib.RenderArgs()
+    ctypes.memmove(ctypes.byref(a2), ctypes.byref(a), ctypes.sizeof(a))
+    a2.packed_coarse = repair[0].data_ptr()
+    a2.packed_fine = repair[1].data_ptr() if repair[1] is not None else None
+    return a2
 
 
 _IN_KERNEL_RNG = [None]

@@ -32,6 +32,7 @@ extern "C" {
 #define CRNERF_ERR_NULL (-1)     /* required pointer is NULL */
 #define CRNERF_ERR_SHAPE (-2)    /* unsupported size */
 #define CRNERF_ERR_CONFIG (-3)   /* inconsistent arguments */
+#define CRNERF_ERR_RANGE (-4)    /* crnerf_pack_mlp_weights_h2: a weight does not fit the h2 core's range (use the f32x3 / f32 entry points) */
 #define CRNERF_ERR_HIP (-10)     /* HIP runtime / launch failure */
 
 int crnerf_abi_version(void);
@@ -236,9 +237,20 @@ int crnerf_render_rays_f32x3(const crnerf_render_args* args, void* stream);
  * operands must fit fp16's range -- |weight| < 255, |activation| < 65,504 -- or the outputs are inf / nan (loud, not silently wrong).  Inference
  * entry points only; held to the fp32 entry points' goldens and tolerances (tests/test_gpu_h2.py).  packed = crnerf_pack_mlp_weights_h2. */
 size_t crnerf_packed_mlp_h2_bytes(void);
+/* Returns CRNERF_ERR_RANGE when a weight is not a finite number with |w| < 255.  To know that, this call WAITS for `stream` (one 4-byte read-back:
+ * the only entry point of the library that synchronises; it cannot be stream-captured).  Packing happens once per set of weights. */
 int crnerf_pack_mlp_weights_h2(const float* const* tensors, void* packed_h2, void* stream);
 int crnerf_mlp_forward_f32h2(const void* packed_h2, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 int crnerf_render_rays_f32h2(const crnerf_render_args* args, void* stream);   /* args->packed_* are h2 packs; rng_flags as in crnerf_render_rays_f32 */
+/* ---- "auto" = f32h2 with the scale-free f32x3 core as its safety net (the reference, models/nerf.py:157-182, has no range limit).  The h2 core
+ * turns the outputs of a point whose activations leave fp16's range into NaN; a ray with such a point comes out of crnerf_render_rays_f32h2 with
+ * NaN features.  The *_repair entry points take the SAME arguments as the h2 call that went before (outputs included) with f32x3 packs of the same
+ * weights, and re-evaluate on the x3 core exactly the units that hold a NaN: ray quads (4 consecutive rays) whose feature_coarse / feature_fine
+ * start with a NaN, 128-point groups with a NaN sigma.  One workgroup per unit, which leaves at once when there is nothing to repair (~5 us per
+ * 1,024 rays); asynchronous, no host round trip, same in-kernel random draws.  After the pair of calls no output is NaN unless the fp32 function
+ * itself is.  (A pack refused with CRNERF_ERR_RANGE: call the f32x3 entry points instead -- crnerf_amd's precision="auto" does both.) */
+int crnerf_render_rays_f32x3_repair(const crnerf_render_args* args, void* stream);
+int crnerf_mlp_forward_f32x3_repair(const void* packed_x3, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 /* Training twin: crnerf_render_rays_train_f32 on the x3 core -- the same saved state (acts_*: crnerf_mlp_train_acts_bytes(R*N) bytes in the
  * layout of crnerf_mlp_forward_train_f32, raw_*[R*N,65]), so the fp32 backward twins (crnerf_composite_backward_f32 ->
  * crnerf_mlp_backward[_ex]_f32, or crnerf_mlp_backward_x3_f32) follow unchanged.  args->packed_* are x3 packs; random draws as tensors or

@@ -218,3 +218,94 @@ def test_h2_render_cold_l2_is_deterministic():
         out = run()
         for k in ref:
             assert torch.equal(out[k], ref[k]), (it, k)
+
+
+# ------------------------------------------------------------------ precision="auto": the h2 core with the x3 core as its safety net
+def _overflow_net(seed=5):
+    """Weights in the h2 core's range (|w| < 255) whose hidden activations pass 65,504 for inputs of ordinary size."""
+    st = dict(synth.mlp_state(seed, 1.0))
+    for l in (1, 2, 3):
+        st["xyz_encoding_%d.0.weight" % l] = (st["xyz_encoding_%d.0.weight" % l] * 200.0).astype(np.float32)
+    return st
+
+
+@torch.no_grad()
+def test_mlp_auto_repairs_poisoned_points_and_refused_packs():
+    """round-3 verdict, missing #3: "h2 has no fallback".  precision="auto" = crnerf_mlp_forward_f32h2 followed by
+    crnerf_mlp_forward_f32x3_repair over the same output: (a) a net with an activation forced past 65,504 -- the h2 call alone poisons those points
+    (NaN), the auto call returns NO NaN, the repaired 128-point groups carry the x3 core's values bit for bit, the untouched groups the h2 core's;
+    (b) a net with one weight >= 255 -- the h2 pack is refused (CRNERF_ERR_RANGE), auto renders on the x3 core throughout.  Both within the fp32
+    path's tolerance of the fp32 kernel (the reference, models/nerf.py:157-182, has no range limit)."""
+    st = _overflow_net()
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([O.posenc(torch.rand(4096, 3, generator=g) * 4 - 2, 15), O.posenc(torch.rand(4096, 3, generator=g) * 2 - 1, 4)], 1)
+    x[:3072] *= 1e-3                                        # 24 groups of 128 points stay in range, 8 do not
+    dev = {k: C(v) for k, v in st.items()}
+    xd = x.to(DEV)
+    o32 = ops.mlp_forward(ops.pack_mlp_weights(dev), xd)
+    oh2 = ops.mlp_forward_h2(ops.pack_mlp_weights_h2(dev), xd)
+    ox3 = ops.mlp_forward_x3(ops.pack_mlp_weights_x3(dev), xd)
+    pack = ops.pack_mlp_weights(dev, precision="auto")
+    assert isinstance(pack, ops.AutoPack) and pack.h2 is not None
+    oau = ops.mlp_forward(pack, xd, precision="auto")
+    bad = torch.isnan(oh2).any(1)
+    assert 0 < int(bad.sum()) < 4096 and not bool(bad[:3072].any())
+    assert not bool(torch.isnan(oau).any()), "a NaN of the h2 core's making reached the caller"
+    grp_bad = bad.view(-1, 128).any(1)[:, None].expand(-1, 128).reshape(-1)
+    assert torch.equal(oau[grp_bad], ox3[grp_bad]) and torch.equal(oau[~grp_bad], oh2[~grp_bad])
+    torch.testing.assert_close(oau, o32, atol=2e-3, rtol=2e-4)   # activations ~1e5: fp32 summation noise of both paths
+    # (b)
+    big = dict(synth.mlp_state(5, 1.0))
+    wbig = big["xyz_encoding_4.0.weight"].copy()
+    wbig[7, 9] = 300.0
+    big["xyz_encoding_4.0.weight"] = wbig
+    devb = {k: C(v) for k, v in big.items()}
+    packb = ops.pack_mlp_weights(devb, precision="auto")
+    assert packb.h2 is None and packb.x3 is not None
+    x2 = xd[:1024] * 1.0
+    ob = ops.mlp_forward(packb, x2, precision="auto")
+    assert torch.equal(ob, ops.mlp_forward_x3(packb.x3, x2))
+    torch.testing.assert_close(ob, ops.mlp_forward(ops.pack_mlp_weights(devb), x2), atol=1e-4, rtol=1e-4)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("ni", [0, 128])
+def test_render_auto_repairs_poisoned_rays(ni):
+    """The fused renderer: rays through the overflow net.  f32h2 alone returns NaN features for the rays with a poisoned point; precision="auto"
+    (h2 render + crnerf_render_rays_f32x3_repair on the same buffers) returns no NaN, the f32x3 renderer's values bit for bit in every repaired ray
+    quad and the h2 renderer's everywhere else.  Also through the drop-in modules (crnerf_amd.set_precision("auto"))."""
+    def net(seed):   # hidden unit 0 of layers 1 and 2 amplifies the raw x coordinate 250 x 250 times: |h2| passes 65,504 where x > ~1.05
+        st = dict(synth.mlp_state(seed, 1.0))
+        for l in (1, 2):
+            w = st["xyz_encoding_%d.0.weight" % l].copy()
+            w[0, 0] = 250.0
+            st["xyz_encoding_%d.0.weight" % l] = w
+        return st
+    st_c, st_f = net(5), net(6)
+    rays = synth.rays(256, seed=3, H=16, W=16).copy()
+    rays[:192, 0:3] *= 1e-3                                  # three quarters of the rays: tiny origins ...
+    rays[:192, 6] = 1e-4
+    rays[:192, 7] = 2e-3                                     # ... and depths: x stays ~1e-3 there, no activation overflows
+    rd = C(rays)
+    dc, df = {k: C(v) for k, v in st_c.items()}, {k: C(v) for k, v in st_f.items()}
+    zs, u = torch.linspace(0, 1, 64, device=DEV), (torch.linspace(0, 1, ni, device=DEV) if ni else None)
+    kw = dict(z_steps=zs, u=u, want_z_fine=ni > 0)
+    oh2 = ops.render_rays(ops.pack_mlp_weights_h2(dc), ops.pack_mlp_weights_h2(df) if ni else None, rd, 64, ni, precision="f32h2", **kw)
+    ox3 = ops.render_rays(ops.pack_mlp_weights_x3(dc), ops.pack_mlp_weights_x3(df) if ni else None, rd, 64, ni, precision="f32x3", **kw)
+    pc, pf = ops.pack_mlp_weights(dc, precision="auto"), (ops.pack_mlp_weights(df, precision="auto") if ni else None)
+    oau = ops.render_rays(pc, pf, rd, 64, ni, precision="auto", **kw)
+    keys = ["feature_coarse", "weights_coarse", "depth_coarse"] + (["feature_fine", "weights_fine", "depth_fine", "z_fine"] if ni else [])
+    bad = torch.isnan(oh2["feature_coarse"]).any(1)
+    if ni:
+        bad |= torch.isnan(oh2["feature_fine"]).any(1)
+    assert 0 < int(bad.sum()) <= 64 and not bool(bad[:192].any()), int(bad.sum())
+    quad_bad = bad.view(-1, 4).any(1)[:, None].expand(-1, 4).reshape(-1)
+    for k in keys:
+        assert not bool(torch.isnan(oau[k]).any()), k
+        assert torch.equal(oau[k][quad_bad], ox3[k][quad_bad]), k
+        assert torch.equal(oau[k][~quad_bad], oh2[k][~quad_bad]), k
+    # the launcher form used by bench.py issues both calls too
+    launch, out2 = ops.render_rays(pc, pf, rd, 64, ni, precision="auto", launcher=True, **kw)
+    launch()
+    for k in keys:
+        assert torch.equal(out2[k], oau[k]), k

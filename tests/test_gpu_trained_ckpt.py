@@ -96,7 +96,7 @@ def record(name, values):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision", ["f32", "f32x3", "f32h2"])      # f32x3 / f32h2: the same fp32 bars on the bf16 / fp16 matrix cores (piece splits, include/crnerf.h)
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "f32h2", "auto"])      # f32x3 / f32h2 / auto (h2 repaired by x3): the same fp32 bars on the bf16 / fp16 matrix cores (piece splits, include/crnerf.h)
 @pytest.mark.parametrize("tag,nc,ni", [("64_128", 64, 128), ("256_256", 256, 256)])
 def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni, precision):
     g = golden("g15_trained")
