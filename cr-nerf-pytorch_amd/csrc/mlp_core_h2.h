@@ -8,21 +8,20 @@
 // so are the biases in the pack's consts block), so an accumulator holds 2^8 x the layer's pre-activation.  Range: |activation| < 65,504 (tracked,
 // see `amax`) and |weight| < 255 (checked by the pack).
 //
-// Round-4 structure ("lazy epilogue on ping-pong accumulators"; the round-3 h2 core was mlp_core_x3.h's code with two pieces: matrix pipe busy
-// 53-56 %, 4 VALU instructions per MFMA, every layer boundary ~0.5 k VALU instructions with no MFMA in flight):
-//   * K-outer as the x3 core -- all output tiles of a layer accumulate while the contraction is walked once, stream "fragH" unchanged -- but a
-//     layer's output is NEVER finished between the layers: the raw accumulators of layer L (128 registers, in the AGPR half of the file) are the
-//     SOURCE of layer L + 1, which accumulates into the OTHER 128-register set.  The eight values of k-step s + 1 are finished while the 3 NT MFMAs
-//     of k-step s run: v_accvgpr_read, relu (fp32), range max, then the split straight into packed operand halves by v_fma_mixlo/mixhi_f16
-//     (h1 = fp16(x * 2^-8), h2 = fp16(x * 2^-8 - h1): scale, subtraction and conversion in ONE instruction each) -- ~5 VALU per value, 1.5 per MFMA,
-//     one value per tile in the MFMAs' shadow.  The operands of a layer's k-step 0 are made in the LAST k-step of the layer before it.
-//   * the registers a k-step has consumed are dead: the next layer's bias is read from LDS straight into them (they are that layer's accumulators),
-//     two ds_read_b128 per k-step -- no accumulator initialisation between layers either.
+// Round-4 structure ("lazy epilogue"; the round-3 h2 core was mlp_core_x3.h's code with two pieces: matrix pipe busy 53-56 %, 4 VALU instructions
+// per MFMA, every layer boundary ~0.5 k VALU instructions with no MFMA in flight):
+//   * K-outer as the x3 core -- all output tiles of a layer accumulate (128 registers in the AGPR half of the file) while the contraction is
+//     walked once, stream "fragH" unchanged -- but a layer's output is NEVER finished between the layers: in a layer's last k-step the third MFMA
+//     of every tile writes its result not back to the accumulator but to a 128-register RAW set in architectural VGPRs (vDst != srcC), and that
+//     set is the SOURCE of the next layer: the eight values of k-step s + 1 are finished while the 3 NT MFMAs of k-step s run -- relu (fp32), range
+//     max, then the split straight into packed operand halves by v_fma_mixlo/mixhi_f16 (h1 = fp16(x * 2^-8), h2 = fp16(x * 2^-8 - h1): scale,
+//     subtraction and conversion in ONE instruction each) -- 4 VALU per value, one value per tile in the MFMAs' shadow, no v_accvgpr_read anywhere.
+//     The operands of a layer's k-step 0 are made in the LAST k-step of the layer before it.
+//   * an accumulator tile its last MFMA has left takes the next layer's bias straight from LDS: no accumulator initialisation between layers.
 //   * the sigma head (256 -> 1, fp32 VALU) rides in xyz_encoding_final's walk of h8: one fma per finished value.
-//   * issue order is pinned with sched_barrier(0), a tile PAIR at a time (consecutive MFMAs on different accumulators: three dependent MFMAs back to
-//     back measured 47 cycles per MFMA): MFMA | finish half | MFMA | finish half | MFMA | split half | MFMA | split half | MFMA | queue refills,
-//     LDS-DMA piece, bias read | MFMA | the same -- hipcc's own schedule of the round-3 core put most fragment reads directly in front of the MFMA
-//     that consumes them.
+//   * issue order is pinned with sched_barrier(0), a tile PAIR at a time (consecutive MFMAs on different accumulators): MFMA | finish half | MFMA |
+//     finish half | MFMA | split half | MFMA | split half | MFMA | queue refills, LDS-DMA piece | MFMA | the same -- hipcc's own schedule of the
+//     round-3 core put most fragment reads directly in front of the MFMA that consumes them.
 // Weights: the seven-slot 16 KiB-stage LDS ring of xcore_pipe.h; a k-step of an eight-tile layer is exactly one stage (8 tiles x 2 pieces).
 #pragma once
 #ifndef CRNERF_X_NP
@@ -67,6 +66,16 @@ __device__ __forceinline__ void h2_split_into(xu32x4& b1, xu32x4& b2, int e, flo
   h2_split_second(b1, b2, e, x, sc);
 }
 
+// acc-layout bias of output tile T straight from LDS: element 4q + j = bias[32T + 8q + 4h + j]
+__device__ __forceinline__ void init_acc_tile(f32x16& acc, const lds_float* bias, int T, int h) {
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias + 32 * T + 8 * qq + 4 * h);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[4 * qq + k] = bv[k];
+  }
+}
+
 // what a tile carries through its layers beside the accumulators
 struct H2Carry {
   float amax;        // running max |raw activation| of this lane, scaled by 2^8 like the accumulators (range guard, see mlp_tile_x3)
@@ -76,32 +85,30 @@ struct H2Carry {
   f32x4 sw0, sw1;    // static_sigma weights of the group being finished
 };
 
-// One layer on NT output tiles (dst[0..NT)).  Its k-steps take their B operands from two parts, in the order PF says: NSP k-steps of ready-made
-// pieces pcs[.] (an embedding) and NSR k-steps of the RAW accumulators raw[.] of the layer before (group g = registers 8(g%2) .. +7 of tile g/2),
-// finished on the way: FIN 1 = relu, 2 = linear (xyz_encoding_final's output).  b: in = the operands of k-step 0, out = those of the NEXT layer's
-// k-step 0 -- made here in the last k-step from dst tile 0 (NEXT_FIN 1 / 2), copied from next0 (NEXT_FIN 0), or left alone (-1).
-// nd / nbias / NGN: the next layer's accumulators get their bias while this layer runs: group j of nd in the k-step after raw group j was consumed
-// (nd is the raw source then), or -- FREE_ND, no raw part -- spread over all k-steps.  SIG / NEXT_SIG: the finished values also feed static_sigma.
-template <int NT, bool PF, int NSP, int NSR, int FIN, int NGN, bool FREE_ND, int NEXT_FIN, bool SIG, bool NEXT_SIG, int NPC>
-__device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD], BOpH& b, const xu32x4 (&pcs)[NPC][2], f32x16 (&raw)[8], f32x16 (&dst)[8],
-                                             f32x16 (&nd)[8], const lds_float* nbias, const xu32x4 (&next0)[2], const lds_float* wsig, H2Carry& c, int h) {
+// One layer on NT output tiles.  acc[0..NT): the accumulators, holding the layer's bias on entry.  Its k-steps take their B operands from two parts, in
+// the order PF says: NSP k-steps of ready-made pieces pcs[.] (an embedding) and NSR k-steps of the RAW outputs raw[.] of the layer before (group g =
+// registers 8(g%2) .. +7 of tile g/2), finished on the way: FIN 1 = relu, 2 = linear (xyz_encoding_final's output).  In the LAST k-step the third
+// MFMA of every tile writes its result to raw[T] (by then the old raw values are all consumed) -- the raw set lives in architectural VGPRs, read by
+// the finishing VALU code directly, the accumulators in the AGPR half -- and acc[T] takes the NEXT layer's bias (NTN tiles from nbias) straight
+// from LDS.  b: in = the operands of k-step 0, out = those of the next layer's k-step 0 -- made here in the last k-step from the new raw tile 0
+// (NEXT_FIN 1 / 2), copied from next0 (NEXT_FIN 0), or left alone (-1).  SIG / NEXT_SIG: the finished values also feed static_sigma.
+template <int NT, bool PF, int NSP, int NSR, int FIN, int NTN, int NEXT_FIN, bool SIG, bool NEXT_SIG, int NPC>
+__device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD], BOpH& b, const xu32x4 (&pcs)[NPC][2], f32x16 (&raw)[8], f32x16 (&acc)[8],
+                                             const lds_float* nbias, const xu32x4 (&next0)[2], const lds_float* wsig, H2Carry& c, int h) {
   constexpr int NS = NSP + NSR;
   static_assert(NSP <= NPC && NSR <= 16 && (NS * NT * 2) % X_STAGE_FRAGS == 0 && (NS * NT * 2) % X_AHEAD == 0, "layer: whole stages, whole queue turns");
   static_assert(NT == 8 || NT == 4 || NT == 2, "tiles");
   static_assert(NT >= 4 || (NEXT_FIN <= 0 && !NEXT_SIG), "a two-tile layer has no room for the next layer's first operands");
+  static_assert(NTN <= NT, "the next layer's bias goes into this layer's accumulators");
   const float inv = H2_INV;
   // queue slot of fragment f refilled with fragment f + X_AHEAD; ring kept going (call in stream order, after the fragment's last use)
   auto refill = [&](int f) {
     const int slot = f % X_STAGE_FRAGS;
     if (slot % (X_STAGE_FRAGS / X_PIECES) == 0) p.issue_piece(slot / (X_STAGE_FRAGS / X_PIECES));
-#ifndef CRNERF_EXP_NOLDSREAD   // (timing experiments only; garbage) the fragments of the first k-step forever
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
-#else
-    asm volatile("" : "+v"(q[f % X_AHEAD]));
-#endif
     if (slot == X_STAGE_FRAGS - 1) p.advance();
   };
-  // one value of the operands being made: fetch + relu + range max (+ sigma) + first piece -- first half; the second piece -- second half
+  // one value of the operands being made: relu + range max (+ sigma) + first piece -- first half; the second piece -- second half
   auto finish_a = [&](BOpH& o, float v, int fin, bool sig, int e, float& xr) {
     xr = fin == 1 ? fmaxf(v, 0.0f) : v;
     // (volatile asm: nothing reads amax / sg before the end of the tile, and hipcc otherwise SINKS these updates there -- with every finished value
@@ -134,55 +141,29 @@ __device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD
       nb.b1 = next0[0];
       nb.b2 = next0[1];
     }
-    // the raw group this k-step itself runs on has been consumed (by the chunks of k-step s - 1): its registers take the next layer's bias
-    const bool sraw = PF ? s >= NSP : s < NSR;
-    const int sg_ = PF ? s - NSP : s;
-    // which tile carries value e's chunk: in the last k-step the chunks read dst tile 0, whose last MFMA is issued with the first tile PAIR
+    // which tile carries value e's chunk: in the last k-step the chunks read the new raw tile 0, whose MFMA is issued with the first tile PAIR
     auto chunk_tile = [&](int e) { return last ? 2 + e * (NT - 2) / 8 : e * NT / 8; };
     auto chunks_a = [&](int T, float (&xr)[8]) {
-#ifdef CRNERF_EXP_NOCHUNKS   // (timing experiments only; garbage) the layer walk without the finishing work
-      return;
-#endif
       if (cfin) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (chunk_tile(e) == T) finish_a(nb, last ? dst[0][e] : raw[ng >> 1][8 * (ng & 1) + e], cfin, csig, e, xr[e]);
+          if (chunk_tile(e) == T) finish_a(nb, last ? raw[0][e] : raw[ng >> 1][8 * (ng & 1) + e], cfin, csig, e, xr[e]);
       }
     };
     auto chunks_b = [&](int T, const float (&xr)[8]) {
-#ifdef CRNERF_EXP_NOCHUNKS
-      return;
-#endif
       if (cfin) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (chunk_tile(e) == T) finish_b(nb, e, xr[e]);
       }
     };
-    // behind a tile's last MFMA: its two queue slots refilled (+ the ring's work), one bias read, and -- last tile -- the static_sigma weights of the
-    // group the NEXT k-step's chunks finish (features 32 (g/2) + 16 (g%2) + 8 (e>>2) + 4h + (e&3))
+    // behind a tile's last MFMA: its two queue slots refilled (+ the ring's work); last k-step: the next layer's bias into the accumulator the MFMA
+    // has just left; last tile: the static_sigma weights of the group the NEXT k-step's chunks finish (features 32 (g/2) + 16 (g%2) + 8 (e>>2) + 4h + (e&3))
     auto tail_gap = [&](int T) {
       const int f = (s * NT + T) * 2;
       refill(f);
       refill(f + 1);
-      if (NGN > 0) {
-        if (FREE_ND) {
-#pragma unroll
-          for (int i = 0; i < 2 * ((NGN + NS - 1) / NS); ++i) {
-            const int j = s + NS * (i >> 1), qq = 2 * (j & 1) + (i & 1);
-            if (i % NT == T && j < NGN) {
-              const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(nbias + 32 * (j >> 1) + 8 * qq + 4 * h);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) nd[j >> 1][4 * qq + k] = bv[k];
-            }
-          }
-        } else if (sraw && sg_ < NGN && T < 2) {
-          const int j = sg_, qq = 2 * (j & 1) + T;
-          const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(nbias + 32 * (j >> 1) + 8 * qq + 4 * h);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) nd[j >> 1][4 * qq + k] = bv[k];
-        }
-      }
+      if (last && T < NTN) init_acc_tile(acc[T], nbias, T, h);
       if (T == NT - 1) {
         const int t = s + 1;   // the k-step whose chunks will use the weights
         const bool traw = t < NS - 1 && (PF ? t + 1 >= NSP : t + 1 < NSR);
@@ -199,27 +180,33 @@ __device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD
       const int f = (s * NT + T) * 2;
       const xu32x4 u1 = q[f % X_AHEAD], u2 = q[(f + 1) % X_AHEAD], w1 = q[(f + 2) % X_AHEAD], w2 = q[(f + 3) % X_AHEAD];
       float xa[8], xb[8];
-      dst[T] = CRNERF_MFMA_H(u2, b.b1, dst[T]);               // small terms first
+      acc[T] = CRNERF_MFMA_H(u2, b.b1, acc[T]);               // small terms first
       CRNERF_H2_PIN();
       chunks_a(T, xa);
       CRNERF_H2_PIN();
-      dst[T + 1] = CRNERF_MFMA_H(w2, b.b1, dst[T + 1]);
+      acc[T + 1] = CRNERF_MFMA_H(w2, b.b1, acc[T + 1]);
       CRNERF_H2_PIN();
       chunks_a(T + 1, xb);
       CRNERF_H2_PIN();
-      dst[T] = CRNERF_MFMA_H(u1, b.b2, dst[T]);
+      acc[T] = CRNERF_MFMA_H(u1, b.b2, acc[T]);
       CRNERF_H2_PIN();
       chunks_b(T, xa);
       CRNERF_H2_PIN();
-      dst[T + 1] = CRNERF_MFMA_H(w1, b.b2, dst[T + 1]);
+      acc[T + 1] = CRNERF_MFMA_H(w1, b.b2, acc[T + 1]);
       CRNERF_H2_PIN();
       chunks_b(T + 1, xb);
       CRNERF_H2_PIN();
-      dst[T] = CRNERF_MFMA_H(u1, b.b1, dst[T]);
+      if (last) {                                             // the layer's output leaves the accumulator file
+        raw[T] = CRNERF_MFMA_H(u1, b.b1, acc[T]);
+        asm volatile("" : "+v"(raw[T]));                      // (into architectural VGPRs: hipcc's own choice is the AGPR half + one v_accvgpr_read per value)
+      } else acc[T] = CRNERF_MFMA_H(u1, b.b1, acc[T]);
       CRNERF_H2_PIN();
       tail_gap(T);
       CRNERF_H2_PIN();
-      dst[T + 1] = CRNERF_MFMA_H(w1, b.b1, dst[T + 1]);
+      if (last) {
+        raw[T + 1] = CRNERF_MFMA_H(w1, b.b1, acc[T + 1]);
+        asm volatile("" : "+v"(raw[T + 1]));
+      } else acc[T + 1] = CRNERF_MFMA_H(w1, b.b1, acc[T + 1]);
       CRNERF_H2_PIN();
       tail_gap(T + 1);
       CRNERF_H2_PIN();
@@ -239,7 +226,7 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
   const lds_float* B1 = C + C_BIAS;
   const lds_float* WS = C + C_WSIG;
-  f32x16 A[8], B[8];
+  f32x16 X[8], R[8];   // X: the accumulators (AGPR half of the register file); R: the raw output of the layer before (architectural VGPRs)
   H2Carry c;
   c.amax = 0.0f;
   c.emax = 0.0f;
@@ -263,38 +250,43 @@ __device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32
       c.emax = fmaxf(c.emax, fabsf(v));
       h2_split_into(dvp[s][0], dvp[s][1], e, v, 1.0f);
     }
-  init_acc<8>(A, B1, h);                                   // xyz_encoding_1's bias (the pack's consts carry the 2^8)
+  // the embedding operands are read by MFMAs only: they live in the AGPR half, next to the accumulators, and leave the VGPRs to the raw set
+#pragma unroll
+  for (int s = 0; s < KS_XYZ; ++s) asm volatile("" : "+a"(pep[s][0]), "+a"(pep[s][1]));
+#pragma unroll
+  for (int s = 0; s < KS_DIR; ++s) asm volatile("" : "+a"(dvp[s][0]), "+a"(dvp[s][1]));
+  init_acc<8>(X, B1, h);                                   // xyz_encoding_1's bias (the pack's consts carry the 2^8)
   BOpH b{pep[0][0], pep[0][1]};
   tm.tick(T_PROLOGUE);
 
-  // layer            NT  PF     NSP     NSR     FIN NGN FREE   NEXT_FIN SIG    NEXT_SIG    pieces raw dst next-dst next-bias      next0   wsig
-  mma_layer_h2<8, true, KS_XYZ, 0, 0, 16, true, 1, false, false>(p, q, b, pep, B, A, B, B1 + 1 * W_HIDDEN, pep[0], WS, c, h);           // xyz_encoding_1
+  // layer     NT  PF    NSP     NSR     FIN NTN NEXT_FIN SIG    NEXT_SIG                       next bias          next0   wsig
+  mma_layer_h2<8, true, KS_XYZ, 0, 0, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 1 * W_HIDDEN, pep[0], WS, c, h);          // xyz_encoding_1
   tm.tick(T_X0);
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 1, false, false>(p, q, b, pep, A, B, A, B1 + 2 * W_HIDDEN, pep[0], WS, c, h);          // 2
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 1, false, false>(p, q, b, pep, B, A, B, B1 + 3 * W_HIDDEN, pep[0], WS, c, h);          // 3
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 0, false, false>(p, q, b, pep, A, B, A, B1 + 4 * W_HIDDEN, pep[0], WS, c, h);          // 4 (5 starts on the embedding)
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 2 * W_HIDDEN, pep[0], WS, c, h);          // 2
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 3 * W_HIDDEN, pep[0], WS, c, h);          // 3
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 0, false, false>(p, q, b, pep, R, X, B1 + 4 * W_HIDDEN, pep[0], WS, c, h);          // 4 (5 starts on the embedding)
   tm.tick(T_X1);
-  mma_layer_h2<8, true, KS_XYZ, KS_HID, 1, 16, false, 1, false, false>(p, q, b, pep, B, A, B, B1 + 5 * W_HIDDEN, pep[0], WS, c, h);     // 5 = Linear(cat[xyz, h])
+  mma_layer_h2<8, true, KS_XYZ, KS_HID, 1, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 5 * W_HIDDEN, pep[0], WS, c, h);     // 5 = Linear(cat[xyz, h])
   tm.tick(T_X2);
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 1, false, false>(p, q, b, pep, A, B, A, B1 + 6 * W_HIDDEN, pep[0], WS, c, h);          // 6
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 1, false, false>(p, q, b, pep, B, A, B, B1 + 7 * W_HIDDEN, pep[0], WS, c, h);          // 7
-  mma_layer_h2<8, true, 0, KS_HID, 1, 16, false, 1, false, true>(p, q, b, pep, A, B, A, C + C_BFIN, pep[0], WS, c, h);                  // 8 (its tail starts static_sigma)
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 6 * W_HIDDEN, pep[0], WS, c, h);          // 6
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 1, false, false>(p, q, b, pep, R, X, B1 + 7 * W_HIDDEN, pep[0], WS, c, h);          // 7
+  mma_layer_h2<8, true, 0, KS_HID, 1, 8, 1, false, true>(p, q, b, pep, R, X, C + C_BFIN, pep[0], WS, c, h);                  // 8 (its tail starts static_sigma)
   tm.tick(T_X3);
-  mma_layer_h2<8, true, 0, KS_HID, 1, 8, false, 2, true, false>(p, q, b, pep, B, A, B, C + C_BDIR, pep[0], WS, c, h);                   // xyz_encoding_final (+ static_sigma on h8)
+  mma_layer_h2<8, true, 0, KS_HID, 1, 4, 2, true, false>(p, q, b, pep, R, X, C + C_BDIR, pep[0], WS, c, h);                  // xyz_encoding_final (+ static_sigma on h8)
   tm.tick(T_X4);
   {
     const float s = c.sg + __shfl_xor(c.sg, 32);
     sigma = softplus_ref(s * H2_INV + C[C_BSIG]);
   }
   tm.tick(T_SIGMA);
-  mma_layer_h2<4, false, KS_DIR, KS_HID, 2, 4, false, 1, false, false>(p, q, b, dvp, A, B, A, C + C_BRGB, pep[0], WS, c, h);            // dir_encoding = relu(Linear(cat[final, dir]))
+  mma_layer_h2<4, false, KS_DIR, KS_HID, 2, 2, 1, false, false>(p, q, b, dvp, R, X, C + C_BRGB, pep[0], WS, c, h);           // dir_encoding = relu(Linear(cat[final, dir]))
   tm.tick(T_X5);
-  mma_layer_h2<2, true, 0, KS_HALF, 1, 0, false, -1, false, false>(p, q, b, pep, B, A, A, C + C_BRGB, pep[0], WS, c, h);                // static_rgb
+  mma_layer_h2<2, true, 0, KS_HALF, 1, 0, -1, false, false>(p, q, b, pep, R, X, C + C_BRGB, pep[0], WS, c, h);               // static_rgb
   tm.tick(T_X6);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(A[t][r] * H2_INV);
+    for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(R[t][r] * H2_INV);
   {   // an operand left fp16's range somewhere in this point's MLP: NaN out, not a finite wrong answer (amax of the raw values is scaled by 2^8)
     float am = fmaxf(c.amax, c.emax * H2_WSCALE);
     am = fmaxf(am, __shfl_xor(am, 32));

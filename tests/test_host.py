@@ -176,7 +176,9 @@ def test_kernels_with_asm_lds_dma_do_not_use_m0_indexing(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "cr-nerf-pytorch_amd", "csrc")
-    units = ["render_fused16.hip", "mlp_forward16.hip", "mlp_train16.hip", "render_fused_bf16.hip", "mlp_forward_bf16.hip"]
+    # (the x3 / h2 units too: xcore_pipe.h's pieces 1..3 of a stage reuse the M0 piece 0 wrote, any number of instructions apart)
+    units = ["render_fused16.hip", "mlp_forward16.hip", "mlp_train16.hip", "render_fused_bf16.hip", "mlp_forward_bf16.hip", "render_fused_x3.hip",
+             "render_fused_h2.hip", "mlp_backward_x3.hip"]
     procs = [(u, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-S",
                                    "--cuda-device-only", "-I", csrc, os.path.join(csrc, u), "-o", str(tmp_path / (u + ".s"))],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)) for u in units]
@@ -187,6 +189,15 @@ def test_kernels_with_asm_lds_dma_do_not_use_m0_indexing(tmp_path):
         assert "global_load_lds_dwordx4" in isa, u
         for bad in ("s_set_gpr_idx", "v_movrel"):
             assert bad not in isa, "%s: %s found -- a dynamic register index would collide with the LDS-DMA asm's use of M0" % (u, bad)
+        in_asm, outside = False, []
+        for line in isa.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and "m0" in line.split(";")[0].replace("vm0", ""):
+                outside.append(line)
+        assert not outside, "%s: the compiler itself touches M0: %s" % (u, outside[:3])
 
 
 def test_parameter_caches_follow_replaced_parameters():
