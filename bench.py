@@ -55,9 +55,15 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank renders its own --rays batch.  strong: ONE unit of --workload is "
                          "split over the ranks (the configs BASELINE.json names for 8 GPUs)")
-    ap.add_argument("--workload", choices=["configs2", "configs3"], default="configs2",
+    ap.add_argument("--workload", choices=["configs2", "configs3", "configs4"], default="configs2",
                     help="--scaling strong only.  configs2: one 800x800 frame, 64+128, cross-ray decoder on, --precision (default there: bf16); "
-                         "configs3: one 65,536-ray training batch with grid-sample masking (fwd + bwd + Adam, exact fp32)")
+                         "configs3: one 65,536-ray training batch with grid-sample masking (fwd + bwd + Adam, exact fp32); "
+                         "configs4: the appearance-hallucination fly-through -- --frames frames of 320x240 at --samples, style-image conditioned, "
+                         "poses and rays made on the device, --video-split frames (no collective) or rays (decoder exchange per frame)")
+    ap.add_argument("--frames", type=int, default=240, help="--workload configs4: frames of the fly-through (the script's 30 fps x 8 s; BASELINE says 120)")
+    ap.add_argument("--samples", default="256+256", help="--workload configs4: N_samples+N_importance (the script's default 256+256; 64+128 = the training setting)")
+    ap.add_argument("--video-split", choices=["frames", "rays"], default="frames",
+                    help="--workload configs4: what the ranks split -- whole frames round-robin (no data-path collective) or every frame's rays")
     ap.add_argument("--frame", default="800x800", help="--workload configs2: frame size HxW")
     ap.add_argument("--train-rays", type=int, default=65536, help="--workload configs3: rays of the ONE batch that is split over the ranks")
     ap.add_argument("--peer-exchange", action="store_true",
@@ -354,6 +360,23 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
                                       "subnormals.  NOT scale-free: |w| < 255 is checked when packing, an activation >= 65,504 turns its point's outputs into NaN "
                                       "(tests/test_gpu_h2.py).  Meets the same fp32 goldens / SURVEY 8d bars and sits at the fp32 MFMA's distance from float64")
 
+    # "auto" = the h2 launch + the x3 repair launch that finds nothing to repair on these weights: what the safety net costs
+    with torch.no_grad():
+        pca, pfa = ops.pack_mlp_weights(to_dev(st_c), precision="auto"), ops.pack_mlp_weights(to_dev(st_f), precision="auto")
+        launcha, _ = ops.render_rays(pca, pfa, rays, NC, NI, z_steps=z_steps, u=u_steps, precision="auto", launcher=True)
+        for _ in range(5):
+            launcha()
+        e6, e7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e6.record()
+        for _ in range(n):
+            launcha()
+        e7.record()
+        torch.cuda.synchronize()
+    extra["auto_kernels"] = {"kernels": "render_rays_h2_kernel + render_rays_x3_kernel (repair: one workgroup per ray quad, all of them leave at once)",
+                             "kernel_ms": e6.elapsed_time(e7) / n, "f32h2_alone_ms": extra["f32h2_kernel"]["kernel_ms"],
+                             "note": "precision='auto' (include/crnerf.h): f32h2 with the scale-free f32x3 core as its safety net -- no NaN of the h2 core's making "
+                                     "reaches the caller (tests/test_gpu_h2.py::test_render_auto_repairs_poisoned_rays)"}
+
     def timed(fn, reps):
         fn()
         torch.cuda.synchronize()
@@ -384,7 +407,7 @@ def evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps
     K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]])
     c2w = np.array([[1, 0, 0, 0.05], [0, -1, 0, 0.02], [0, 0, -1, 0.1]], dtype=np.float32)
     photo = torch.rand(1, 3, 100, 100, device=dev)
-    for prec, reps in (("bf16", 3), ("f32h2", 2), ("f32x3", 2), ("f32", 1)):
+    for prec, reps in (("bf16", 3), ("bf16_hc", 2), ("auto", 2), ("f32h2", 2), ("f32x3", 2), ("f32", 1)):
         t = timed(lambda: pipeline.render_frame(m, emb, enc, photo, 800, 800, K, c2w, hp, chunk=32768, precision=prec), reps)
         extra["configs2_full_image_%s" % prec] = {"rays_per_s": 640000 / t, "ms_per_frame": t * 1e3, "tflops": FLOP_PER_POINT * (NC + NC + NI) * 640000 / t / 1e12,
                                                   "workload": "800x800 rays in 32,768-ray chunks x (64+128), appearance encoder + on-device rays + "
@@ -491,6 +514,81 @@ def strong_configs2(a, dev, world, rank, use_dist, dist, exchange):
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "traffic_source": None, "kernel_ms": render_ms,
                          "flops_per_launch": issued * flops_local, "note": "rank 0's render chunks of one frame (HIP events around the chunk loop)"},
             "image_checksum": float(last.double().sum())}
+
+
+def strong_configs4(a, dev, world, rank, use_dist, dist, exchange):
+    """BASELINE configs[4]: the appearance-hallucination video path (appearance_modification_video.py:121-189 poses, :224-262 frame loop) --
+    ONE fly-through of --frames frames of 320x240 at --samples, the style image encoded once, every frame = camera pose -> rays on the device ->
+    render_rays_cross_ray -> cross-ray decode -> uint8.  The unit that is split over the ranks: --video-split frames = frames rank, rank + N, ...
+    (independent: no collective on the data path, SURVEY 8e "video"), rays = every frame's pixel rows in contiguous blocks (the decoder's two
+    all-reduces + the RGB all-gather per frame).  value = rays of the WHOLE fly-through per second."""
+    import numpy as np
+    import crnerf_amd.synth as synth
+    from crnerf_amd import parallel, pipeline, video
+    nc, ni = (int(v) for v in a.samples.split("+"))
+    prec = a.precision
+    W, H = 320, 240
+
+    class HP:
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance = [W, H], nc, ni
+    hp = HP()
+    with torch.no_grad():
+        m, emb = pipeline.get_model(hp, dev), pipeline.get_embeddings(hp)
+        m["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 3.0, 1.0).items()})
+        m["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 3.0, 1.0).items()})
+        m["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+        enc = pipeline.encoder_sameoutputsize(64).to(dev)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+        style = torch.rand(1, 3, H // 4, W // 4, generator=torch.Generator().manual_seed(0)).to(dev)
+        K, poses = video.define_camera(hp.img_wh), video.define_poses("brandenburg_gate", a.frames).astype(np.float32)
+        by_rays = a.video_split == "rays" and world > 1
+        lo, hi = parallel.shard_bounds(H * W, world, rank) if by_rays else (0, H * W)
+        mine = range(a.frames) if by_rays else range(rank, a.frames, world)
+        ev = []
+
+        def step():
+            a_emb = enc(style)                                   # once per style image (appearance_modification_video.py:239)
+            checksum = torch.zeros((), dtype=torch.float64, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            render_ms = 0.0
+            for i in mine:
+                rays = pipeline.generate_rays(H, W, K, poses[i], 0.0, 5.0, device=dev)[lo:hi]
+                res = pipeline.batched_inference(m, emb, rays, None, nc, ni, False, 76800, False, args=hp, a_embedded_from_img=a_emb, precision=prec)
+                if by_rays:
+                    rgb = parallel.decode_sharded(m["decoder"], res["feature_fine"], a_emb, gather=True, equal_shards=((H * W) % world == 0),
+                                                  exchange=exchange, check_exchange=False)
+                    img = rgb.reshape(3, H * W).t().reshape(H, W, 3)
+                else:
+                    img = pipeline.decode_image(m, res, H, W, a_emb).reshape(H, W, 3)
+                frame = (img.clamp(0, 1) * 255).to(torch.uint8)  # what the script writes out (:255-262); stays on the device here
+                checksum += frame.double().sum()
+            return checksum
+
+        dt, last = timed_steps(a, step, use_dist, dist, dev)
+        total = last.clone()
+        if use_dist and not by_rays:
+            dist.all_reduce(total)                               # (untimed) the whole fly-through's checksum: every rank holds only its frames
+    R = a.frames * H * W
+    pts = (nc + nc + ni)
+    flops_local = FLOP_PER_POINT * pts * len(mine) * (hi - lo)
+    peak = PEAK_BF16_MFMA_TFLOPS if prec in ("bf16", "f32x3", "f32h2") else PEAK_F32_MFMA_TFLOPS
+    issued = {"f32x3": 6.0 * 7296.0 / 7248.0, "f32h2": 3.0 * 7296.0 / 7248.0}.get(prec, 1.0)
+    achieved = issued * flops_local / (dt / a.steps) / 1e12
+    kernel = {"bf16": "render_rays_bf16p_kernel", "f32x3": "render_rays_x3_kernel", "f32h2": "render_rays_h2_kernel"}.get(prec, "render_rays16_kernel")
+    return {"metric": "rays/sec (%d+%d samples, 8-layer W=256 MLP)" % (nc, ni), "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": prec,
+            "data": "synthetic", "frames_per_s": a.frames * a.steps / dt,
+            "config": {"workload": "BASELINE configs[4]: appearance-hallucination fly-through, %d frames of %dx%d x (%d coarse + %d fine), style-image "
+                                   "conditioned decoder, poses + rays made on the device, split over %d rank(s) by %s"
+                                   % (a.frames, W, H, nc, ni, world, "rays of every frame (decoder exchange per frame)" if by_rays else "whole frames (no collective)"),
+                       "rays_total": R, "frames": a.frames, "frames_this_rank": len(mine), "rays_per_frame_this_rank": hi - lo, "n_samples": nc, "n_importance": ni,
+                       "parallelism": ("every frame's rays sharded %d-way" if by_rays else "frames round-robin over %d rank(s), no data-path collective") % world,
+                       "reductions": "none" if not by_rays else ("peer windows (HIP IPC)" if exchange is not None else "RCCL all-reduce")},
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "traffic_source": None, "flops_per_launch": issued * FLOP_PER_POINT * pts * min(76800, hi - lo),
+                         "note": "this rank's share of the fly-through over the WHOLE step time (ray generation, encoder, decoder, uint8 conversion included)"},
+            "image_checksum": float(last), "frames_checksum_all_ranks": float(total)}
 
 
 def strong_configs3(a, dev, world, rank, use_dist, dist):
@@ -621,6 +719,8 @@ def main():
             if "--precision" not in sys.argv:
                 a.precision = "bf16"                 # BASELINE configs[2]: "1x MI355X bf16"
             return finish(strong_configs2(a, dev, world, rank, use_dist, dist, exchange))
+        if a.workload == "configs4":
+            return finish(strong_configs4(a, dev, world, rank, use_dist, dist, exchange))
         return finish(strong_configs3(a, dev, world, rank, use_dist, dist))
 
     R = a.rays

@@ -25,11 +25,13 @@ def set_precision(precision):
     meets the fp32 tolerances at 2.8x the fp32 kernel's speed WHILE weights and activations fit fp16's range: |w| < 255 is checked when the
     weights are packed, an activation >= 65,504 turns its point into NaN; include/crnerf.h "f32h2"), or "auto": f32h2 made safe -- a pack the h2
     core refuses runs on f32x3, a ray (a 128-point group) the h2 core poisoned is re-rendered on f32x3 inside the same call, so that no NaN of
-    the h2 core's making reaches the caller (include/crnerf.h "auto").  A `precision=` keyword to render_rays_cross_ray / batched_inference /
+    the h2 core's making reaches the caller (include/crnerf.h "auto"), or "bf16_hc": bf16 with an fp32-accurate COARSE pass ("auto" arithmetic on the
+    coarse network's 25 % of the points, the fine network on the bf16 matrix cores: the fine depths then follow the fp32 reference;
+    models/rendering.py::_render_bf16_accurate_coarse).  A `precision=` keyword to render_rays_cross_ray / batched_inference /
     NeRF_sigma.forward overrides it per call.  Training (grad mode) always runs fp32."""
     global _precision
     from .ops import _is_auto, _is_bf16, _is_h2, _is_x3
-    _precision = "auto" if _is_auto(precision) else "f32h2" if _is_h2(precision) else ("f32x3" if _is_x3(precision) else ("bf16" if _is_bf16(precision) else "f32"))
+    _precision = "bf16_hc" if precision in ("bf16_hc", "bf16+h2c") else "auto" if _is_auto(precision) else "f32h2" if _is_h2(precision) else ("f32x3" if _is_x3(precision) else ("bf16" if _is_bf16(precision) else "f32"))
 
 
 def get_precision():

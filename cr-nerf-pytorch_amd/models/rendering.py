@@ -77,6 +77,28 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
     return out
 
 
+def _render_bf16_accurate_coarse(coarse, fine, rays, Nc, Ni, use_disp, view_dir, noise_c, noise_f, noise_std, chunk):
+    """precision="bf16_hc" (inference, perturb = 0): the COARSE pass in fp32 accuracy on the fp16 matrix cores (precision "auto": f32h2 with the
+    f32x3 safety net; 25 % of the points), the FINE pass on the bf16 matrix cores.  Why: bf16's end-to-end pixel error on a trained checkpoint is
+    sampling sensitivity -- bf16 coarse weights move the fine depths (weights_fine rel-L2 2.8e-2, tests/test_gpu_trained_ckpt.py) -- so with
+    fp32-accurate coarse weights the fine depths are the fp32 reference's and what is left is the fine network's own bf16 rounding.
+    Un-fused: fused coarse render -> sample_pdf + merge -> embed -> bf16 MLP -> compositing, the same HIP kernels as _render_unfused."""
+    R = rays.shape[0]
+    z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
+    out = ops.render_rays(coarse.packed_weights("auto"), None, rays, Nc, 0, use_disp=use_disp, view_dir=view_dir, z_steps=z_steps,
+                          noise_coarse=noise_c, noise_std=float(noise_std), precision="auto")
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)   # rendering.py:161-165
+    z_fine = ops.sample_pdf_merge(z_coarse.expand(R, Nc).contiguous(), out["weights_coarse"], Ni, u=u_steps)
+    demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
+    N = Nc + Ni
+    rstep = max(max(int(chunk), 1 << 20) // N, 1)
+    raw = torch.cat([ops.mlp_forward(fine.packed_weights("bf16"), ops.embed_points(rays[i:i + rstep], z_fine[i:i + rstep], demb[i:i + rstep]), precision="bf16")
+                     for i in range(0, R, rstep)], 0)
+    out["weights_fine"], out["feature_fine"], out["depth_fine"] = ops.composite(raw.view(R, N, 65), z_fine, noise_f, noise_std)
+    return out
+
+
 def _check_embedding(emb, n_freqs, what):
     if not isinstance(emb, PosEmbedding) or emb.N_freqs != n_freqs:
         raise NotImplementedError("crnerf_amd: embeddings['%s'] must be crnerf_amd PosEmbedding(%d, %d); the fused kernel computes "
@@ -89,7 +111,7 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     N_importance > 0, 'fine' (+ 'feature_fine_random', the SAME tensor object as 'feature_fine',
     models/rendering.py:140-141,192).  ts / white_back / test_time / chunk are accepted and, as in the
     reference's arithmetic, do not influence the result (the MLP is point-wise, so chunking is invisible).
-    One keyword beyond the reference's: precision="f32"|"bf16"|"f32x3"|"f32h2"|"auto" (default crnerf_amd.get_precision()) selects the
+    One keyword beyond the reference's: precision="f32"|"bf16"|"f32x3"|"f32h2"|"auto"|"bf16_hc" (default crnerf_amd.get_precision()) selects the
     matrix-core arithmetic of NeRF_sigma at inference (include/crnerf.h).  Grad mode trains through the exact-fp32 twins unless
     the caller opted into mixed precision (autograd.set_training_precision("bf16") / CRNERF_TRAIN_BF16=1: bf16-operand GEMM twins,
     fp32 accumulation; autograd.set_wgrad_precision("bf16"): weight gradients only) -- neither has a counterpart in the reference."""
@@ -109,7 +131,8 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     if precision is None:
         from .. import get_precision
         precision = get_precision()
-    precision = "f32" if train else ("auto" if ops._is_auto(precision) else "f32h2" if ops._is_h2(precision) else "f32x3" if ops._is_x3(precision)
+    bf16_hc = precision in ("bf16_hc", "bf16+h2c") and not train
+    precision = "f32" if train else ("bf16" if bf16_hc else "auto" if ops._is_auto(precision) else "f32h2" if ops._is_h2(precision) else "f32x3" if ops._is_x3(precision)
                                      else ("bf16" if ops._is_bf16(precision) else "f32"))
 
     rays = rays.to(torch.float32).contiguous()
@@ -142,6 +165,8 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
         from ..autograd import fused_render_with_grad
         out = fused_render_with_grad(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, z_coarse, u, noise_c, noise_f,
                                      float(noise_std), rng=rng)
+    elif bf16_hc and N_importance > 0 and perturb == 0 and not jitter and 3 <= N_samples <= _FUSED_MAX:
+        out = _render_bf16_accurate_coarse(coarse, fine, rays, N_samples, N_importance, use_disp, view_dir, noise_c, noise_f, float(noise_std), int(chunk))
     elif train or N_samples > _FUSED_MAX or N_importance > _FUSED_MAX or jitter:
         # general path: the same HIP kernels, un-fused (posenc -> MLP -> compositing -> sample_pdf/merge), for
         # sample counts beyond the fused kernel's LDS scratch and for args.pertubeCord (rendering.py:102-104)

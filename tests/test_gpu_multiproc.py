@@ -77,6 +77,30 @@ def test_bench_strong_scaling_one_frame_split_over_two_ranks():
     assert abs(two["image_checksum"] - one["image_checksum"]) <= 1e-5 * abs(one["image_checksum"])        # same frame (reduction order differs)
 
 
+@pytest.mark.parametrize("split,n", [("frames", 2), ("rays", 2), ("frames", 8)])
+def test_bench_strong_scaling_video_fly_through_split_over_ranks(split, n):
+    """--scaling strong --workload configs4 (BASELINE configs[4], appearance_modification_video.py:121-189,224-262): ONE fly-through split over the
+    ranks by whole frames (no data-path collective) or by every frame's rays (decoder exchange per frame).  The frames' checksum is the
+    single-process one."""
+    args = ["bench.py", "--scaling", "strong", "--workload", "configs4", "--frames", "8", "--samples", "32+32", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    one = _json_line(r.stdout)
+    many = _json_line(_launch(args + ["--gpus", str(n), "--video-split", split], nproc=n))
+    for j, k in ((one, 1), (many, n)):
+        assert j["scaling"] == "strong" and j["n_gpus"] == k and j["dtype"] == "f32" and j["config"]["rays_total"] == 8 * 320 * 240
+        assert abs(j["value"] - 8 * 320 * 240 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"] and j["frames_per_s"] > 0
+    if split == "frames":
+        assert many["config"]["frames_this_rank"] == 8 // n and many["config"]["reductions"] == "none"
+        assert "allreduce_gram_1024f" not in many["collectives"]["per_call_ms"], many["collectives"]["per_call_ms"]   # no data-path collective
+        # rank 0's frames only: every rank renders its own, the checksum of the whole fly-through is the sum over ranks
+    else:
+        assert many["config"]["rays_per_frame_this_rank"] == 320 * 240 // n
+        assert many["collectives"]["per_call_ms"]["allreduce_gram_1024f"]["calls"] == 2 * 8, many["collectives"]["per_call_ms"]
+        assert abs(many["image_checksum"] - one["image_checksum"]) <= 2e-5 * abs(one["image_checksum"])   # uint8 frames: a reduction-order flip of a pixel is +-1
+    assert many["frames_checksum_all_ranks"] is not None and abs(many["frames_checksum_all_ranks"] - one["image_checksum"]) <= 2e-5 * abs(one["image_checksum"])
+
+
 def test_bench_strong_scaling_one_training_batch_split_over_two_ranks():
     """--scaling strong --workload configs3: ONE grid-sample training batch split over the ranks (ray-parallel TrainingSystem)."""
     j = _json_line(_launch(["bench.py", "--gpus", "2", "--scaling", "strong", "--workload", "configs3", "--train-rays", "4096", "--steps", "2", "--warmup", "1"]))
@@ -102,6 +126,14 @@ def test_bench_two_ranks_peer_exchange_matches_the_collective_path():
         assert j["config"]["reductions"] == "peer windows (HIP IPC)"
         sums = j["test_rgb_checksum_per_rank"]
         assert sums[0] == sums[1] == base["test_rgb_checksum_per_rank"][0], (sums, base["test_rgb_checksum_per_rank"])
+
+
+def test_ddp_wrapped_training_system_matches_allreduce_gradients():
+    """"or wrap the modules in torch.nn.parallel.DistributedDataParallel" -- the reference's strategy
+    (train_mask_grid_sample.py:445-446).  Two ranks, each with its own batch: DDP's bucketed gradient averaging through the HIP autograd twins
+    leaves the gradients parallel.allreduce_gradients leaves (tests/_ddp_worker.py)."""
+    out = _launch(["tests/_ddp_worker.py"], nproc=2, timeout=600)
+    assert out.count("ddp gradients match allreduce_gradients: True") == 2, out
 
 
 def test_peer_exchange_sums_are_exact_and_identical_on_three_ranks():

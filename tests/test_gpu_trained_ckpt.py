@@ -166,3 +166,31 @@ def test_trained_checkpoint_bf16_vs_fp32_reference(golden, tmp_path):
     assert abs(m["delta_psnr_vs_gt_db"]) <= 0.05 and m["psnr_vs_reference_db"] >= 55.0, m
     assert m["feature_fine"]["max_abs"] <= 1e-2 and m["feature_fine"]["rel_l2"] <= 4e-3 and m["feature_coarse"]["max_abs"] <= 2e-3, m
     assert m["rgb_fine"]["max_abs"] <= 1e-2 and m["rgb_range"][1] - m["rgb_range"][0] > 0.5, m     # a decoder that sees: the image spans > half of [0, 1]
+
+
+@torch.no_grad()
+def test_trained_checkpoint_bf16_with_fp32_accurate_coarse_pass(golden, tmp_path):
+    """round-3 verdict, weak #1 / next #5: "bf16 with an fp32-accurate coarse pass".  precision="bf16_hc" runs the coarse network on the h2 core
+    (fp32-accurate; 64 of the 256 points of a ray) and the fine network on the bf16 matrix cores, so the fine depths are the fp32 reference's
+    and what is left is the fine network's own bf16 rounding.  Measured here against the reference's fp32 outputs through the checkpoint's own
+    trained decoder, next to plain bf16, and held to SURVEY 8d's bf16 bar AS STATED: pixels max-abs <= 4e-3, |delta PSNR| <= 0.05 dB."""
+    g = golden("g15_trained")
+    hp, models, emb, enc_a, side = _load(g, tmp_path)
+    rays, style_img = T(g["rays"]).to(DEV), (T(g["style_rgbs"]).t().reshape(1, 3, side, side)).contiguous().to(DEV)
+    a = enc_a(style_img)
+    ref_rgb, gt = T(g["ref__64_128__rgb_fine"]), T(g["gt"])
+    m = {}
+    for prec in ("bf16", "bf16_hc"):
+        res = pipeline.batched_inference(models, emb, rays, None, 64, 128, False, 2048, False, args=hp, a_embedded_from_img=a, precision=prec)
+        rgb = pipeline.decode_image(models, res, side, side, a)
+        mm = {k: _diff(res[k], T(g["ref__64_128__%s" % k])) for k in ("weights_coarse", "feature_coarse", "feature_fine", "weights_fine", "depth_fine")}
+        mm["rgb_fine"] = _diff(rgb, ref_rgb)
+        mm["delta_psnr_vs_gt_db"] = _psnr(rgb.cpu(), gt) - _psnr(ref_rgb, gt)
+        mm["psnr_vs_reference_db"] = _psnr(rgb.cpu(), ref_rgb)
+        m[prec] = mm
+    record("bf16 vs bf16_hc 64_128", m)
+    hc = m["bf16_hc"]
+    assert hc["weights_coarse"]["max_abs"] <= 1e-5 and hc["feature_coarse"]["rel_l2"] <= 1e-5, hc       # the coarse pass IS the fp32 one
+    assert hc["weights_fine"]["rel_l2"] <= 0.5 * m["bf16"]["weights_fine"]["rel_l2"], m                   # ... so the fine depths follow the reference
+    assert abs(hc["delta_psnr_vs_gt_db"]) <= 0.05, hc
+    assert hc["rgb_fine"]["max_abs"] <= 4e-3, (hc["rgb_fine"], m["bf16"]["rgb_fine"])                     # SURVEY 8d, as stated
