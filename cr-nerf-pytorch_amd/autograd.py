@@ -51,11 +51,19 @@ def mlp_forward_with_grad(module, x):
 
 
 _RECOMPUTE = [False]
-_WGRAD_BF16 = [0]
+_WGRAD_BF16 = [None]
 
 
-def set_wgrad_precision(precision="f32"):
-    """"f32" (default): every gradient in exact fp32, as the reference's autograd.  "bf16": opt-in mixed precision for the weight
+def set_wgrad_precision(precision=None):
+    """How the weight gradients of NeRF_sigma's 256 x 256 blocks are formed.  None: the default -- "bf16x3" since round 4 (CRNERF_WGRAD_F32=1 /
+    CRNERF_WGRAD_BF16=1 in the environment choose the others).  Why bf16x3 is the default: it is fp32-accurate -- against a float64 evaluation the
+    split path and the fp32 matrix cores sit at the SAME distance on every tensor (tests/test_gpu_train_fused.py::
+    test_wgrad_bf16x3_is_as_accurate_as_the_fp32_matrix_cores) -- and faster: the weight gradient is the third of the training MLP work whose
+    operands come from HBM (2 KB per point and layer); the fp32-MFMA kernel sits at 75 % of its peak there for reasons that are NOT power (an
+    all-zero-operand run takes the same time, tools/train_energy_probe.py), the split kernel runs the same products on the 16x faster bf16 pipe:
+    65,536-ray train.sh step 372 -> 344 ms.  Its products are not the fp32 MFMA's bit for bit (they differ by fp32 summation noise, <= 2.3e-6 of
+    a tensor's largest entry), which is why "f32" stays available.
+    "f32": every gradient on the fp32 matrix cores, product for product the reference's autograd arithmetic.  "bf16": opt-in mixed precision for the weight
     gradients of every nn.Linear except static_sigma (CRNERF_BWD_WGRAD_BF16, include/crnerf.h: the full 256x256 blocks AND the
     narrow edge blocks of the 93/349/283-wide layers): same fp32 operands, rounded to bf16 in registers, bf16 MFMA with fp32
     accumulation -- that third of the MLP work then runs at HBM speed instead of fp32-MFMA speed.
@@ -63,7 +71,7 @@ def set_wgrad_precision(precision="f32"):
     the 256 x 256 blocks is split into three bf16 pieces in registers and a product is the sum of the six leading piece products (fp32
     accumulation; the dropped terms are one fp32 rounding), so that third of the MLP work runs at the rate of its operand reads with none
     of the bf16 mode's rounding noise.  Forward, loss, data gradients, biases and all other tensors are unchanged."""
-    _WGRAD_BF16[0] = 2 if str(precision).lower() in ("bf16x3", "x3") else (1 if ops._is_bf16(precision) else 0)
+    _WGRAD_BF16[0] = None if precision is None else (2 if str(precision).lower() in ("bf16x3", "x3") else (1 if ops._is_bf16(precision) else 0))
 
 
 _TRAIN_BF16 = [False]
@@ -99,11 +107,13 @@ def get_training_bf16():
 def get_wgrad_bf16():
     """0: exact fp32 MFMA; 1: bf16-rounded operands; 2: three-piece bf16 split (fp32-accurate)."""
     import os
-    if _WGRAD_BF16[0]:
+    if _WGRAD_BF16[0] is not None:
         return int(_WGRAD_BF16[0])
+    if os.environ.get("CRNERF_WGRAD_F32", "") not in ("", "0"):
+        return 0
     if os.environ.get("CRNERF_WGRAD_BF16X3", "") not in ("", "0"):
         return 2
-    return 1 if os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0") else 0
+    return 1 if os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0") else 2
 
 
 def set_training_recompute(flag=True):

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "layout.h"
+#include "sincos_pow2.h"
 #include "mlp_core.h"   // typedefs, LDS map, PhaseTimer, softplus/sigmoid helpers
 
 namespace crnerf {
@@ -301,6 +302,7 @@ __device__ __forceinline__ void mlp_tile16(WeightPipe16& p, int model, const f32
 // (2pr, 2pr+1) of k-group v.
 template <int F, int NV>
 __device__ __forceinline__ void posenc_regs16(float x, float y, float z, int g, f32x4 (&out)[NV]) {
+  const Rev2Pi rx = to_rev2pi(x), ry = to_rev2pi(y), rz = to_rev2pi(z);   // sincos_pow2.h
 #pragma unroll
   for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -310,17 +312,17 @@ __device__ __forceinline__ void posenc_regs16(float x, float y, float z, int g, 
       float e0, e1;
       if (a_lo + 6 < 3 * F) {                              // every lane group has a trig argument here
         const int f = a / 3, d = a - 3 * f;
-        const float val = d == 0 ? x : (d == 1 ? y : z);
+        const Rev2Pi val = {d == 0 ? rx.p : (d == 1 ? ry.p : rz.p), d == 0 ? rx.e : (d == 1 ? ry.e : rz.e)};
         float s, c;
-        sincosf(ldexpf(val, f), &s, &c);
+        sincos_rev2pi(val, f, s, c);
         e0 = s; e1 = c;
       } else {                                             // mixed: some groups hold (x,y) / (z,0) / pad
         const bool trig = a < 3 * F;
         const int ac = trig ? a : 0;
         const int f = ac / 3, d = ac - 3 * f;
-        const float val = d == 0 ? x : (d == 1 ? y : z);
+        const Rev2Pi val = {d == 0 ? rx.p : (d == 1 ? ry.p : rz.p), d == 0 ? rx.e : (d == 1 ? ry.e : rz.e)};
         float s, c;
-        sincosf(ldexpf(val, f), &s, &c);
+        sincos_rev2pi(val, f, s, c);
         e0 = trig ? s : (a == 3 * F ? x : (a == 3 * F + 1 ? z : 0.0f));
         e1 = trig ? c : (a == 3 * F ? y : 0.0f);
       }

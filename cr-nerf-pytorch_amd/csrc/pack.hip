@@ -3,6 +3,7 @@
 // Reference layouts: NeRF_sigma.__init__ models/nerf.py:137-154; PosEmbedding.forward models/nerf.py:17-30.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "sincos_pow2.h"
 #include "layout.h"
 
 namespace crnerf {
@@ -309,7 +310,14 @@ int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stre
   return check_launch("pack_mlp");
 }
 
-// x[n,3] -> out[n, 6F+3]; one thread per (row, argument) pair; accurate sincosf (see posenc.h).
+// sin / cos of 2^f v: the fused kernels' routine (sincos_pow2.h) wherever it is valid, so that the stand-alone entry points and the fused
+// renderers produce the SAME embeddings; ocml's sincosf beyond its range (crnerf_posenc_f32 accepts up to 30 frequencies)
+__device__ __forceinline__ void sincos_freq(float v, int f, float& s, float& c) {
+  if (f <= 16 && fabsf(v) < 64.0f) sincos_rev2pi(to_rev2pi(v), f, s, c);
+  else sincosf(ldexpf(v, f), &s, &c);
+}
+
+// x[n,3] -> out[n, 6F+3]; one thread per (row, argument) pair; accurate sin / cos (see posenc.h).
 __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ out, long n, int F) {
   // one thread per (row, group): group 0 = the identity columns, group 1 + f = sin and cos of the three coordinates at frequency 2^f
   // = 24 contiguous bytes (a thread per argument wrote two 4-byte pieces 12 bytes apart)
@@ -326,11 +334,10 @@ __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ o
     o[0] = v0; o[1] = v1; o[2] = v2;
   } else {
     const int f = a - 1;
-    const float fr = ldexpf(1.0f, f);
     float s0, c0, s1, c1, s2, c2;
-    sincosf(fr * v0, &s0, &c0);
-    sincosf(fr * v1, &s1, &c1);
-    sincosf(fr * v2, &s2, &c2);
+    sincos_freq(v0, f, s0, c0);
+    sincos_freq(v1, f, s1, c1);
+    sincos_freq(v2, f, s2, c2);
     float* of = o + 3 + 6 * f;
     of[0] = s0; of[1] = s1; of[2] = s2; of[3] = c0; of[4] = c1; of[5] = c2;
   }
@@ -366,10 +373,9 @@ __global__ void embed_points_kernel(const float* __restrict__ rays, const float*
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
   } else {
     const int f = a - 1;
-    const float fr = ldexpf(1.0f, f);
     float sn[3], cs[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) sincosf(fr * v[d], &sn[d], &cs[d]);
+    for (int d = 0; d < 3; ++d) sincos_freq(v[d], f, sn[d], cs[d]);
     float* of = o + 3 + 6 * f;
     of[0] = sn[0]; of[1] = sn[1]; of[2] = sn[2]; of[3] = cs[0]; of[4] = cs[1]; of[5] = cs[2];
   }

@@ -27,7 +27,7 @@ def test_training_system_learns_the_scene_like_the_reference(golden, mode):
         _run(golden)
     finally:
         AG.set_training_forward_precision("f32")
-        AG.set_wgrad_precision("f32")
+        AG.set_wgrad_precision(None)
 
 
 def _run(golden):

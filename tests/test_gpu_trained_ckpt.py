@@ -15,6 +15,10 @@ the same sampling decisions, i.e. it is ~40x closer to the fp32 reference than t
 So SURVEY 8d's fp32 bars are asserted AS STATED on the trained checkpoint:
   pixels max-abs <= 2e-5, features rel-L2 <= 1e-5 (coarse and fine), |delta PSNR| <= 0.05 dB vs the held-out ground truth;
   at identical depths (oracle re-evaluated at the kernel's z_fine): kernel arithmetic only, same bars.
+g16_trained.npz is the same recipe run for 5,000 steps (make_golden_trained.py --steps 5000 --out g16_trained.npz --eval-modules-only; training
+PSNR 35-38 dB, round-3 verdict next #6): the reference's own fp64 - fp32 gap there is 1.8e-4 (fine features) / 2.0e-4 (pixels) at 64+128 and
+5.6e-5 / 7.2e-5 at 256+256; the HIP paths (fp32 MFMA, f32x3, f32h2, auto -- indistinguishable) land at 2.3e-5 / 2.5e-5 and 7.8e-5 / 6.3e-5 max-abs,
+rel-L2 1.8e-6 / 2.6e-6 and 4.8e-6 / 6.3e-6, PSNR vs the reference's image 118 / 110 dB: see the g16 branch of the first test.
 bf16 (configs[2]'s arithmetic) against the FP32 reference through the checkpoint's own trained decoder (image spans rgb 0.19..0.79,
 a decoder that "sees" feature errors): |delta PSNR| 0.004 dB -- north_star's 0.05 dB bar holds with 10x margin -- but pixels differ
 by 6.1e-3 max: SURVEY 8d's 4e-3 pixel figure is NOT met through a seeing decoder (round-2 verdict, weak #1), and no cheap kernel
@@ -98,8 +102,9 @@ def record(name, values):
 @torch.no_grad()
 @pytest.mark.parametrize("precision", ["f32", "f32x3", "f32h2", "auto"])      # f32x3 / f32h2 / auto (h2 repaired by x3): the same fp32 bars on the bf16 / fp16 matrix cores (piece splits, include/crnerf.h)
 @pytest.mark.parametrize("tag,nc,ni", [("64_128", 64, 128), ("256_256", 256, 256)])
-def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni, precision):
-    g = golden("g15_trained")
+@pytest.mark.parametrize("fixture", ["g15_trained", "g16_trained"])      # g16: the reference trained 5,000 steps (train PSNR ~37 dB), see the module docstring
+def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni, precision, fixture):
+    g = golden(fixture)
     hp, models, emb, enc_a, side = _load(g, tmp_path)
     rays, style_img = T(g["rays"]).to(DEV), (T(g["style_rgbs"]).t().reshape(1, 3, side, side)).contiguous().to(DEV)   # enc_a input in [0, 1]
     a = enc_a(style_img)
@@ -117,15 +122,28 @@ def test_trained_checkpoint_fp32_vs_reference(golden, tmp_path, tag, nc, ni, pre
     gt = T(g["gt"])
     m["psnr_vs_gt_reference"], m["psnr_vs_gt_hip"] = _psnr(T(g["ref__%s__rgb_fine" % tag]), gt), _psnr(rgb_f.cpu(), gt)
     m["psnr_hip_vs_reference"] = _psnr(rgb_f.cpu(), T(g["ref__%s__rgb_fine" % tag]))
-    record("%s %s" % ("fp32" if precision == "f32" else precision, tag), m)
-    # SURVEY 8d's fp32 bars, as stated, END TO END against the reference's outputs on its own trained checkpoint
-    assert m["rgb_fine"]["max_abs"] <= 2e-5 and m["rgb_coarse"]["max_abs"] <= 2e-5, m
-    assert m["feature_fine"]["rel_l2"] <= 1e-5 and m["feature_coarse"]["rel_l2"] <= 1e-5, m
-    assert m["weights_coarse"]["max_abs"] <= 1e-5 and m["weights_fine"]["max_abs"] <= 5e-5 and m["depth_fine"]["max_abs"] <= 5e-5, m
-    # ... which is well inside what the reference itself moves by between fp32 and fp64 on this checkpoint
-    for k in ("weights_fine", "feature_fine", "depth_fine", "rgb_fine"):
-        assert m[k]["max_abs"] <= max(m[k]["reference_fp64_minus_fp32"], 2e-5), (k, m[k])
-    assert abs(m["psnr_vs_gt_hip"] - m["psnr_vs_gt_reference"]) <= 0.05 and m["psnr_hip_vs_reference"] >= 100.0, m
+    record("%s%s %s" % ("" if fixture == "g15_trained" else "g16 ", "fp32" if precision == "f32" else precision, tag), m)
+    assert abs(m["psnr_vs_gt_hip"] - m["psnr_vs_gt_reference"]) <= 0.05, m
+    assert m["feature_fine"]["rel_l2"] <= 1e-5 and m["feature_coarse"]["rel_l2"] <= 1e-5 and m["rgb_fine"]["rel_l2"] <= 1e-5, m
+    assert m["weights_coarse"]["max_abs"] <= 1e-5 and m["rgb_coarse"]["max_abs"] <= 2e-5, m       # the coarse pass: no sampling step in it
+    if fixture == "g15_trained":
+        # SURVEY 8d's fp32 bars, as stated, END TO END against the reference's outputs on its own trained checkpoint
+        assert m["rgb_fine"]["max_abs"] <= 2e-5, m
+        assert m["weights_fine"]["max_abs"] <= 5e-5 and m["depth_fine"]["max_abs"] <= 5e-5, m
+        # ... which is well inside what the reference itself moves by between fp32 and fp64 on this checkpoint
+        for k in ("weights_fine", "feature_fine", "depth_fine", "rgb_fine"):
+            assert m[k]["max_abs"] <= max(m[k]["reference_fp64_minus_fp32"], 2e-5), (k, m[k])
+        assert m["psnr_hip_vs_reference"] >= 100.0, m
+    else:
+        # g16, the 5,000-step checkpoint (training PSNR ~37 dB): density is sharper, and a handful of rays sit where one fp32 rounding of a coarse
+        # weight moves a fine sample across a surface.  Measured (all four fp32-accurate paths alike): pixels max-abs 2.5e-5 at 64+128 (the
+        # reference's own fp64 - fp32: 2.0e-4), 6.3e-5 at 256+256 (7.2e-5); rel-L2 2.6e-6 / 6.3e-6; PSNR vs the reference's image 118 / 110 dB.
+        # SURVEY 8d's rel-L2 bars hold as stated (above); its ABSOLUTE 2e-5 pixel figure does not on this checkpoint -- neither does the reference
+        # hold it against itself -- so the max-abs bar here is the reference's own fp32 noise: no output further from the fp32 reference than
+        # twice the distance of that reference from its fp64 evaluation.
+        for k in ("weights_fine", "feature_fine", "depth_fine", "rgb_fine"):
+            assert m[k]["max_abs"] <= 2.0 * max(m[k]["reference_fp64_minus_fp32"], 1e-5), (k, m[k])
+        assert m["rgb_fine"]["max_abs"] <= 1e-4 and m["psnr_hip_vs_reference"] >= 105.0, m
 
 
 @torch.no_grad()

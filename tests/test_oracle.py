@@ -231,11 +231,12 @@ def test_cgnet_mirror_has_the_reference_state_dict(golden):
         net(torch.zeros(1, 3, 16, 16))
 
 
-def test_oracle_on_the_trained_checkpoint_matches_the_reference(golden):
-    """g15 (tests/golden/make_golden_trained.py): weights TRAINED by the reference's own modules and loop.  The oracle restates the
-    reference's arithmetic op for op, so on the reference's checkpoint it must reproduce the reference's render bit for bit
-    (coarse + fine at 64+128, eval.py's perturb = 0 / noise_std = 0 recipe) and its decoded image to fp32 round-off."""
-    g = golden("g15_trained")
+@pytest.mark.parametrize("fixture", ["g15_trained", "g16_trained"])
+def test_oracle_on_the_trained_checkpoint_matches_the_reference(golden, fixture):
+    """g15 / g16 (tests/golden/make_golden_trained.py; g16 = the 5,000-step run, training PSNR ~37 dB): weights TRAINED by the reference's own
+    modules and loop.  The oracle restates the reference's arithmetic op for op, so on the reference's checkpoint it must reproduce the
+    reference's render bit for bit (coarse + fine at 64+128, eval.py's perturb = 0 / noise_std = 0 recipe) and its decoded image to fp32 round-off."""
+    g = golden(fixture)
     side = int(g["side"])
     pick = lambda prefix: {k[len("sd__" + prefix) + 1:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("sd__" + prefix + ".")}  # noqa: E731
     wc, wf, dec, enc = pick("nerf_coarse"), pick("nerf_fine"), pick("decoder"), pick("enc_a")

@@ -70,3 +70,40 @@ def test_fp16_split_precision_by_magnitude():
     assert (np.abs(h[0] + h[1] - small) <= 2.0 ** -25).all()
     over = fp16_pieces(np.array([70000.0, -1e6], np.float32))
     assert not np.isfinite(over[0]).any()
+
+
+def test_sincos_pow2_reduction_is_accurate_in_fp32():
+    """csrc/sincos_pow2.h (the embeddings' sin / cos of 2^k x since round 4), restated operation for operation in numpy float32 (fma = one rounding
+    of the exact product-sum): against float64 over x in [-6, 6] and the tiny-coordinate range, k = 0 .. 16, the error stays below 1.1e-7 --
+    ~1.3 ulp of a value in [0.5, 1) -- with a mean of 1.5e-8; ocml's sincosf, which it replaces, is specified to 2 ulp."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+    c_hi, c_lo, tp_hi, tp_lo = f32(0.159154937), f32(6.42063824e-09), f32(6.28318548), f32(-1.74845553e-07)
+    assert abs(float(c_hi) + float(c_lo) - 1 / (2 * np.pi)) < 1e-16 and abs(float(tp_hi) + float(tp_lo) - 2 * np.pi) < 1e-14
+
+    def sincos(x, k):
+        p = (x * c_hi).astype(f32)
+        e = (fma(x, c_hi, -p) + (x * c_lo).astype(f32)).astype(f32)
+        p4 = (p * f32(2.0 ** (k + 2))).astype(f32)
+        j = np.rint(p4).astype(f32)
+        y = fma((p4 - j).astype(f32), f32(0.25), (e * f32(2.0 ** k)).astype(f32))
+        th = fma(y, tp_hi, (y * tp_lo).astype(f32))
+        z = (th * th).astype(f32)
+        ps = fma(fma(f32(-1.9515295891e-4), z, f32(8.3321608736e-3)), z, f32(-1.6666654611e-1))
+        sn = fma((th * z).astype(f32), ps, th)
+        pc = fma(fma(fma(f32(2.443315711809948e-5), z, f32(-1.388731625493765e-3)), z, f32(4.166664568298827e-2)), z, f32(-0.5))
+        cs = fma(z, pc, f32(1.0))
+        q = j.astype(np.int64) & 3
+        s = np.where(q == 0, sn, np.where(q == 1, cs, np.where(q == 2, -sn, -cs)))
+        c = np.where(q == 0, cs, np.where(q == 1, -sn, np.where(q == 2, -cs, sn)))
+        return s.astype(f32), c.astype(f32)
+
+    rng = np.random.default_rng(0)
+    for k in range(17):
+        x = np.concatenate([rng.uniform(-6, 6, 200000), rng.uniform(-0.01, 0.01, 20000), [0.0, np.pi, -np.pi, np.pi / 2, 1e-8, 5.0, -5.0]]).astype(f32)
+        s, c = sincos(x, k)
+        arg = x.astype(np.float64) * 2.0 ** k
+        es, ec = np.abs(s - np.sin(arg)), np.abs(c - np.cos(arg))
+        assert es.max() <= 1.1e-7 and ec.max() <= 1.1e-7 and es.mean() <= 2e-8 and ec.mean() <= 2e-8, (k, es.max(), ec.max(), es.mean(), ec.mean())
