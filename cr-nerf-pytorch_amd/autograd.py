@@ -75,20 +75,57 @@ def set_wgrad_precision(precision=None):
 
 
 _TRAIN_BF16 = [False]
-_TRAIN_FWD_X3 = [False]
+_TRAIN_FWD = [None]
 
 
 def set_training_forward_precision(precision="f32"):
     """"f32" (default): the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
     fp32 forward on the bf16 matrix cores (crnerf_render_rays_train_f32x3: three-piece bf16 splits of every fp32 operand, six MFMAs per
     product -- include/crnerf.h "f32x3"), and with it the data gradient on the same core (crnerf_mlp_backward_x3_f32): same saved state and
-    scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws in-kernel from the same Philox counters as the fp32 twin."""
-    _TRAIN_FWD_X3[0] = ops._is_x3(precision)
+    scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws in-kernel from the same Philox counters as the fp32 twin.
+    "f32h2": forward and data gradient on the fp16 matrix cores from two-piece fp16 splits, three MFMAs per product
+    (crnerf_render_rays_train_f32h2 / crnerf_mlp_backward_h2_f32) -- fp32-accurate within fp16's range: a weight >= 255 raises when packing, a
+    point whose activations pass 65,504 comes out NaN; the gradient side rescales every point's deltas per layer and has no range limit.
+    "auto": "f32h2" with the scale-free f32x3 twins as its safety net -- poisoned ray quads are rendered again (saved rows included) by
+    crnerf_render_rays_train_f32x3_repair on the device, a refused pack trains that step on f32x3; no NaN of the h2 core's making reaches the loss."""
+    _TRAIN_FWD[0] = ("f32x3" if ops._is_x3(precision) else "f32h2" if ops._is_h2(precision) else "auto" if ops._is_auto(precision) else
+                     (None if not ops._is_bf16(precision) else _bad_fwd_precision(precision)))
+
+
+def _bad_fwd_precision(precision):
+    raise ValueError("crnerf_amd: set_training_forward_precision takes 'f32', 'f32x3', 'f32h2' or 'auto' (mixed precision: set_training_precision('bf16')), got %r"
+                     % (precision,))
+
+
+def get_training_forward_mode():
+    """"f32" | "f32x3" | "f32h2" | "auto" (environment: CRNERF_TRAIN_FWD=x3|h2|auto, or the older CRNERF_TRAIN_FWD_X3=1)."""
+    import os
+    if _TRAIN_FWD[0] is not None:
+        return _TRAIN_FWD[0]
+    env = os.environ.get("CRNERF_TRAIN_FWD", "").lower()
+    if env in ("x3", "f32x3"):
+        return "f32x3"
+    if env in ("h2", "f32h2"):
+        return "f32h2"
+    if env == "auto":
+        return "auto"
+    return "f32x3" if os.environ.get("CRNERF_TRAIN_FWD_X3", "") not in ("", "0") else "f32"
 
 
 def get_training_forward_x3():
-    import os
-    return _TRAIN_FWD_X3[0] or os.environ.get("CRNERF_TRAIN_FWD_X3", "") not in ("", "0")
+    return get_training_forward_mode() == "f32x3"
+
+
+def _pack_for_training(mode, state):
+    return (ops.pack_mlp_weights_x3(state) if mode == "f32x3" else ops.pack_mlp_weights_h2(state) if mode == "f32h2" else
+            ops.pack_mlp_weights_auto(state) if mode == "auto" else ops.pack_mlp_weights(state))
+
+
+def _effective_mode(mode, packed):
+    """What "auto" turned into for this set of packs: the h2 core when every pack was accepted, else f32x3."""
+    if mode != "auto":
+        return mode
+    return "f32x3" if any(pk.h2 is None for pk in packed) else "auto"
 
 
 def set_training_precision(precision="f32"):
@@ -150,14 +187,14 @@ class FusedRenderFn(torch.autograd.Function):
         for mod in cfg["modules"]:
             if mod is not None and hasattr(mod, "invalidate_packed"):
                 mod.invalidate_packed()      # an optimiser step follows (see MlpFn)
-        x3 = get_training_forward_x3()
-        packed = [ops.pack_mlp_weights_x3(st) if x3 else ops.pack_mlp_weights(st) for st in states]
+        mode = get_training_forward_mode()
+        packed = [_pack_for_training(mode, st) for st in states]
         recompute = get_training_recompute()
-        ctx.x3 = x3
+        ctx.mode = _effective_mode(mode, packed)   # the backward follows the forward's core
         out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                               z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
                               noise_std=cfg["noise_std"], want_z_fine=True, train=not recompute, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"),
-                              precision="f32x3" if x3 else "f32")
+                              precision=mode)
         if cfg.get("rng") is not None:       # what the kernel drew is what the backward composites with (a few KB per ray chunk)
             cfg = dict(cfg, z_coarse_bwd=out["z_coarse_used"], noise_c_bwd=out.get("noise_coarse_used", cfg["noise_c"]),
                        noise_f_bwd=out.get("noise_fine_used", cfg["noise_f"]))
@@ -181,11 +218,11 @@ class FusedRenderFn(torch.autograd.Function):
         rays, z_fine = keep[0], keep[1]
         states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(ctx.n_models)]
         if ctx.recompute:
-            packed = [ops.pack_mlp_weights_x3(st) if ctx.x3 else ops.pack_mlp_weights(st) for st in states]
+            packed = [_pack_for_training(ctx.mode, st) for st in states]
             out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                                   z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
                                   noise_std=cfg["noise_std"], train=True, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"),
-                                  precision="f32x3" if ctx.x3 else "f32")   # same (seed, ray, sample) -> same draws
+                                  precision=ctx.mode)   # same (seed, ray, sample) -> same draws
             per_pass = [(out["acts_coarse"], out["raw_coarse"])] + ([(out["acts_fine"], out["raw_fine"])] if Ni > 0 else [])
             z_fine = out["z_fine"] if Ni > 0 else z_fine
             del out
@@ -204,9 +241,10 @@ class FusedRenderFn(torch.autograd.Function):
             d_raw = ops.composite_backward(raw, z, d_f.contiguous(), None if d_d is None else d_d.contiguous(),
                                            None if d_w is None else d_w.contiguous(), noise=noise, noise_std=cfg["noise_std"])
             x = _embed_points(rays, z, cfg["view_dir"])
-            x3 = getattr(ctx, "x3", False)       # the f32x3 forward brings the x3 data gradient with it (set_training_forward_precision)
-            grads += ops.mlp_backward(ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]), x, raw.view(-1, 65),
-                                      d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3)
+            mode = getattr(ctx, "mode", "f32")   # a split-core forward brings the data gradient on the same core with it (set_training_forward_precision)
+            x3, h2 = mode == "f32x3", mode in ("f32h2", "auto")
+            packed_t = ops.pack_mlp_weights_t_h2(states[m]) if h2 else (ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]))
+            grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3, dgrad_h2=h2)
             del x, d_raw
         return (None, None) + tuple(grads)
 

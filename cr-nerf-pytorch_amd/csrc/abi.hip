@@ -331,6 +331,27 @@ int crnerf_mlp_backward_x3_f32(const void* packed_t_x3, const float* x, const fl
   return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, packed_t_x3);
 }
 
+size_t crnerf_packed_mlp_t_h2_bytes(void) { return PACKEDHT_BYTES; }
+
+int crnerf_pack_mlp_weights_t_h2(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_t_h2: a tensor pointer is NULL");
+  return launch_pack_mlp_h2t(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
+                               float* const* grads, int64_t n, int flags, void* stream) {
+  if (n == 0) return 0;
+  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: unknown flag bits");
+  if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: the two weight-gradient modes are exclusive");
+  REQUIRE(packed_t_h2, "packed_t_h2"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
+  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_h2: a gradient pointer is NULL");
+  return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, nullptr, packed_t_h2);
+}
+
 size_t crnerf_packed_mlp_x3_bytes(void) { return PACKEDX_BYTES; }
 
 int crnerf_pack_mlp_weights_x3(const float* const* tensors, void* packed, void* stream) {
@@ -380,6 +401,22 @@ int crnerf_render_rays_train_f32x3(const crnerf_render_args* a, void* acts_coars
   REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
   if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
   return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine, true);
+}
+
+int crnerf_render_rays_train_f32h2(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine, void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
+  if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
+  return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine, 2);
+}
+
+int crnerf_render_rays_train_f32x3_repair(const crnerf_render_args* a, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine, void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  REQUIRE(acts_coarse, "acts_coarse"); REQUIRE(raw_coarse, "raw_coarse");
+  if (a->n_importance > 0) { REQUIRE(acts_fine, "acts_fine"); REQUIRE(raw_fine, "raw_fine"); REQUIRE(a->z_fine, "z_fine"); }
+  return render_rays_common(a, stream, false, acts_coarse, acts_fine, raw_coarse, raw_fine, 3);
 }
 
 size_t crnerf_packed_mlp_bf16_bytes(void) { return PACKEDB_BYTES; }

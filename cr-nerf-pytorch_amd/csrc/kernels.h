@@ -37,7 +37,7 @@ size_t mlp_train_scratch_bytes(long P);
 int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream);
 // flags: bit 0 = weight gradients of every Linear except static_sigma from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16, include/crnerf.h)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
-                        float* const* grads, long P, hipStream_t stream, int flags = 0, const void* packedT_x3 = nullptr);
+                        float* const* grads, long P, hipStream_t stream, int flags = 0, const void* packedT_x3 = nullptr, const void* packedT_h2 = nullptr);
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
                       long P, hipStream_t stream, int wb);
 // mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs; activations, deltas and the embedded input travel as bf16
@@ -125,6 +125,9 @@ int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_h2(const RenderArgs& a, hipStream_t stream);
+int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
+                        hipStream_t stream);
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream);
 int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);

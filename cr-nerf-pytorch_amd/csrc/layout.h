@@ -234,4 +234,17 @@ static_assert(STREAMXT_FRAGS % STAGE_FRAGS == 0 && FXT_RGB % STAGE_FRAGS == 0 &&
               "transposed x3 layers must be whole stages and whole queue turns");
 constexpr size_t PACKEDXT_BYTES = (size_t)CONST_BYTES + (size_t)STREAMXT_FRAGS * FRAG_BYTES;
 
+// ---- "fragHT": the transposed stream with TWO fp16 pieces per weight, scaled by H2_WSCALE like fragH, for the backward-data pass on the h2 core
+// (mlp_backward_h2.hip): fragXT's geometry and layer order with two pieces per (k-step, tile).
+constexpr int FHT_RGB = (FEAT_DIM / 16) * 4 * 2;     //  32: static_rgb^T      64 -> 128
+constexpr int FHT_DIR = (128 / 16) * 8 * 2;          // 128: dir_encoding^T   128 -> 256
+constexpr int FHT_HID = KS_HID * 8 * 2;              // 256: xyz_encoding_final^T and xyz_encoding_{8..2}^T
+constexpr int OFFHT_RGB = 0;
+constexpr int OFFHT_DIR = OFFHT_RGB + FHT_RGB;
+constexpr int OFFHT_FIN = OFFHT_DIR + FHT_DIR;
+constexpr int OFFHT_L8 = OFFHT_FIN + FHT_HID;        // L8, L7, ..., L2 contiguous
+constexpr int STREAMHT_FRAGS = OFFHT_L8 + 7 * FHT_HID;               // 2208
+static_assert(STREAMHT_FRAGS % STAGE_FRAGS == 0 && FHT_RGB % STAGE_FRAGS == 0 && FHT_DIR % STAGE_FRAGS == 0, "transposed h2 layers must be whole stages");
+constexpr size_t PACKEDHT_BYTES = (size_t)CONST_BYTES + (size_t)STREAMHT_FRAGS * FRAG_BYTES;
+
 }  // namespace crnerf

@@ -219,10 +219,9 @@ __device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD
 // takes them.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both lane halves).
 // Range guard: an activation beyond fp16's range would split into (inf, -inf) pieces, turn into NaN in the next layer and be clamped to 0 by its
 // relu -- a finite, wrong result -- so the tile tracks max |operand| and POISONS the 65 outputs of such a point with NaN.
-template <class SV = NoSaveX>
-__device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1], f32x16 (&feat)[2], float& sigma,
-                                            int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm, const SV& sv = SV()) {
-  static_assert(!SV::on, "the h2 training twin is not built yet");
+// (The kernels call mlp_tile_x3 -- mlp_core_h2t.h -- which is this function for inference and the training form mlp_tile_h2t when rows are saved.)
+__device__ __forceinline__ void mlp_tile_h2i(WeightPipeX& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1], f32x16 (&feat)[2], float& sigma,
+                                             int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm) {
   const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
   const lds_float* B1 = C + C_BIAS;
   const lds_float* WS = C + C_WSIG;

@@ -12,8 +12,7 @@
 // finished output (scale 2^-8, relu, range max) sits in 128 registers and is split, eight values per k-step, when the NEXT layer walks it -- which
 // is also when its two 16-byte row pieces leave for HBM.  The stores, not the epilogue, are what this form's time goes to (10.5 KB per point).
 //
-// Operand scale: mma_layer_h2t splits x * sc with a per-LANE power of two sc (v_fma_mix: scale, subtraction and conversion in one instruction per
-// piece).  Forward: sc = 1.  Backward: the deltas of a point span whatever the loss hands down (1e-9 is ordinary), far below fp16's normal range;
+// Operand scale: mma_layer_h2t splits x * sc with a per-LANE power of two sc.  Forward: sc = 1.  Backward: the deltas of a point span whatever the loss hands down (1e-9 is ordinary), far below fp16's normal range;
 // every point's delta vector is therefore scaled so that its largest entry sits in [2^7, 2^8) -- the products are linear in it, the accumulator
 // is scaled back by the exact inverse -- and a point's small entries degrade to an absolute error of 2^-25 x 2^-7 of its largest one, invisible
 // in a dot product the large entries dominate.  So the backward has no range failure of its own.
@@ -42,8 +41,10 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
       // row stores issued since this wave's pieces of the stage the barrier certifies (mma_layer_x3 has the derivation): a lower bound
       constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
       int st = 0;
+      // (the stores of k-step ks are issued by prepare(ks), in front of the take() of fragment (ks - 1) NT 2; k-step 0's in front of the layer)
+      const int fp = f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP);   // the fragment whose take() issued that piece
       for (int ks = 0; ks < NS; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * 2 > f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP) && ks * NT * 2 <= f) st += 2;
+        if ((ks < NSA ? SAVEA : SAVEB) && (ks == 0 ? fp < 0 : ((ks - 1) * NT * 2 > fp && (ks - 1) * NT * 2 <= f))) st += 2;
       p.advance(st);
     }
     return w;
@@ -61,10 +62,20 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
       __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * ss), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * ss + 32u), 0, 0);
     }
+    // The split in plain arithmetic (v_cvt_f16_f32 rounds to nearest even and keeps subnormals; x * sc and the difference are exact).  NOT the
+    // two-instruction v_fma_mix form of the inference core: with this kernel's register pressure (58-95 spilled registers) that form produced
+    // wrong operands for single tiles -- bit-exact again with the conversions below (tests/test_gpu_h2.py; measured round 4, cause not isolated:
+    // suspected a partial-register-write hazard between the asm statements and the MFMA that reads the operand).  ~5 VALU instructions per value
+    // beside 3 NT MFMAs per k-step: hidden.
+    typedef _Float16 h2pair __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h2_split_first(o.b1, e, v[e], sc);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) h2_split_second(o.b1, o.b2, e, v[e], sc);
+    for (int d = 0; d < 4; ++d) {
+      const float x0 = v[2 * d] * sc, x1 = v[2 * d + 1] * sc;
+      const h2pair p1 = {(_Float16)x0, (_Float16)x1};
+      const h2pair p2 = {(_Float16)(x0 - (float)p1[0]), (_Float16)(x1 - (float)p1[1])};
+      o.b1[d] = __builtin_bit_cast(uint32_t, p1);
+      o.b2[d] = __builtin_bit_cast(uint32_t, p2);
+    }
   };
   BOpH b;
   prepare(0, b);
@@ -197,6 +208,15 @@ __device__ __forceinline__ void mlp_tile_h2t(WeightPipeX& p, int model, const f3
     }
   }
   tm.tick(T_EPILOGUE);
+}
+
+// What the kernels built on the h2 core call (the x3 core's name, so that render_fused_x3.hip / mlp_forward_x3.hip compile against either core):
+// the lazy-epilogue inference tile, or -- when the caller saves rows -- the training form.
+template <class SV = NoSaveX>
+__device__ __forceinline__ void mlp_tile_x3(WeightPipeX& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1], f32x16 (&feat)[2], float& sigma,
+                                            int h, xu32x4 (&q)[X_AHEAD], PhaseTimer& tm, const SV& sv = SV()) {
+  if constexpr (SV::on) mlp_tile_h2t(p, model, pe, dv, feat, sigma, h, q, tm, sv);
+  else mlp_tile_h2i(p, model, pe, dv, feat, sigma, h, q, tm);
 }
 
 }  // inline namespace xcore_h2

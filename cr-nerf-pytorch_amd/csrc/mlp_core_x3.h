@@ -75,8 +75,12 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
       // (the previous layer's are ignored)
       constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
       int st = 0;
+      // (the stores of k-step ks are issued by prepare(ks), in front of the take() of fragment (ks - 1) NT XNP; k-step 0's in front of the layer.
+      // Round 4: the count used ks NT XNP and was two stores too high in a layer's last k-step -- this wave's last two pieces of the certified
+      // stage could then still be in flight at the barrier; never observed, three stages of slack)
+      const int fp = f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP);   // the fragment whose take() issued that piece
       for (int ks = 0; ks < NSA + NSB; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && ks * NT * XNP > f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP) && ks * NT * XNP <= f) st += 2;
+        if ((ks < NSA ? SAVEA : SAVEB) && (ks == 0 ? fp < 0 : ((ks - 1) * NT * XNP > fp && (ks - 1) * NT * XNP <= f))) st += 2;
       p.advance(st);
     }
     return w;

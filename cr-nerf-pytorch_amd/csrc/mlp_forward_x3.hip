@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #if defined(CRNERF_X_NP) && CRNERF_X_NP == 2
-#include "mlp_core_h2.h"
+#include "mlp_core_h2t.h"
 #else
 #include "mlp_core_x3.h"
 #endif

@@ -938,7 +938,7 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
 
 // grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
-                        float* const* grads, long P, hipStream_t stream, int flags, const void* packedT_x3) {
+                        float* const* grads, long P, hipStream_t stream, int flags, const void* packedT_x3, const void* packedT_h2) {
   const int wb = (flags & 2) ? 2 : (flags & 1);   // CRNERF_BWD_WGRAD_BF16X3 / CRNERF_BWD_WGRAD_BF16
   if (P <= 0) return 0;
   float* deltas = (float*)scratch;
@@ -948,7 +948,9 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   const long groups = (P + 127) / 128;
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
-  if (packedT_x3) {   // crnerf_mlp_backward_x3_f32: the data gradient on the x3 core (mlp_backward_x3.hip), same scratch layout
+  if (packedT_h2) {   // crnerf_mlp_backward_h2_f32: the data gradient on the h2 core (mlp_backward_h2.hip), same scratch layout
+    if (int rc = launch_mlp_dgrad_h2(packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, stream)) return rc;
+  } else if (packedT_x3) {   // crnerf_mlp_backward_x3_f32: the data gradient on the x3 core (mlp_backward_x3.hip), same scratch layout
     if (int rc = launch_mlp_dgrad_x3(packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, stream)) return rc;
   } else {
     if (int rc = launch_core((const void*)mlp_backward16_kernel, grid, LDS_SCRATCH)) return rc;

@@ -301,6 +301,44 @@ int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream) {
   return check_launch("pack_mlp_x3t");
 }
 
+// transposed h2 stream (layout.h "fragHT"): fragXT's element map, two fp16 pieces of 2^8 w.  No range flag of its own: the forward pack of the same
+// weights (crnerf_pack_mlp_weights_h2) is where |w| < 255 is checked; a weight beyond it gives inf pieces here and inf / NaN deltas, never a
+// finite wrong gradient.
+__global__ void pack_stream_h2t_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)STREAMHT_FRAGS * 512) return;
+  const int frag = (int)(idx / 512);
+  const int lane = (int)(idx % 512) / 8, e = (int)(idx % 8);
+  const int i = lane & 31, hh = lane >> 5;
+  const float* W;
+  int in_dim, col0, nt, phi;   // W[k][col0 + r]: k = the layer's output feature (contraction), r = its hidden input (tile row)
+  if (frag < OFFHT_DIR) { W = t.w_rgb; in_dim = 128; col0 = 0; nt = 4; phi = frag - OFFHT_RGB; }
+  else if (frag < OFFHT_FIN) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; col0 = 0; nt = 8; phi = frag - OFFHT_DIR; }
+  else if (frag < OFFHT_L8) { W = t.w_final; in_dim = W_HIDDEN; col0 = 0; nt = 8; phi = frag - OFFHT_FIN; }
+  else {
+    const int j = (frag - OFFHT_L8) / FHT_HID;          // 0..6 <-> xyz_encoding_{8 - j}
+    const int l = 7 - j;                                 // index into t.w
+    W = t.w[l]; in_dim = l == 4 ? XYZ_DIM + W_HIDDEN : W_HIDDEN; col0 = l == 4 ? XYZ_DIM : 0; nt = 8; phi = (frag - OFFHT_L8) % FHT_HID;
+  }
+  const int piece = phi % 2, st = phi / 2;
+  const int s = st / nt, T = st % nt;
+  const int k = 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
+  const int r = 32 * T + i;
+  const float w = W[(long)k * in_dim + col0 + r] * H2_WSCALE;
+  const _Float16 p1 = (_Float16)w;
+  const _Float16 p2 = (_Float16)(w - (float)p1);
+  stream[idx] = __builtin_bit_cast(unsigned short, piece == 0 ? p1 : p2);
+}
+
+int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream) {
+  float* consts = (float*)packed;
+  unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
+  hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, H2_WSCALE);
+  const long n = (long)STREAMHT_FRAGS * 512;
+  hipLaunchKernelGGL(pack_stream_h2t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  return check_launch("pack_mlp_h2t");
+}
+
 int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);

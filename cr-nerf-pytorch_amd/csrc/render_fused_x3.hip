@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #if defined(CRNERF_X_NP) && CRNERF_X_NP == 2
-#include "mlp_core_h2.h"
+#include "mlp_core_h2t.h"
 #else
 #include "mlp_core_x3.h"
 #endif
@@ -57,7 +57,6 @@ struct NoHookX {
   __device__ __forceinline__ NoSaveX saver(int, long, int, int, bool, int) const { return NoSaveX(); }
   __device__ __forceinline__ void raw(int, long, int, int, bool, int, const f32x16 (&)[2], float) const {}
 };
-#if CRNERF_X_NP == 3
 struct TrainHookX {
   float* acts[2];   // [10][R*N][256] + masks, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
   float* rawo[2];   // [R*N][65]
@@ -75,7 +74,6 @@ struct TrainHookX {
     if (h == 0) o[FEAT_DIM] = sigma;
   }
 };
-#endif
 
 // RNG: the instantiation with the in-kernel draws -- a template parameter like render_fused16.hip's, so the kernels without draws carry no
 // Philox registers through the MLP loop
@@ -210,10 +208,8 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
 
 __global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) { render_rays_x3_body<false>(a, NoHookX()); }
 __global__ __launch_bounds__(256, 1) void render_rays_x3_rng_kernel(RenderParamsX a) { render_rays_x3_body<true>(a, NoHookX()); }
-#if CRNERF_X_NP == 3
 __global__ __launch_bounds__(256, 1) void render_rays_train_x3_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body<false>(a, hook); }
 __global__ __launch_bounds__(256, 1) void render_rays_train_x3_rng_kernel(RenderParamsX a, TrainHookX hook) { render_rays_x3_body<true>(a, hook); }
-#endif
 
 int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
@@ -234,15 +230,12 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
   const long quads = (a.R + 3) / 4;
   const int cus = num_cus();
-  if (a.repair && (a.train_acts_coarse || quads > 0x7fffffffL)) return set_error(-3, "render_rays_f32x3_repair: inference renders of < 2^33 rays only");
+  if (a.repair && quads > 0x7fffffffL) return set_error(-3, "render_rays_f32x3_repair: renders of < 2^33 rays only");
   k.repair = a.repair;
   const int grid = a.repair ? (int)quads : (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads (repair: one per quad)
   k.iters = (int)((quads + grid - 1) / grid);
   const size_t shmem = LDS_SCRATCH_X + 4 * SCRATCH_BYTES;
-#if CRNERF_X_NP != 3
-  if (a.train_acts_coarse) return set_error(-2, "render_rays_f32h2: there is no training twin on the h2 core");
-#else
-  if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_f32x3)
+  if (a.train_acts_coarse) {   // training twin (crnerf_render_rays_train_f32x3 / _f32h2; repair: the rays the h2 twin poisoned, saved rows included)
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train_f32x3: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train_f32x3: raw_coarse is NULL");
     if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 1024ull >= (unsigned long long)SAVEX_OOB)
@@ -254,7 +247,6 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
     return check_launch("render_rays_train_x3_kernel");
   }
-#endif
   const void* fn = rngk ? (const void*)render_rays_x3_rng_kernel : (const void*)render_rays_x3_kernel;
   if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_x3_kernel")) return rc;
   if (rngk) hipLaunchKernelGGL(render_rays_x3_rng_kernel, dim3(grid), dim3(256), shmem, stream, k);

@@ -234,7 +234,18 @@ def pack_mlp_weights_t_x3(state):
     return out
 
 
-def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False):
+def pack_mlp_weights_t_h2(state):
+    """Transposed h2 fragment stream for the backward-data kernel on the h2 core (crnerf_mlp_backward_h2_f32): two fp16 pieces of 2^8 w.  No range
+    check of its own -- pack_mlp_weights_h2 / pack_mlp_weights(..., precision="auto") of the same weights is the check."""
+    lib = _lib.load()
+    tensors = _mlp_tensor_list(state)
+    out = torch.empty(lib.crnerf_packed_mlp_t_h2_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    _lib.check(lib.crnerf_pack_mlp_weights_t_h2(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()),
+               "crnerf_pack_mlp_weights_t_h2")
+    return out
+
+
+def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False, dgrad_h2=False):
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
     (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
     CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
@@ -244,15 +255,16 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False
     n = x.shape[0]
     grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
     scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
-    fn = lib.crnerf_mlp_backward_x3_f32 if dgrad_x3 else lib.crnerf_mlp_backward_ex_f32     # dgrad_x3: packed_t is a pack_mlp_weights_t_x3 pack
-    want = lib.crnerf_packed_mlp_t_x3_bytes() if dgrad_x3 else lib.crnerf_packed_mlp_t_bytes()
+    # dgrad_x3 / dgrad_h2: the data gradient on the x3 / h2 core; packed_t is then a pack_mlp_weights_t_x3 / pack_mlp_weights_t_h2 pack
+    fn, name, want = ((lib.crnerf_mlp_backward_h2_f32, "crnerf_mlp_backward_h2_f32", lib.crnerf_packed_mlp_t_h2_bytes()) if dgrad_h2 else
+                      (lib.crnerf_mlp_backward_x3_f32, "crnerf_mlp_backward_x3_f32", lib.crnerf_packed_mlp_t_x3_bytes()) if dgrad_x3 else
+                      (lib.crnerf_mlp_backward_ex_f32, "crnerf_mlp_backward_ex_f32", lib.crnerf_packed_mlp_t_bytes()))
     if packed_t.numel() != want:
-        raise ValueError("crnerf_amd: mlp_backward(dgrad_x3=%s) needs a %d-byte transposed pack, got %d" % (dgrad_x3, want, packed_t.numel()))
+        raise ValueError("crnerf_amd: %s needs a %d-byte transposed pack, got %d" % (name, want, packed_t.numel()))
     _lib.check(fn(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
                   ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
                   _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
-                  _lib.stream_ptr()),
-               "crnerf_mlp_backward_x3_f32" if dgrad_x3 else "crnerf_mlp_backward_ex_f32")
+                  _lib.stream_ptr()), name)
     return grads
 
 
@@ -417,7 +429,8 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     acts_coarse / acts_fine (crnerf_mlp_forward_train_f32 layout, point = ray * N + sample) and raw_coarse / raw_fine [R,N,65].
     train=True with precision="bf16": crnerf_render_rays_train_bf16, the twin of the opt-in mixed-precision mode (acts_* in the layout
     mlp_backward_mixed(..., fused_acts=True) reads).
-    precision="auto": packs from pack_mlp_weights(..., precision="auto"); the h2 core, repaired by the x3 core where it poisoned a ray.
+    precision="auto": packs from pack_mlp_weights(..., precision="auto"); the h2 core, repaired by the x3 core where it poisoned a ray
+    (train=True: crnerf_render_rays_train_f32h2, then crnerf_render_rays_train_f32x3_repair -- saved rows included).
     rng (fp32 and f32x3): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
     steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
@@ -426,11 +439,11 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     repair = None
     if _is_auto(precision):
         # the h2 core with the x3 core as its safety net: render on h2, then crnerf_render_rays_f32x3_repair re-renders the ray quads that came out NaN
-        # (a point's activations left fp16's range).  A refused h2 pack (a weight >= 255) or a training twin: the x3 core throughout.
+        # (a point's activations left fp16's range).  A refused h2 pack (a weight >= 255): the x3 core throughout.
         packs = [pk for pk in (packed_coarse, packed_fine) if pk is not None]
         if any(not isinstance(pk, AutoPack) for pk in packs):
             raise ValueError("crnerf_amd: precision='auto' needs packs from pack_mlp_weights(..., precision='auto')")
-        if train or any(pk.h2 is None for pk in packs):
+        if any(pk.h2 is None for pk in packs):
             precision = "f32x3"
             packed_coarse, packed_fine = packed_coarse.x3, (packed_fine.x3 if packed_fine is not None else None)
         else:
@@ -442,8 +455,6 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     bf16 = False if (x3 or h2) else _is_bf16(precision)
     want_z_fine = want_z_fine or train
     if h2:
-        if train:
-            raise ValueError("crnerf_amd: precision='f32h2' has no training twin")
         for pk in (packed_coarse, packed_fine):
             if pk is not None and pk.numel() != lib.crnerf_packed_mlp_h2_bytes():
                 raise ValueError("crnerf_amd: precision='f32h2' needs packs from pack_mlp_weights_h2")
@@ -517,9 +528,15 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
             out["acts_fine"] = torch.empty(acts_bytes(R * Nf), dtype=torch.uint8, device=dev)
             out["raw_fine"] = new(R, Nf, 65)
         vp = lambda k: ctypes.c_void_p(out[k].data_ptr()) if k in out else None  # noqa: E731
-        fn = lib.crnerf_render_rays_train_f32x3 if x3 else (lib.crnerf_render_rays_train_bf16 if bf16 else lib.crnerf_render_rays_train_f32)
-        _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()),
-                   "crnerf_render_rays_train_f32x3" if x3 else ("crnerf_render_rays_train_bf16" if bf16 else "crnerf_render_rays_train_f32"))
+        fn, name = ((lib.crnerf_render_rays_train_f32h2, "crnerf_render_rays_train_f32h2") if h2 else
+                    (lib.crnerf_render_rays_train_f32x3, "crnerf_render_rays_train_f32x3") if x3 else
+                    (lib.crnerf_render_rays_train_bf16, "crnerf_render_rays_train_bf16") if bf16 else
+                    (lib.crnerf_render_rays_train_f32, "crnerf_render_rays_train_f32"))
+        _lib.check(fn(ctypes.byref(a), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"), _lib.stream_ptr()), name)
+        a2 = _repair_args(a, repair)
+        if a2 is not None:        # precision="auto": the ray quads the h2 twin poisoned, once more on the scale-free core -- outputs AND saved state
+            _lib.check(lib.crnerf_render_rays_train_f32x3_repair(ctypes.byref(a2), vp("acts_coarse"), vp("acts_fine"), vp("raw_coarse"), vp("raw_fine"),
+                                                                 _lib.stream_ptr()), "crnerf_render_rays_train_f32x3_repair")
         return out
     if h2:
         _lib.check(lib.crnerf_render_rays_f32h2(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_f32h2")

@@ -309,3 +309,144 @@ def test_render_auto_repairs_poisoned_rays(ni):
     launch()
     for k in keys:
         assert torch.equal(out2[k], oau[k]), k
+
+
+# ------------------------------------------------------------------ training on the h2 core (round 4): crnerf_render_rays_train_f32h2, crnerf_mlp_backward_h2_f32
+@torch.no_grad()
+@pytest.mark.parametrize("R,Nc,Ni", [(37, 64, 64), (5, 33, 20), (16, 64, 0)])
+def test_h2_train_forward_saves_what_the_fp32_twin_saves(R, Nc, Ni):
+    """crnerf_render_rays_train_f32h2 (tests/test_gpu_x3.py has the same test for the x3 twin): outputs within fp32 noise of the f32h2 inference
+    renderer (the training form finishes a layer in a different instruction order, not bit-identical), saved activations / relu bits / raw rows
+    in the fp32 training twins' layout and equal to what crnerf_render_rays_train_f32 saves up to the two paths' fp32-level difference."""
+    st_c, st_f = {k: C(v) for k, v in synth.mlp_state(5, 1.0, 0.5).items()}, {k: C(v) for k, v in synth.mlp_state(6, 1.0, 0.5).items()}
+    ph = [ops.pack_mlp_weights_h2(st_c), ops.pack_mlp_weights_h2(st_f)]
+    p32 = [ops.pack_mlp_weights(st_c), ops.pack_mlp_weights(st_f)]
+    rng = np.random.default_rng(R)
+    rays = C(synth.rays(R, seed=R))
+    z = C(np.sort(rng.uniform(2, 6, (R, Nc)).astype(np.float32), -1))
+    u = C(rng.uniform(0, 1, (R, max(Ni, 1))).astype(np.float32))
+    kw = dict(z_coarse=z, u=u if Ni else None, noise_std=0.0)
+    inf = ops.render_rays(ph[0], ph[1] if Ni else None, rays, Nc, Ni, want_z_fine=True, precision="f32h2", **kw)
+    trn = ops.render_rays(ph[0], ph[1] if Ni else None, rays, Nc, Ni, train=True, precision="f32h2", **kw)
+    for k in ("feature_coarse", "weights_coarse", "depth_coarse"):      # (the sigma head sums in another order: 1e-7 of sigma x the last sample's delta = 1e2, rendering.py:121-123)
+        torch.testing.assert_close(trn[k], inf[k], atol=5e-5, rtol=1e-4)
+    ref = ops.render_rays(p32[0], p32[1] if Ni else None, rays, Nc, Ni, train=True, **kw)
+    for tag, N in (("coarse", Nc),) + ((("fine", Nc + Ni),) if Ni else ()):
+        P = R * N
+        if tag == "fine" and not torch.equal(trn["z_fine"], ref["z_fine"]):
+            continue                                    # the two paths sampled (slightly) different depths: rows are not comparable point by point
+        n_act = 10 * P * 256
+        a, b = trn["acts_" + tag][:4 * n_act].view(torch.float32).view(10, P, 256), ref["acts_" + tag][:4 * n_act].view(torch.float32).view(10, P, 256)
+        assert float((a[:9] - b[:9]).abs().max()) <= 2e-5 * float(b[:9].abs().max()) and float((a[9, :, :128] - b[9, :, :128]).abs().max()) <= 2e-5, tag
+        assert float((trn["raw_" + tag] - ref["raw_" + tag]).abs().max()) <= 2e-6, tag
+        ma, mb = trn["acts_" + tag][4 * n_act:4 * n_act + 320 * P].view(10, P, 32), ref["acts_" + tag][4 * n_act:4 * n_act + 320 * P].view(10, P, 32)
+        for s in (0, 1, 2, 3, 4, 5, 6, 7):
+            assert float((ma[s] == mb[s]).float().mean()) >= 0.999, (tag, s)
+        assert float((ma[9].view(P, 4, 8)[:, :, :4] == mb[9].view(P, 4, 8)[:, :, :4]).float().mean()) >= 0.999, tag
+        k = torch.arange(64, device=DEV)
+        for s in (0, 5):                                # the bits are the record of the saved rows themselves
+            want = a[s].view(P, 16, 4, 4) > 0
+            bits = trn["acts_" + tag][4 * n_act:].view(torch.int64)[:10 * P * 4].view(10, P, 4)[s]
+            got = ((bits[:, :, None] >> k[None, None, :]) & 1).bool().view(P, 4, 16, 4).permute(0, 2, 1, 3)
+            assert torch.equal(want, got), (tag, s)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("n,log2s", [(1, 0), (33, 0), (4099, 0), (70000, 0), (4099, -40), (4099, 40), (513, -100), (513, 90)])
+def test_mlp_backward_h2_matches_the_fp32_data_gradient(n, log2s):
+    """crnerf_mlp_backward_h2_f32: the deltas of the h2 core equal the fp32 kernel's up to fp32 summation noise (seen through every weight / bias
+    gradient, formed by the SAME weight-gradient kernels from them) -- at ordinary gradient magnitudes and with d_out scaled by 2^-100 ... 2^90
+    (fp16 alone would lose everything below 6e-8: every point's delta vector is rescaled per layer, include/crnerf.h); against torch autograd
+    through the oracle at the fp32 twin's own tolerance."""
+    st = synth.mlp_state(13, 2.0 if n > 100 else 1.0, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32))
+    d_out[::7] *= 1e-6                                  # points of very different gradient size side by side in one tile
+    d_out[::11, :64] = 0.0                              # points whose rgb head gets no gradient at all
+    d_out = d_out * float(2.0 ** log2s)
+    dev = {k: C(v) for k, v in st.items()}
+    out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev), x.to(DEV))
+    g32 = ops.mlp_backward(ops.pack_mlp_weights_t(dev), x.to(DEV), out, d_out.to(DEV), acts)
+    gh2 = ops.mlp_backward(ops.pack_mlp_weights_t_h2(dev), x.to(DEV), out, d_out.to(DEV), acts, dgrad_h2=True)
+    for name, a, b in zip(ops.MLP_TENSOR_NAMES, gh2, g32):
+        assert bool(torch.isfinite(a).all()), name
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + (1e-7 if log2s == 0 else 0.0), (name, float((a - b).abs().max()), scale)
+    if n <= 100:
+        with torch.enable_grad():
+            w = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+            (O.mlp_forward(w, x) * d_out).sum().backward()
+        for name, gq in zip(ops.MLP_TENSOR_NAMES, gh2):
+            ref = w[name].grad
+            assert float((gq.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-5, name
+
+
+@pytest.mark.parametrize("mode", ["f32h2", "auto"])
+def test_h2_training_forward_gradients_match_the_fp32_forward(mode):
+    """set_training_forward_precision("f32h2" / "auto"): FusedRenderFn on the h2 training twin + the h2 data gradient, against the all-fp32 path on
+    the same rays / depths / noise (tests/test_gpu_x3.py::test_x3_training_forward_gradients_match_the_fp32_forward, same bar)."""
+    from crnerf_amd import autograd as AG
+    from test_gpu_train_fused import _grads, _inputs, _modules
+    models, emb, args = _modules(gain=2.45, sigma_bias=-1.0, band_limit=4)
+    R = 128
+    rays, z, u, nc, nf = _inputs(R, 64, 64, seed=5)
+    gw = torch.randn(R, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run():
+        out = AG.fused_render_with_grad(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0)
+        return (out["feature_fine"] * gw).sum() + 0.5 * (out["feature_coarse"] * gw).sum() + 0.1 * (out["weights_fine"] ** 2).sum()
+    g32 = _grads(models, run)
+    AG.set_training_forward_precision(mode)
+    try:
+        gh2 = _grads(models, run)
+    finally:
+        AG.set_training_forward_precision("f32")
+    for k in g32:
+        rel = float((gh2[k] - g32[k]).norm() / (g32[k].norm() + 1e-30))
+        assert rel <= 2e-3, (k, rel)
+
+
+@torch.no_grad()
+def test_train_auto_repairs_poisoned_rays_and_their_saved_rows():
+    """Training under precision="auto": rays through a net whose hidden activations pass 65,504 for a quarter of the rays.  The h2 twin alone
+    returns NaN features there; auto (h2 twin, then crnerf_render_rays_train_f32x3_repair on the same buffers) returns no NaN, and in every
+    repaired ray quad the outputs, raw rows AND saved activation rows / relu bits are the x3 twin's bit for bit; everywhere else the h2 twin's."""
+    def net(seed):
+        st = dict(synth.mlp_state(seed, 1.0))
+        for l in (1, 2):
+            w = st["xyz_encoding_%d.0.weight" % l].copy()
+            w[0, 0] = 250.0
+            st["xyz_encoding_%d.0.weight" % l] = w
+        return st
+    st_c, st_f = net(5), net(6)
+    R, Nc, Ni = 256, 64, 64
+    rays = synth.rays(R, seed=3, H=16, W=16).copy()
+    rays[:192, 0:3] *= 1e-3
+    rays[:192, 6] = 1e-4
+    rays[:192, 7] = 2e-3
+    rd = C(rays)
+    dc, df = {k: C(v) for k, v in st_c.items()}, {k: C(v) for k, v in st_f.items()}
+    zs, u = torch.linspace(0, 1, Nc, device=DEV), torch.linspace(0, 1, Ni, device=DEV)
+    kw = dict(z_steps=zs, u=u, train=True)
+    oh2 = ops.render_rays(ops.pack_mlp_weights_h2(dc), ops.pack_mlp_weights_h2(df), rd, Nc, Ni, precision="f32h2", **kw)
+    ox3 = ops.render_rays(ops.pack_mlp_weights_x3(dc), ops.pack_mlp_weights_x3(df), rd, Nc, Ni, precision="f32x3", **kw)
+    oau = ops.render_rays(ops.pack_mlp_weights(dc, precision="auto"), ops.pack_mlp_weights(df, precision="auto"), rd, Nc, Ni, precision="auto", **kw)
+    bad = torch.isnan(oh2["feature_coarse"]).any(1) | torch.isnan(oh2["feature_fine"]).any(1)
+    assert 0 < int(bad.sum()) <= 64 and not bool(bad[:192].any()), int(bad.sum())
+    quad_bad = bad.view(-1, 4).any(1)[:, None].expand(-1, 4).reshape(-1)
+    for k in ("feature_coarse", "weights_coarse", "depth_coarse", "feature_fine", "weights_fine", "depth_fine", "z_fine", "raw_coarse", "raw_fine"):
+        assert not bool(torch.isnan(oau[k]).any()), k
+        assert torch.equal(oau[k][quad_bad], ox3[k][quad_bad]), k
+        assert torch.equal(oau[k][~quad_bad], oh2[k][~quad_bad]), k
+    for tag, N in (("coarse", Nc), ("fine", Nc + Ni)):
+        P = R * N
+        pt_bad = quad_bad[:, None].expand(-1, N).reshape(-1)
+        rows = lambda o: o["acts_" + tag][:40 * P * 256].view(torch.float32).view(10, P, 256)        # noqa: E731
+        bits = lambda o: o["acts_" + tag][40 * P * 256:40 * P * 256 + 320 * P].view(10, P, 32)       # noqa: E731
+        for src, sel in ((ox3, pt_bad), (oh2, ~pt_bad)):
+            assert torch.equal(rows(oau)[:9, sel].view(torch.int32), rows(src)[:9, sel].view(torch.int32)), tag
+            assert torch.equal(rows(oau)[9, sel, :128].view(torch.int32), rows(src)[9, sel, :128].view(torch.int32)), tag     # slot 9 is 128 wide
+            assert torch.equal(bits(oau)[:8, sel], bits(src)[:8, sel]), tag                                                   # slot 8 is linear: no bits
+            assert torch.equal(bits(oau)[9, sel].view(-1, 4, 8)[:, :, :4], bits(src)[9, sel].view(-1, 4, 8)[:, :, :4]), tag

@@ -49,6 +49,12 @@ print("backward, x3 data gradient + bf16x3 weight gradients   %7.2f ms" % (t_bx 
 px = ops.pack_mlp_weights_x3(st)
 t_fx, _ = timed(lambda: ops.mlp_forward_x3(px, x))
 print("forward, f32x3 (inference kernel)  %7.2f ms" % (t_fx * 1e3))
+packed_th = ops.pack_mlp_weights_t_h2(st)
+t_bh, _ = timed(lambda: ops.mlp_backward(packed_th, x, out, d_out, acts, wgrad_bf16=2, dgrad_h2=True))
+print("backward, h2 data gradient + bf16x3 weight gradients   %7.2f ms" % (t_bh * 1e3))
+ph = ops.pack_mlp_weights_h2(st)
+t_fh, _ = timed(lambda: ops.mlp_forward_h2(ph, x))
+print("forward, f32h2 (inference kernel)  %7.2f ms" % (t_fh * 1e3))
 if flags and not os.environ.get("CRNERF_KEEP_BUILD"):
     env = {k: v for k, v in os.environ.items() if k != "CRNERF_EXTRA_FLAGS"}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL, env=env)
