@@ -78,8 +78,8 @@ _TRAIN_BF16 = [False]
 _TRAIN_FWD = [None]
 
 
-def set_training_forward_precision(precision="f32"):
-    """"f32" (default): the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
+def set_training_forward_precision(precision=None):
+    """None: the default ("auto", see get_training_forward_mode).  "f32": the grad-mode forward of render_rays_cross_ray on the fp32 matrix cores (crnerf_render_rays_train_f32).  "f32x3": the same
     fp32 forward on the bf16 matrix cores (crnerf_render_rays_train_f32x3: three-piece bf16 splits of every fp32 operand, six MFMAs per
     product -- include/crnerf.h "f32x3"), and with it the data gradient on the same core (crnerf_mlp_backward_x3_f32): same saved state and
     scratch layouts, the weight gradients as set_wgrad_precision says; the stochastic draws in-kernel from the same Philox counters as the fp32 twin.
@@ -87,9 +87,10 @@ def set_training_forward_precision(precision="f32"):
     (crnerf_render_rays_train_f32h2 / crnerf_mlp_backward_h2_f32) -- fp32-accurate within fp16's range: a weight >= 255 raises when packing, a
     point whose activations pass 65,504 comes out NaN; the gradient side rescales every point's deltas per layer and has no range limit.
     "auto": "f32h2" with the scale-free f32x3 twins as its safety net -- poisoned ray quads are rendered again (saved rows included) by
-    crnerf_render_rays_train_f32x3_repair on the device, a refused pack trains that step on f32x3; no NaN of the h2 core's making reaches the loss."""
-    _TRAIN_FWD[0] = ("f32x3" if ops._is_x3(precision) else "f32h2" if ops._is_h2(precision) else "auto" if ops._is_auto(precision) else
-                     (None if not ops._is_bf16(precision) else _bad_fwd_precision(precision)))
+    crnerf_render_rays_train_f32x3_repair on the device; a weight >= 255 leaves a flag in the (asynchronous) pack that makes the h2 kernels hand
+    the whole step to the f32x3 ones, also on the device: no host round trip, no NaN of the h2 core's making in the loss."""
+    _TRAIN_FWD[0] = (None if precision is None else "f32x3" if ops._is_x3(precision) else "f32h2" if ops._is_h2(precision) else
+                     "auto" if ops._is_auto(precision) else ("f32" if not ops._is_bf16(precision) else _bad_fwd_precision(precision)))
 
 
 def _bad_fwd_precision(precision):
@@ -98,7 +99,10 @@ def _bad_fwd_precision(precision):
 
 
 def get_training_forward_mode():
-    """"f32" | "f32x3" | "f32h2" | "auto" (environment: CRNERF_TRAIN_FWD=x3|h2|auto, or the older CRNERF_TRAIN_FWD_X3=1)."""
+    """"auto" (the default since round 4) | "f32" | "f32x3" | "f32h2" (environment: CRNERF_TRAIN_FWD=f32|x3|h2|auto, or the older CRNERF_TRAIN_FWD_X3=1).
+    Why "auto" is the default: it is fp32-accurate (every saved row, output and gradient held to the fp32 twins' bars, tests/test_gpu_h2.py), it
+    cannot fail on range (device-side fall-back to the scale-free f32x3 twins), and it is what the part is fast at -- the 65,536-ray train.sh
+    step 343 -> 256 ms, the 1,024-ray one 9.1 -> 7.6-8.1 ms.  "f32" keeps every product on the fp32 matrix cores, the reference's arithmetic."""
     import os
     if _TRAIN_FWD[0] is not None:
         return _TRAIN_FWD[0]
@@ -107,9 +111,11 @@ def get_training_forward_mode():
         return "f32x3"
     if env in ("h2", "f32h2"):
         return "f32h2"
+    if env in ("f32", "fp32"):
+        return "f32"
     if env == "auto":
         return "auto"
-    return "f32x3" if os.environ.get("CRNERF_TRAIN_FWD_X3", "") not in ("", "0") else "f32"
+    return "f32x3" if os.environ.get("CRNERF_TRAIN_FWD_X3", "") not in ("", "0") else "auto"
 
 
 def get_training_forward_x3():
@@ -118,7 +124,7 @@ def get_training_forward_x3():
 
 def _pack_for_training(mode, state):
     return (ops.pack_mlp_weights_x3(state) if mode == "f32x3" else ops.pack_mlp_weights_h2(state) if mode == "f32h2" else
-            ops.pack_mlp_weights_auto(state) if mode == "auto" else ops.pack_mlp_weights(state))
+            ops.pack_mlp_weights_auto(state, check=False) if mode == "auto" else ops.pack_mlp_weights(state))
 
 
 def _effective_mode(mode, packed):
@@ -244,7 +250,9 @@ class FusedRenderFn(torch.autograd.Function):
             mode = getattr(ctx, "mode", "f32")   # a split-core forward brings the data gradient on the same core with it (set_training_forward_precision)
             x3, h2 = mode == "f32x3", mode in ("f32h2", "auto")
             packed_t = ops.pack_mlp_weights_t_h2(states[m]) if h2 else (ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]))
-            grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3, dgrad_h2=h2)
+            net = ops.pack_mlp_weights_t_x3(states[m]) if mode == "auto" else None      # "auto": the f32x3 data gradient stands by (device-side range flag)
+            grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3, dgrad_h2=h2,
+                                      fallback_t_x3=net)
             del x, d_raw
         return (None, None) + tuple(grads)
 

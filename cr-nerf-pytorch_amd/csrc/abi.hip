@@ -340,8 +340,8 @@ int crnerf_pack_mlp_weights_t_h2(const float* const* tensors, void* packed, void
   return launch_pack_mlp_h2t(to_tensors(tensors), packed, (hipStream_t)stream);
 }
 
-int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
-                               float* const* grads, int64_t n, int flags, void* stream) {
+int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts,
+                               void* scratch, float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
   if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: unknown flag bits");
   if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: the two weight-gradient modes are exclusive");
@@ -349,7 +349,7 @@ int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const float* x, const fl
   REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_h2: a gradient pointer is NULL");
-  return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, nullptr, packed_t_h2);
+  return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, packed_t_x3, packed_t_h2);
 }
 
 size_t crnerf_packed_mlp_x3_bytes(void) { return PACKEDX_BYTES; }
@@ -377,6 +377,18 @@ int crnerf_pack_mlp_weights_h2(const float* const* tensors, void* packed, void* 
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
     if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_h2: a tensor pointer is NULL");
   return launch_pack_mlp_h2(to_tensors(tensors), packed, (hipStream_t)stream);
+}
+
+int crnerf_pack_mlp_weights_h2_async(const float* const* tensors, void* packed, void* stream) {
+  REQUIRE(tensors, "tensors"); REQUIRE(packed, "packed");
+  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+    if (!tensors[i]) return set_error(CRNERF_ERR_NULL, "pack_mlp_weights_h2_async: a tensor pointer is NULL");
+  return launch_pack_mlp_h2(to_tensors(tensors), packed, (hipStream_t)stream, false);
+}
+
+int crnerf_pack_h2_status(const void* packed_h2, void* stream) {
+  REQUIRE(packed_h2, "packed_h2");
+  return pack_h2_status(packed_h2, (hipStream_t)stream);
 }
 
 int crnerf_mlp_forward_f32h2(const void* packed, const float* x, float* out, int64_t n, int sigma_only, void* stream) {

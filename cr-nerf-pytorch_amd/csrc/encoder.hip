@@ -26,6 +26,18 @@ __global__ void transpose_weights_kernel(const float* __restrict__ w, float* __r
   wt[r * cout + o] = w[idx];
 }
 
+// all seven re-layouts of a training forward in ONE launch (a block belongs to the job whose block range holds it; jobs by value)
+struct TransposeJobs { const float* w[7]; float* wt[7]; int cout[7], rows[7], first_block[8]; };
+__global__ void transpose_weights_batch_kernel(TransposeJobs j) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < 7; ++k) l += (int)blockIdx.x >= j.first_block[k];
+  const int idx = ((int)blockIdx.x - j.first_block[l]) * blockDim.x + threadIdx.x;
+  if (idx >= j.cout[l] * j.rows[l]) return;
+  const int o = idx / j.rows[l], r = idx % j.rows[l];
+  j.wt[l][r * j.cout[l] + o] = j.w[l][idx];
+}
+
 // NCHW [C,H,W] -> HWC [H*W, C]
 __global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,6 +233,18 @@ void enc_conv(int taps, bool act, const float* in, const float* wt, const float*
 void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st) {
   const int n = cout * cin * taps;
   hipLaunchKernelGGL(transpose_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, wt, cout, cin, taps);
+}
+// w: the encoder's 14 tensors (weights at even indices); wt[l] = where layer l's [cin][tap][cout] copy goes
+void enc_transpose_weights_all(const float* const* w, float* const* wt, const int* cout, const int* cin, const int* taps, hipStream_t st) {
+  TransposeJobs j;
+  int blocks = 0;
+  for (int l = 0; l < 7; ++l) {
+    j.w[l] = w[2 * l]; j.wt[l] = wt[l]; j.cout[l] = cout[l]; j.rows[l] = cin[l] * taps[l];
+    j.first_block[l] = blocks;
+    blocks += (cout[l] * cin[l] * taps[l] + 255) / 256;
+  }
+  j.first_block[7] = blocks;
+  hipLaunchKernelGGL(transpose_weights_batch_kernel, dim3(blocks), dim3(256), 0, st, j);
 }
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st) {
   hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, in, out, C, HW);

@@ -14,6 +14,7 @@ __device__ __forceinline__ float lrelu_grad(float y) { return y > 0.0f ? 1.0f : 
 // forward kernels are encoder.hip's; redeclared here through small wrappers in that file
 void enc_conv(int taps, bool act, const float* in, const float* wt, const float* b, float* out, int H, int W, int cin, int cout, hipStream_t st);
 void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st);
+void enc_transpose_weights_all(const float* const* w, float* const* wt, const int* cout, const int* cin, const int* taps, hipStream_t st);
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st);
 void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st);
 void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st);
@@ -80,7 +81,8 @@ int launch_encoder_forward_train(const float* img, int H, int W, const float* co
   float* s = (float*)saved;
   float* wt[7];
   float* p = s + L.end;
-  for (int l = 0; l < 7; ++l) { wt[l] = p; enc_transpose_weights(w[2 * l], wt[l], TCOUT[l], TCIN[l], TTAPS[l], st); p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
+  for (int l = 0; l < 7; ++l) { wt[l] = p; p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
+  enc_transpose_weights_all(w, wt, TCOUT, TCIN, TTAPS, st);     // one launch (seven before: 28 of the 570 launches of a 1,024-ray train.sh step)
   enc_chw_to_hwc(img, s + L.a0, 3, H * W, st);
   enc_conv(1, false, s + L.a0, wt[0], w[1], s + L.y1, H, W, 3, 3, st);
   enc_conv(9, true, s + L.y1, wt[1], w[3], s + L.y2, H, W, 3, 64, st);

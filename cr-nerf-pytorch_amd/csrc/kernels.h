@@ -122,14 +122,16 @@ int launch_mlp_forward_x3(const void* packed, const float* x, float* out, long P
 int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream);
 int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream);
 // "h2" core (mlp_core_x3.h built with two fp16 pieces per operand): packs, module forward, fused renderer (inference)
-int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream);
+int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream, bool check = true);
+int pack_h2_status(const void* packed, hipStream_t stream);
 int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_h2(const RenderArgs& a, hipStream_t stream);
 int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream);
+// only_if: device word; the kernel leaves at once when it is 0 (the f32x3 stand-in of an h2 data gradient whose pack was refused); null: always
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
-                        hipStream_t stream);
+                        hipStream_t stream, const int* only_if = nullptr);
 int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);    // one ray per wave, 64-point tiles, one wave per SIMD (render_fused_bf16.hip)
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);

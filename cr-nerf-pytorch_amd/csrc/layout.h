@@ -200,6 +200,12 @@ constexpr size_t PACKEDX_BYTES = (size_t)CONST_BYTES + (size_t)STREAMX_FRAGS * F
 // the core scales the bias up and the layer output down, both exact): piece 0 = fp16(256 w), piece 1 = fp16(256 w - piece 0).  Same
 // fragment geometry and order as fragX with two pieces per (k-step, tile); dir_encoding needs no padding (144 = 9 stages = 36 queue turns).
 constexpr float H2_WSCALE = 256.0f;
+// the range flag of an h2 / h2t pack: one word of the pack's own consts block behind CONST_FLOATS (zeroed by pack_consts_kernel), set by the stream
+// packers when a scaled weight is not a finite fp16 number.  The host reads it in crnerf_pack_mlp_weights_h2 / crnerf_pack_h2_status; the h2 kernels
+// read it from the LDS copy of the consts: a refused pack poisons every ray (the f32x3 repair then renders all of them) / skips the h2 data gradient
+// (the f32x3 one runs instead) -- precision "auto" without a host round trip.
+constexpr int H2_FLAG_WORD = CONST_FLOATS;
+static_assert((H2_FLAG_WORD + 1) * 4 <= CONST_BYTES, "no spare word in the consts block");
 constexpr int FH_L1 = KS_XYZ * 8 * 2;                //   96
 constexpr int FH_HID = KS_HID * 8 * 2;               //  256
 constexpr int FH_L5 = (KS_XYZ + KS_HID) * 8 * 2;     //  352

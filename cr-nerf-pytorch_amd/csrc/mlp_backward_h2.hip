@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
   const int p = lane & 31, h = lane >> 5;
   load_consts(lds, packedT, packedT);   // the consts block carries the sigma-head weights (unscaled)
   const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
+  if (__float_as_uint(C[H2_FLAG_WORD]) != 0u) return;   // a weight is outside fp16's range: the f32x3 data gradient runs instead (launch_mlp_backward)
   WeightPipeX pipe;
   pipe.set_stream_frags(STREAMHT_FRAGS);
   pipe.start(lds, packedT + CONST_BYTES, packedT + CONST_BYTES, 1, 1, lane, wave);

@@ -41,9 +41,10 @@ __device__ __forceinline__ void finish_delta_x(const f32x16 (&acc)[NT], f32x16 (
 
 __global__ __launch_bounds__(256, 1) void mlp_backward_x3_kernel(const char* __restrict__ packedT, const float* __restrict__ out, const float* __restrict__ d_out,
                                                                  const float* __restrict__ acts, float* __restrict__ deltas, float* __restrict__ d_rgb,
-                                                                 float* __restrict__ d_sig, long P, int iters) {
+                                                                 float* __restrict__ d_sig, long P, int iters, const int* __restrict__ only_if) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
+  if (only_if && *only_if == 0) return;   // the h2 data gradient did the work (launch_mlp_backward)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = lane & 31, h = lane >> 5;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_x3_kernel(const char* __r
 }
 
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
-                        hipStream_t stream) {
+                        hipStream_t stream, const int* only_if) {
   if (P <= 0) return 0;
   if ((unsigned long long)P * 1024ull >= (unsigned long long)SAVEX_OOB)
     return set_error(-2, "mlp_backward_x3: more than 3.9 M points per call (the delta rows are addressed with 32-bit offsets)");
@@ -144,7 +145,7 @@ int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (int rc = ensure_dynamic_lds((const void*)mlp_backward_x3_kernel, LDS_SCRATCH_X, "mlp_backward_x3_kernel")) return rc;
-  hipLaunchKernelGGL(mlp_backward_x3_kernel, dim3(grid), dim3(256), LDS_SCRATCH_X, stream, (const char*)packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
+  hipLaunchKernelGGL(mlp_backward_x3_kernel, dim3(grid), dim3(256), LDS_SCRATCH_X, stream, (const char*)packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, iters, only_if);
   return check_launch("mlp_backward_x3_kernel");
 }
 

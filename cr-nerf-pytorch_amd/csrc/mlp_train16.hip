@@ -950,6 +950,8 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (packedT_h2) {   // crnerf_mlp_backward_h2_f32: the data gradient on the h2 core (mlp_backward_h2.hip), same scratch layout
     if (int rc = launch_mlp_dgrad_h2(packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, stream)) return rc;
+    if (packedT_x3)   // its safety net: the same deltas on the scale-free core, only when the h2 pack carries the range flag (device-side test)
+      if (int rc = launch_mlp_dgrad_x3(packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, stream, (const int*)packedT_h2 + H2_FLAG_WORD)) return rc;
   } else if (packedT_x3) {   // crnerf_mlp_backward_x3_f32: the data gradient on the x3 core (mlp_backward_x3.hip), same scratch layout
     if (int rc = launch_mlp_dgrad_x3(packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, stream)) return rc;
   } else {

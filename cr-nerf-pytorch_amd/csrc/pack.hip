@@ -196,8 +196,6 @@ __global__ void pack_stream_x3_kernel(MlpTensors t, unsigned short* __restrict__
 // A weight whose scaled value leaves the fp16 range becomes inf: the outputs are then inf / nan, not silently wrong.
 // range_flag: one word of the pack's own consts block (behind CONST_FLOATS, zeroed by pack_consts_kernel; no kernel reads it), set when a scaled
 // weight is not a finite fp16 number -- per pack, so concurrent packs on different streams / threads do not share state
-constexpr int H2_FLAG_WORD = CONST_FLOATS;
-static_assert((H2_FLAG_WORD + 1) * 4 <= CONST_BYTES, "no spare word in the consts block");
 __global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__ stream, int* __restrict__ range_flag) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)STREAMH_FRAGS * 512) return;
@@ -236,7 +234,7 @@ __global__ void pack_stream_h2_kernel(MlpTensors t, unsigned short* __restrict__
   stream[idx] = __builtin_bit_cast(unsigned short, piece == 0 ? p1 : p2);
 }
 
-int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
+int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream, bool check) {
   float* consts = (float*)packed;
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
   hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, H2_WSCALE);
@@ -247,6 +245,7 @@ int launch_pack_mlp_h2(const MlpTensors& t, void* packed, hipStream_t stream) {
   int* dflag = (int*)consts + H2_FLAG_WORD;
   hipLaunchKernelGGL(pack_stream_h2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream, dflag);
   if (int rc = check_launch("pack_mlp_h2")) return rc;
+  if (!check) return 0;   // crnerf_pack_mlp_weights_h2_async: the flag stays on the device (crnerf_pack_h2_status reads it; the h2 kernels honour it)
   if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
     return set_error(-10, "pack_mlp_h2: reading the range flag failed");
   if (flag) return set_error(-4, "pack_mlp_weights_h2: a weight is outside the h2 core's range (|w| < 255, finite); use the f32x3 or fp32 entry points");
@@ -301,10 +300,9 @@ int launch_pack_mlp_x3t(const MlpTensors& t, void* packed, hipStream_t stream) {
   return check_launch("pack_mlp_x3t");
 }
 
-// transposed h2 stream (layout.h "fragHT"): fragXT's element map, two fp16 pieces of 2^8 w.  No range flag of its own: the forward pack of the same
-// weights (crnerf_pack_mlp_weights_h2) is where |w| < 255 is checked; a weight beyond it gives inf pieces here and inf / NaN deltas, never a
-// finite wrong gradient.
-__global__ void pack_stream_h2t_kernel(MlpTensors t, unsigned short* __restrict__ stream) {
+// transposed h2 stream (layout.h "fragHT"): fragXT's element map, two fp16 pieces of 2^8 w; the range flag as in the forward pack (never read back
+// here: mlp_backward_h2_kernel leaves at once when it is set and the f32x3 data gradient runs in its place, mlp_train16.hip launch_mlp_backward).
+__global__ void pack_stream_h2t_kernel(MlpTensors t, unsigned short* __restrict__ stream, int* __restrict__ range_flag) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)STREAMHT_FRAGS * 512) return;
   const int frag = (int)(idx / 512);
@@ -325,9 +323,18 @@ __global__ void pack_stream_h2t_kernel(MlpTensors t, unsigned short* __restrict_
   const int k = 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
   const int r = 32 * T + i;
   const float w = W[(long)k * in_dim + col0 + r] * H2_WSCALE;
+  if ((__float_as_uint(w) & 0x7fffffffu) >= 0x477fe000u && piece == 0) atomicOr(range_flag, 1);   // as pack_stream_h2_kernel
   const _Float16 p1 = (_Float16)w;
   const _Float16 p2 = (_Float16)(w - (float)p1);
   stream[idx] = __builtin_bit_cast(unsigned short, piece == 0 ? p1 : p2);
+}
+
+int pack_h2_status(const void* packed, hipStream_t stream) {
+  int flag = 0;
+  if (hipMemcpyAsync(&flag, (const int*)packed + H2_FLAG_WORD, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+    return set_error(-10, "pack_h2_status: reading the range flag failed");
+  if (flag) return set_error(-4, "pack_h2_status: a weight of this pack is outside the h2 core's range (|w| < 255, finite)");
+  return 0;
 }
 
 int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream) {
@@ -335,7 +342,7 @@ int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream) {
   unsigned short* wstream = (unsigned short*)((char*)packed + CONST_BYTES);
   hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, H2_WSCALE);
   const long n = (long)STREAMHT_FRAGS * 512;
-  hipLaunchKernelGGL(pack_stream_h2t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
+  hipLaunchKernelGGL(pack_stream_h2t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream, (int*)consts + H2_FLAG_WORD);
   return check_launch("pack_mlp_h2t");
 }
 

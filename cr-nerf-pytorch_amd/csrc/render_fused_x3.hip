@@ -93,6 +93,20 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
     if (!__syncthreads_or(bad)) return;
   }
   load_consts(lds, a.packed0, a.packed1);
+#if CRNERF_X_NP == 2
+  // a pack that carries the range flag (crnerf_pack_mlp_weights_h2_async of a weight >= 255): nothing is rendered, every ray of this workgroup is
+  // marked NaN -- what crnerf_render_rays[_train]_f32x3_repair looks for -- so precision "auto" needs no host round trip to fall back
+  if ((__float_as_uint(((const lds_float*)(lds + LDS_CONST0))[H2_FLAG_WORD]) | __float_as_uint(((const lds_float*)(lds + LDS_CONST1))[H2_FLAG_WORD])) != 0u) {
+    for (int it = 0; it < a.iters; ++it) {
+      const long rr = ((long)it * gridDim.x + blockIdx.x) * 4 + wave;
+      if (rr < a.R && lane == 0) {
+        a.feature_c[rr * FEAT_DIM] = __uint_as_float(0x7fc00000u);
+        if (Ni > 0) a.feature_f[rr * FEAT_DIM] = __uint_as_float(0x7fc00000u);
+      }
+    }
+    return;
+  }
+#endif
   RayScratch scr;
   scr.bind(lds + LDS_SCRATCH_X + wave * SCRATCH_BYTES);
 

@@ -23,6 +23,10 @@ class GridSampleBatcher:
         self.batch_size, self.scale_anneal, self.min_scale = batch_size, scale_anneal, min_scale
         self.iterations = all_rays.shape[0] // batch_size               # :227
         self._offsets = torch.cat([torch.zeros(1, dtype=torch.long), (self.all_imgs_wh[:, 0] * self.all_imgs_wh[:, 1]).cumsum(0)])
+        # every image's id (column 8 of its rays) on the HOST, read once: the training step indexes its appearance table with it
+        # (train_mask_grid_sample.py:221 `ts[0]`) and must not wait for the device to learn it
+        first = self._offsets[:-1].to(self.all_rays.device)
+        self._image_ids = self.all_rays[first, 8].to(torch.int64).cpu().tolist() if self.all_rays.shape[1] > 8 and len(first) else []
         self._tables = {}
 
     def __len__(self):
@@ -57,4 +61,6 @@ class GridSampleBatcher:
                                   self._lin(img_w, side), self._lin(img_h, side), scale, h_offset, w_offset)
         s.update({'whole_img': self.all_imgs[sample_ts] if self.all_imgs is not None else None, 'min_scale_cur': min_scale_cur,
                   'img_wh': self.all_imgs_wh[sample_ts]})
+        if self._image_ids:
+            s['image_id'] = self._image_ids[sample_ts]          # == int(s['ts'][0]), without the device round trip
         return s

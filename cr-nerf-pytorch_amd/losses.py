@@ -34,6 +34,11 @@ _GRAD_OF = {"rgb_coarse": "rgb_coarse", "rgb_fine": "rgb_fine", "out_mask": "mas
             "a_embedded_random_rec": "a_embedded_random_rec", "content_wo_a_embed": "content_wo", "content_with_a_embed": "content_with"}
 
 
+# what each of the kernel's seven terms (ops.LOSS_KEYS order) reads beside rgb_coarse / targets: a term whose inputs are absent is an exact zero
+_TERM_NEEDS = {"kl_a": ("a_embedded",), "rec_a_random": ("a_embedded", "a_embedded_random_rec"), "c_l": (), "content_constraint": ("content_wo_a_embed", "content_with_a_embed"),
+               "r_ms": ("out_mask", "rgb_fine"), "r_md": ("out_mask", "rgb_fine"), "f_l": ("rgb_fine",)}
+
+
 class _LossFn(torch.autograd.Function):
     """losses[7] = crnerf_loss_f32(...); backward = crnerf_loss_backward_f32 with autograd's upstream[7]."""
 
@@ -56,6 +61,16 @@ class _LossFn(torch.autograd.Function):
         for n, s, need in zip(ctx.names, ctx.shapes, ctx.needs_input_grad[2:]):
             grads.append(got[_GRAD_OF[n]].view(s) if (need and n in _GRAD_OF) else None)
         return (None, None) + tuple(grads)
+
+
+class LossTerms(dict):
+    """The reference's loss dict (same keys, same insertion order, each value a 0-dim tensor) that also remembers the kernel's 7-vector it was cut
+    from: total() is the reference's `sum(l for l in loss_d.values())` as ONE reduction (absent terms are exact zeros in the vector) instead of
+    seven selects, seven adds and their twenty-odd backward launches."""
+    vector = None
+
+    def total(self):
+        return self.vector.sum() if self.vector is not None else sum(l for l in self.values())
 
 
 class CRNeRFLoss(nn.Module):
@@ -94,7 +109,10 @@ class CRNeRFLoss(nn.Module):
                    mask_size_weight=ann, mask_digit_weight=getattr(hparams, "maskrd", 0.0))
         names = tuple(use.keys())
         losses = _LossFn.apply(cfg, names, *[use[n] for n in names])
-        return {k: losses[ops.LOSS_KEYS.index(k)] for k in keys}, ann
+        out = LossTerms((k, losses[ops.LOSS_KEYS.index(k)]) for k in keys)
+        if set(keys) >= {k for k in ops.LOSS_KEYS if all(n in use for n in _TERM_NEEDS[k])}:    # every term the kernel can have filled is a key
+            out.vector = losses
+        return out, ann
 
 
 class ColorLoss(nn.Module):

@@ -75,16 +75,32 @@ class AutoPack:
         self.h2, self.x3 = h2, x3
 
 
-def pack_mlp_weights_auto(state):
+def pack_mlp_weights_auto(state, check=True):
+    """check=False (training: a pack per optimiser step): crnerf_pack_mlp_weights_h2_async -- no wait for the stream; a refused pack carries its verdict
+    as a flag word the h2 kernels read on the device (they then leave everything to the f32x3 repair), so `h2` is never None."""
     lib = _lib.load()
     tensors = _mlp_tensor_list(state)
     h2 = torch.empty(lib.crnerf_packed_mlp_h2_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    if not check:
+        _lib.check(lib.crnerf_pack_mlp_weights_h2_async(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(h2.data_ptr()), _lib.stream_ptr()),
+                   "crnerf_pack_mlp_weights_h2_async")
+        return AutoPack(h2, pack_mlp_weights_x3(state))
     rc = lib.crnerf_pack_mlp_weights_h2(_lib.ptr_array(tensors, "mlp tensor"), ctypes.c_void_p(h2.data_ptr()), _lib.stream_ptr())
     if rc == _lib.ERR_RANGE:
         h2 = None
     else:
         _lib.check(rc, "crnerf_pack_mlp_weights_h2")
     return AutoPack(h2, pack_mlp_weights_x3(state))
+
+
+def pack_h2_in_range(packed_h2):
+    """True when the h2 / transposed-h2 pack carries no range flag (crnerf_pack_h2_status; waits for the stream)."""
+    lib = _lib.load()
+    rc = lib.crnerf_pack_h2_status(ctypes.c_void_p(packed_h2.data_ptr()), _lib.stream_ptr())
+    if rc == _lib.ERR_RANGE:
+        return False
+    _lib.check(rc, "crnerf_pack_h2_status")
+    return True
 
 
 def pack_mlp_weights(state, out=None, precision="f32"):
@@ -245,7 +261,7 @@ def pack_mlp_weights_t_h2(state):
     return out
 
 
-def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False, dgrad_h2=False):
+def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False, dgrad_h2=False, fallback_t_x3=None):
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
     (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
     CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
@@ -261,7 +277,10 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False
                       (lib.crnerf_mlp_backward_ex_f32, "crnerf_mlp_backward_ex_f32", lib.crnerf_packed_mlp_t_bytes()))
     if packed_t.numel() != want:
         raise ValueError("crnerf_amd: %s needs a %d-byte transposed pack, got %d" % (name, want, packed_t.numel()))
-    _lib.check(fn(ctypes.c_void_p(packed_t.data_ptr()), _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
+    if fallback_t_x3 is not None and (not dgrad_h2 or fallback_t_x3.numel() != lib.crnerf_packed_mlp_t_x3_bytes()):
+        raise ValueError("crnerf_amd: fallback_t_x3 is the pack_mlp_weights_t_x3 safety net of dgrad_h2")
+    head = (ctypes.c_void_p(packed_t.data_ptr()),) + ((ctypes.c_void_p(fallback_t_x3.data_ptr() if fallback_t_x3 is not None else None),) if dgrad_h2 else ())
+    _lib.check(fn(*head, _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
                   ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
                   _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
                   _lib.stream_ptr()), name)

@@ -179,7 +179,7 @@ class TrainingSystem:
         results['rgb_' + type] = rgbs_pred
         return results
 
-    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None, hw_whole=None, val_mode=False):   # :151-226
+    def forward(self, rays, ts, whole_img, W, H, rgb_idx=None, hw_whole=None, val_mode=False, image_id=None):   # :151-226
         """val_mode=True (validation_step, :362): the transient mask is the whole interpolated image (no rgb_idx gather, :174-175)
         and the reference switches to 2,048-ray chunks (:181-182) -- a memory bound only: rays are independent, so the chunk
         size never changes the result and the renderer's own chunking is kept."""
@@ -200,7 +200,7 @@ class TrainingSystem:
             kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, None if val_mode else rgb_idx.reshape(-1))
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
-        image_id = int(ts[0])
+        image_id = int(ts[0]) if image_id is None else int(image_id)   # (int(ts[0]) waits for the device; the batcher knows it on the host)
         if self.ray_group is not False:                                                     # this rank's block of the batch
             from .parallel import gather_rays, shard_rays
             rays, (lo, hi) = shard_rays(rays, self.ray_group)
@@ -212,7 +212,7 @@ class TrainingSystem:
             for k, v in part.items():
                 results[k] += [v]
         for k, v in results.items():
-            results[k] = torch.cat(v, 0)
+            results[k] = v[0] if len(v) == 1 else torch.cat(v, 0)    # (one chunk is the rule here: cat of a single tensor would copy it)
         if self.ray_group is not False:      # the decoder is cross-ray: every rank gets the whole feature grid (weights_* / depth_* stay local)
             for k in ("feature_coarse", "feature_fine"):
                 if k in results:
@@ -246,9 +246,9 @@ class TrainingSystem:
         if batch.get('img_wh') is not None:
             w_whole, h_whole = (int(v) for v in batch['img_wh'])                            # :272
             hw_whole = (h_whole, w_whole)
-        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'), hw_whole)
+        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'), hw_whole, image_id=batch.get('image_id'))
         loss_d, annealing = self.loss(results, rgbs, self.hparams_, self.global_step)
-        loss = sum(l for l in loss_d.values())
+        loss = loss_d.total() if hasattr(loss_d, "total") else sum(l for l in loss_d.values())   # (:286; one reduction of the kernel's 7-vector)
         self.global_step += 1
         return loss, loss_d, results
 

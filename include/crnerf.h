@@ -270,7 +270,7 @@ int crnerf_mlp_backward_x3_f32(const void* packed_t_x3, const float* x, const fl
  * crnerf_render_rays_train_f32x3_repair -- the SAME arguments with f32x3 packs of the same weights -- renders exactly those ray quads again on the
  * scale-free core, saved rows, raw rows and *_out draws included (one workgroup per quad, leaves at once when nothing is NaN; no host round trip).
  * crnerf_mlp_backward_h2_f32: crnerf_mlp_backward_x3_f32 with the data gradient on the h2 core; packed_t_h2 = crnerf_pack_mlp_weights_t_h2 (the
- * transposed weights as two fp16 pieces of 2^8 w; no range check of its own -- crnerf_pack_mlp_weights_h2 of the same weights is the check).  Every
+ * transposed weights as two fp16 pieces of 2^8 w; its range flag stays on the device, see crnerf_pack_mlp_weights_h2_async below).  Every
  * point's delta vector is rescaled by an exact power of two per layer so that its largest entry sits in [2^7, 2^8): gradients of any magnitude
  * (1e-30 ... 1e30) go through at fp32 accuracy, there is no range failure on this side.  n < 3.9 M points per call. */
 int crnerf_render_rays_train_f32h2(const crnerf_render_args* args, void* acts_coarse, void* acts_fine, float* raw_coarse, float* raw_fine,
@@ -279,8 +279,16 @@ int crnerf_render_rays_train_f32x3_repair(const crnerf_render_args* args, void* 
                                           void* stream);
 size_t crnerf_packed_mlp_t_h2_bytes(void);
 int crnerf_pack_mlp_weights_t_h2(const float* const* tensors, void* packed_t_h2, void* stream);
-int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
-                               float* const* grads, int64_t n, int flags, void* stream);
+int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts,
+                               void* scratch, float* const* grads, int64_t n, int flags, void* stream);
+/* The range verdict without a host round trip (training packs every step).  crnerf_pack_mlp_weights_h2_async packs like crnerf_pack_mlp_weights_h2 but
+ * never waits for the stream and never returns CRNERF_ERR_RANGE: a weight outside |w| < 255 leaves a flag word in the pack itself, and so does
+ * crnerf_pack_mlp_weights_t_h2.  The h2 kernels read it on the device: crnerf_render_rays[_train]_f32h2 then render nothing and mark every ray NaN
+ * (the *_f32x3_repair call that precision "auto" issues next renders them all on the scale-free core), crnerf_mlp_backward_h2_f32 leaves its data
+ * gradient to the f32x3 kernel when packed_t_x3 (optional, may be NULL) is given -- that kernel is launched behind the h2 one and exits at once unless
+ * the flag is set.  crnerf_pack_h2_status reads the flag back (this one waits for the stream): 0 or CRNERF_ERR_RANGE. */
+int crnerf_pack_mlp_weights_h2_async(const float* const* tensors, void* packed_h2, void* stream);
+int crnerf_pack_h2_status(const void* packed_h2, void* stream);
 
 /* Appearance encoder: encoder_sameoutputsize.forward, models/linearStyleTransfer.py:208-276.
  * image[3,H,W] (NCHW, values in [0,1]) -> out[1024,64], the pixel-major 32x32 style grid the decoder consumes.

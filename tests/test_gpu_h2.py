@@ -397,12 +397,13 @@ def test_h2_training_forward_gradients_match_the_fp32_forward(mode):
     def run():
         out = AG.fused_render_with_grad(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0)
         return (out["feature_fine"] * gw).sum() + 0.5 * (out["feature_coarse"] * gw).sum() + 0.1 * (out["weights_fine"] ** 2).sum()
+    AG.set_training_forward_precision("f32")
     g32 = _grads(models, run)
     AG.set_training_forward_precision(mode)
     try:
         gh2 = _grads(models, run)
     finally:
-        AG.set_training_forward_precision("f32")
+        AG.set_training_forward_precision(None)
     for k in g32:
         rel = float((gh2[k] - g32[k]).norm() / (g32[k].norm() + 1e-30))
         assert rel <= 2e-3, (k, rel)
@@ -450,3 +451,43 @@ def test_train_auto_repairs_poisoned_rays_and_their_saved_rows():
             assert torch.equal(rows(oau)[9, sel, :128].view(torch.int32), rows(src)[9, sel, :128].view(torch.int32)), tag     # slot 9 is 128 wide
             assert torch.equal(bits(oau)[:8, sel], bits(src)[:8, sel]), tag                                                   # slot 8 is linear: no bits
             assert torch.equal(bits(oau)[9, sel].view(-1, 4, 8)[:, :, :4], bits(src)[9, sel].view(-1, 4, 8)[:, :, :4]), tag
+
+
+def test_train_auto_with_a_refused_pack_falls_back_on_the_device():
+    """A weight >= 255 under set_training_forward_precision("auto"): the asynchronous h2 packs carry the range flag (crnerf_pack_h2_status says so),
+    the h2 training twin marks every ray NaN, crnerf_render_rays_train_f32x3_repair renders them all, the h2 data gradient stands aside for the
+    f32x3 one -- all decided on the device.  Outputs and the refused model's gradients are then the f32x3 mode's, bit for bit."""
+    from crnerf_amd import autograd as AG
+    from test_gpu_train_fused import _grads, _inputs, _modules
+    models, emb, args = _modules(gain=2.45, sigma_bias=-1.0, band_limit=4)
+    with torch.no_grad():
+        models["fine"].state_dict()["xyz_encoding_4.0.weight"][7, 9] = 300.0
+    st = {k: v.detach() for k, v in models["fine"].state_dict().items()}
+    pk = ops.pack_mlp_weights_auto(st, check=False)
+    assert pk.h2 is not None and not ops.pack_h2_in_range(pk.h2) and not ops.pack_h2_in_range(ops.pack_mlp_weights_t_h2(st))
+    assert ops.pack_h2_in_range(ops.pack_mlp_weights_auto({k: v.detach() for k, v in models["coarse"].state_dict().items()}, check=False).h2)
+    R = 64
+    rays, z, u, nc, nf = _inputs(R, 64, 64, seed=5)
+    gw = torch.randn(R, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    outs = {}
+
+    def run(tag):
+        def f():
+            out = AG.fused_render_with_grad(models["coarse"], models["fine"], rays, 64, 64, False, None, z, u, nc, nf, 1.0)
+            outs[tag] = {k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}
+            return (out["feature_fine"] * gw).sum() + 0.5 * (out["feature_coarse"] * gw).sum() + 0.1 * (out["weights_fine"] ** 2).sum()
+        return f
+    try:
+        AG.set_training_forward_precision("f32x3")
+        gx3 = _grads(models, run("x3"))
+        AG.set_training_forward_precision("auto")
+        gau = _grads(models, run("auto"))
+    finally:
+        AG.set_training_forward_precision(None)
+    for k in ("feature_coarse", "feature_fine", "weights_fine", "depth_fine"):
+        assert not bool(torch.isnan(outs["auto"][k]).any()) and torch.equal(outs["auto"][k], outs["x3"][k]), k
+    for k in gx3:     # the fine model (refused pack): the f32x3 data gradient, bit for bit; the coarse model (accepted): the h2 one, fp32-level apart
+        if k.startswith("fine"):
+            assert torch.equal(gau[k], gx3[k]), k
+        else:
+            assert float((gau[k] - gx3[k]).norm() / (gx3[k].norm() + 1e-30)) <= 1e-4, k

@@ -145,7 +145,7 @@ def test_training_through_the_shim_in_kernel_vs_tensor_draws(recompute, forward)
     finally:
         ops.set_in_kernel_rng(True)
         ag.set_training_recompute(False)
-        ag.set_training_forward_precision("f32")
+        ag.set_training_forward_precision(None)
     for k in ("weights_coarse", "feature_coarse", "depth_coarse", "weights_fine", "feature_fine", "depth_fine"):
         assert torch.equal(out_k[k], out_t[k]), k
     for a, b in zip(g_k, g_t):

@@ -26,7 +26,7 @@ def test_training_system_learns_the_scene_like_the_reference(golden, mode):
     try:
         _run(golden)
     finally:
-        AG.set_training_forward_precision("f32")
+        AG.set_training_forward_precision(None)
         AG.set_wgrad_precision(None)
 
 

@@ -86,9 +86,21 @@ def _grads(models, fn):
     return {"%s.%s" % (t, n): p.grad.clone() for t, m in models.items() for n, p in m.named_parameters()}
 
 
+@pytest.mark.parametrize("mode", ["f32", "auto"])
 @pytest.mark.parametrize("R", [64, 8200])     # 8200 rays x 128 samples: two ray chunks of the fused path
-def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R):
+def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R, mode):
+    """mode "f32": the fused training renderer against the un-fused fp32 twins -- the same arithmetic, 3e-4 of each gradient's largest entry.
+    mode "auto" (the default forward / data-gradient mode since round 4: the h2 core with its f32x3 safety net): fp32-accurate, not the same
+    products, and these gain-2.45 nets turn a 1e-7 difference of a coarse weight into another fine depth -- 1e-2; recompute stays bit-identical."""
     from crnerf_amd.models import rendering
+    AG.set_training_forward_precision(mode)
+    try:
+        _fused_vs_unfused(R, 3e-4 if mode == "f32" else 1e-2, rendering)
+    finally:
+        AG.set_training_forward_precision(None)
+
+
+def _fused_vs_unfused(R, bar, rendering):
     models, emb, args = _modules()
     rays, z, u, nc, nf = _inputs(R, 64, 64, seed=3)
     gw = torch.randn(R, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -108,7 +120,7 @@ def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R):
     g_u = _grads(models, unfused)
     for k in g_u:
         scale = float(g_u[k].abs().max()) + 1e-12
-        assert float((g_f[k] - g_u[k]).abs().max()) <= 3e-4 * scale, (k, float((g_f[k] - g_u[k]).abs().max()), scale)
+        assert float((g_f[k] - g_u[k]).abs().max()) <= bar * scale, (k, float((g_f[k] - g_u[k]).abs().max()), scale)
     AG.set_training_recompute(True)
     try:
         g_r = _grads(models, fused)
