@@ -219,12 +219,14 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
   if (a->rng_flags) {
     if (a->rng_flags & ~(CRNERF_RNG_JITTER | CRNERF_RNG_U | CRNERF_RNG_NOISE)) return set_error(CRNERF_ERR_CONFIG, "render_rays: unknown rng_flags bits");
-    if (bf16 || !(x3 || acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4 and f32x3 kernels only");
+    if (bf16 || !(x3 || acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4, f32x3 and f32h2 kernels only");
     if ((a->rng_flags & CRNERF_RNG_JITTER) && a->z_coarse) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_JITTER and z_coarse are exclusive");
     if ((a->rng_flags & CRNERF_RNG_U) && a->u) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_U and u are exclusive");
     if ((a->rng_flags & CRNERF_RNG_NOISE) && (a->noise_coarse || a->noise_fine)) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_NOISE and noise_* are exclusive");
     r.rng_seed = a->rng_seed; r.rng_ray_offset = (long)a->rng_ray_offset; r.rng_flags = a->rng_flags; r.perturb = a->perturb;
   }
+  if ((a->z_coarse_out || a->noise_coarse_out || a->noise_fine_out) && (bf16 || !(x3 || acts_c || g_core16)))   // (the bf16 kernels and the round-1 32x32x2 core do not write them)
+    return set_error(CRNERF_ERR_CONFIG, "render_rays: z_coarse_out / noise_*_out are written by the fp32 16x16x4, f32x3 and f32h2 kernels only");
   r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
   if (x3 == 2) return launch_render_rays_h2(r, (hipStream_t)stream);
   if (x3 == 3) r.repair = 1;

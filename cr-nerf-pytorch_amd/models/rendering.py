@@ -146,8 +146,10 @@ def render_rays_cross_ray(models, embeddings, rays, ts, N_samples=64, use_disp=F
     if fused_train and (perturb > 0 or noise_std != 0) and ops.in_kernel_rng():
         # the fused fp32 training kernel draws the jitter / sample_pdf uniforms / density noise itself (csrc/philox.h): no [R,N] random
         # tensors, no launches for them.  The seed comes from torch's CPU generator, so torch.manual_seed() governs the run.
+        # rng_ray_offset (kwarg of this mirror only): the index of rays[0] in the caller's whole batch -- the draws are keyed on (seed, GLOBAL ray,
+        # sample), so a batch rendered in ray chunks or sharded over ranks (pipeline.TrainingSystem) draws what one call over all of it would
         rng = {"seed": int(torch.randint(0, 2 ** 62, (1,), device="cpu")), "perturb": float(perturb), "jitter": perturb > 0, "u": perturb > 0,
-               "noise": noise_std != 0}
+               "noise": noise_std != 0, "ray_offset": int(kwargs.get("rng_ray_offset", 0))}
     if rng is None and perturb > 0:
         z_coarse = _coarse_depths(rays, N_samples, use_disp, perturb)
         if N_importance > 0:

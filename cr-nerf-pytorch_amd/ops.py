@@ -450,7 +450,7 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     mlp_backward_mixed(..., fused_acts=True) reads).
     precision="auto": packs from pack_mlp_weights(..., precision="auto"); the h2 core, repaired by the x3 core where it poisoned a ray
     (train=True: crnerf_render_rays_train_f32h2, then crnerf_render_rays_train_f32x3_repair -- saved rows included).
-    rng (fp32 and f32x3): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
+    rng (fp32, f32x3, f32h2, auto): {"seed": int, "ray_offset": int, "perturb": float, "jitter": bool, "u": bool, "noise": bool} -- the stochastic
     steps of rendering.py:125 / :169-176 / :30 drawn INSIDE the kernel (include/crnerf.h CRNERF_RNG_*, csrc/philox.h) instead of
     handed over as tensors; the dict then also holds what was drawn: "z_coarse_used" [R,Nc], and with noise "noise_coarse_used" /
     "noise_fine_used" (standard normal, before noise_std).  rng_fill() returns the same draws as tensors."""

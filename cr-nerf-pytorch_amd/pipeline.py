@@ -45,9 +45,17 @@ def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(
     trust_checkpoint=True falls back to the unrestricted pickle loader the reference itself uses (torch 1.13's torch.load,
     utils/__init__.py:68) for files that hold other Python objects: only for files you wrote yourself."""
     import argparse
+    import collections
     import pickle
+    # what a Lightning checkpoint of the reference's trainer holds beside tensors: the hparams Namespace and ordinary containers
+    allowed = [argparse.Namespace, collections.OrderedDict, collections.defaultdict]
     try:
-        with torch.serialization.safe_globals([argparse.Namespace]):
+        if hasattr(torch.serialization, "safe_globals"):                 # torch >= 2.5
+            with torch.serialization.safe_globals(allowed):
+                ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        else:                                                            # 2.4: the allow-list is process-wide
+            if hasattr(torch.serialization, "add_safe_globals"):
+                torch.serialization.add_safe_globals(allowed)
             ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError as e:
         if not trust_checkpoint:
@@ -201,14 +209,17 @@ class TrainingSystem:
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
         image_id = int(ts[0]) if image_id is None else int(image_id)   # (int(ts[0]) waits for the device; the batcher knows it on the host)
+        lo = 0
         if self.ray_group is not False:                                                     # this rank's block of the batch
             from .parallel import gather_rays, shard_rays
             rays, (lo, hi) = shard_rays(rays, self.ray_group)
             ts = ts[lo:hi]
         ray_chunk = max(int(hp.chunk), 1 << 16)   # the reference's 8,192-ray chunks (:185-197) only bound its memory; rays are independent
         for i in range(0, rays.shape[0], ray_chunk):
+            # rng_ray_offset: ray i of this rank's shard is ray lo + i of the batch -- every rank seeds alike (one seed per step), so without it ray j of
+            # EVERY shard would get the same jitter / noise; with it an N-rank step draws exactly what the 1-rank step draws
             part = render_rays_cross_ray(self.models, self.embeddings, rays[i:i + ray_chunk], ts[i:i + ray_chunk], hp.N_samples, hp.use_disp,
-                                         hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, False, **kwargs)
+                                         hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, False, rng_ray_offset=lo + i, **kwargs)
             for k, v in part.items():
                 results[k] += [v]
         for k, v in results.items():

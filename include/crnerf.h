@@ -163,7 +163,8 @@ typedef struct crnerf_render_args {
   float* feature_fine;          /* [R,64] */
   float* depth_fine;            /* [R] */
   float* z_fine;                /* [R,Nc+Ni] optional debug/test output, NULL to skip */
-  /* ---- in-kernel random draws (ABI 2; crnerf_render_rays_f32 / _train_f32 and crnerf_render_rays_f32x3 / _train_f32x3).  rng_flags == 0: everything
+  /* ---- in-kernel random draws (ABI 2; crnerf_render_rays_f32 / _f32x3 / _f32h2 and their _train_ twins; the bf16 entry points and the *_out pointers
+   * below on kernels that do not write them return CRNERF_ERR_CONFIG).  rng_flags == 0: everything
    * above is used as given.  Draws are Philox4x32-10 keyed on rng_seed, counter = (sample, stream, rng_ray_offset + ray): a pure
    * function of the GLOBAL ray index, so ray chunks and the backward's recomputation see the same numbers.  The same draws as
    * tensors: crnerf_rng_fill_f32 (feeding them through z_coarse / u / noise_* gives bit-identical results). */
