@@ -446,7 +446,9 @@ int crnerf_mlp_forward_bf16(const void* packed, const float* x, float* out, int6
   if (n == 0) return 0;
   REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_bf16: negative n");
-  return launch_mlp_forward_bf16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();   // the round-1/2 kernel, for A/B runs
+  return core64 ? launch_mlp_forward_bf16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream)
+                : launch_mlp_forward_bf16p(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
 size_t crnerf_encoder_workspace_bytes(int H, int W) { return encoder_workspace_bytes(H, W); }

@@ -132,7 +132,8 @@ int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d
 // only_if: device word; the kernel leaves at once when it is 0 (the f32x3 stand-in of an h2 data gradient whose pack was refused); null: always
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream, const int* only_if = nullptr);
-int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
+int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);    // round-1/2 core (CRNERF_BF16_CORE=64)
+int launch_mlp_forward_bf16p(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);   // pair core: the module entry
 int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);    // one ray per wave, 64-point tiles, one wave per SIMD (render_fused_bf16.hip)
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);
 int launch_rng_fill(float* out, long R, int n, unsigned long long seed, int stream_id, long ray_offset, hipStream_t stream);   // one ray per wave PAIR, 32-point tiles, two waves per SIMD (render_fused_bf16p.hip)
