@@ -57,7 +57,7 @@ def parse():
                          "split over the ranks (the configs BASELINE.json names for 8 GPUs)")
     ap.add_argument("--workload", choices=["configs2", "configs3", "configs4"], default="configs2",
                     help="--scaling strong only.  configs2: one 800x800 frame, 64+128, cross-ray decoder on, --precision (default there: bf16); "
-                         "configs3: one 65,536-ray training batch with grid-sample masking (fwd + bwd + Adam, exact fp32); "
+                         "configs3: one 65,536-ray training batch with grid-sample masking (fwd + bwd + Adam, --train-precision); "
                          "configs4: the appearance-hallucination fly-through -- --frames frames of 320x240 at --samples, style-image conditioned, "
                          "poses and rays made on the device, --video-split frames (no collective) or rays (decoder exchange per frame)")
     ap.add_argument("--frames", type=int, default=240, help="--workload configs4: frames of the fly-through (the script's 30 fps x 8 s; BASELINE says 120)")
@@ -66,6 +66,10 @@ def parse():
                     help="--workload configs4: what the ranks split -- whole frames round-robin (no data-path collective) or every frame's rays")
     ap.add_argument("--frame", default="800x800", help="--workload configs2: frame size HxW")
     ap.add_argument("--train-rays", type=int, default=65536, help="--workload configs3: rays of the ONE batch that is split over the ranks")
+    ap.add_argument("--train-precision", choices=["auto", "f32"], default="auto",
+                    help="--workload configs3.  auto = the training default (crnerf_amd.autograd.get_training_forward_mode): forward and data gradient in fp32 "
+                         "accuracy on the fp16 matrix cores with the f32x3 safety net, weight gradients from three-piece bf16 splits; f32 = every product on "
+                         "the fp32 matrix cores (the reference's arithmetic)")
     ap.add_argument("--peer-exchange", action="store_true",
                     help="N > 1: carry the decoder's two reductions through HIP-IPC peer windows (parallel.PeerExchange) instead of RCCL")
     return ap.parse_args()
@@ -593,11 +597,14 @@ def strong_configs4(a, dev, world, rank, use_dist, dist, exchange):
 
 def strong_configs3(a, dev, world, rank, use_dist, dist):
     """ONE configs[3] training batch (default 65,536 rays = a 256x256 grid-sample batch with transient masking, 64+64 samples as
-    command/train.sh trains) split over the ranks: ray-parallel TrainingSystem (parallel.GatherRays + sync_gradients), exact fp32,
-    forward + backward + Adam per step."""
+    command/train.sh trains) split over the ranks: ray-parallel TrainingSystem (parallel.GatherRays + sync_gradients), forward + backward +
+    Adam per step, in --train-precision (auto: fp32-accurate split-operand products on the fp16 / bf16 matrix cores; f32: the fp32 matrix cores)."""
     import numpy as np
     import crnerf_amd.synth as synth
-    from crnerf_amd import pipeline
+    from crnerf_amd import autograd as AG, pipeline
+    exact = a.train_precision == "f32"
+    AG.set_training_forward_precision("f32" if exact else "auto")
+    AG.set_wgrad_precision("f32" if exact else "bf16x3")
     from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
     R = a.train_rays
     side = int(R ** 0.5)
@@ -639,17 +646,27 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
 
     dt, last = timed_steps(a, step, use_dist, dist, dev)
     pts = R * (nc + nc + ni)
-    achieved = 3 * pts * FLOP_PER_POINT / dt * a.steps / 1e12 / world      # per GPU
+    achieved = 3 * pts * FLOP_PER_POINT / dt * a.steps / 1e12 / world      # per GPU: algorithmic fp32 FLOPs of forward + data gradient + weight gradient
+    # auto: what the matrix cores are ISSUED -- forward 3.02 x (two fp16 pieces, three MFMAs per product), data gradient 3 x, weight gradient 6 x
+    # (three bf16 pieces) the algorithmic FLOPs of their third of the step
+    issued = achieved if exact else achieved * (3.02 + 3.0 + 6.0) / 3.0
+    peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_BF16_MFMA_TFLOPS
     line = {"metric": "rays/sec (64+64 samples, training step: fwd + bwd + Adam)", "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if exact else "f32h2 / bf16x3 (fp32 operands split into fp16 / bf16 pieces, fp32 accumulation)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: ONE %d-ray grid-sample training batch (%dx%d grid, transient mask, encode_a / encode_c / "
                                    "encode_random) x (%d+%d) split over %d rank(s): rays sharded, feature rows all-gathered, decoder / encoders / mask "
-                                   "network replicated, one flat gradient all-reduce" % (R, side, side, nc, ni, world),
-                       "rays_total": R, "n_samples": nc, "n_importance": ni, "parallelism": "one batch's rays sharded %d-way" % world},
-            "roofline": {"bound": "mfma", "kernel": "render_rays_train16_kernel + mlp_backward16_kernel + wgrad_kernel", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
-                         "note": "whole step per GPU: 3 x the forward's MLP FLOPs of this rank's rays / step time (decoder, encoders, mask network and Adam included in the time)"},
+                                   "network replicated, one flat gradient all-reduce; --train-precision %s" % (R, side, side, nc, ni, world, a.train_precision),
+                       "rays_total": R, "n_samples": nc, "n_importance": ni, "parallelism": "one batch's rays sharded %d-way" % world,
+                       "train_precision": a.train_precision},
+            "roofline": {"bound": "mfma",
+                         "kernel": ("render_rays_train16_kernel + mlp_backward16_kernel + wgrad_kernel" if exact else
+                                    "render_rays_train_h2_kernel + mlp_backward_h2_kernel + wgrad_x3_batch_kernel"),
+                         "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": None, "traffic_source": None,
+                         "fp32_work_tflops": achieved,
+                         "note": "whole step per GPU: the MLP work of this rank's rays / step time (decoder, encoders, mask network and Adam included in the "
+                                 "time).  f32: 3 x the forward's algorithmic FLOPs on the fp32 MFMA.  auto: the ISSUED fp16 / bf16 MFMA work (12.02 x the "
+                                 "forward's algorithmic FLOPs) against the nominal 2.5 PFLOP/s; fp32_work_tflops = the algorithmic fp32 work"},
             "loss": float(last), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
     if use_dist and world > 1:
         chk = torch.tensor([float(last), float(sum(p.detach().double().sum() for p in sysm.parameters()))], dtype=torch.float64, device=dev)

@@ -438,18 +438,86 @@ class CompositeFn(torch.autograd.Function):
         return d_raw, None, None, None
 
 
+# ---- deferred accumulation of parameter gradients for modules that are called several times per step.  The reference calls its appearance
+# encoder three times, its decoder three times and its content encoder twice per training step (train_mask_grid_sample.py:151-226); PyTorch's
+# AccumulateGrad then adds every further use's gradient to .grad tensor by tensor -- 72 launches of ~2 us per step.  With deferral ON (read when the
+# forward runs: pipeline.TrainingSystem switches it on around its forward unless torch DDP may be listening) the backward of these nodes hands the
+# engine None for the parameters, keeps the gradients, and ONE callback at the end of the backward pass sums them with multi-tensor adds and
+# writes / accumulates .grad.  Not for torch.autograd.grad() callers, parameter hooks or DDP's reducer: those need AccumulateGrad to run.
+_DEFER_ON = [False]
+_DEFERRED = {"pending": {}, "scheduled": False}
+
+
+class deferred_param_grads:
+    """with deferred_param_grads(True): ... -- the nodes created inside defer their parameter gradients (see above)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _DEFER_ON[0] = _DEFER_ON[0], self.on
+
+    def __exit__(self, *exc):
+        _DEFER_ON[0] = self.prev
+
+
+def _defer(params, grads):
+    pend = _DEFERRED["pending"]
+    for p, g in zip(params, grads):
+        pend.setdefault(id(p), (p, []))[1].append(g)
+    if not _DEFERRED["scheduled"]:
+        _DEFERRED["scheduled"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+
+
+def _flush_deferred():
+    pend = _DEFERRED["pending"]
+    _DEFERRED["pending"], _DEFERRED["scheduled"] = {}, False
+    with torch.no_grad():
+        total = {pid: gs[0] for pid, (_, gs) in pend.items()}
+        for k in range(1, max(len(gs) for _, gs in pend.values())):       # use k + 1 of every parameter that has one: one multi-tensor add
+            ids = [pid for pid, (_, gs) in pend.items() if len(gs) > k]
+            torch._foreach_add_([total[i] for i in ids], [pend[i][1][k] for i in ids])
+        had = [(p, total[pid]) for pid, (p, _) in pend.items() if p.grad is not None]
+        for pid, (p, _) in pend.items():
+            if p.grad is None:
+                p.grad = total[pid]
+        if had:                                                           # gradient accumulation over several backward passes
+            torch._foreach_add_([p.grad for p, _ in had], [g for _, g in had])
+
+
+def _leaf_of(t):
+    """The Parameter a tensor handed to a node stands for: itself, or the leaf it is a same-size view of (conv weights travel as [cout, cin] views
+    of their [cout, cin, 1, 1] parameters); None: anything else keeps going through the engine."""
+    if t.is_leaf:
+        return t
+    base = t._base if t._is_view() else None
+    return base if (base is not None and base.is_leaf and base.numel() == t.numel() and base.is_contiguous() and t.is_contiguous()) else None
+
+
+def _param_grads(ctx, params, grads):
+    """What a multi-use node returns for its parameters: the gradients, or -- deferred -- None for every tensor whose leaf is known (ctx.leaves)."""
+    grads = [g.view_as(t) for g, t in zip(grads, params)]
+    if not getattr(ctx, "defer", False):
+        return tuple(grads)
+    keep = [(leaf, g.view(leaf.shape)) for leaf, g in zip(ctx.leaves, grads) if leaf is not None]
+    _defer([k[0] for k in keep], [k[1] for k in keep])
+    return tuple(None if leaf is not None else g for leaf, g in zip(ctx.leaves, grads))
+
+
 class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, sp, *w):
         out = ops.crossray_decode(xp, sp, w)
         ctx.save_for_backward(xp, sp, *w)
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(t) for t in w] if _DEFER_ON[0] else None)
         return out
 
     @staticmethod
     def backward(ctx, d_rgb):
         xp, sp, *w = ctx.saved_tensors
         dx, ds, grads = ops.crossray_decode_backward(xp, sp, w, d_rgb.contiguous())
-        return (dx, ds) + tuple(g.view_as(t) for g, t in zip(grads, w))
+        return (dx, ds) + _param_grads(ctx, w, grads)
 
 
 class EncoderFn(torch.autograd.Function):
@@ -460,13 +528,14 @@ class EncoderFn(torch.autograd.Function):
         out, saved, hw = ops.encoder_forward_train(image, w)
         ctx.save_for_backward(out, saved, *w)
         ctx.hw, ctx.image_shape = hw, image.shape
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(t) for t in w] if _DEFER_ON[0] else None)     # (the Parameter objects: .grad is theirs)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         out, saved, *w = ctx.saved_tensors
         grads, d_img = ops.encoder_backward(w, saved, ctx.hw, out, d_out.contiguous(), want_d_image=ctx.needs_input_grad[0])
-        return (d_img.view(ctx.image_shape) if d_img is not None else None,) + tuple(g.view_as(t) for g, t in zip(grads, w))
+        return (d_img.view(ctx.image_shape) if d_img is not None else None,) + _param_grads(ctx, w, grads)
 
 
 class ContentDecoderFn(torch.autograd.Function):
@@ -478,13 +547,15 @@ class ContentDecoderFn(torch.autograd.Function):
         out = ops.crossray_decode(xp, None, all_weights)          # planar [3,HW]
         ctx.save_for_backward(xp, rgb_w, out)
         ctx.w_shape = rgb_w.shape
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(rgb_w), _leaf_of(rgb_b)] if _DEFER_ON[0] else None)   # the decoder's fourth use of these two
         return out
 
     @staticmethod
     def backward(ctx, d_rgb):
         xp, rgb_w, out = ctx.saved_tensors
         dx, dw, db = ops.decoder_content_backward(xp, rgb_w, out, d_rgb.contiguous())
-        return dx, dw.view(ctx.w_shape), db, None
+        gw, gb = _param_grads(ctx, (rgb_w, db), (dw.view(ctx.w_shape), db))
+        return dx, gw, gb, None
 
 
 # ---------------------------------------------------------------- transient-mask network (models/lightweight_seg.py)

@@ -70,6 +70,102 @@ def _timed(name, fn, device):
 
 
 
+def shard_bounds(n, world_size, rank):
+    """Contiguous near-equal block [lo, hi) of n items for `rank` (the first n % world_size ranks get one extra)."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rays(rays, group=None):
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(rays.shape[0], ws, rk)
+    return rays[lo:hi].contiguous(), (lo, hi)
+
+
+class PeerExchange:
+    """All-reduce of <= 1024 floats through HIP-IPC peer windows (crnerf_peer_* in include/crnerf.h) instead of RCCL.
+
+    Collective constructor: every rank of `group` (one process per GPU, all on one node, at most 8) creates its window and
+    the 64-byte IPC handles are exchanged through the group itself (all_gather_object).  `all_reduce(t)` then sums a
+    contiguous float32 device tensor in place on the CURRENT stream with one kernel launch and no host synchronisation;
+    every rank must issue the same sequence of calls.  Sums are formed in rank order on every rank (bit-identical
+    replicas).  A peer that does not arrive within `timeout_s` (default 60 s: first-call weight packing, uneven shards and a
+    slow rank easily skew ranks by seconds, and RCCL would simply have waited) turns the result into NaN; `check()`
+    (synchronising) raises and names it -- after that the exchange is out of step and must be rebuilt.  decode_sharded calls
+    check() itself unless told not to.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC."""
+
+    def __init__(self, group=None, timeout_s=60.0):
+        from . import _lib
+        self._lib_mod = _lib
+        lib = _lib.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise ValueError("crnerf_amd: PeerExchange serves the GPUs of one node (world_size <= 8), got %d" % self.world)
+        self.timeout_us = int(timeout_s * 1e6)
+        self.device = torch.cuda.current_device()
+        own = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(lib.crnerf_peer_window_create(ctypes.byref(own), handle), "crnerf_peer_window_create")
+        self._own = own
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (bytes(handle.raw), os.uname().nodename), group=group)
+        if len({h[1] for h in handles}) != 1:
+            lib.crnerf_peer_window_destroy(own)
+            raise RuntimeError("crnerf_amd: PeerExchange: ranks on different hosts (%s); IPC windows are node-local" % sorted({h[1] for h in handles}))
+        self._windows = (ctypes.c_void_p * self.world)()
+        self._opened = []
+        for r, (h, _) in enumerate(handles):
+            if r == self.rank:
+                self._windows[r] = own.value
+                continue
+            w = ctypes.c_void_p()
+            _lib.check(lib.crnerf_peer_window_open(h, ctypes.byref(w)), "crnerf_peer_window_open")
+            self._windows[r] = w.value
+            self._opened.append(w)
+        self.epoch = 0
+        dist.barrier(group=group)   # every window is open everywhere before the first push
+
+    def all_reduce(self, t):
+        if self._own is None:
+            raise RuntimeError("crnerf_amd: PeerExchange is closed")
+        if t.numel() > 1024:
+            raise ValueError("crnerf_amd: PeerExchange.all_reduce carries at most 1024 floats, got %d" % t.numel())
+        self.epoch = self.epoch + 1 if self.epoch < 0xFFFFFFFE else 1
+        lib = self._lib_mod.load()
+        self._lib_mod.check(lib.crnerf_peer_allreduce_f32(self._lib_mod.dev_ptr(t, "all_reduce tensor"), t.numel(), self._windows, self.rank, self.world,
+                                                          self.epoch, self.timeout_us, self._lib_mod.stream_ptr()), "crnerf_peer_allreduce_f32")
+        return t
+
+    def check(self):
+        """Synchronises the device; raises if any reduction so far gave up waiting for a peer."""
+        st = ctypes.c_int(0)
+        self._lib_mod.check(self._lib_mod.load().crnerf_peer_window_status(self._own, ctypes.byref(st)), "crnerf_peer_window_status")
+        if st.value:
+            raise RuntimeError("crnerf_amd: PeerExchange: rank %d did not arrive within %.1f s at rank %d; results since then are NaN and the "
+                               "exchange must be rebuilt" % (st.value - 1, self.timeout_us / 1e6, self.rank))
+
+    def close(self):
+        """Collective: no rank may free its window while a peer can still push into it."""
+        if self._own is None:
+            return
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        lib = self._lib_mod.load()
+        for w in self._opened:
+            lib.crnerf_peer_window_close(w)
+        dist.barrier(group=self.group)
+        lib.crnerf_peer_window_destroy(self._own)
+        self._own, self._opened = None, []
+
+
+class _HipKernels:
+    def __getattr__(self, name):
+        from . import ops
+        return getattr(ops, name)
+
+
 def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False, exchange=None,
                    check_exchange=16):
     """Cross-ray decode of a ray-sharded feature grid.

@@ -141,6 +141,10 @@ class TrainingSystem:
             self.models_to_train += [self.implicit_mask]
         self.global_step = 0
         self.training = True
+        # the modules a step calls several times (enc_a x3, decoder x3, enc_cont x2) sum their parameter gradients in ONE multi-tensor add at the
+        # end of backward instead of one AccumulateGrad add per tensor and use (autograd.deferred_param_grads).  Off where torch DDP may be
+        # listening on AccumulateGrad (a process group exists and this system does not shard rays itself); set the attribute to override.
+        self.fused_grad_accumulation = (ray_parallel_group is not False) or not (torch.distributed.is_available() and torch.distributed.is_initialized())
 
     def parameters(self):
         return [p for m in self.models_to_train for p in m.parameters()]
@@ -257,7 +261,9 @@ class TrainingSystem:
         if batch.get('img_wh') is not None:
             w_whole, h_whole = (int(v) for v in batch['img_wh'])                            # :272
             hw_whole = (h_whole, w_whole)
-        results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'), hw_whole, image_id=batch.get('image_id'))
+        from .autograd import deferred_param_grads
+        with deferred_param_grads(self.fused_grad_accumulation):
+            results = self.forward(rays, ts, batch['whole_img'], side, side, batch.get('rgb_idx'), hw_whole, image_id=batch.get('image_id'))
         loss_d, annealing = self.loss(results, rgbs, self.hparams_, self.global_step)
         loss = loss_d.total() if hasattr(loss_d, "total") else sum(l for l in loss_d.values())   # (:286; one reduction of the kernel's 7-vector)
         self.global_step += 1

@@ -101,10 +101,15 @@ def test_bench_strong_scaling_video_fly_through_split_over_ranks(split, n):
     assert many["frames_checksum_all_ranks"] is not None and abs(many["frames_checksum_all_ranks"] - one["image_checksum"]) <= 2e-5 * abs(one["image_checksum"])
 
 
-def test_bench_strong_scaling_one_training_batch_split_over_two_ranks():
-    """--scaling strong --workload configs3: ONE grid-sample training batch split over the ranks (ray-parallel TrainingSystem)."""
-    j = _json_line(_launch(["bench.py", "--gpus", "2", "--scaling", "strong", "--workload", "configs3", "--train-rays", "4096", "--steps", "2", "--warmup", "1"]))
-    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["dtype"] == "f32" and j["config"]["rays_total"] == 4096
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+def test_bench_strong_scaling_one_training_batch_split_over_two_ranks(precision):
+    """--scaling strong --workload configs3: ONE grid-sample training batch split over the ranks (ray-parallel TrainingSystem), in the training
+    default (auto: split-operand products on the fp16 / bf16 matrix cores) and on the fp32 matrix cores."""
+    j = _json_line(_launch(["bench.py", "--gpus", "2", "--scaling", "strong", "--workload", "configs3", "--train-rays", "4096", "--steps", "2", "--warmup", "1",
+                            "--train-precision", precision]))
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["rays_total"] == 4096 and j["config"]["train_precision"] == precision
+    assert j["dtype"] == "f32" if precision == "f32" else j["dtype"].startswith("f32h2"), j["dtype"]
+    assert j["roofline"]["peak"] == (157.3 if precision == "f32" else 2500.0) and 0 < j["roofline"]["frac"] < 1
     assert j["replicas_identical"] is True and j["loss"] > 0
     times = j["collectives"]["per_call_ms"]
     assert any(k.startswith("allreduce_gradients_flat") for k in times) and times["allgather_feature_rows"]["calls"] >= 6, times

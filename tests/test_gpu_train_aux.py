@@ -288,3 +288,45 @@ def test_packed_weight_cache_follows_p_data_updates_through_train_and_invalidate
     assert float((y2[:, :64] - y1[:, :64]).abs().max()) > 1e-3
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(3, 2.0).items()})
     assert torch.equal(m(x), y0)
+
+
+def test_fused_grad_accumulation_equals_accumulategrad_bit_for_bit():
+    """pipeline.TrainingSystem.fused_grad_accumulation (autograd.deferred_param_grads): the modules a step calls several times -- enc_a x3,
+    decoder x3, enc_cont x2 (train_mask_grid_sample.py:151-226) -- hand the engine no parameter gradients and sum them in one multi-tensor add at the
+    end of backward.  Same uses, same order of additions: after one backward every .grad equals what AccumulateGrad leaves, bit for bit; a second backward
+    accumulates onto it."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import pipeline
+
+    class HPT(HP):
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [16, 16], 32, 32, 0.0, 0.0, 128, 8
+        encode_c, use_mask = True, True
+    R = 256
+    batch = {"rays": torch.from_numpy(synth.rays(R, H=16, W=16)).to(DEV), "ts": torch.full((R,), 3, dtype=torch.int64, device=DEV),
+             "rgbs": torch.rand(R, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(1)), "whole_img": torch.rand(1, 3, 64, 80, device=DEV) * 2 - 1,
+             "rgb_idx": torch.arange(R, device=DEV) * 7, "img_wh": torch.tensor([640, 512])}
+    grads = {}
+    for fused in (False, True):
+        torch.manual_seed(0)
+        sys_ = pipeline.TrainingSystem(HPT(), device=DEV)
+        assert sys_.fused_grad_accumulation is True          # single process, no process group: nothing listens on AccumulateGrad
+        sys_.fused_grad_accumulation = fused
+        sys_.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
+        sys_.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+        sys_.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+        loss, _, _ = sys_.training_step(batch)
+        loss.backward()
+        once = [p.grad.clone() for p in sys_.parameters()]
+        loss, _, _ = sys_.training_step(batch)               # a second backward accumulates onto the first one's .grad
+        loss.backward()
+        grads[fused] = (once, [p.grad.clone() for p in sys_.parameters()])
+    assert len(grads[True][0]) == len(grads[False][0])
+    n_exact = len(grads[True][0]) - len(list(sys_.implicit_mask.parameters()))   # (the mask network's weight gradients sum with float atomics: not
+    for i, (a, b) in enumerate(zip(grads[True][0], grads[False][0])):            # reproducible run to run, with or without the deferral)
+        if i < n_exact:
+            assert torch.equal(a, b), i
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-2, atol=1e-3 * float(b.abs().max()))
+    for i, (a, b) in enumerate(zip(grads[True][1], grads[False][1])):    # (grad + (a + b + c) against ((grad + a) + b) + c: one rounding apart)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
