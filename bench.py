@@ -850,22 +850,26 @@ def main():
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
+
+                for kx in ("f32x3_kernel", "f32h2_kernel"):
+                    if not bf16 and kx in line["extra"]:
+                        line["extra"][kx]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"][kx]["kernel_ms"]
+            except Exception as e:   # noqa: BLE001
+                line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
                 # configs[3]'s training step at the reference's own batch (command/train.sh:24: 1,024 rays) and at 16,384 rays: the whole
                 # train.sh configuration (batcher, encoders, mask network, grad-mode render, decodes, loss, backward, Adam), training defaults
                 import argparse
                 for tr, st in ((1024, 30), (16384, 6)):
                     ta = argparse.Namespace(**dict(vars(a), train_rays=tr, steps=st, warmup=5, train_precision="auto"))
                     tl = strong_configs3(ta, dev, 1, 0, False, None)
-                    line["extra"]["train_step_%d" % tr] = {"ms_per_step": tl["ms_per_step"], "rays_per_s": tl["value"], "dtype": tl["dtype"], "steps": st,
+                    line.setdefault("extra", {})["train_step_%d" % tr] = {"ms_per_step": tl["ms_per_step"], "rays_per_s": tl["value"], "dtype": tl["dtype"], "steps": st,
                                                            "fp32_work_tflops": tl["roofline"]["fp32_work_tflops"], "workload": tl["config"]["workload"]}
                 from crnerf_amd import autograd as _AG
                 _AG.set_training_forward_precision(None)
                 _AG.set_wgrad_precision(None)
-                for kx in ("f32x3_kernel", "f32h2_kernel"):
-                    if not bf16 and kx in line["extra"]:
-                        line["extra"][kx]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"][kx]["kernel_ms"]
             except Exception as e:   # noqa: BLE001
-                line["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                line.setdefault("extra", {})["train_step_error"] = "%s: %s" % (type(e).__name__, e)
         if rgb_sums is not None:
             line["test_rgb_checksum_per_rank"] = rgb_sums
     finish(line if rank == 0 else None)

@@ -228,31 +228,50 @@ def check(code, what):
         raise RuntimeError("%s failed (code %d): %s" % (what, code, msg.decode() if msg else "?"))
 
 
+# Host cost matters at the reference's 1,024-ray training batch (~450 launches per step, the step is host-bound): these helpers run once per
+# pointer / launch, so they use torch's raw accessors -- no Stream object per launch, no string formatting unless something is wrong.
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _current_device():
+    return _get_device() if _get_device is not None else torch.cuda.current_device()
+
+
 def stream_ptr():
+    if _get_raw_stream is not None:
+        return ctypes.c_void_p(_get_raw_stream(_current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bad_tensor(t, name, dtype):
+    if not t.is_cuda:
+        return RuntimeError("crnerf_amd: %s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.device.index != _current_device():
+        # kernels are enqueued on the CURRENT device's stream (stream_ptr): a tensor of another GPU would be reached through peer
+        # access, unordered with its producers -- one process drives one GPU (torch.cuda.set_device(LOCAL_RANK) first)
+        return RuntimeError("crnerf_amd: %s lives on cuda:%d but the current device is cuda:%d; call torch.cuda.set_device(%d) "
+                            "(or wrap the call in torch.cuda.device) before using the HIP path"
+                            % (name, t.device.index, _current_device(), t.device.index))
+    if t.dtype != dtype:
+        return TypeError("crnerf_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    return ValueError("crnerf_amd: %s must be contiguous" % name)
 
 
 def dev_ptr(t, name="tensor", dtype=torch.float32):
     """Pointer of a contiguous device tensor; None -> NULL."""
     if t is None:
         return None
-    if not t.is_cuda:
-        raise RuntimeError("crnerf_amd: %s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
-    if t.device.index != torch.cuda.current_device():
-        # kernels are enqueued on the CURRENT device's stream (stream_ptr): a tensor of another GPU would be reached through peer
-        # access, unordered with its producers -- one process drives one GPU (torch.cuda.set_device(LOCAL_RANK) first)
-        raise RuntimeError("crnerf_amd: %s lives on cuda:%d but the current device is cuda:%d; call torch.cuda.set_device(%d) "
-                           "(or wrap the call in torch.cuda.device) before using the HIP path"
-                           % (name, t.device.index, torch.cuda.current_device(), t.device.index))
-    if t.dtype != dtype:
-        raise TypeError("crnerf_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
-        raise ValueError("crnerf_amd: %s must be contiguous" % name)
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or t.device.index != _current_device():
+        raise _bad_tensor(t, name, dtype)
     return ctypes.c_void_p(t.data_ptr())
 
 
 def ptr_array(tensors, name):
     arr = (ctypes.c_void_p * len(tensors))()
+    dev = _current_device()
     for i, t in enumerate(tensors):
-        arr[i] = dev_ptr(t, "%s[%d]" % (name, i)).value
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.device.index != dev:
+            raise _bad_tensor(t, "%s[%d]" % (name, i), torch.float32)
+        arr[i] = t.data_ptr()
     return arr
