@@ -113,7 +113,9 @@ __global__ void enc_act_grad_kernel(const float* __restrict__ d_out, const float
 // d_in[px][c] = sum over (patch row q, tap) with reflect(q + tap) == px of dX[q][c*9 + tap]: the adjoint of the reflection-padded
 // gather, applied to the patch-matrix gradient dX = g W that the GEMM path produces (pixels in row / column 1 and n-2 also
 // collect what the padding mirrored)
-__global__ void enc_col2im_kernel(const float* __restrict__ dX, float* __restrict__ d_in, int H, int W, int cin) {
+// yact != null: what is written is g = d_in * lrelu'(yact) -- the upstream gradient of the layer BELOW with its activation's derivative already in it
+// (round 4: the separate enc_act_grad pass per layer is gone; `d_in` is then that layer's g buffer)
+__global__ void enc_col2im_kernel(const float* __restrict__ dX, float* __restrict__ d_in, int H, int W, int cin, const float* __restrict__ yact) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)H * W * cin) return;
   const int c = (int)(idx % cin);
@@ -133,22 +135,16 @@ __global__ void enc_col2im_kernel(const float* __restrict__ dX, float* __restric
           acc += dX[((long)qy * W + qx) * cin * 9 + c * 9 + ky * 3 + kx];
         }
     }
-  d_in[idx] = acc;
-}
-
-// w[o][c][tap] -> wd[tap][o][c]
-__global__ void enc_weights_for_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int cout, int cin, int taps) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= cout * cin * taps) return;
-  const int o = idx / (cin * taps), c = (idx / taps) % cin, t = idx % taps;
-  wd[((long)t * cout + o) * cin + c] = w[idx];
+  d_in[idx] = yact ? acc * lrelu_grad(yact[idx]) : acc;
 }
 
 // d_in[px][c] = sum over (output pixel q, tap) with reflect(q + tap) == px of sum_o g[q][o] * w[o][c][tap]   (g already carries lrelu')
 // (the adjoint of the reflection-padded gather: pixels in row / column 1 and n-2 also collect what the padding mirrored)
+// w: the layer's own [cout][cin][taps] weights, indexed in place (round 4: the [tap][o][c] re-layout launch in front of this kernel is gone -- it
+// only ever serves the two 3-channel layers); yact as in enc_col2im_kernel
 template <int TAPS>
-__global__ __launch_bounds__(256) void enc_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ wd,
-                                                        float* __restrict__ d_in, int H, int W, int cin, int cout) {
+__global__ __launch_bounds__(256) void enc_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                        float* __restrict__ d_in, int H, int W, int cin, int cout, const float* __restrict__ yact) {
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int px = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: g[q][o] becomes a scalar load
   if (px >= H * W) return;
@@ -167,24 +163,25 @@ __global__ __launch_bounds__(256) void enc_dgrad_kernel(const float* __restrict_
             const int qx = tx[b] - kx + 1;
             if (qx < 0 || qx >= W) continue;
             const long q = (long)qy * W + qx;
-            const float* wp = wd + (long)(ky * 3 + kx) * cout * cin + c;
             const float* gq = g + q * cout;
             const int cc = c < cin ? c : cin - 1;
+            const float* wp = w + (long)cc * 9 + ky * 3 + kx;
 #pragma unroll 8
-            for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], wp[(long)o * cin + (cc - c)], acc);
+            for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], wp[(long)o * cin * 9], acc);
           }
       }
   } else {
     const float* gq = g + (long)px * cout;
     const int cc = c < cin ? c : cin - 1;
 #pragma unroll 8
-    for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], wd[(long)o * cin + cc], acc);
+    for (int o = 0; o < cout; ++o) acc = fmaf(gq[o], w[(long)o * cin + cc], acc);
   }
-  if (c < cin) d_in[(long)px * cin + c] = acc;
+  if (c < cin) d_in[(long)px * cin + c] = yact ? acc * lrelu_grad(yact[(long)px * cin + c]) : acc;
 }
 
 // MaxPool2d(2,2) backward: the gradient goes to the first maximum of the window in scan order (ATen's tie rule)
-__global__ void enc_maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C) {
+// act: `in` is the output of a LeakyReLU layer and d_in receives g = d(in) * lrelu'(in) (the pooled position's value is bv itself)
+__global__ void enc_maxpool2_bwd_kernel(const float* __restrict__ in, const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C, int act) {
   const int Ho = H / 2, Wo = W / 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Ho * Wo * C) return;
@@ -199,11 +196,11 @@ __global__ void enc_maxpool2_bwd_kernel(const float* __restrict__ in, const floa
     if (v > bv) { bv = v; best = k; }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) d_in[base + off[k]] = k == best ? d_out[idx] : 0.0f;
+  for (int k = 0; k < 4; ++k) d_in[base + off[k]] = k == best ? (act ? d_out[idx] * lrelu_grad(bv) : d_out[idx]) : 0.0f;
 }
 
 // AdaptiveAvgPool2d(S) backward: every input position collects d_out / window_area from the windows that contain it
-__global__ void enc_avgpool_bwd_kernel(const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C, int S) {
+__global__ void enc_avgpool_bwd_kernel(const float* __restrict__ d_out, float* __restrict__ d_in, int H, int W, int C, int S, const float* __restrict__ yact) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= H * W * C) return;
   const int c = idx % C, px = idx / C, yy = px / W, xx = px % W;
@@ -217,7 +214,7 @@ __global__ void enc_avgpool_bwd_kernel(const float* __restrict__ d_out, float* _
       acc += d_out[((long)oy * S + ox) * C + c] / (float)((y1 - y0) * (x1 - x0));
     }
   }
-  d_in[idx] = acc;
+  d_in[idx] = yact ? acc * lrelu_grad(yact[idx]) : acc;
 }
 
 // HWC [HW,C] -> NCHW [C,HW]
@@ -233,11 +230,12 @@ struct BwdBufs { float* X; float* wd; WgradSpec* specs; int* nspec; };
 // xsaved: the layer's patch matrix kept by the forward (GEMM layers) or null (built here); wt: the forward's [cin*taps][cout]
 // re-layout of the weights (kept in `saved`): for cin >= 64 the data gradient is the GEMM dX[px][k] = sum_o g[px][o] wt[k][o] on the
 // fp32 matrix cores + the gather over the padding's adjoint, instead of a 1,152-step dependent chain per pixel
+// g: this layer's upstream gradient with its own lrelu' already applied (made by the producer above it; only the top layer runs enc_act_grad).
+// d_in / yact: where the gradient w.r.t. this layer's input goes, and -- when that input is a LeakyReLU layer's output consumed directly --
+// that output, so that what is written is already the NEXT layer's g.
 template <int TAPS>
-static void conv_bwd(const float* d_out, const float* y, const float* in, const float* w, const BwdBufs& B, float* g, float* dW, float* db, float* d_in,
+static void conv_bwd(const float* g, const float* in, const float* w, const BwdBufs& B, float* dW, float* db, float* d_in, const float* yact,
                      int H, int W, int cin, int cout, hipStream_t st, const float* xsaved = nullptr, const float* wt = nullptr) {
-  const long n = (long)H * W * cout;
-  hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, y, g, n);
   const float* X = in;
   if (TAPS == 9) {
     if (xsaved) X = xsaved;
@@ -251,15 +249,13 @@ static void conv_bwd(const float* d_out, const float* y, const float* in, const 
     if (TAPS == 9) {
       enc_gemm_nt(false, g, cout, wt, cout, nullptr, B.X, cin * 9, H * W, cin * 9, cout, st);   // B.X is free: the patch matrix came from `saved`
       const long nd = (long)H * W * cin;
-      hipLaunchKernelGGL(enc_col2im_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, B.X, d_in, H, W, cin);
+      hipLaunchKernelGGL(enc_col2im_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, B.X, d_in, H, W, cin, yact);
     } else {
-      enc_gemm_nt(false, g, cout, wt, cout, nullptr, d_in, cin, H * W, cin, cout, st);
+      enc_gemm_nt(false, g, cout, wt, cout, nullptr, d_in, cin, H * W, cin, cout, st);          // (1 x 1: its consumer applies the derivative)
     }
     return;
   }
-  const int nw = cout * cin * TAPS;
-  hipLaunchKernelGGL(enc_weights_for_dgrad_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, w, B.wd, cout, cin, TAPS);
-  hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, g, B.wd, d_in, H, W, cin, cout);
+  hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, g, w, d_in, H, W, cin, cout, yact);
 }
 
 // saved: from launch_encoder_forward_train; out: its output (for lrelu7'); d_out[1024,64]; grads[14] in weight order;
@@ -281,18 +277,23 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
     const float* p = s + L.end;
     for (int l = 0; l < 7; ++l) { wt[l] = p; p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
   }
-  conv_bwd<1>(d_out, out, s + L.p6, w[12], B, base + SL.g[6], grads[12], grads[13], ga, 32, 32, 128, 64, st, nullptr, wt[6]);     // conv7 -> d p6
-  hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, gb, L.H4, L.W4, 128, 32); // -> d y6
-  conv_bwd<9>(gb, s + L.y6, s + L.p5, w[10], B, base + SL.g[5], grads[10], grads[11], ga, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);   // conv6 -> d p5
-  (void)hipMemsetAsync(gb, 0, (size_t)n2 * 128 * sizeof(float), st);
-  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, gb, L.H2, L.W2, 128);  // -> d y5
-  conv_bwd<9>(gb, s + L.y5, s + L.y4, w[8], B, base + SL.g[4], grads[8], grads[9], ga, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);   // conv5 -> d y4
-  conv_bwd<9>(ga, s + L.y4, s + L.p3, w[6], B, base + SL.g[3], grads[6], grads[7], gb, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);    // conv4 -> d p3
-  (void)hipMemsetAsync(ga, 0, (size_t)n0 * 64 * sizeof(float), st);
-  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, ga, H, W, 64);  // -> d y3
-  conv_bwd<9>(ga, s + L.y3, s + L.y2, w[4], B, base + SL.g[2], grads[4], grads[5], gb, H, W, 64, 64, st, s + L.x3, wt[2]);         // conv3 -> d y2
-  conv_bwd<9>(gb, s + L.y2, s + L.y1, w[2], B, base + SL.g[1], grads[2], grads[3], ga, H, W, 3, 64, st);                          // conv2 -> d y1
-  conv_bwd<1>(ga, nullptr, s + L.a0, w[0], B, base + SL.g[0], grads[0], grads[1], d_img ? gb : nullptr, H, W, 3, 3, st);         // conv1 -> d a0
+  float* g[7];
+  for (int l = 0; l < 7; ++l) g[l] = base + SL.g[l];
+  // the top layer's g from the caller's gradient; every other g[l] is written by the kernel that produces that layer's upstream gradient,
+  // derivative included (seven elementwise passes and two memsets per backward before round 4)
+  hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((1024L * 64 + 255) / 256)), dim3(256), 0, st, d_out, out, g[6], 1024L * 64);
+  conv_bwd<1>(g[6], s + L.p6, w[12], B, grads[12], grads[13], ga, nullptr, 32, 32, 128, 64, st, nullptr, wt[6]);                  // conv7 -> d p6
+  hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, g[5], L.H4, L.W4, 128, 32, s + L.y6);   // -> g of conv6
+  conv_bwd<9>(g[5], s + L.p5, w[10], B, grads[10], grads[11], ga, nullptr, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);             // conv6 -> d p5
+  if ((L.H2 | L.W2) & 1) (void)hipMemsetAsync(g[4], 0, (size_t)n2 * 128 * sizeof(float), st);   // (an odd row / column lies in no pooling window)
+  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, g[4], L.H2, L.W2, 128, 1);   // -> g of conv5
+  conv_bwd<9>(g[4], s + L.y4, w[8], B, grads[8], grads[9], g[3], s + L.y4, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);             // conv5 -> g of conv4
+  conv_bwd<9>(g[3], s + L.p3, w[6], B, grads[6], grads[7], gb, nullptr, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);                 // conv4 -> d p3
+  if ((H | W) & 1) (void)hipMemsetAsync(g[2], 0, (size_t)n0 * 64 * sizeof(float), st);
+  hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, g[2], H, W, 64, 1);           // -> g of conv3
+  conv_bwd<9>(g[2], s + L.y2, w[4], B, grads[4], grads[5], g[1], s + L.y2, H, W, 64, 64, st, s + L.x3, wt[2]);                     // conv3 -> g of conv2
+  conv_bwd<9>(g[1], s + L.y1, w[2], B, grads[2], grads[3], g[0], nullptr, H, W, 3, 64, st);                                         // conv2 -> g of conv1 (no activation)
+  conv_bwd<1>(g[0], s + L.a0, w[0], B, grads[0], grads[1], d_img ? gb : nullptr, nullptr, H, W, 3, 3, st);                           // conv1 -> d a0
   if (d_img) hipLaunchKernelGGL(enc_hwc_to_chw_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, st, gb, d_img, 3, n0);
   if (int rc = wgrad_batch(specs, nspec, base + SL.ws, SL.ws_floats, st)) return rc;        // the seven weight / bias gradients: two launches
   return check_launch("encoder_backward");
