@@ -601,7 +601,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
     Adam per step, in --train-precision (auto: fp32-accurate split-operand products on the fp16 / bf16 matrix cores; f32: the fp32 matrix cores)."""
     import numpy as np
     import crnerf_amd.synth as synth
-    from crnerf_amd import autograd as AG, pipeline
+    from crnerf_amd import autograd as AG, optim as crnerf_optim, pipeline
     exact = a.train_precision == "f32"
     AG.set_training_forward_precision("f32" if exact else "auto")
     AG.set_wgrad_precision("f32" if exact else "bf16x3")
@@ -630,7 +630,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
     rgbs = torch.rand(n_img * iw * ih, 3, device=dev)
     imgs = [torch.rand(1, 3, ih // 8, iw // 8, device=dev) * 2 - 1 for _ in range(n_img)]
     batcher = GridSampleBatcher(rays, rgbs, np.array([[iw, ih]] * n_img), batch_size=R, all_imgs=imgs)
-    opt = torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True)
+    opt = crnerf_optim.FlatAdam(sysm.parameters(), lr=5e-4, eps=1e-8)      # utils/__init__.py:31 Adam(lr, eps=1e-8), one HIP launch (crnerf_adam_step_f32)
     counter = [0]
 
     def step():

@@ -30,9 +30,10 @@ EXPORTS = [
     "crnerf_packed_mlp_x3_bytes", "crnerf_pack_mlp_weights_x3", "crnerf_mlp_forward_f32x3", "crnerf_render_rays_f32x3", "crnerf_render_rays_train_f32x3", "crnerf_packed_mlp_t_x3_bytes", "crnerf_pack_mlp_weights_t_x3", "crnerf_mlp_backward_x3_f32", "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16",
     "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
-    "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32",
+    "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32", "crnerf_adam_max_tensors", "crnerf_adam_step_f32",
     "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_train_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
     "crnerf_fglo_f32", "crnerf_fglo_backward_f32", "crnerf_bilinear_gather_f32", "crnerf_bilinear_gather_backward_f32",
+    "crnerf_cgnet_param_count", "crnerf_cgnet_bn_count", "crnerf_cgnet_arena_bytes", "crnerf_cgnet_forward_train_f32", "crnerf_cgnet_backward_f32",
     "crnerf_peer_window_bytes", "crnerf_peer_window_create", "crnerf_peer_window_open", "crnerf_peer_window_close", "crnerf_peer_window_destroy",
     "crnerf_peer_window_status", "crnerf_peer_allreduce_f32",
 ]
@@ -196,6 +197,8 @@ def load():
             "crnerf_loss_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, vp, vp]),
             "crnerf_loss_backward_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, ctypes.POINTER(LossGrads), vp]),
             "crnerf_grid_sample_batch_f32": (ctypes.c_int, [ctypes.POINTER(BatchArgs), vp]),
+            "crnerf_adam_max_tensors": (ctypes.c_int, []),
+            "crnerf_adam_step_f32": (ctypes.c_int, [vp, vp, vp, vp, i32, pp, i32, f32, f32, f32, f32, f32, f32, vp]),
             "crnerf_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp]),
             "crnerf_conv2d_backward_f32": (ctypes.c_int, [ctypes.POINTER(ConvGeom), vp, vp, vp, vp, vp, vp]),
             "crnerf_bn_prelu_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, vp]),
@@ -206,6 +209,11 @@ def load():
             "crnerf_fglo_backward_f32": (ctypes.c_int, [vp] * 11 + [i32, i32, i64, vp]),
             "crnerf_bilinear_gather_f32": (ctypes.c_int, [vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
             "crnerf_bilinear_gather_backward_f32": (ctypes.c_int, [vp, vp, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
+            "crnerf_cgnet_param_count": (ctypes.c_int, []),
+            "crnerf_cgnet_bn_count": (ctypes.c_int, []),
+            "crnerf_cgnet_arena_bytes": (ctypes.c_size_t, [i32, i32, i32]),
+            "crnerf_cgnet_forward_train_f32": (ctypes.c_int, [vp, i32, i32, i32, pp, pp, pp, pp, f32, f32, vp, vp, vp]),
+            "crnerf_cgnet_backward_f32": (ctypes.c_int, [vp, i32, i32, i32, pp, vp, vp, vp, vp, pp, vp]),
             "crnerf_peer_window_bytes": (ctypes.c_size_t, []),
             "crnerf_peer_window_create": (ctypes.c_int, [pp, ctypes.c_char_p]),
             "crnerf_peer_window_open": (ctypes.c_int, [ctypes.c_char_p, pp]),

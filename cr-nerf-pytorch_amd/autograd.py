@@ -642,3 +642,21 @@ class BilinearGatherFn(torch.autograd.Function):
         out, idx = ctx.saved_tensors
         in_hw, size, sigmoid = ctx.cfg
         return ops.bilinear_gather_backward(out, d_out, in_hw, size, idx, sigmoid), None, None, None
+
+
+class CGNetFn(torch.autograd.Function):
+    """Context_Guided_Network(classes=1, M=2, N=2) in train mode as ONE autograd node: forward = crnerf_cgnet_forward_train_f32, backward =
+    crnerf_cgnet_backward_f32 (csrc/cgnet_chain.hip: the operator kernels of the per-module path enqueued back to back, no torch.cat / add /
+    gradient-sum launches, no autograd node per layer).  `bns`: the 14 BatchNorm2d modules (running buffers); the image receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, image, bns, *params):
+        mask, saved = ops.cgnet_forward_train(image, params, [b.running_mean for b in bns], [b.running_var for b in bns],
+                                              [b.num_batches_tracked for b in bns], bns[0].momentum, bns[0].eps)
+        ctx.save_for_backward(image, mask, saved, *params)
+        return mask
+
+    @staticmethod
+    def backward(ctx, d_mask):
+        image, mask, saved, *params = ctx.saved_tensors
+        return (None, None) + tuple(ops.cgnet_backward(image, params, saved, mask, d_mask))

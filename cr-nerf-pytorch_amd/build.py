@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "mlp_forward_bf16p.hip", "mlp_forward_x3.hip", "mlp_forward_h2.hip", "render_fused_h2.hip", "mlp_backward_x3.hip", "mlp_backward_h2.hip", "render_fused_bf16.hip", "render_fused_bf16p.hip", "render_fused_x3.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip",
+SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "mlp_forward_bf16p.hip", "mlp_forward_x3.hip", "mlp_forward_h2.hip", "render_fused_h2.hip", "mlp_backward_x3.hip", "mlp_backward_h2.hip", "render_fused_bf16.hip", "render_fused_bf16p.hip", "render_fused_x3.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip", "cgnet_chain.hip",
            "crossray.hip", "peer_xchg.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/crnerf.h"]   # every header: any edit rebuilds
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;

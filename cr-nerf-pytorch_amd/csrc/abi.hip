@@ -653,6 +653,19 @@ int crnerf_grid_sample_batch_f32(const crnerf_batch_args* a, void* stream) {
   return launch_grid_batch(k, (hipStream_t)stream);
 }
 
+int crnerf_adam_max_tensors(void) { return ADAM_MAX_TENSORS; }
+
+int crnerf_adam_step_f32(float* params, float* exp_avg, float* exp_avg_sq, const int32_t* blocks, int32_t n_blocks, const float* const* grads,
+                         int32_t n_tensors, float step_size, float beta1, float beta2, float eps, float weight_decay, float bias_correction2_sqrt,
+                         void* stream) {
+  if (n_blocks <= 0) return 0;
+  REQUIRE(params, "params"); REQUIRE(exp_avg, "exp_avg"); REQUIRE(exp_avg_sq, "exp_avg_sq"); REQUIRE(blocks, "blocks"); REQUIRE(grads, "grads");
+  if (n_tensors <= 0 || n_tensors > ADAM_MAX_TENSORS) return set_error(CRNERF_ERR_SHAPE, "adam_step: n_tensors outside 1 ... crnerf_adam_max_tensors()");
+  if (!(bias_correction2_sqrt > 0.0f) || !(eps >= 0.0f)) return set_error(CRNERF_ERR_CONFIG, "adam_step: bias_correction2_sqrt must be positive and eps non-negative");
+  const AdamHyper h{step_size, beta1, beta2, eps, weight_decay, bias_correction2_sqrt};
+  return launch_adam_step(params, exp_avg, exp_avg_sq, blocks, n_blocks, grads, n_tensors, h, (hipStream_t)stream);
+}
+
 static int to_geom(const crnerf_conv_geom* a, ConvGeom& g) {
   if (a->cin <= 0 || a->cout <= 0 || a->H <= 0 || a->W <= 0 || a->k <= 0 || a->stride <= 0 || a->dil <= 0 || a->pad < 0)
     return set_error(CRNERF_ERR_SHAPE, "conv2d: non-positive geometry");
@@ -741,6 +754,43 @@ int crnerf_bilinear_gather_backward_f32(const float* out, const float* d_out, in
   if (n > 0) { REQUIRE(d_out, "d_out"); if (sigmoid) REQUIRE(out, "out"); }
   if (!idx && n != (int64_t)Ho * Wo) return set_error(CRNERF_ERR_SHAPE, "bilinear_gather_backward: idx == NULL means every output pixel");
   return launch_cg_bilinear_backward(out, d_out, (const long*)idx, d_in, (long)n, h, w, Ho, Wo, sigmoid, (hipStream_t)stream);
+}
+
+int crnerf_cgnet_param_count(void) { return CGNET_PARAMS; }
+int crnerf_cgnet_bn_count(void) { return CGNET_BNS; }
+size_t crnerf_cgnet_arena_bytes(int32_t cin, int32_t H, int32_t W) {
+  if (cin <= 0 || H <= 0 || W <= 0) return 0;
+  return cgnet_arena_floats(cin, H, W) * sizeof(float);
+}
+
+static int cgnet_args(const char* who, int32_t cin, int32_t H, int32_t W, const float* const* params) {
+  if (cin <= 0 || H < 1 || W < 1 || (long)H * W > (1L << 24)) return set_error(CRNERF_ERR_SHAPE, "cgnet: image must be cin >= 1 channels of 1 ... 2^24 pixels");
+  REQUIRE(params, "params");
+  for (int i = 0; i < CGNET_PARAMS; ++i)
+    if (!params[i]) return set_error(CRNERF_ERR_NULL, who);
+  return 0;
+}
+
+int crnerf_cgnet_forward_train_f32(const float* image, int32_t cin, int32_t H, int32_t W, const float* const* params, float* const* running_mean,
+                                   float* const* running_var, int64_t* const* num_batches_tracked, float momentum, float eps, void* saved,
+                                   float* mask, void* stream) {
+  REQUIRE(image, "image"); REQUIRE(saved, "saved"); REQUIRE(mask, "mask"); REQUIRE(running_mean, "running_mean"); REQUIRE(running_var, "running_var");
+  if (int rc = cgnet_args("cgnet_forward_train: a params[] entry is NULL", cin, H, W, params)) return rc;
+  for (int i = 0; i < CGNET_BNS; ++i)
+    if (!running_mean[i] || !running_var[i]) return set_error(CRNERF_ERR_NULL, "cgnet_forward_train: a running_mean / running_var entry is NULL");
+  if (!(eps > 0.0f) || !(momentum >= 0.0f && momentum <= 1.0f)) return set_error(CRNERF_ERR_CONFIG, "cgnet_forward_train: eps must be positive and momentum in [0, 1]");
+  const CgNetArgs a{cin, H, W, params, running_mean, running_var, (long long* const*)num_batches_tracked, momentum, eps};
+  return launch_cgnet_forward_train(a, image, (float*)saved, mask, (hipStream_t)stream);
+}
+
+int crnerf_cgnet_backward_f32(const float* image, int32_t cin, int32_t H, int32_t W, const float* const* params, const void* saved, const float* mask,
+                              const float* d_mask, void* scratch, float* const* grads, void* stream) {
+  REQUIRE(image, "image"); REQUIRE(saved, "saved"); REQUIRE(mask, "mask"); REQUIRE(d_mask, "d_mask"); REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  if (int rc = cgnet_args("cgnet_backward: a params[] entry is NULL", cin, H, W, params)) return rc;
+  for (int i = 0; i < CGNET_PARAMS; ++i)
+    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "cgnet_backward: a grads[] entry is NULL");
+  const CgNetArgs a{cin, H, W, params, nullptr, nullptr, nullptr, 0.0f, 1e-3f};
+  return launch_cgnet_backward(a, image, (const float*)saved, mask, d_mask, (float*)scratch, grads, (hipStream_t)stream);
 }
 
 }  // extern "C"

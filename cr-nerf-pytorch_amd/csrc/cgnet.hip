@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void cg_conv_dgrad_wave_kernel(ConvGeom g, con
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-  if (lane == 0) dx[in] = acc;
+  if (lane == 0) dx[in] = g.accum ? dx[in] + acc : acc;
 }
 
 __global__ void cg_conv_dgrad_kernel(ConvGeom g, const float* __restrict__ w, const float* __restrict__ dy, float* __restrict__ dx) {
@@ -95,7 +95,7 @@ __global__ void cg_conv_dgrad_kernel(ConvGeom g, const float* __restrict__ w, co
         for (int co = 0; co < g.cout; ++co) acc = fmaf(w[((co * cpg + ci) * g.k + ky) * g.k + kx], dy[(co * g.Ho + oy) * g.Wo + ox], acc);
     }
   }
-  dx[idx] = acc;
+  dx[idx] = g.accum ? dx[idx] + acc : acc;
 }
 
 // one 64-lane block per weight element: sum over output pixels
@@ -287,12 +287,23 @@ __global__ __launch_bounds__(256) void cg_fglo_fc_kernel(const float* __restrict
     stats[C + R + c] = 1.0f / (1.0f + expf(-a));
   }
 }
+// res (may be null): the block's residual input, added after the product is rounded -- what `x + F_glo(...)` gives (ContextGuidedBlock, add=True)
 __global__ void cg_fglo_scale_kernel(const float* __restrict__ x, const float* __restrict__ gate, const float* __restrict__ extra, float* __restrict__ y, int C,
-                                     int HW) {
+                                     int HW, const float* __restrict__ res) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * HW) return;
   const int c = idx / HW;
-  y[idx] = x[idx] * gate[c] + (extra ? extra[c] : 0.0f);
+  const float v = x[idx] * gate[c] + (extra ? extra[c] : 0.0f);
+  y[idx] = res ? res[idx] + v : v;
+}
+__global__ void cg_add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) dst[idx] += src[idx];
+}
+int launch_cg_add_inplace(float* dst, const float* src, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cg_add_inplace_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n);
+  return check_launch("cg_add_inplace");
 }
 // ds[c] = sum dy*x  ->  through sigmoid, fc2, relu, fc1  ->  dm[c] / HW added to every pixel of channel c
 __global__ __launch_bounds__(256) void cg_fglo_fc_bwd_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ stats,
@@ -327,11 +338,11 @@ __global__ __launch_bounds__(256) void cg_fglo_fc_bwd_kernel(const float* __rest
   }
 }
 int launch_cg_fglo_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R, int HW,
-                           hipStream_t st) {
+                           hipStream_t st, const float* residual) {
   if (C > 256 || R > 64) return set_error(-2, "fglo: C <= 256 and C/reduction <= 64 expected");
   hipLaunchKernelGGL(cg_chan_reduce_kernel, dim3(C), dim3(256), 0, st, x, (const float*)nullptr, stats, HW, 1.0f / (float)HW);
   hipLaunchKernelGGL(cg_fglo_fc_kernel, dim3(1), dim3(256), 0, st, w1, b1, w2, b2, stats, C, R);
-  hipLaunchKernelGGL(cg_fglo_scale_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, x, stats + C + R, (const float*)nullptr, y, C, HW);
+  hipLaunchKernelGGL(cg_fglo_scale_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, x, stats + C + R, (const float*)nullptr, y, C, HW, residual);
   return check_launch("cg_fglo_forward");
 }
 // scratch: 2C floats
@@ -341,7 +352,7 @@ int launch_cg_fglo_backward(const float* x, const float* w1, const float* w2, co
   float* dmean = scratch + C;
   hipLaunchKernelGGL(cg_chan_reduce_kernel, dim3(C), dim3(256), 0, st, dy, x, dsum, HW, 1.0f);
   hipLaunchKernelGGL(cg_fglo_fc_bwd_kernel, dim3(1), dim3(256), 0, st, w1, w2, stats, dsum, dw1, db1, dw2, db2, dmean, C, R, 1.0f / (float)HW);
-  hipLaunchKernelGGL(cg_fglo_scale_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, dy, stats + C + R, dmean, dx, C, HW);
+  hipLaunchKernelGGL(cg_fglo_scale_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, dy, stats + C + R, dmean, dx, C, HW, (const float*)nullptr);
   return check_launch("cg_fglo_backward");
 }
 

@@ -149,7 +149,7 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
                             float* const* grads, float* d_img, hipStream_t st);
 
 // ---- transient-mask network operators (cgnet.hip)
-struct ConvGeom { int cin, cout, H, W, Ho, Wo, k, stride, pad, dil, depthwise; };
+struct ConvGeom { int cin, cout, H, W, Ho, Wo, k, stride, pad, dil, depthwise; int accum = 0; };   // accum: the data gradient is ADDED to d_x (chain only)
 int launch_cg_conv_forward(const ConvGeom& g, const float* x, const float* w, float* y, hipStream_t st);
 int launch_cg_conv_backward(const ConvGeom& g, const float* x, const float* w, const float* dy, float* dx, float* dw, hipStream_t st);
 int launch_cg_bn_prelu_forward(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
@@ -159,12 +159,27 @@ int launch_cg_bn_prelu_backward(const float* x, const float* gamma, const float*
                                 const float* dy, float* dx, float* dgamma, float* dbeta, float* dalpha, int C, int HW, int training, hipStream_t st);
 int launch_cg_avgpool(const float* in, float* out, int C, int H, int W, int backward, hipStream_t st);
 int launch_cg_fglo_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R, int HW,
-                           hipStream_t st);
+                           hipStream_t st, const float* residual = nullptr);
+int launch_cg_add_inplace(float* dst, const float* src, int n, hipStream_t st);
 int launch_cg_fglo_backward(const float* x, const float* w1, const float* w2, const float* stats, const float* dy, float* scratch, float* dx, float* dw1,
                             float* db1, float* dw2, float* db2, int C, int R, int HW, hipStream_t st);
 int launch_cg_bilinear(const float* in, const long* idx, float* out, long n, int h, int w, int Ho, int Wo, int sigmoid, hipStream_t st);
 int launch_cg_bilinear_backward(const float* out, const float* d_out, const long* idx, float* d_in, long n, int h, int w, int Ho, int Wo, int sigmoid,
                                 hipStream_t st);
+
+// the whole network of a training step as two calls (cgnet_chain.hip); parameter / BatchNorm order documented there
+constexpr int CGNET_PARAMS = 76, CGNET_BNS = 14;
+struct CgNetArgs {
+  int cin, H, W;
+  const float* const* params;                       // [CGNET_PARAMS]
+  float* const* run_mean; float* const* run_var;    // [CGNET_BNS] running buffers, updated by the forward
+  long long* const* tracked;                        // [CGNET_BNS] num_batches_tracked (array or entries may be null)
+  float momentum, eps;
+};
+size_t cgnet_arena_floats(int cin, int H, int W);   // floats of `saved` (forward) and of `scratch` (backward)
+int launch_cgnet_forward_train(const CgNetArgs& a, const float* image, float* saved, float* mask, hipStream_t st);
+int launch_cgnet_backward(const CgNetArgs& a, const float* image, const float* saved, const float* mask, const float* d_mask, float* scratch,
+                          float* const* grads, hipStream_t st);
 
 // ---- training-side neighbours (train_aux.hip)
 struct LossArgs {
@@ -187,5 +202,10 @@ struct BatchArgs {
   float* rays; long* ts; float* rgbs; long* rgb_idx; float* uv;
 };
 int launch_grid_batch(const BatchArgs& a, hipStream_t stream);
+constexpr int ADAM_MAX_TENSORS = 448;             // gradient pointers ride in the kernel arguments (3.5 KB of the 4 KB)
+constexpr int ADAM_BLOCK_ELEMS = 4096;            // elements one workgroup updates
+struct AdamHyper { float step_size, beta1, beta2, eps, weight_decay, bias_correction2_sqrt; };
+int launch_adam_step(float* p, float* m, float* v, const int* blocks, int n_blocks, const float* const* grads, int n_tensors,
+                     const AdamHyper& h, hipStream_t stream);
 
 }  // namespace crnerf

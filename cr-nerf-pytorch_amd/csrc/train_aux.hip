@@ -164,4 +164,62 @@ int launch_grid_batch(const BatchArgs& a, hipStream_t stream) {
   return check_launch("grid_batch_kernel");
 }
 
+// ---------------------------------------------------------------- Adam over one flat parameter buffer
+// The reference's optimiser is torch.optim.Adam(parameters, lr, eps=1e-8, weight_decay) (utils/__init__.py:24-33) stepped once per
+// batch by Lightning (train_mask_grid_sample.py:249-252).  Parameters, first and second moments live in three flat fp32 buffers with
+// the same offsets; the gradients stay where autograd left them (one pointer per tensor, handed over in the kernel arguments), so a
+// step is ONE launch instead of a multi-tensor launch per 30-odd tensors plus the step-counter adds.  The arithmetic follows
+// torch/optim/adam.py `_single_tensor_adam` (lerp for the first moment, sqrt / bias_correction2_sqrt + eps, addcdiv by lr /
+// bias_correction1) in fp32; a tensor whose gradient pointer is null is skipped like a parameter whose .grad is None.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct AdamGradPtrs { const float* g[ADAM_MAX_TENSORS]; };
+
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamHyper& h) {
+  if (h.weight_decay != 0.0f) g = fmaf(h.weight_decay, p, g);
+  m = m + (g - m) * (1.0f - h.beta1);                         // exp_avg.lerp_(grad, 1 - beta1)
+  v = h.beta2 * v + (1.0f - h.beta2) * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  const float denom = sqrtf(v) / h.bias_correction2_sqrt + h.eps;
+  p = p - h.step_size * (m / denom);                          // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// block b updates elements [blocks[b].y, blocks[b].y + blocks[b].z) of the flat buffers = elements blocks[b].w ... of tensor blocks[b].x
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        const int4* __restrict__ blocks, AdamGradPtrs grads, AdamHyper h) {
+  const int4 b = blocks[blockIdx.x];
+  const float* g = grads.g[b.x];
+  if (g == nullptr) return;
+  g += b.w;
+  const long base = b.y;
+  const int n = b.z;
+  if ((((uintptr_t)g) & 15) == 0 && (base & 3) == 0) {
+    for (int i = 4 * threadIdx.x; i < n; i += 1024) {
+      if (i + 4 <= n) {
+        f32x4 pv = *(const f32x4*)(p + base + i), mv = *(const f32x4*)(m + base + i), vv = *(const f32x4*)(v + base + i);
+        const f32x4 gv = *(const f32x4*)(g + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = pv[e], me = mv[e], ve = vv[e];
+          adam_one(pe, me, ve, gv[e], h);
+          pv[e] = pe; mv[e] = me; vv[e] = ve;
+        }
+        *(f32x4*)(p + base + i) = pv; *(f32x4*)(m + base + i) = mv; *(f32x4*)(v + base + i) = vv;
+      } else {
+        for (int e = i; e < n; ++e) adam_one(p[base + e], m[base + e], v[base + e], g[e], h);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) adam_one(p[base + i], m[base + i], v[base + i], g[i], h);
+  }
+}
+
+int launch_adam_step(float* p, float* m, float* v, const int* blocks, int n_blocks, const float* const* grads, int n_tensors,
+                     const AdamHyper& h, hipStream_t stream) {
+  if (n_blocks <= 0) return 0;
+  AdamGradPtrs gp;
+  for (int t = 0; t < ADAM_MAX_TENSORS; ++t) gp.g[t] = t < n_tensors ? grads[t] : nullptr;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, p, m, v, (const int4*)blocks, gp, h);
+  return check_launch("adam_step_kernel");
+}
+
+
 }  // namespace crnerf

@@ -14,9 +14,18 @@ models/lightweight_seg.py; only that schema is shared -- every forward here disp
 import torch
 from torch import nn
 
-from ..autograd import AvgPool3s2Fn, BilinearGatherFn, BNPReLUFn, Conv2dFn, FGloFn
+import os
 
-__all__ = ["Context_Guided_Network", "mask_at_pixels"]
+from ..autograd import AvgPool3s2Fn, BilinearGatherFn, BNPReLUFn, CGNetFn, Conv2dFn, FGloFn
+
+__all__ = ["Context_Guided_Network", "mask_at_pixels", "set_chain"]
+
+_CHAIN = [os.environ.get("CRNERF_CGNET_CHAIN", "1") != "0"]
+
+
+def set_chain(on):
+    """Training-mode forward as one autograd node (default) or module by module (the path eval mode and other M / N always take)."""
+    _CHAIN[0] = bool(on)
 
 
 class _ConvParam(nn.Module):
@@ -162,9 +171,52 @@ class Context_Guided_Network(nn.Module):
         self.bn_prelu_3 = BNPReLU(256)
         self.classifier = nn.Sequential(Conv(256, classes, 1, 1))
 
+    # ---- the training step's fast path: the whole network as one autograd node (csrc/cgnet_chain.hip) ----
+    def _chain_modules(self):
+        """(parameter list, BatchNorm list) in the order csrc/cgnet_chain.hip documents -- the module tree's own order."""
+        def cbp(m):
+            return [m.conv.weight, m.bn.weight, m.bn.bias, m.act.weight], [m.bn]
+
+        def down(m):
+            p, b = cbp(m.conv1x1)
+            return (p + [m.F_loc.conv.weight, m.F_sur.conv.weight, m.bn.weight, m.bn.bias, m.act.weight, m.reduce.conv.weight,
+                         m.F_glo.fc[0].weight, m.F_glo.fc[0].bias, m.F_glo.fc[2].weight, m.F_glo.fc[2].bias], b + [m.bn])
+
+        def block(m):
+            p, b = cbp(m.conv1x1)
+            return (p + [m.F_loc.conv.weight, m.F_sur.conv.weight, m.bn_prelu.bn.weight, m.bn_prelu.bn.bias, m.bn_prelu.act.weight,
+                         m.F_glo.fc[0].weight, m.F_glo.fc[0].bias, m.F_glo.fc[2].weight, m.F_glo.fc[2].bias], b + [m.bn_prelu.bn])
+
+        def bp(m):
+            return [m.bn.weight, m.bn.bias, m.act.weight], [m.bn]
+
+        params, bns = [], []
+        for p, b in (cbp(self.level1_0), cbp(self.level1_1), cbp(self.level1_2), bp(self.b1), down(self.level2_0), block(self.level2[0]),
+                     bp(self.bn_prelu_2), down(self.level3_0), block(self.level3[0]), bp(self.bn_prelu_3)):
+            params += p
+            bns += b
+        return params + [self.classifier[0].conv.weight], bns
+
+    def _chain_applies(self, image, modules=None):
+        """One node for the whole network when this is the reference's training configuration: M = N = 2, train mode under autograd, every
+        BatchNorm tracking running statistics with one momentum / eps, fp32 parameters, an image that needs no gradient."""
+        if not (_CHAIN[0] and self.training and torch.is_grad_enabled() and len(self.level2) == 1 and len(self.level3) == 1):
+            return False
+        if image.requires_grad or image.dim() != 4 or image.shape[0] != 1:
+            return False
+        params, bns = modules if modules is not None else self._chain_modules()
+        b0 = bns[0]
+        if b0.momentum is None or any(b.running_mean is None or not b.track_running_stats or b.momentum != b0.momentum or b.eps != b0.eps
+                                      or b.running_mean.dtype != torch.float32 or not b.running_mean.is_cuda for b in bns):
+            return False
+        return all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in params)
+
     def forward(self, image):
         if not image.is_cuda:
             raise RuntimeError("crnerf_amd: Context_Guided_Network runs on the HIP operators only; input is on %s" % image.device)
+        modules = self._chain_modules() if _CHAIN[0] and self.training and len(self.level2) == 1 and len(self.level3) == 1 else None
+        if modules is not None and self._chain_applies(image, modules):
+            return CGNetFn.apply(image, modules[1], *modules[0])
         stage1 = self.level1_2(self.level1_1(self.level1_0(image)))                     # 1/2 scale, 32 channels
         half, quarter = self.sample1(image), self.sample2(image)                        # the image itself, re-injected at 1/2 and 1/4
         stage2_in = self.level2_0(self.b1(torch.cat([stage1, half], 1)))                # 1/4 scale, 64 channels

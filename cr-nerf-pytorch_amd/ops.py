@@ -1047,3 +1047,39 @@ def bilinear_gather_backward(out, d_out, in_hw, size, idx=None, sigmoid=False):
                                                        _lib.dev_ptr(idx.contiguous(), "idx", torch.int64) if idx is not None else None, n,
                                                        int(bool(sigmoid)), _lib.dev_ptr(d_in), _lib.stream_ptr()), "crnerf_bilinear_gather_backward_f32")
     return d_in
+
+
+# ---------------------------------------------------------------- the mask network of a training step as two calls (csrc/cgnet_chain.hip)
+def cgnet_forward_train(image, params, running_mean, running_var, num_batches_tracked, momentum, eps):
+    """Context_Guided_Network(classes=1, M=2, N=2).forward in train mode (lightweight_seg.py:274-368): image[1,C,H,W] -> (mask[1,1,H,W], saved).
+    params: the 76 tensors in state_dict order; running_mean / running_var / num_batches_tracked: the 14 BatchNorm layers' buffers (updated)."""
+    lib = _lib.load()
+    image, (C, H, W) = _chw(image, "image")
+    if len(params) != lib.crnerf_cgnet_param_count() or len(running_mean) != lib.crnerf_cgnet_bn_count():
+        raise ValueError("crnerf_amd: cgnet_forward_train takes %d parameters and %d BatchNorm layers" % (lib.crnerf_cgnet_param_count(), lib.crnerf_cgnet_bn_count()))
+    saved = torch.empty(lib.crnerf_cgnet_arena_bytes(C, H, W) // 4, device=image.device)
+    mask = torch.empty(1, 1, H, W, device=image.device)
+    nbt = (ctypes.c_void_p * len(running_mean))()
+    for i, t in enumerate(num_batches_tracked):
+        if t is not None:
+            if not t.is_cuda or t.dtype != torch.int64:
+                raise ValueError("crnerf_amd: num_batches_tracked must be an int64 GPU buffer")
+            nbt[i] = t.data_ptr()
+    _lib.check(lib.crnerf_cgnet_forward_train_f32(_lib.dev_ptr(image), C, H, W, _lib.ptr_array(params, "params"), _lib.ptr_array(running_mean, "running_mean"),
+                                                  _lib.ptr_array(running_var, "running_var"), nbt, float(momentum), float(eps), _lib.dev_ptr(saved),
+                                                  _lib.dev_ptr(mask), _lib.stream_ptr()), "crnerf_cgnet_forward_train_f32")
+    return mask, saved
+
+
+def cgnet_backward(image, params, saved, mask, d_mask):
+    """-> the 76 parameter gradients (views of one buffer, shapes of `params`)."""
+    lib = _lib.load()
+    image, (C, H, W) = _chw(image, "image")
+    d_mask = _f32c(d_mask, "d_mask")
+    scratch = torch.empty_like(saved)
+    sizes = [p.numel() for p in params]
+    grads = [g.view(p.shape) for g, p in zip(torch.empty(sum(sizes), device=image.device).split(sizes), params)]
+    _lib.check(lib.crnerf_cgnet_backward_f32(_lib.dev_ptr(image), C, H, W, _lib.ptr_array(params, "params"), _lib.dev_ptr(saved), _lib.dev_ptr(mask),
+                                             _lib.dev_ptr(d_mask), _lib.dev_ptr(scratch), _lib.ptr_array(grads, "grads"), _lib.stream_ptr()),
+               "crnerf_cgnet_backward_f32")
+    return grads

@@ -433,6 +433,18 @@ typedef struct crnerf_batch_args {
 } crnerf_batch_args;
 int crnerf_grid_sample_batch_f32(const crnerf_batch_args* args, void* stream);
 
+/* -------- the optimiser step: torch.optim.Adam(get_parameters(models), lr, eps=1e-8, weight_decay) -- utils/__init__.py:24-33,
+ * stepped once per batch (train_mask_grid_sample.py:249-252).  One launch over flat parameter / first-moment / second-moment
+ * buffers that share offsets; gradients stay where they are (grads[t] = device pointer of tensor t's gradient, null = that
+ * parameter has no gradient this step and is skipped, as torch skips `p.grad is None`).  blocks[n_blocks][4] (device, int32):
+ * {tensor index, flat offset, element count, offset inside the tensor} per workgroup -- built once by the host.
+ * step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) for step t (1-based), computed by the host in
+ * double like torch/optim/adam.py.  n_tensors <= crnerf_adam_max_tensors() per call. */
+int crnerf_adam_max_tensors(void);
+int crnerf_adam_step_f32(float* params, float* exp_avg, float* exp_avg_sq, const int32_t* blocks, int32_t n_blocks,
+                         const float* const* grads, int32_t n_tensors, float step_size, float beta1, float beta2, float eps,
+                         float weight_decay, float bias_correction2_sqrt, void* stream);
+
 /* Operators of the transient-mask network: Context_Guided_Network(classes=1, M=2, N=2, input_channel=3),
  * models/lightweight_seg.py:274-368, applied once per step to the 1/8-scale photo (train_mask_grid_sample.py:170-176).
  * All tensors NCHW fp32, batch 1, contiguous; every backward OVERWRITES its gradient outputs. */
@@ -475,6 +487,22 @@ int crnerf_bilinear_gather_f32(const float* in, int h, int w, int Ho, int Wo, co
                                void* stream);
 int crnerf_bilinear_gather_backward_f32(const float* out, const float* d_out, int h, int w, int Ho, int Wo, const int64_t* idx, int64_t n,
                                         int sigmoid, float* d_in, void* stream);
+
+/* The whole Context_Guided_Network(classes=1, M=2, N=2, input_channel=cin) of a TRAINING step as two calls (lightweight_seg.py:274-368,
+ * train_mask_grid_sample.py:170-176): the operators above enqueued back to back, channel concatenations written in place, gradient sums
+ * accumulated by the producing kernels.  image[cin,H,W] -> mask[H,W] = sigmoid(upsample(classifier(...))).  BatchNorm runs on batch
+ * statistics and updates running_mean / running_var / num_batches_tracked (momentum, eps shared by the 14 layers, as the reference builds
+ * them).  params[crnerf_cgnet_param_count()] and bn buffers [crnerf_cgnet_bn_count()] in the order csrc/cgnet_chain.hip documents (the
+ * reference's state_dict order).  saved / scratch: crnerf_cgnet_arena_bytes(cin, H, W) each; `saved` and `mask` are read by the backward.
+ * The backward OVERWRITES grads[i] (same shapes as params[i]); the image receives no gradient (it is data). */
+int crnerf_cgnet_param_count(void);
+int crnerf_cgnet_bn_count(void);
+size_t crnerf_cgnet_arena_bytes(int32_t cin, int32_t H, int32_t W);
+int crnerf_cgnet_forward_train_f32(const float* image, int32_t cin, int32_t H, int32_t W, const float* const* params, float* const* running_mean,
+                                   float* const* running_var, int64_t* const* num_batches_tracked, float momentum, float eps, void* saved,
+                                   float* mask, void* stream);
+int crnerf_cgnet_backward_f32(const float* image, int32_t cin, int32_t H, int32_t W, const float* const* params, const void* saved,
+                              const float* mask, const float* d_mask, void* scratch, float* const* grads, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ import torch
 from _cgnet_fixture import probe_positions, seeded_state
 from crnerf_amd import ops
 from crnerf_amd.autograd import AvgPool3s2Fn, BilinearGatherFn, BNPReLUFn, Conv2dFn, FGloFn
+from crnerf_amd.models import lightweight_seg as LS
 from crnerf_amd.models.lightweight_seg import Context_Guided_Network, mask_at_pixels
 from oracle import cgnet_ref as C
 
@@ -147,10 +148,22 @@ def _net(seed):
     return net.to(DEV)
 
 
+@pytest.fixture
+def chain_mode():
+    """Restores the default (training forward as one autograd node, csrc/cgnet_chain.hip) after a test that switches it."""
+    yield LS.set_chain
+    LS.set_chain(True)
+
+
+@pytest.mark.parametrize("chain", [True, False])
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_cgnet_matches_reference(golden, tag):
+def test_cgnet_matches_reference(golden, tag, chain, chain_mode):
+    """chain=True: the training-mode forward / backward are crnerf_cgnet_forward_train_f32 / crnerf_cgnet_backward_f32 (one autograd node);
+    chain=False: one node per module (the path eval mode always takes).  Same fixture, same bars."""
+    chain_mode(chain)
     g = golden("g13_cgnet")
     net = _net(int(g[tag + "_seed"])).train()
+    assert net._chain_applies(torch.from_numpy(g[tag + "_img"]).to(DEV)) == chain
     img = torch.from_numpy(g[tag + "_img"]).to(DEV)
     mask = net(img)
     np.testing.assert_allclose(mask.detach().cpu().numpy(), g[tag + "_mask_train"], atol=5e-6, rtol=0)
@@ -196,3 +209,41 @@ def test_cgnet_matches_oracle_at_another_size():
         np.testing.assert_allclose(net(img.to(DEV))[0, 0].cpu().numpy(), C.cgnet_forward(img[0].numpy().astype(np.float64), p, False), atol=5e-6, rtol=0)
     idx = torch.randint(0, 530 * 780, (1024,), generator=g)
     np.testing.assert_allclose(mask_at_pixels(got, (530, 780), idx.to(DEV)).cpu().numpy(), C.mask_at_pixels(want, (530, 780), idx.numpy()), atol=5e-6, rtol=0)
+
+
+@pytest.mark.parametrize("hw", [(44, 60), (33, 47), (9, 13)])
+def test_cgnet_chain_equals_the_module_by_module_path(hw, chain_mode):
+    """The one-node training path enqueues the same kernels in the same order: masks and BatchNorm buffers bit for bit; parameter gradients
+    differ only where a fan-out's contributions are summed in another order (1e-5 of the tensor's norm; measured ~1e-7)."""
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(1, 3, *hw, generator=g) * 2 - 1).to(DEV)
+    G = torch.randn(1, 1, *hw, generator=g).to(DEV)
+    out = {}
+    for chain in (True, False):
+        chain_mode(chain)
+        net = _net(21).train()
+        assert net._chain_applies(img) == chain
+        mask = net(img)
+        assert (mask.grad_fn.name() == "CGNetFnBackward") == chain
+        (mask * G).sum().backward()
+        out[chain] = (mask.detach(), {k: v.clone() for k, v in net.state_dict().items()}, {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert torch.equal(out[True][0], out[False][0])
+    for k, v in out[True][1].items():
+        assert torch.equal(v, out[False][1][k]), k
+    worst = 0.0
+    for k, gr in out[True][2].items():
+        ref = out[False][2][k]
+        assert gr.shape == ref.shape and gr.is_contiguous(), k
+        err = float((gr - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert err <= 1e-5, (k, err)
+        worst = max(worst, err)
+    print("worst gradient difference / norm:", worst)
+    # the conditions that hand the network back to the module-by-module path
+    chain_mode(True)
+    net = _net(21).train()
+    assert not net.eval()._chain_applies(img) and net.train()._chain_applies(img)
+    with torch.no_grad():
+        assert not net._chain_applies(img)
+    assert not net._chain_applies(img.clone().requires_grad_(True))
+    net.b1.bn.momentum = 0.2
+    assert not net._chain_applies(img)

@@ -10,34 +10,35 @@ import pytest
 import torch
 
 import _procedural_scene as S
-from crnerf_amd import pipeline
+from crnerf_amd import optim, pipeline
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32x3", "auto"])
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "auto", "auto+FlatAdam"])
 def test_training_system_learns_the_scene_like_the_reference(golden, mode):
     """mode f32x3: forward, data gradient and weight gradients on the bf16 matrix cores at fp32 accuracy (three-piece splits; DESIGN 3.4b / 3.5:
     set_training_forward_precision("f32x3") + set_wgrad_precision("bf16x3")) -- held to the same curve."""
     from crnerf_amd import autograd as AG
+    mode, _, flat = mode.partition("+")         # "+FlatAdam": the optimiser step as one HIP launch (crnerf_amd/optim.py) instead of torch's multi-tensor Adam
     AG.set_training_forward_precision(mode)
     AG.set_wgrad_precision("f32" if mode == "f32" else "bf16x3")   # "auto": h2 forward / data gradient with the x3 safety net, bf16x3 weight gradients
     try:
-        _run(golden)
+        _run(golden, bool(flat))
     finally:
         AG.set_training_forward_precision(None)
         AG.set_wgrad_precision(None)
 
 
-def _run(golden):
+def _run(golden, flat_adam=False):
     ref = golden("g15_trained")["train_log"]                    # [1500, 3]: step, loss, psnr_fine of the batch
     torch.manual_seed(11)
     rng = np.random.default_rng(7)
     data = S.make_dataset(rng)[:S.N_IMAGES]                     # the same generator state as the fixture's run: identical images
     hp = S.hparams()
     sysm = pipeline.TrainingSystem(hp, device=DEV)
-    opt = torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
+    opt = optim.FlatAdam(sysm.parameters(), lr=hp.lr, eps=1e-8) if flat_adam else torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
     idx = torch.arange(S.SIDE * S.SIDE, device=DEV)
     batches = [dict(rays=b["rays"].to(DEV), ts=b["ts"].to(DEV), rgbs=b["rgbs"].to(DEV), whole_img=S.whole_image(b["rgbs"]).to(DEV), rgb_idx=idx,
                     img_wh=(S.SIDE, S.SIDE)) for b in data]

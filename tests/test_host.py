@@ -254,3 +254,30 @@ def test_checkpoint_loader_is_restricted_unless_trusted(tmp_path):
     with pytest.raises(RuntimeError, match="trust_checkpoint"):
         pipeline.extract_model_state_dict(path, "nerf_coarse")
     assert torch.equal(pipeline.extract_model_state_dict(path, "nerf_coarse", trust_checkpoint=True)["bias"], lin.bias)
+
+
+def test_flat_adam_has_no_cpu_path():
+    """optim.FlatAdam drives crnerf_adam_step_f32 only: CPU parameters are refused at construction, before anything is re-pointed."""
+    import torch
+    from crnerf_amd import optim
+    lin = torch.nn.Linear(3, 2)
+    with pytest.raises(TypeError, match="no CPU path"):
+        optim.FlatAdam(lin.parameters(), lr=1e-3)
+    assert lin.weight.data.storage_offset() == 0 and lin.weight.numel() == 6
+    with pytest.raises(ValueError, match="invalid hyper-parameters"):
+        optim.FlatAdam(lin.parameters(), lr=-1.0)
+
+
+def test_cgnet_chain_parameter_order_is_the_state_dict_order():
+    """csrc/cgnet_chain.hip indexes the 76 parameters / 14 BatchNorm layers by position: the module's list must be the module tree's own
+    order (the reference's state_dict order, lightweight_seg.py:274-368), and as long as crnerf_cgnet_param_count() says."""
+    import torch
+    from crnerf_amd.models.lightweight_seg import Context_Guided_Network
+    net = Context_Guided_Network(classes=1, M=2, N=2, input_channel=3)
+    params, bns = net._chain_modules()
+    assert [id(p) for p in params] == [id(p) for p in net.parameters()]
+    assert [id(b) for b in bns] == [id(m) for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    lib = _lib.load()
+    assert len(params) == lib.crnerf_cgnet_param_count() == 76 and len(bns) == lib.crnerf_cgnet_bn_count() == 14
+    assert lib.crnerf_cgnet_arena_bytes(3, 48, 64) > 4 * 32 * 24 * 32 and lib.crnerf_cgnet_arena_bytes(0, 48, 64) == 0
+    assert not net._chain_applies(torch.zeros(1, 3, 48, 64))          # CPU parameters: never the chain (the module path then raises, as before)

@@ -7,7 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import crnerf_amd.synth as synth
-from crnerf_amd import pipeline
+from crnerf_amd import optim, pipeline
 from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -56,7 +56,9 @@ rgbs = torch.rand(n_img * iw * ih, 3, device=dev)
 imgs = [torch.rand(1, 3, ih // 8, iw // 8, device=dev) * 2 - 1 for _ in range(n_img)]     # 1/8-scale appearance images, in [-1, 1]
 wh = np.array([[iw, ih]] * n_img)
 batcher = GridSampleBatcher(rays, rgbs, wh, batch_size=R, all_imgs=imgs)
-opt = torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True)   # the reference: Adam(lr, eps=1e-8) (utils/__init__.py get_optimizer); fused = one multi-tensor launch
+# the reference: Adam(lr, eps=1e-8) (utils/__init__.py get_optimizer).  FlatAdam = the same update in one HIP launch; CRNERF_TORCH_ADAM=1: torch's multi-tensor Adam
+opt = (torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True) if os.environ.get("CRNERF_TORCH_ADAM") == "1"
+       else optim.FlatAdam(sysm.parameters(), lr=5e-4, eps=1e-8))
 
 
 def step(i):
