@@ -11,6 +11,7 @@
 //                   [out,in] layout (saved activations are in reference feature order, so no un-pack);
 //                   db[m] = sum_p delta[p][m]
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "kernels.h"
 #include "mlp_core16.h"
@@ -420,7 +421,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 // X3: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3) -- see the full-tile branch below
 template <bool X3 = false>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the wave's tile origin lives in SGPRs
   const int i = lane & 31, kk = lane >> 5;
   // The workgroup's 256 x 256 block holds tm x tn live 32 x 32 MFMA tiles (<= 8 x 8).  Its four waves are laid out 2 x 2,
   // 1 x 4 or 4 x 1 over them -- whichever keeps the most waves busy and, among those, gives the busiest wave the fewest
@@ -484,11 +485,16 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 #else
           const long pc = pt < plast ? pt : plast;
 #endif
-          const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
-          const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
-          const float keep = pt < p1 ? 1.0f : 0.0f;
-          d[e] = dv * keep;
-          a[e] = av;
+          d[e] = *(const f32x4*)(dbase + pc * j.ldd);      // raw: rows past the chunk are zeroed where the registers are handed to the
+          a[e] = *(const f32x4*)(abase + pc * j.lda);      // next k-step (take16) -- a multiply here would wait for the load just issued
+        }
+      };
+      auto take16 = [&](long pb) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dcur[e] = dnxt[e] * (pb + 8 * kk + e < p1 ? 1.0f : 0.0f);
+          acur[e] = anxt[e];
         }
       };
       // column t of eight points -> the three piece fragments (dword q = points 2q, 2q + 1)
@@ -517,7 +523,93 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       };
       const bool do_bias3 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum3 = {0.0f, 0.0f, 0.0f, 0.0f};
-      fetch16(p0, dcur, acur);
+      if (((p1 - p0) & 31) == 0 && p1 > p0) {
+        // ---- the stream for whole pairs of k-steps (every chunk but a ragged last one): software-pipelined by hand, because one wave per SIMD
+        // hides nothing by itself -- hipcc's schedule of the loop below is [~530 VALU: addresses, splits] then [96 MFMAs] in clumps, 2.8 us per
+        // k-step where the MFMAs alone are 1.3.  Here a k-step is four phases of 24 MFMAs (one delta column each); the VALU work rides under
+        // them: phases 0-1 split the next delta column, phases 2-3 also the NEXT k-step's activation columns (whose loads were issued at the
+        // top of this k-step) and its first delta column.  Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight
+        // per-lane byte offsets computed once -- no 64-bit multiplies in the loop.  Two k-steps per trip so that the double-buffered
+        // pieces are compile-time registers.  Same products, same accumulation order per accumulator as the loop below: same bits.
+        const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
+        uint32_t vd[8], va[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vd[e] = (uint32_t)(8 * kk + e) * rowd + 16u * i; va[e] = (uint32_t)(8 * kk + e) * rowa + 16u * i; }
+        const char* db = (const char*)(j.D + m0) + p0 * (long)rowd;
+        const char* ab = (const char*)(j.A + n0) + p0 * (long)rowa;
+        const long sd = 16L * rowd, sa = 16L * rowa;
+        f32x4 draw[2][8], araw[8];
+        xbf16x8_t A1[2][4], A2[2][4], A3[2][4], D1[2], D2[2], D3[2];
+        long left = (p1 - p0) / 16;                                    // k-steps still to multiply (even)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { draw[0][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split3(araw, t, A1[0][t], A2[0][t], A3[0][t]);
+        split3(draw[0], 0, D1[0], D2[0], D3[0]);
+        auto column = [&](int a, const xbf16x8_t& d1, const xbf16x8_t& d2, const xbf16x8_t& d3, const xbf16x8_t (&a1)[4], const xbf16x8_t (&a2)[4],
+                          const xbf16x8_t (&a3)[4]) {
+          // six products per accumulator, small terms first; the four accumulators of the column take turns so no MFMA waits for its predecessor
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d3, a1[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a3[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a2[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a1[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a2[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a1[b], acc[a][b], 0, 0, 0);
+        };
+        auto kstep = [&](auto CUR) {
+          constexpr int c = decltype(CUR)::value, n = 1 - c;
+          // the next k-step's rows (the last k-step re-reads its own: harmless, and the loop stays free of branches)
+          left -= 1;
+          const long adv = left > 0 ? 1 : 0;
+          db += adv * sd;
+          ab += adv * sa;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { draw[n][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
+          __builtin_amdgcn_sched_barrier(0);
+          // phase 0: column 0 | bias sums, split of delta column 1
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum3 += draw[c][e];
+          column(0, D1[0], D2[0], D3[0], A1[c], A2[c], A3[c]);
+          split3(draw[c], 1, D1[1], D2[1], D3[1]);
+#pragma unroll
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+          // phase 1: column 1 | split of delta column 2
+          column(1, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
+          split3(draw[c], 2, D1[0], D2[0], D3[0]);
+#pragma unroll
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+          // phase 2: column 2 | split of delta column 3, of the next k-step's activation columns 0 and 1
+          column(2, D1[0], D2[0], D3[0], A1[c], A2[c], A3[c]);
+          split3(draw[c], 3, D1[1], D2[1], D3[1]);
+          split3(araw, 0, A1[n][0], A2[n][0], A3[n][0]);
+          split3(araw, 1, A1[n][1], A2[n][1], A3[n][1]);
+#pragma unroll
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+          // phase 3: column 3 | the next k-step's activation columns 2 and 3 and its delta column 0
+          column(3, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
+          split3(araw, 2, A1[n][2], A2[n][2], A3[n][2]);
+          split3(araw, 3, A1[n][3], A2[n][3], A3[n][3]);
+          split3(draw[n], 0, D1[0], D2[0], D3[0]);
+#pragma unroll
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        while (left > 0) {
+          kstep(std::integral_constant<int, 0>{});
+          kstep(std::integral_constant<int, 1>{});
+        }
+      } else {
+      fetch16(p0, dnxt, anxt);
+      take16(p0);
       for (long pb = p0; pb < p1; pb += 16) {
         fetch16(pb + 16, dnxt, anxt);
         if (do_bias3) {
@@ -542,14 +634,14 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a1[b], c, 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
         // ask the scheduler to thread the splits' VALU work between the MFMAs (three behind each; measured 18.29 -> 17.85 ms per 2^20-point backward;
 #pragma unroll            // without the hint hipcc emits the MFMAs of a column back to back and the splits in clumps)
         for (int g = 0; g < 96; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
+        take16(pb + 16);
+      }
       }
       if (do_bias3) {
 #pragma unroll
@@ -581,11 +673,16 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         for (int e = 0; e < 8; ++e) {
           const long pt = pb + 8 * kk + e;
           const long pc = pt < plast ? pt : plast;
-          const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
-          const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
-          const float keep = pt < p1 ? 1.0f : 0.0f;
-          d[e] = dv * keep;
-          a[e] = av;
+          d[e] = *(const f32x4*)(dbase + pc * j.ldd);      // raw: rows past the chunk are zeroed where the registers are handed to the
+          a[e] = *(const f32x4*)(abase + pc * j.lda);      // next k-step (take16) -- a multiply here would wait for the load just issued
+        }
+      };
+      auto take16 = [&](long pb) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dcur[e] = dnxt[e] * (pb + 8 * kk + e < p1 ? 1.0f : 0.0f);
+          acur[e] = anxt[e];
         }
       };
       auto frag = [&](const f32x4 (&v)[8], int t) {
@@ -596,7 +693,8 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       };
       const bool do_bias16 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};
-      fetch16(p0, dcur, acur);
+      fetch16(p0, dnxt, anxt);
+      take16(p0);
       for (long pb = p0; pb < p1; pb += 16) {
         fetch16(pb + 16, dnxt, anxt);
         if (do_bias16) {
@@ -610,8 +708,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[a], af[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dcur[e] = dnxt[e]; acur[e] = anxt[e]; }
+        take16(pb + 16);
       }
       if (do_bias16) {
 #pragma unroll
@@ -636,16 +733,24 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       for (int s = 0; s < KF; ++s) {
         const long pt = pb + 2 * s + kk;
         const long pc = pt < plast ? pt : plast;                      // clamped: always a readable row
-        const f32x4 dv = *(const f32x4*)(dbase + pc * j.ldd);
-        const f32x4 av = *(const f32x4*)(abase + pc * j.lda);
-        const float keep = pt < p1 ? 1.0f : 0.0f;                     // rows past the chunk contribute nothing
-        d[s] = dv * keep;
-        a[s] = av;
+        d[s] = *(const f32x4*)(dbase + pc * j.ldd);                   // raw: see take4
+        a[s] = *(const f32x4*)(abase + pc * j.lda);
+      }
+    };
+    // hand the prefetched rows to the next k-steps; rows past the chunk contribute nothing (zeroed HERE, behind the MFMAs: a multiply inside
+    // fetch4 makes hipcc wait for the delta loads right after issuing them, and the k-step then runs loads and MFMAs one after the other)
+    auto take4 = [&](long pb) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KF; ++s) {
+        dc[s] = dnx[s] * (pb + 2 * s + kk < p1 ? 1.0f : 0.0f);
+        ac[s] = anx[s];
       }
     };
     const bool do_bias4 = j.bias_partial && bz == 0 && bias_wave;
     f32x4 bs4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    fetch4(p0, dc, ac);
+    fetch4(p0, dnx, anx);
+    take4(p0);
     for (long pb = p0; pb < p1; pb += 2 * KF) {
       fetch4(pb + 2 * KF, dnx, anx);
       if (do_bias4) {
@@ -658,8 +763,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[s][a], ac[s][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < KF; ++s) { dc[s] = dnx[s]; ac[s] = anx[s]; }
+      take4(pb + 2 * KF);
     }
     if (do_bias4) {
 #pragma unroll
@@ -761,7 +865,7 @@ int launch_wgrad_reduce(const float* partial, int nchunk, int M, int N, float* d
 // partial-sum workspace (nchunk x M x N) stays ~50 MB per layer at 65k-ray batches
 static int wg_chunk(long P) {
   long c = (P + 255) / 256;             // ~one 256x256 workgroup per CU
-  c = (c + 15) / 16 * 16;
+  c = (c + 31) / 32 * 32;               // whole pairs of 16-point k-steps: the bf16x3 stream's fast path
   return (int)(c < 128 ? 128 : c);
 }
 
@@ -820,7 +924,7 @@ static void wgrad_batch_plan(const WgradSpec* specs, int n, long* chunk, int* nc
   const double per = total / (double)wgrad_batch_blocks();
   for (int k = 0; k < n; ++k) {
     long c = (long)(per / specs[k].weight);
-    c = (c + 15) / 16 * 16;
+    c = (c + 31) / 32 * 32;
     if (c < 128) c = 128;
     chunk[k] = c;
     nchunk[k] = (int)((specs[k].P + c - 1) / c);
