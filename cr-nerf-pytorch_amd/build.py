@@ -29,6 +29,9 @@ PER_FILE_FLAGS = {"mlp_forward_bf16.hip": ["-fno-slp-vectorize"], "render_fused_
                   # and every ring constant of the pair core depends on full unrolling
                   "render_fused_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
                   "mlp_forward_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+for _kv in os.environ.get("CRNERF_EXTRA_FILE_FLAGS", "").split(";"):      # tuning builds only: "mlp_train16.hip=-fno-slp-vectorize -DX;other.hip=..."
+    if "=" in _kv:
+        PER_FILE_FLAGS.setdefault(_kv.split("=", 1)[0].strip(), []).extend(_kv.split("=", 1)[1].split())
 
 
 def _hipcc():

@@ -526,11 +526,15 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       if (((p1 - p0) & 31) == 0 && p1 > p0) {
         // ---- the stream for whole pairs of k-steps (every chunk but a ragged last one): software-pipelined by hand, because one wave per SIMD
         // hides nothing by itself -- hipcc's schedule of the loop below is [~530 VALU: addresses, splits] then [96 MFMAs] in clumps, 2.8 us per
-        // k-step where the MFMAs alone are 1.3.  Here a k-step is four phases of 24 MFMAs (one delta column each); the VALU work rides under
-        // them: phases 0-1 split the next delta column, phases 2-3 also the NEXT k-step's activation columns (whose loads were issued at the
-        // top of this k-step) and its first delta column.  Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight
-        // per-lane byte offsets computed once -- no 64-bit multiplies in the loop.  Two k-steps per trip so that the double-buffered
-        // pieces are compile-time registers.  Same products, same accumulation order per accumulator as the loop below: same bits.
+        // k-step where the MFMAs alone are 1.3-1.6.  Here a k-step is four phases of 24 MFMAs (one delta column each) and the VALU work rides
+        // under them, a share per phase (kstep below); the rows of the NEXT k-step are requested at the top of a k-step and first touched in
+        // phase 1.  Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight per-lane byte offsets computed once -- no 64-bit
+        // multiplies in the loop.  Two k-steps per trip so that the double-buffered pieces are compile-time registers.  Same products, same
+        // accumulation order per accumulator as the loop below: same bits.  Measured (2^20 points, 13 jobs): 9.1 -> 7.2 ms; per k-step of a
+        // 256 x 256 job ~5,100 cycles at 1.9 GHz against 3,072 of MFMA (SQ: 55 % issuing, 32 % issue-stalled, 13 % in s_waitcnt; MFMA pipe 60 %
+        // busy) -- what is left is the serial chains hipcc emits for the splits (v_cvt_pk -> shift / and -> v_pk_add, one pair after the
+        // other), not the placement of the phases: moving splits between phases and -fno-slp-vectorize measure the same; operands served from
+        // L2 (CRNERF_EXP_WGRAD_L2) take 1.0 of the 7.2 ms off.
         const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
         uint32_t vd[8], va[8];
 #pragma unroll
@@ -539,7 +543,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         const char* ab = (const char*)(j.A + n0) + p0 * (long)rowa;
         const long sd = 16L * rowd, sa = 16L * rowa;
         f32x4 draw[2][8], araw[8];
-        xbf16x8_t A1[2][4], A2[2][4], A3[2][4], D1[2], D2[2], D3[2];
+        xbf16x8_t A1[2][4], A2[2][4], A3[2][4], D1[3], D2[3], D3[3];
         long left = (p1 - p0) / 16;                                    // k-steps still to multiply (even)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { draw[0][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
@@ -566,37 +570,42 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           constexpr int c = decltype(CUR)::value, n = 1 - c;
           // the next k-step's rows (the last k-step re-reads its own: harmless, and the loop stays free of branches)
           left -= 1;
+#ifdef CRNERF_EXP_WGRAD_L2   // (timing experiments only; garbage) the same rows again and again: operands from L1 / L2, i.e. the loop's compute time
+          const long adv = 0;
+#else
           const long adv = left > 0 ? 1 : 0;
+#endif
           db += adv * sd;
           ab += adv * sa;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { draw[n][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
           __builtin_amdgcn_sched_barrier(0);
-          // phase 0: column 0 | bias sums, split of delta column 1
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum3 += draw[c][e];
+          // One wave per SIMD hides at most ~5 single-issue instructions behind a 32x32x16 MFMA (MI355X guide), and a k-step's splits come to
+          // ~4.5 per MFMA: they only disappear if every phase carries its share.  Eight column splits (~48 VALU each) + the bias sums:
+          //   phase 0: column 0 | delta columns 1, 2                      phase 1: column 1 | bias sums, next activation columns 0 (and 1)
+          //   phase 2: column 2 | delta column 3, next activation column  phase 3: column 3 | next activation column(s), next delta column 0
+          // (delta pieces rotate through three register sets so that no split overwrites pieces the phase's own MFMAs still read)
           column(0, D1[0], D2[0], D3[0], A1[c], A2[c], A3[c]);
           split3(draw[c], 1, D1[1], D2[1], D3[1]);
+          split3(draw[c], 2, D1[2], D2[2], D3[2]);
 #pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
           __builtin_amdgcn_sched_barrier(0);
-          // phase 1: column 1 | split of delta column 2
           column(1, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
-          split3(draw[c], 2, D1[0], D2[0], D3[0]);
 #pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-          __builtin_amdgcn_sched_barrier(0);
-          // phase 2: column 2 | split of delta column 3, of the next k-step's activation columns 0 and 1
-          column(2, D1[0], D2[0], D3[0], A1[c], A2[c], A3[c]);
-          split3(draw[c], 3, D1[1], D2[1], D3[1]);
+          for (int e = 0; e < 8; ++e) bsum3 += draw[c][e];
           split3(araw, 0, A1[n][0], A2[n][0], A3[n][0]);
           split3(araw, 1, A1[n][1], A2[n][1], A3[n][1]);
 #pragma unroll
           for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
           __builtin_amdgcn_sched_barrier(0);
-          // phase 3: column 3 | the next k-step's activation columns 2 and 3 and its delta column 0
-          column(3, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
+          column(2, D1[2], D2[2], D3[2], A1[c], A2[c], A3[c]);
+          split3(draw[c], 3, D1[1], D2[1], D3[1]);
           split3(araw, 2, A1[n][2], A2[n][2], A3[n][2]);
+#pragma unroll
+          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+          column(3, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
           split3(araw, 3, A1[n][3], A2[n][3], A3[n][3]);
           split3(draw[n], 0, D1[0], D2[0], D3[0]);
 #pragma unroll
