@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["FlatAdam", "get_parameters", "get_optimizer"]
+__all__ = ["FlatAdam", "get_parameters", "get_optimizer", "get_scheduler", "get_learning_rate"]
 
 _ALIGN = 64            # elements: every tensor starts on a 256-byte boundary of the flat buffers
 _BLOCK = 4096          # elements one workgroup updates (csrc/kernels.h ADAM_BLOCK_ELEMS)
@@ -181,3 +181,27 @@ def get_optimizer(hparams, models):
         cls = torch_optimizer.RAdam if hparams.optimizer == "radam" else torch_optimizer.Ranger
         return cls(parameters, lr=hparams.lr, eps=eps, weight_decay=hparams.weight_decay)
     raise ValueError("optimizer not recognized!")
+
+
+def get_scheduler(hparams, optimizer):
+    """utils/__init__.py:45-63: 'steplr' / 'cosine' / 'poly' over epochs.  The reference wraps the result in its GradualWarmupScheduler when
+    hparams.warmup_epochs > 0 (utils/warmup_scheduler.py; no shipped recipe sets it): that wrapper is not rebuilt here."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR, MultiStepLR
+    if hparams.lr_scheduler == "steplr":
+        scheduler = MultiStepLR(optimizer, milestones=hparams.decay_step, gamma=hparams.decay_gamma)
+    elif hparams.lr_scheduler == "cosine":
+        scheduler = CosineAnnealingLR(optimizer, T_max=hparams.num_epochs, eta_min=1e-8)
+    elif hparams.lr_scheduler == "poly":
+        scheduler = LambdaLR(optimizer, lambda epoch: (1 - epoch / hparams.num_epochs) ** hparams.poly_exp)
+    else:
+        raise ValueError("scheduler not recognized!")
+    if getattr(hparams, "warmup_epochs", 0) > 0 and hparams.optimizer not in ("radam", "ranger"):
+        raise NotImplementedError("crnerf_amd: warmup_epochs > 0 needs the reference's GradualWarmupScheduler (utils/warmup_scheduler.py), "
+                                  "which is outside the hot path and not rebuilt; wrap the returned scheduler yourself")
+    return scheduler
+
+
+def get_learning_rate(optimizer):
+    """utils/__init__.py:65-67."""
+    for param_group in optimizer.param_groups:
+        return param_group["lr"]

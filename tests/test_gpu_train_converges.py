@@ -38,7 +38,11 @@ def _run(golden, flat_adam=False):
     data = S.make_dataset(rng)[:S.N_IMAGES]                     # the same generator state as the fixture's run: identical images
     hp = S.hparams()
     sysm = pipeline.TrainingSystem(hp, device=DEV)
-    opt = optim.FlatAdam(sysm.parameters(), lr=hp.lr, eps=1e-8) if flat_adam else torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
+    if flat_adam:
+        (opt,), (sched,) = sysm.configure_optimizers()           # NeRFSystem.configure_optimizers (:249-252): get_optimizer -> FlatAdam, get_scheduler -> cosine over epochs
+        assert isinstance(opt, optim.FlatAdam) and opt.param_groups[0]["eps"] == 1e-8 and isinstance(sched, torch.optim.lr_scheduler.CosineAnnealingLR)
+    else:
+        opt = torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
     idx = torch.arange(S.SIDE * S.SIDE, device=DEV)
     batches = [dict(rays=b["rays"].to(DEV), ts=b["ts"].to(DEV), rgbs=b["rgbs"].to(DEV), whole_img=S.whole_image(b["rgbs"]).to(DEV), rgb_idx=idx,
                     img_wh=(S.SIDE, S.SIDE)) for b in data]

@@ -281,3 +281,26 @@ def test_cgnet_chain_parameter_order_is_the_state_dict_order():
     assert len(params) == lib.crnerf_cgnet_param_count() == 76 and len(bns) == lib.crnerf_cgnet_bn_count() == 14
     assert lib.crnerf_cgnet_arena_bytes(3, 48, 64) > 4 * 32 * 24 * 32 and lib.crnerf_cgnet_arena_bytes(0, 48, 64) == 0
     assert not net._chain_applies(torch.zeros(1, 3, 48, 64))          # CPU parameters: never the chain (the module path then raises, as before)
+
+
+def test_get_scheduler_mirrors_the_reference_factory():
+    """optim.get_scheduler = utils/__init__.py:45-63 ('steplr', 'cosine', 'poly'); the warm-up wrapper is refused loudly, not silently dropped."""
+    import types
+    import torch
+    from crnerf_amd import optim
+    lin = torch.nn.Linear(2, 2)
+    hp = types.SimpleNamespace(optimizer="sgd", lr=0.1, momentum=0.9, weight_decay=0.0, lr_scheduler="steplr", decay_step=[1], decay_gamma=0.5,
+                               num_epochs=4, poly_exp=0.9, warmup_epochs=0)
+    opt = optim.get_optimizer(hp, [lin])
+    sch = optim.get_scheduler(hp, opt)
+    opt.step(); sch.step()
+    assert abs(optim.get_learning_rate(opt) - 0.05) < 1e-12
+    for name, want in (("cosine", torch.optim.lr_scheduler.CosineAnnealingLR), ("poly", torch.optim.lr_scheduler.LambdaLR)):
+        hp.lr_scheduler = name
+        assert isinstance(optim.get_scheduler(hp, optim.get_optimizer(hp, [lin])), want)
+    hp.lr_scheduler = "exp"
+    with pytest.raises(ValueError, match="scheduler not recognized"):
+        optim.get_scheduler(hp, opt)
+    hp.lr_scheduler, hp.warmup_epochs = "cosine", 2
+    with pytest.raises(NotImplementedError, match="GradualWarmupScheduler"):
+        optim.get_scheduler(hp, opt)
