@@ -12,6 +12,7 @@
 //                   db[m] = sum_p delta[p][m]
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 #include "kernels.h"
 #include "mlp_core16.h"
@@ -418,6 +419,38 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 // (bx, by, bz): the workgroup's chunk / row-block / column-block inside job j -- blockIdx for a single-job launch, decoded from a flat
 // block index by the batched launch below.
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// The three-piece bf16 split of column T of eight fp32 rows, cut into eleven micro-stages of FOUR independent VALU instructions each (one per
+// point pair): stage K + 1 reads what stage K wrote, so with an MFMA between two stages no instruction ever waits for its predecessor --
+// hipcc's own schedule of the same arithmetic runs each pair's chain (cvt -> shift / and -> subtract -> cvt ...) to its end before the next.
+//   w[0] = bf16(x), r = x - w[0], w[1] = bf16(r), r' = r - w[1], w[2] = bf16(r');   dword q of a piece = points 2q (low half), 2q + 1 (high half)
+// (inline asm, one statement per instruction: written as C++ the stages do not survive -- instcombine turns `w << 16` into a second conversion
+// and sinks the masks into the subtractions' stage, so half the MFMA gaps get eight instructions and the others none)
+template <int K, int T>
+__device__ __forceinline__ void split_stage(const float __attribute__((ext_vector_type(4))) (&v)[8], uint32_t (&w)[3][4], float (&r)[8], float (&u)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (K == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[0][q]) : "v"(v[2 * q][T]), "v"(v[2 * q + 1][T]));
+    else if constexpr (K == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[2 * q]) : "v"(w[0][q]));
+    else if constexpr (K == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u[2 * q + 1]) : "v"(w[0][q]));
+    else if constexpr (K == 3) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r[2 * q]) : "v"(v[2 * q][T]), "v"(u[2 * q]));
+    else if constexpr (K == 4) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r[2 * q + 1]) : "v"(v[2 * q + 1][T]), "v"(u[2 * q + 1]));
+    else if constexpr (K == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[1][q]) : "v"(r[2 * q]), "v"(r[2 * q + 1]));
+    else if constexpr (K == 6) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[2 * q]) : "v"(w[1][q]));
+    else if constexpr (K == 7) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u[2 * q + 1]) : "v"(w[1][q]));
+    else if constexpr (K == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r[2 * q]) : "v"(u[2 * q]));
+    else if constexpr (K == 9) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r[2 * q + 1]) : "v"(u[2 * q + 1]));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[2][q]) : "v"(r[2 * q]), "v"(r[2 * q + 1]));
+  }
+}
+template <int T>
+__device__ __forceinline__ void split_all(const float __attribute__((ext_vector_type(4))) (&v)[8], uint32_t (&w)[3][4], float (&r)[8], float (&u)[8]) {
+  static_for<11>([&](auto K) { split_stage<decltype(K)::value, T>(v, w, r, u); });
+}
+
 // X3: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3) -- see the full-tile branch below
 template <bool X3 = false>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
@@ -524,17 +557,17 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       const bool do_bias3 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum3 = {0.0f, 0.0f, 0.0f, 0.0f};
       if (((p1 - p0) & 31) == 0 && p1 > p0) {
-        // ---- the stream for whole pairs of k-steps (every chunk but a ragged last one): software-pipelined by hand, because one wave per SIMD
-        // hides nothing by itself -- hipcc's schedule of the loop below is [~530 VALU: addresses, splits] then [96 MFMAs] in clumps, 2.8 us per
-        // k-step where the MFMAs alone are 1.3-1.6.  Here a k-step is four phases of 24 MFMAs (one delta column each) and the VALU work rides
-        // under them, a share per phase (kstep below); the rows of the NEXT k-step are requested at the top of a k-step and first touched in
-        // phase 1.  Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight per-lane byte offsets computed once -- no 64-bit
+        // ---- the stream for whole pairs of k-steps (every chunk but a ragged last one), placed by hand, because one wave per SIMD hides nothing by
+        // itself: hipcc's schedule of the loop below is [~530 VALU: addresses, splits] then [96 MFMAs] in clumps -- 2.8 us per k-step where the
+        // MFMAs alone are 1.6 (1.9 GHz).  Here a k-step is four phases of 24 MFMAs (one delta column each) and behind EVERY MFMA ride four
+        // independent VALU instructions of a split (split_stage: inline asm, fenced by sched_barrier -- the stream is emitted exactly as
+        // written: M vvvv x 96, no s_nop, no moves); the rows of the NEXT k-step are requested at the top of a k-step and first touched in phase 1.
+        // Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight per-lane byte offsets computed once -- no 64-bit
         // multiplies in the loop.  Two k-steps per trip so that the double-buffered pieces are compile-time registers.  Same products, same
-        // accumulation order per accumulator as the loop below: same bits.  Measured (2^20 points, 13 jobs): 9.1 -> 7.2 ms; per k-step of a
-        // 256 x 256 job ~5,100 cycles at 1.9 GHz against 3,072 of MFMA (SQ: 55 % issuing, 32 % issue-stalled, 13 % in s_waitcnt; MFMA pipe 60 %
-        // busy) -- what is left is the serial chains hipcc emits for the splits (v_cvt_pk -> shift / and -> v_pk_add, one pair after the
-        // other), not the placement of the phases: moving splits between phases and -fno-slp-vectorize measure the same; operands served from
-        // L2 (CRNERF_EXP_WGRAD_L2) take 1.0 of the 7.2 ms off.
+        // accumulation order per accumulator as the loop below: same bits.  Measured (2^20 points, 13 jobs, profiles/r4/): 9.1 -> 7.1 ms; a
+        // 256 x 256 job 550-645 us = 3.3-3.8 TB/s of operand rows, against 480 us with the rows served from L1 / L2 (CRNERF_EXP_WGRAD_L2: the
+        // stream's own time, ~3,600 cycles per k-step for 3,072 of MFMA) -- the kernel now sits where its matrix stream and its HBM rows cost
+        // about the same, and what is left is the part of the row latency one k-step of prefetch (all the registers allow) does not cover.
         const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
         uint32_t vd[8], va[8];
 #pragma unroll
@@ -543,31 +576,34 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         const char* ab = (const char*)(j.A + n0) + p0 * (long)rowa;
         const long sd = 16L * rowd, sa = 16L * rowa;
         f32x4 draw[2][8], araw[8];
-        xbf16x8_t A1[2][4], A2[2][4], A3[2][4], D1[3], D2[3], D3[3];
+        uint32_t Aw[2][4][3][4], Dw[3][3][4];                          // piece dwords: [buffer][column][piece][dword], [set][piece][dword]
+        float sr[8], su[8];                                            // the split's temporaries
         long left = (p1 - p0) / 16;                                    // k-steps still to multiply (even)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { draw[0][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) split3(araw, t, A1[0][t], A2[0][t], A3[0][t]);
-        split3(draw[0], 0, D1[0], D2[0], D3[0]);
-        auto column = [&](int a, const xbf16x8_t& d1, const xbf16x8_t& d2, const xbf16x8_t& d3, const xbf16x8_t (&a1)[4], const xbf16x8_t (&a2)[4],
-                          const xbf16x8_t (&a3)[4]) {
-          // six products per accumulator, small terms first; the four accumulators of the column take turns so no MFMA waits for its predecessor
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d3, a1[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a3[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a2[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, a1[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a2[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, a1[b], acc[a][b], 0, 0, 0);
+        split_all<0>(araw, Aw[0][0], sr, su); split_all<1>(araw, Aw[0][1], sr, su); split_all<2>(araw, Aw[0][2], sr, su); split_all<3>(araw, Aw[0][3], sr, su);
+        split_all<0>(draw[0], Dw[0], sr, su);
+        auto frag3 = [](const uint32_t (&w)[4]) { return __builtin_bit_cast(xbf16x8_t, make_uint4(w[0], w[1], w[2], w[3])); };
+        // One phase = the 24 MFMAs of delta column A (pieces in set DS) against the four activation columns of buffer C, in the order that
+        // gives every accumulator its six products small terms first (d3 a1, d1 a3, d2 a2, d2 a1, d1 a2, d1 a1) and lets the four accumulators
+        // take turns; behind MFMA g rides micro-stage g of split X (g < 11), g - 11 of split Y (g < 22), or one row of the bias sums, and a
+        // scheduling fence -- the stream is emitted as written.
+        auto phase = [&](auto A_, auto DS_, auto C_, auto&& x_stage, auto&& y_stage, auto&& tail) {
+          constexpr int a = decltype(A_)::value, ds = decltype(DS_)::value, c = decltype(C_)::value;
+          static_for<24>([&](auto G) {
+            constexpr int g = decltype(G)::value, p = g / 4, b = g % 4;
+            constexpr int dp = p == 0 ? 2 : (p == 1 || p >= 4 ? 0 : 1), ap = p == 0 ? 0 : (p == 1 ? 2 : (p == 2 || p == 4 ? 1 : 0));
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag3(Dw[ds][dp]), frag3(Aw[c][b][ap]), acc[a][b], 0, 0, 0);
+            if constexpr (g < 11) x_stage(G);
+            else if constexpr (g < 22) y_stage(std::integral_constant<int, g - 11>{});
+            else tail(std::integral_constant<int, g - 22>{});
+            __builtin_amdgcn_sched_barrier(0);
+          });
         };
         auto kstep = [&](auto CUR) {
           constexpr int c = decltype(CUR)::value, n = 1 - c;
+          using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+          using I3 = std::integral_constant<int, 3>; using IC = std::integral_constant<int, c>;
           // the next k-step's rows (the last k-step re-reads its own: harmless, and the loop stays free of branches)
           left -= 1;
 #ifdef CRNERF_EXP_WGRAD_L2   // (timing experiments only; garbage) the same rows again and again: operands from L1 / L2, i.e. the loop's compute time
@@ -580,37 +616,16 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 #pragma unroll
           for (int e = 0; e < 8; ++e) { draw[n][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
           __builtin_amdgcn_sched_barrier(0);
-          // One wave per SIMD hides at most ~5 single-issue instructions behind a 32x32x16 MFMA (MI355X guide), and a k-step's splits come to
-          // ~4.5 per MFMA: they only disappear if every phase carries its share.  Eight column splits (~48 VALU each) + the bias sums:
-          //   phase 0: column 0 | delta columns 1, 2                      phase 1: column 1 | bias sums, next activation columns 0 (and 1)
-          //   phase 2: column 2 | delta column 3, next activation column  phase 3: column 3 | next activation column(s), next delta column 0
-          // (delta pieces rotate through three register sets so that no split overwrites pieces the phase's own MFMAs still read)
-          column(0, D1[0], D2[0], D3[0], A1[c], A2[c], A3[c]);
-          split3(draw[c], 1, D1[1], D2[1], D3[1]);
-          split3(draw[c], 2, D1[2], D2[2], D3[2]);
-#pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
-          __builtin_amdgcn_sched_barrier(0);
-          column(1, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum3 += draw[c][e];
-          split3(araw, 0, A1[n][0], A2[n][0], A3[n][0]);
-          split3(araw, 1, A1[n][1], A2[n][1], A3[n][1]);
-#pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
-          __builtin_amdgcn_sched_barrier(0);
-          column(2, D1[2], D2[2], D3[2], A1[c], A2[c], A3[c]);
-          split3(draw[c], 3, D1[1], D2[1], D3[1]);
-          split3(araw, 2, A1[n][2], A2[n][2], A3[n][2]);
-#pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
-          __builtin_amdgcn_sched_barrier(0);
-          column(3, D1[1], D2[1], D3[1], A1[c], A2[c], A3[c]);
-          split3(araw, 3, A1[n][3], A2[n][3], A3[n][3]);
-          split3(draw[n], 0, D1[0], D2[0], D3[0]);
-#pragma unroll
-          for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
-          __builtin_amdgcn_sched_barrier(0);
+          // delta pieces rotate through three sets (no split overwrites pieces the running phase still reads); the bias sums take the two spare
+          // slots of every phase, one delta row each.  The next k-step's activation rows are first touched in phase 1.
+          phase(I0{}, I0{}, IC{}, [&](auto K) { split_stage<decltype(K)::value, 1>(draw[c], Dw[1], sr, su); },
+                [&](auto K) { split_stage<decltype(K)::value, 2>(draw[c], Dw[2], sr, su); }, [&](auto R) { bsum3 += draw[c][decltype(R)::value]; });
+          phase(I1{}, I1{}, IC{}, [&](auto K) { split_stage<decltype(K)::value, 0>(araw, Aw[n][0], sr, su); },
+                [&](auto K) { split_stage<decltype(K)::value, 1>(araw, Aw[n][1], sr, su); }, [&](auto R) { bsum3 += draw[c][2 + decltype(R)::value]; });
+          phase(I2{}, I2{}, IC{}, [&](auto K) { split_stage<decltype(K)::value, 3>(draw[c], Dw[1], sr, su); },
+                [&](auto K) { split_stage<decltype(K)::value, 2>(araw, Aw[n][2], sr, su); }, [&](auto R) { bsum3 += draw[c][4 + decltype(R)::value]; });
+          phase(I3{}, I1{}, IC{}, [&](auto K) { split_stage<decltype(K)::value, 3>(araw, Aw[n][3], sr, su); },
+                [&](auto K) { split_stage<decltype(K)::value, 0>(draw[n], Dw[0], sr, su); }, [&](auto R) { bsum3 += draw[c][6 + decltype(R)::value]; });
         };
         while (left > 0) {
           kstep(std::integral_constant<int, 0>{});
