@@ -314,7 +314,7 @@ def test_embed_points_equals_the_torch_composition_bitwise(R, N):
         assert got.shape == (R * N, 120) and torch.equal(got, want)
 
 
-@pytest.mark.parametrize("n", [50000, 300000])      # batched launch (<= 2^18 points) / per-layer launches
+@pytest.mark.parametrize("n", [4111, 50000, 300000])      # a 15-point ragged last chunk / batched launch (<= 2^18 points) / per-layer launches (whole k-step pairs only)
 def test_wgrad_bf16x3_is_as_accurate_as_the_fp32_matrix_cores(n):
     """CRNERF_BWD_WGRAD_BF16X3 (opt-in): the 256 x 256 weight-gradient blocks from three-piece bf16 splits of the fp32 operands, six bf16
     MFMAs per product.  Held against (i) the exact fp32-MFMA path on the same deltas / activations -- the two may differ by fp32 summation
