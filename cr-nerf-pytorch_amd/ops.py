@@ -792,6 +792,20 @@ def _rgb2d(t, name):
     return t
 
 
+def _dense_flat(t):
+    """1-D view of t's elements in MEMORY order when t is a permutation of a contiguous tensor (non-overlapping, no gaps), else None."""
+    if t.is_contiguous():
+        return t.reshape(-1)
+    expect = 1
+    for d in sorted(range(t.dim()), key=lambda d: t.stride(d)):
+        if t.shape[d] == 1:
+            continue
+        if t.stride(d) != expect:
+            return None
+        expect *= t.shape[d]
+    return t.as_strided((t.numel(),), (1,))
+
+
 def loss_args(rgb_coarse, targets, rgb_fine=None, mask=None, a_embedded=None, a_embedded_random=None, a_embedded_random_rec=None,
               content_wo=None, content_with=None, mse_on_appearance=False, coef=1.0, weight_kl=0.0, weight_rec_a=0.0,
               weight_content=0.0, mask_size_weight=0.0, mask_digit_weight=0.0):
@@ -812,9 +826,31 @@ def loss_args(rgb_coarse, targets, rgb_fine=None, mask=None, a_embedded=None, a_
         setattr(a, name + "_row_stride", t.stride(0))
         setattr(a, name + "_chan_stride", t.stride(1))
     flat = lambda t, n: None if t is None else _f32c(t.detach(), n).reshape(-1)  # noqa: E731
-    m, ae, ar, arr, cw, cwi = (flat(t, n) for t, n in ((mask, "out_mask"), (a_embedded, "a_embedded"), (a_embedded_random, "a_embedded_random"),
-                                                        (a_embedded_random_rec, "a_embedded_random_rec"), (content_wo, "content_wo_a_embed"),
-                                                        (content_with, "content_with_a_embed")))
+    # The embedding / content terms are full reductions over one tensor or over a same-shaped pair: the element ORDER does not matter as long
+    # as both members of a pair are walked in the same one.  The encoders' outputs are NCHW *views* of pixel-major memory; read in memory order
+    # they need no transposing copy here (and their gradients, written in the same order, none in the encoder's backward).
+    def memory_order(*ts):
+        if any(t is None for t in ts):
+            return None
+        ts = [t.detach() for t in ts]
+        if any(t.dtype != torch.float32 or not t.is_cuda or t.shape != ts[0].shape or t.stride() != ts[0].stride() for t in ts):
+            return None
+        views = [_dense_flat(t) for t in ts]
+        return None if any(v is None for v in views) else views
+    layouts = {}
+    m = flat(mask, "out_mask")
+    got = memory_order(a_embedded)
+    ae = got[0] if got else flat(a_embedded, "a_embedded")
+    if got and not a_embedded.is_contiguous():
+        layouts["a_embedded"] = a_embedded.stride()
+    got = memory_order(a_embedded_random, a_embedded_random_rec)
+    ar, arr = got if got else (flat(a_embedded_random, "a_embedded_random"), flat(a_embedded_random_rec, "a_embedded_random_rec"))
+    if got and not a_embedded_random_rec.is_contiguous():
+        layouts["a_embedded_random_rec"] = a_embedded_random_rec.stride()
+    got = memory_order(content_wo, content_with)
+    cw, cwi = got if got else (flat(content_wo, "content_wo_a_embed"), flat(content_with, "content_with_a_embed"))
+    if got and not content_wo.is_contiguous():
+        layouts["content_wo_a_embed"] = layouts["content_with_a_embed"] = content_wo.stride()
     if m is not None and m.numel() != R:
         raise ValueError("crnerf_amd: out_mask must have one value per ray")
     if arr is not None and (ar is None or ar.numel() != arr.numel()):
@@ -831,6 +867,7 @@ def loss_args(rgb_coarse, targets, rgb_fine=None, mask=None, a_embedded=None, a_
     a.mse_on_appearance = int(bool(mse_on_appearance))
     a.coef, a.weight_kl, a.weight_rec_a, a.weight_content = float(coef), float(weight_kl), float(weight_rec_a), float(weight_content)
     a.mask_size_weight, a.mask_digit_weight = float(mask_size_weight), float(mask_digit_weight)
+    a._memory_order = layouts       # inputs handed over in memory order (name -> strides): their gradients must be allocated with the same strides
     return a, keep
 
 
@@ -854,7 +891,11 @@ def loss_backward(args, upstream, want):
     g = _lib.LossGrads()
     out = {}
     for name, shape in want.items():
-        out[name] = torch.empty(shape, dtype=torch.float32, device=upstream.device)
+        strides = None
+        if isinstance(shape, tuple) and len(shape) == 2 and isinstance(shape[1], tuple) and isinstance(shape[0], (tuple, torch.Size)):
+            shape, strides = shape             # (shape, strides): written in the memory order the forward read the input in
+        out[name] = (torch.empty_strided(tuple(shape), strides, dtype=torch.float32, device=upstream.device) if strides is not None
+                     else torch.empty(shape, dtype=torch.float32, device=upstream.device))
         setattr(g, "d_" + name, out[name].data_ptr())
     _lib.check(lib.crnerf_loss_backward_f32(ctypes.byref(args), _lib.dev_ptr(_f32c(upstream, "upstream")), ctypes.byref(g), _lib.stream_ptr()),
                "crnerf_loss_backward_f32")

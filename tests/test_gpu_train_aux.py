@@ -333,3 +333,35 @@ def test_fused_grad_accumulation_equals_accumulategrad_bit_for_bit():
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
         else:
             torch.testing.assert_close(a, b, rtol=1e-2, atol=1e-3 * float(b.abs().max()))
+
+
+def test_loss_reads_encoder_views_in_memory_order():
+    """The encoders hand the loss NCHW *views* of pixel-major memory.  The embedding / content terms are order-free reductions, so the kernel
+    reads such views in memory order (no transposing copy) and writes their gradients with the same strides: values equal to the contiguous
+    path up to summation order, gradients element for element; a pair whose members are laid out differently still goes through copies."""
+    gen = torch.Generator().manual_seed(5)
+    R = 256
+    rc, tg = torch.rand(R, 3, generator=gen).to(DEV), torch.rand(R, 3, generator=gen).to(DEV)
+    base = {k: torch.randn(1, 32, 32, 64, generator=gen).to(DEV) for k in ("a_embedded", "a_embedded_random", "a_embedded_random_rec", "content_wo_a_embed", "content_with_a_embed")}
+    hp = HP()
+
+    def run(make):
+        inp = {k: make(k, v).requires_grad_(k != "a_embedded_random") for k, v in base.items()}
+        ret, _ = CRNeRFLoss(hp)({"rgb_coarse": rc, **{k: (v.permute(0, 3, 1, 2) if v.shape[-1] == 64 else v) for k, v in inp.items()}}, tg, hp, 0)
+        (ret["kl_a"] + 2.0 * ret["rec_a_random"] + 3.0 * ret["content_constraint"]).backward()
+        return {k: float(v) for k, v in ret.items()}, {k: v.grad for k, v in inp.items() if v.grad is not None}
+
+    views, gv = run(lambda k, v: v.clone())                                               # [1,64,32,32] views of pixel-major memory, as the encoders return them
+    dense, gd = run(lambda k, v: v.permute(0, 3, 1, 2).contiguous())                      # the same values as plain NCHW tensors
+    mixed, gm = run(lambda k, v: v.permute(0, 3, 1, 2).contiguous() if k == "content_with_a_embed" else v.clone())   # a mismatched pair
+    for k in views:
+        assert abs(views[k] - dense[k]) <= 1e-6 * abs(dense[k]) + 1e-12 and abs(mixed[k] - dense[k]) <= 1e-6 * abs(dense[k]) + 1e-12, k
+    assert set(gv) == set(gd) == set(gm) == {"a_embedded", "a_embedded_random_rec", "content_wo_a_embed", "content_with_a_embed"}
+    for k in gv:
+        want = gd[k].permute(0, 2, 3, 1)                                                  # back to the [1,32,32,64] leaf's indexing
+        got_m = gm[k] if gm[k].shape == want.shape else gm[k].permute(0, 2, 3, 1)
+        torch.testing.assert_close(gv[k], want, rtol=1e-6, atol=1e-12)
+        torch.testing.assert_close(got_m, want, rtol=1e-6, atol=1e-12)
+    from crnerf_amd import ops
+    assert ops._dense_flat(base["a_embedded"].permute(0, 3, 1, 2)).data_ptr() == base["a_embedded"].data_ptr()
+    assert ops._dense_flat(base["a_embedded"][:, ::2]) is None and ops._dense_flat(base["a_embedded"].expand(2, 32, 32, 64)) is None
