@@ -54,10 +54,10 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, upstream):
-        order = getattr(ctx.args, "_memory_order", {})      # inputs the kernel read in memory order: their gradients get the same strides
-        want = {_GRAD_OF[n]: ((tuple(s), tuple(order[n])) if n in order else (s if n not in ("rgb_coarse", "rgb_fine") else (s[0], 3)))
+        want = {_GRAD_OF[n]: (s if n not in ("rgb_coarse", "rgb_fine") else (s[0], 3))
                 for n, s, need in zip(ctx.names, ctx.shapes, ctx.needs_input_grad[2:]) if need and n in _GRAD_OF}
-        got = ops.loss_backward(ctx.args, upstream.contiguous(), want) if want else {}
+        order = getattr(ctx.args, "_memory_order", {})      # inputs the kernel read in memory order: their gradients get the same strides
+        got = ops.loss_backward(ctx.args, upstream.contiguous(), want, {_GRAD_OF[n]: st for n, st in order.items() if n in _GRAD_OF}) if want else {}
         grads = []
         for n, s, need in zip(ctx.names, ctx.shapes, ctx.needs_input_grad[2:]):
             grads.append(got[_GRAD_OF[n]].view(s) if (need and n in _GRAD_OF) else None)

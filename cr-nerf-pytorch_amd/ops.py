@@ -885,16 +885,15 @@ def loss_forward(args):
     return losses
 
 
-def loss_backward(args, upstream, want):
-    """want: dict name -> shape of the gradients to produce (names of struct crnerf_loss_grads without the d_ prefix)."""
+def loss_backward(args, upstream, want, strides=None):
+    """want: dict name -> shape of the gradients to produce (names of struct crnerf_loss_grads without the d_ prefix); strides: name -> strides
+    for the inputs loss_args handed over in memory order (their gradients are written in that order too)."""
     lib = _lib.load()
     g = _lib.LossGrads()
     out = {}
     for name, shape in want.items():
-        strides = None
-        if isinstance(shape, tuple) and len(shape) == 2 and isinstance(shape[1], tuple) and isinstance(shape[0], (tuple, torch.Size)):
-            shape, strides = shape             # (shape, strides): written in the memory order the forward read the input in
-        out[name] = (torch.empty_strided(tuple(shape), strides, dtype=torch.float32, device=upstream.device) if strides is not None
+        st = (strides or {}).get(name)
+        out[name] = (torch.empty_strided(tuple(shape), tuple(st), dtype=torch.float32, device=upstream.device) if st is not None
                      else torch.empty(shape, dtype=torch.float32, device=upstream.device))
         setattr(g, "d_" + name, out[name].data_ptr())
     _lib.check(lib.crnerf_loss_backward_f32(ctypes.byref(args), _lib.dev_ptr(_f32c(upstream, "upstream")), ctypes.byref(g), _lib.stream_ptr()),
