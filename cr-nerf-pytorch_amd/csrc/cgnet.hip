@@ -144,13 +144,11 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 }
 
 // training: batch statistics (biased variance for the normalisation), written to mean / invstd; eval: mean / invstd given
-__global__ __launch_bounds__(256) void cg_bn_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+__device__ __forceinline__ void cg_bn_prelu_fwd_body(const int c, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ alpha, float* __restrict__ mean, float* __restrict__ invstd,
                                                               float* __restrict__ var_unbiased, float* __restrict__ y, int HW, float eps, int training,
                                                               float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ n_tracked,
-                                                              float momentum) {
-  __shared__ float red[4];
-  const int c = blockIdx.x;
+                                                              float momentum, float* red) {
   const float* xc = x + (long)c * HW;
   float m, is;
   if (training) {
@@ -181,13 +179,53 @@ __global__ __launch_bounds__(256) void cg_bn_prelu_fwd_kernel(const float* __res
   }
 }
 
+__global__ __launch_bounds__(256) void cg_bn_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ alpha, float* __restrict__ mean, float* __restrict__ invstd,
+                                                              float* __restrict__ var_unbiased, float* __restrict__ y, int HW, float eps, int training,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ n_tracked,
+                                                              float momentum) {
+  __shared__ float red[4];
+  cg_bn_prelu_fwd_body(blockIdx.x, x, gamma, beta, alpha, mean, invstd, var_unbiased, y, HW, eps, training, run_mean, run_var, n_tracked, momentum, red);
+}
+
+// F_loc / F_sur -> concatenation -> BatchNorm + PReLU of a ContextGuidedBlock[_Down] in ONE launch (training chain): channel c of the
+// concatenation is a depth-wise 3x3 convolution of input channel c % n (dilation 1 for c < n, `dil` above), so the block of channel c
+// computes its own pre-BN map -- kept in `cat`, the backward reads it -- in cg_conv_fwd_kernel's order of products, and the statistics
+// and the normalisation are cg_bn_prelu_fwd_body on it (every thread reads back the pixels it wrote itself).
+__global__ __launch_bounds__(256) void cg_dwpair_bn_prelu_fwd_kernel(const float* __restrict__ yin, const float* __restrict__ w_loc, const float* __restrict__ w_sur,
+                                                                     int n, int H, int W, int dil, float* cat, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ alpha, float* __restrict__ mean,
+                                                                     float* __restrict__ invstd, float* __restrict__ var_unbiased, float* __restrict__ z, float eps,
+                                                                     float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ n_tracked,
+                                                                     float momentum) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, src = c % n, d = c >= n ? dil : 1, HW = H * W;
+  const float* w = (c >= n ? w_sur : w_loc) + src * 9;
+  const float* xs = yin + (long)src * HW;
+  float* xc = cat + (long)c * HW;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int ox = p % W, oy = p / W;
+    float acc = 0.0f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy + (ky - 1) * d;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox + (kx - 1) * d;
+        if (ix < 0 || ix >= W) continue;
+        acc = fmaf(w[ky * 3 + kx], xs[iy * W + ix], acc);
+      }
+    }
+    xc[p] = acc;
+  }
+  __syncthreads();
+  cg_bn_prelu_fwd_body(c, cat, gamma, beta, alpha, mean, invstd, var_unbiased, z, HW, eps, 1, run_mean, run_var, n_tracked, momentum, red);
+}
+
 // training == 0 (eval): mean / invstd are constants, so dx = dz * gamma * invstd
-__global__ __launch_bounds__(256) void cg_bn_prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+__device__ __forceinline__ void cg_bn_prelu_bwd_body(const int c, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ alpha, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ dalpha, int HW, int training) {
-  __shared__ float red[4];
-  const int c = blockIdx.x;
+                                                              float* __restrict__ dbeta, float* __restrict__ dalpha, int HW, int training, float* red) {
   const float* xc = x + (long)c * HW;
   const float* dyc = dy + (long)c * HW;
   const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], al = alpha[c];
@@ -211,6 +249,68 @@ __global__ __launch_bounds__(256) void cg_bn_prelu_bwd_kernel(const float* __res
   }
 }
 
+__global__ __launch_bounds__(256) void cg_bn_prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ alpha, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dalpha, int HW, int training) {
+  __shared__ float red[4];
+  cg_bn_prelu_bwd_body(blockIdx.x, x, gamma, beta, alpha, mean, invstd, dy, dx, dgamma, dbeta, dalpha, HW, training, red);
+}
+
+// The backward of cg_dwpair_bn_prelu_fwd_kernel, one block per INPUT channel s: BatchNorm + PReLU backward of concatenation channels s
+// (F_loc) and s + n (F_sur) into d_cat, then both depth-wise convolutions' weight gradients (nine taps each) and the sum of their data
+// gradients -- d_y[s] is written once, F_loc's contribution first, as the two accumulating launches did.
+__global__ __launch_bounds__(256) void cg_dwpair_bn_prelu_bwd_kernel(const float* __restrict__ yin, const float* __restrict__ w_loc, const float* __restrict__ w_sur,
+                                                                     int n, int H, int W, int dil, const float* __restrict__ cat, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ alpha, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, const float* __restrict__ dz, float* d_cat,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
+                                                                     float* __restrict__ dw_loc, float* __restrict__ dw_sur, float* __restrict__ d_y) {
+  __shared__ float red[4];
+  const int s = blockIdx.x, HW = H * W;
+  cg_bn_prelu_bwd_body(s, cat, gamma, beta, alpha, mean, invstd, dz, d_cat, dgamma, dbeta, dalpha, HW, 1, red);
+  cg_bn_prelu_bwd_body(s + n, cat, gamma, beta, alpha, mean, invstd, dz, d_cat, dgamma, dbeta, dalpha, HW, 1, red);
+  __syncthreads();                                           // d_cat[s], d_cat[s + n] are complete (and visible) for the whole block
+  const float* xs = yin + (long)s * HW;
+  for (int h = 0; h < 2; ++h) {
+    const float* dc = d_cat + (long)(s + h * n) * HW;
+    const int d = h ? dil : 1;
+    float* dw = (h ? dw_sur : dw_loc) + s * 9;
+    for (int t = 0; t < 9; ++t) {
+      const int offy = (t / 3 - 1) * d, offx = (t % 3 - 1) * d;
+      float acc = 0.0f;
+      for (int p = threadIdx.x; p < HW; p += 256) {
+        const int iy = p / W + offy, ix = p % W + offx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        acc = fmaf(dc[p], xs[iy * W + ix], acc);
+      }
+      acc = block_sum256(acc, red);
+      if (threadIdx.x == 0) dw[t] = acc;
+    }
+  }
+  for (int q = threadIdx.x; q < HW; q += 256) {
+    const int ix = q % W, iy = q / W;
+    float tot = 0.0f;
+    for (int h = 0; h < 2; ++h) {
+      const float* dc = d_cat + (long)(s + h * n) * HW;
+      const float* w = (h ? w_sur : w_loc) + s * 9;
+      const int d = h ? dil : 1;
+      float acc = 0.0f;
+      for (int ky = 0; ky < 3; ++ky) {                       // cg_conv_dgrad_kernel's order (stride 1, pad = d): output row oy = iy + d - ky d
+        const int oy = iy + d - ky * d;
+        if (oy < 0 || oy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix + d - kx * d;
+          if (ox < 0 || ox >= W) continue;
+          acc = fmaf(w[ky * 3 + kx], dc[oy * W + ox], acc);
+        }
+      }
+      tot = h ? tot + acc : acc;
+    }
+    d_y[(long)s * HW + q] = tot;
+  }
+}
+
 int launch_cg_bn_prelu_forward(const float* x, const float* gamma, const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased,
                                float* y, int C, int HW, float eps, int training, hipStream_t st, float* run_mean, float* run_var, long long* n_tracked,
                                float momentum) {
@@ -222,6 +322,21 @@ int launch_cg_bn_prelu_backward(const float* x, const float* gamma, const float*
                                 const float* dy, float* dx, float* dgamma, float* dbeta, float* dalpha, int C, int HW, int training, hipStream_t st) {
   hipLaunchKernelGGL(cg_bn_prelu_bwd_kernel, dim3(C), dim3(256), 0, st, x, gamma, beta, alpha, mean, invstd, dy, dx, dgamma, dbeta, dalpha, HW, training);
   return check_launch("cg_bn_prelu_backward");
+}
+
+int launch_cg_dwpair_bn_prelu_forward(const float* y, const float* w_loc, const float* w_sur, int n, int H, int W, int dil, float* cat, const float* gamma,
+                                      const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased, float* z, float eps,
+                                      float* run_mean, float* run_var, long long* n_tracked, float momentum, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dwpair_bn_prelu_fwd_kernel, dim3(2 * n), dim3(256), 0, st, y, w_loc, w_sur, n, H, W, dil, cat, gamma, beta, alpha, mean, invstd,
+                     var_unbiased, z, eps, run_mean, run_var, n_tracked, momentum);
+  return check_launch("cg_dwpair_bn_prelu_forward");
+}
+int launch_cg_dwpair_bn_prelu_backward(const float* y, const float* w_loc, const float* w_sur, int n, int H, int W, int dil, const float* cat, const float* gamma,
+                                       const float* beta, const float* alpha, const float* mean, const float* invstd, const float* dz, float* d_cat,
+                                       float* dgamma, float* dbeta, float* dalpha, float* dw_loc, float* dw_sur, float* d_y, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dwpair_bn_prelu_bwd_kernel, dim3(n), dim3(256), 0, st, y, w_loc, w_sur, n, H, W, dil, cat, gamma, beta, alpha, mean, invstd, dz, d_cat,
+                     dgamma, dbeta, dalpha, dw_loc, dw_sur, d_y);
+  return check_launch("cg_dwpair_bn_prelu_backward");
 }
 
 // ---------------------------------------------------------------- AvgPool2d(3, stride 2, padding 1), count_include_pad

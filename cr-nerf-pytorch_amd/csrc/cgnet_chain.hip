@@ -3,7 +3,8 @@
 // once per step on the 1/8-scale photo, in train mode: BatchNorm on batch statistics, running buffers updated).
 //
 // Nothing new is computed here: the chain enqueues cgnet.hip's operators back to back, in the order the module tree evaluates them.  What
-// it removes is everything between the launches -- 56 autograd nodes per direction, nine torch.cat / add launches in the forward and
+// it removes is everything between the launches (and, for F_loc | F_sur -> BatchNorm + PReLU, the launches themselves: one per direction) --
+// 56 autograd nodes per direction, nine torch.cat / add launches in the forward and
 // seventeen gradient-sum launches in the backward: with batch 1 and NCHW a channel concatenation is two producers writing adjacent slices
 // of one buffer, a fan-out's gradient sum is the second data gradient accumulating into the first (ConvGeom::accum), and a block's
 // residual add rides in FGlo's scaling pass.  The forward's values are those of the operator-by-operator path bit for bit; gradient sums
@@ -91,15 +92,19 @@ struct Fwd {
     return launch_cg_bn_prelu_forward(x, P(pb), P(pb + 1), P(pb + 2), S + stats, S + stats + C, S + stats + 2 * C, y, C, (int)hw, a.eps, 1, st,
                                       a.run_mean[ibn], a.run_var[ibn], a.tracked ? a.tracked[ibn] : nullptr, a.momentum);
   }
+  // F_loc | F_sur -> cat[2n] -> BatchNorm + PReLU in one launch; pw = index of F_loc.conv.weight (F_sur's, bn.weight, bn.bias, act.weight follow)
+  int dwpair(int ibn, int pw, int n, int H, int W, int dil, const float* y, float* cat, long stats, float* z) const {
+    const int C = 2 * n;
+    return launch_cg_dwpair_bn_prelu_forward(y, P(pw), P(pw + 1), n, H, W, dil, cat, P(pw + 2), P(pw + 3), P(pw + 4), S + stats, S + stats + C, S + stats + 2 * C,
+                                             z, a.eps, a.run_mean[ibn], a.run_var[ibn], a.tracked ? a.tracked[ibn] : nullptr, a.momentum, st);
+  }
   // ContextGuidedBlock_Down (lightweight_seg.py:164-211): x[nIn,H,W] -> out[nOut,Ho,Wo]
   int down(const float* x, int nIn, int nOut, int H, int W, int dil, int R, int pb, int ibn, const DownBuf& d, float* out) const {
     const ConvGeom g1 = geom(nIn, nOut, H, W, 3, 2, 1, 0);
     const long hw = (long)g1.Ho * g1.Wo;
     CG_TRY(launch_cg_conv_forward(g1, x, P(pb), S + d.d0, st));
     CG_TRY(bn(ibn, pb + 1, nOut, hw, S + d.d0, d.bn_a, S + d.y));
-    CG_TRY(launch_cg_conv_forward(geom(nOut, nOut, g1.Ho, g1.Wo, 3, 1, 1, 1), S + d.y, P(pb + 4), S + d.cat, st));
-    CG_TRY(launch_cg_conv_forward(geom(nOut, nOut, g1.Ho, g1.Wo, 3, 1, dil, 1), S + d.y, P(pb + 5), S + d.cat + nOut * hw, st));
-    CG_TRY(bn(ibn + 1, pb + 6, 2 * nOut, hw, S + d.cat, d.bn_b, S + d.z));
+    CG_TRY(dwpair(ibn + 1, pb + 4, nOut, g1.Ho, g1.Wo, dil, S + d.y, S + d.cat, d.bn_b, S + d.z));
     CG_TRY(launch_cg_conv_forward(geom(2 * nOut, nOut, g1.Ho, g1.Wo, 1, 1, 1, 0), S + d.z, P(pb + 9), S + d.r, st));
     return launch_cg_fglo_forward(S + d.r, P(pb + 10), P(pb + 11), P(pb + 12), P(pb + 13), S + d.stats, out, nOut, R, (int)hw, st);
   }
@@ -109,9 +114,7 @@ struct Fwd {
     const long hw = (long)H * W;
     CG_TRY(launch_cg_conv_forward(geom(nOut, n, H, W, 1, 1, 1, 0), x, P(pb), S + k.e0, st));
     CG_TRY(bn(ibn, pb + 1, n, hw, S + k.e0, k.bn_a, S + k.y));
-    CG_TRY(launch_cg_conv_forward(geom(n, n, H, W, 3, 1, 1, 1), S + k.y, P(pb + 4), S + k.cat, st));
-    CG_TRY(launch_cg_conv_forward(geom(n, n, H, W, 3, 1, dil, 1), S + k.y, P(pb + 5), S + k.cat + n * hw, st));
-    CG_TRY(bn(ibn + 1, pb + 6, nOut, hw, S + k.cat, k.bn_b, S + k.z));
+    CG_TRY(dwpair(ibn + 1, pb + 4, n, H, W, dil, S + k.y, S + k.cat, k.bn_b, S + k.z));
     return launch_cg_fglo_forward(S + k.z, P(pb + 9), P(pb + 10), P(pb + 11), P(pb + 12), S + k.stats, out, nOut, R, (int)hw, st, x);
   }
 };
@@ -122,6 +125,12 @@ struct Bwd {
   int bn(int pb, int C, long hw, const float* x, long stats, const float* dy, float* dx) const {
     return launch_cg_bn_prelu_backward(x, P(pb), P(pb + 1), P(pb + 2), S + stats, S + stats + C, dy, dx, G[pb], G[pb + 1], G[pb + 2], C, (int)hw, 1, st);
   }
+  // backward of Fwd::dwpair: dz[2n] -> d_cat[2n] (scratch), the five parameter gradients, d_y[n] = both data gradients summed
+  int dwpair(int pw, int n, int H, int W, int dil, const float* y, const float* cat, long stats, const float* dz, float* d_cat, float* d_y) const {
+    const int C = 2 * n;
+    return launch_cg_dwpair_bn_prelu_backward(y, P(pw), P(pw + 1), n, H, W, dil, cat, P(pw + 2), P(pw + 3), P(pw + 4), S + stats, S + stats + C, dz, d_cat,
+                                              G[pw + 2], G[pw + 3], G[pw + 4], G[pw], G[pw + 1], d_y, st);
+  }
   int conv(const ConvGeom& g, const float* x, int pw, const float* dy, float* dx) const { return launch_cg_conv_backward(g, x, P(pw), dy, dx, G[pw], st); }
   // d_out[nOut,Ho,Wo] -> d_x (written, or added to when accum)
   int down(const float* x, float* d_x, int accum, int nIn, int nOut, int H, int W, int dil, int R, int pb, const DownBuf& d, const float* d_out,
@@ -131,9 +140,7 @@ struct Bwd {
     CG_TRY(launch_cg_fglo_backward(S + d.r, P(pb + 10), P(pb + 12), S + d.stats, d_out, D + p.fglo_scratch, D + d.r, G[pb + 10], G[pb + 11], G[pb + 12],
                                    G[pb + 13], nOut, R, (int)hw, st));
     CG_TRY(conv(geom(2 * nOut, nOut, g1.Ho, g1.Wo, 1, 1, 1, 0), S + d.z, pb + 9, D + d.r, D + d.z));
-    CG_TRY(bn(pb + 6, 2 * nOut, hw, S + d.cat, d.bn_b, D + d.z, D + d.cat));
-    CG_TRY(conv(geom(nOut, nOut, g1.Ho, g1.Wo, 3, 1, 1, 1), S + d.y, pb + 4, D + d.cat, D + d.y));
-    CG_TRY(conv(geom(nOut, nOut, g1.Ho, g1.Wo, 3, 1, dil, 1, 1), S + d.y, pb + 5, D + d.cat + nOut * hw, D + d.y));
+    CG_TRY(dwpair(pb + 4, nOut, g1.Ho, g1.Wo, dil, S + d.y, S + d.cat, d.bn_b, D + d.z, D + d.cat, D + d.y));
     CG_TRY(bn(pb + 1, nOut, hw, S + d.d0, d.bn_a, D + d.y, D + d.d0));
     return conv(g1, x, pb, D + d.d0, d_x);
   }
@@ -143,9 +150,7 @@ struct Bwd {
     const long hw = (long)H * W;
     CG_TRY(launch_cg_fglo_backward(S + k.z, P(pb + 9), P(pb + 11), S + k.stats, d_out, D + p.fglo_scratch, D + k.z, G[pb + 9], G[pb + 10], G[pb + 11],
                                    G[pb + 12], nOut, R, (int)hw, st));
-    CG_TRY(bn(pb + 6, nOut, hw, S + k.cat, k.bn_b, D + k.z, D + k.cat));
-    CG_TRY(conv(geom(n, n, H, W, 3, 1, 1, 1), S + k.y, pb + 4, D + k.cat, D + k.y));
-    CG_TRY(conv(geom(n, n, H, W, 3, 1, dil, 1, 1), S + k.y, pb + 5, D + k.cat + n * hw, D + k.y));
+    CG_TRY(dwpair(pb + 4, n, H, W, dil, S + k.y, S + k.cat, k.bn_b, D + k.z, D + k.cat, D + k.y));
     CG_TRY(bn(pb + 1, n, hw, S + k.e0, k.bn_a, D + k.y, D + k.e0));
     CG_TRY(conv(geom(nOut, n, H, W, 1, 1, 1, 0, 1), x, pb, D + k.e0, d_x));
     return launch_cg_add_inplace(d_x, d_out, (int)(nOut * hw), st);

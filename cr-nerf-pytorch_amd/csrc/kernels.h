@@ -161,6 +161,14 @@ int launch_cg_avgpool(const float* in, float* out, int C, int H, int W, int back
 int launch_cg_fglo_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* stats, float* y, int C, int R, int HW,
                            hipStream_t st, const float* residual = nullptr);
 int launch_cg_add_inplace(float* dst, const float* src, int n, hipStream_t st);
+// F_loc / F_sur (depth-wise 3x3, dilation 1 / dil) -> cat -> BatchNorm + PReLU as one launch each way (the training chain, cgnet_chain.hip)
+int launch_cg_dwpair_bn_prelu_forward(const float* y, const float* w_loc, const float* w_sur, int n, int H, int W, int dil, float* cat, const float* gamma,
+                                      const float* beta, const float* alpha, float* mean, float* invstd, float* var_unbiased, float* z, float eps,
+                                      float* run_mean, float* run_var, long long* n_tracked, float momentum, hipStream_t st);
+int launch_cg_dwpair_bn_prelu_backward(const float* y, const float* w_loc, const float* w_sur, int n, int H, int W, int dil, const float* cat, const float* gamma,
+                                       const float* beta, const float* alpha, const float* mean, const float* invstd, const float* dz, float* d_cat,
+                                       float* dgamma, float* dbeta, float* dalpha, float* dw_loc, float* dw_sur, float* d_y, hipStream_t st);
+
 int launch_cg_fglo_backward(const float* x, const float* w1, const float* w2, const float* stats, const float* dy, float* scratch, float* dx, float* dw1,
                             float* db1, float* dw2, float* db2, int C, int R, int HW, hipStream_t st);
 int launch_cg_bilinear(const float* in, const long* idx, float* out, long n, int h, int w, int Ho, int Wo, int sigmoid, hipStream_t st);
