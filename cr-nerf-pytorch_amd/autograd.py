@@ -210,6 +210,9 @@ class FusedRenderFn(torch.autograd.Function):
             keep += [out["acts_coarse"], out["raw_coarse"]] + ([out["acts_fine"], out["raw_fine"]] if Ni > 0 else [])
         ctx.n_keep = len(keep)
         ctx.save_for_backward(*keep, *params)
+        # a batch of more rays than hparams.chunk runs this node once per chunk: with deferral on, the chunks' parameter gradients are summed by one
+        # multi-tensor add per chunk at the end of backward instead of 48 AccumulateGrad adds per chunk (336 launches of a 65,536-ray step)
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(t) for t in params] if _DEFER_ON[0] else None)
         res = (out["weights_coarse"], out["feature_coarse"], out["depth_coarse"])
         if Ni > 0:
             res += (out["weights_fine"], out["feature_fine"], out["depth_fine"])
@@ -254,6 +257,10 @@ class FusedRenderFn(torch.autograd.Function):
             grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3, dgrad_h2=h2,
                                       fallback_t_x3=net)
             del x, d_raw
+        if getattr(ctx, "defer", False):
+            todo = [(leaf, gr.view(leaf.shape)) for leaf, gr in zip(ctx.leaves, grads) if leaf is not None and gr is not None]
+            _defer([t[0] for t in todo], [t[1] for t in todo])
+            grads = [None if (leaf is not None or gr is None) else gr for leaf, gr in zip(ctx.leaves, grads)]
         return (None, None) + tuple(grads)
 
 
