@@ -46,6 +46,24 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restric
   out[idx] = in[c * HW + px];
 }
 
+// The first layer (conv1: 1x1, 3 -> 3, no activation) together with the NCHW -> pixel-major re-layout of the photo: a0[px][c] = img[c][px],
+// y1[px][o] = b[o] + sum_c a0[px][c] wt[c][o] with the products chained in conv_kernel<1, false>'s order (c = 0, 1, 2 onto 0, then + bias):
+// the same bits as chw_to_hwc_kernel + that kernel, one launch instead of two per encoder pass.
+__global__ void chw_conv1_kernel(const float* __restrict__ img, const float* __restrict__ wt, const float* __restrict__ b, float* __restrict__ a0,
+                                 float* __restrict__ y1, int HW) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const float x0 = img[px], x1 = img[HW + px], x2 = img[2 * HW + px];
+  a0[3 * px + 0] = x0; a0[3 * px + 1] = x1; a0[3 * px + 2] = x2;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    float acc = fmaf(x0, wt[o], 0.0f);
+    acc = fmaf(x1, wt[3 + o], acc);
+    acc = fmaf(x2, wt[6 + o], acc);
+    y1[3 * px + o] = b[o] + (((acc + 0.0f) + 0.0f) + 0.0f);   // (conv_kernel adds the three idle waves' zero partial sums: -0 becomes +0 there too)
+  }
+}
+
 // out[px][o] = act(b[o] + sum_{c,tap} in[reflect(px+tap)][c] * wt[c][tap][o]);  TAPS = 9 (3x3, reflection pad 1) or 1.
 // One workgroup = PX horizontally adjacent pixels x 64 output channels; its four waves split the input channels (a
 // quarter each when cin % 16 == 0) and their partial sums are added in wave order through LDS.  Per wave the weight row is
@@ -246,6 +264,9 @@ void enc_transpose_weights_all(const float* const* w, float* const* wt, const in
   j.first_block[7] = blocks;
   hipLaunchKernelGGL(transpose_weights_batch_kernel, dim3(blocks), dim3(256), 0, st, j);
 }
+void enc_chw_conv1(const float* img, const float* wt, const float* b, float* a0, float* y1, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(chw_conv1_kernel, dim3((HW + 255) / 256), dim3(256), 0, st, img, wt, b, a0, y1, HW);
+}
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st) {
   hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((C * HW + 255) / 256), dim3(256), 0, st, in, out, C, HW);
 }
@@ -289,8 +310,7 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
   float* a = p;
   float* b = p + act;
   float* xc = b + act;                                          // patch matrix of the layer in flight
-  hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((3 * H * W + 255) / 256), dim3(256), 0, st, img, a, 3, H * W);
-  conv<1, false>(a, wt[0], w[1], b, H, W, 3, 3, st);            // conv1
+  enc_chw_conv1(img, wt[0], w[1], a, b, H * W, st);             // NCHW -> pixel-major + conv1
   conv<9, true>(b, wt[1], w[3], a, H, W, 3, 64, st);            // conv2 + relu2
   enc_conv_gemm(9, a, xc, w[4], w[5], b, H, W, 64, 64, st);     // conv3 + relu3 (fp32 MFMA GEMM over the patch matrix)
   hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * 64 + 255) / 256), dim3(256), 0, st, b, a, H, W, 64);

@@ -16,6 +16,7 @@ void enc_conv(int taps, bool act, const float* in, const float* wt, const float*
 void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st);
 void enc_transpose_weights_all(const float* const* w, float* const* wt, const int* cout, const int* cin, const int* taps, hipStream_t st);
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st);
+void enc_chw_conv1(const float* img, const float* wt, const float* b, float* a0, float* y1, int HW, hipStream_t st);
 void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st);
 void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st);
 void enc_im2col(const float* in, float* X, int H, int W, int cin, hipStream_t st);
@@ -83,8 +84,7 @@ int launch_encoder_forward_train(const float* img, int H, int W, const float* co
   float* p = s + L.end;
   for (int l = 0; l < 7; ++l) { wt[l] = p; p += TCIN[l] * TCOUT[l] * TTAPS[l]; }
   enc_transpose_weights_all(w, wt, TCOUT, TCIN, TTAPS, st);     // one launch (seven before: 28 of the 570 launches of a 1,024-ray train.sh step)
-  enc_chw_to_hwc(img, s + L.a0, 3, H * W, st);
-  enc_conv(1, false, s + L.a0, wt[0], w[1], s + L.y1, H, W, 3, 3, st);
+  enc_chw_conv1(img, wt[0], w[1], s + L.a0, s + L.y1, H * W, st);      // NCHW -> pixel-major (kept: conv1's weight gradient reads it) + conv1
   enc_conv(9, true, s + L.y1, wt[1], w[3], s + L.y2, H, W, 3, 64, st);
   // cin >= 64: fp32 MFMA GEMMs over the patch matrices (encoder.hip), which stay in `saved` for the weight gradients
   enc_conv_gemm(9, s + L.y2, s + L.x3, w[4], w[5], s + L.y3, H, W, 64, 64, st);
