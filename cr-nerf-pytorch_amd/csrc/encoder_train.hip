@@ -217,14 +217,6 @@ __global__ void enc_avgpool_bwd_kernel(const float* __restrict__ d_out, float* _
   d_in[idx] = yact ? acc * lrelu_grad(yact[idx]) : acc;
 }
 
-// HWC [HW,C] -> NCHW [C,HW]
-__global__ void enc_hwc_to_chw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * HW) return;
-  const int c = idx / HW, px = idx % HW;
-  out[idx] = in[(long)px * C + c];
-}
-
 struct BwdBufs { float* X; float* wd; WgradSpec* specs; int* nspec; };
 
 // xsaved: the layer's patch matrix kept by the forward (GEMM layers) or null (built here); wt: the forward's [cin*taps][cout]
@@ -256,6 +248,16 @@ static void conv_bwd(const float* g, const float* in, const float* w, const BwdB
     return;
   }
   hipLaunchKernelGGL((enc_dgrad_kernel<TAPS>), dim3((H * W + 3) / 4, (cin + 63) / 64), dim3(256), 0, st, g, w, d_in, H, W, cin, cout, yact);
+}
+
+// conv1's data gradient (1x1, 3 -> 3; enc_dgrad_kernel<1>'s products in its order) written straight into the photo's NCHW layout:
+// d_img[c][px] = sum_o g[px][o] w[o][c] -- one launch instead of the pixel-major data gradient + its re-layout
+__global__ void conv1_dgrad_chw_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ d_img, int HW) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const float g0 = g[3 * px], g1 = g[3 * px + 1], g2 = g[3 * px + 2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d_img[(long)c * HW + px] = fmaf(g2, w[6 + c], fmaf(g1, w[3 + c], fmaf(g0, w[c], 0.0f)));
 }
 
 // saved: from launch_encoder_forward_train; out: its output (for lrelu7'); d_out[1024,64]; grads[14] in weight order;
@@ -293,8 +295,8 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, g[2], H, W, 64, 1);           // -> g of conv3
   conv_bwd<9>(g[2], s + L.y2, w[4], B, grads[4], grads[5], g[1], s + L.y2, H, W, 64, 64, st, s + L.x3, wt[2]);                     // conv3 -> g of conv2
   conv_bwd<9>(g[1], s + L.y1, w[2], B, grads[2], grads[3], g[0], nullptr, H, W, 3, 64, st);                                         // conv2 -> g of conv1 (no activation)
-  conv_bwd<1>(g[0], s + L.a0, w[0], B, grads[0], grads[1], d_img ? gb : nullptr, nullptr, H, W, 3, 3, st);                           // conv1 -> d a0
-  if (d_img) hipLaunchKernelGGL(enc_hwc_to_chw_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, st, gb, d_img, 3, n0);
+  conv_bwd<1>(g[0], s + L.a0, w[0], B, grads[0], grads[1], nullptr, nullptr, H, W, 3, 3, st);                                        // conv1: weight / bias gradient
+  if (d_img) hipLaunchKernelGGL(conv1_dgrad_chw_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, g[0], w[0], d_img, n0);            // its data gradient, NCHW
   if (int rc = wgrad_batch(specs, nspec, base + SL.ws, SL.ws_floats, st)) return rc;        // the seven weight / bias gradients: two launches
   return check_launch("encoder_backward");
 }
