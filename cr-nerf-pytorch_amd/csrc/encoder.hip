@@ -200,6 +200,21 @@ __global__ void enc_im2col_kernel(const float* __restrict__ in, float* __restric
   X[idx] = in[((long)reflect(py + tap / 3 - 1, H) * W + reflect(pxx + tap % 3 - 1, W)) * cin + c];
 }
 
+// The same patch matrix over MaxPool2d(2, 2)(in): the pooled map is never written -- every patch element takes the maximum of its 2 x 2 window
+// of the un-pooled [Hs, Ws] map (maxpool2_kernel's expression), H = Hs / 2, W = Ws / 2.  One launch instead of pool + im2col.
+__global__ void enc_im2col_pooled_kernel(const float* __restrict__ in, float* __restrict__ X, int Hs, int Ws, int cin) {
+  const int H = Hs / 2, W = Ws / 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)H * W * cin * 9;
+  if (idx >= n) return;
+  const int col = (int)(idx % (cin * 9)), c = col / 9, tap = col % 9;
+  const long px = idx / (cin * 9);
+  const int py = (int)(px / W), pxx = (int)(px % W);
+  const int y = reflect(py + tap / 3 - 1, H), x = reflect(pxx + tap % 3 - 1, W);
+  const float* p = in + ((long)(2 * y) * Ws + 2 * x) * cin + c;
+  X[idx] = fmaxf(fmaxf(p[0], p[cin]), fmaxf(p[(long)Ws * cin], p[(long)Ws * cin + cin]));
+}
+
 void enc_im2col(const float* in, float* X, int H, int W, int cin, hipStream_t st) {
   const long nx = (long)H * W * cin * 9;
   hipLaunchKernelGGL(enc_im2col_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, in, X, H, W, cin);
@@ -215,6 +230,14 @@ void enc_conv_gemm(int taps, const float* in, float* xcol, const float* w, const
   const float* X = in;
   if (taps == 9) { enc_im2col(in, xcol, H, W, cin, st); X = xcol; }
   enc_gemm_nt(true, X, cin * taps, w, cin * taps, b, out, cout, H * W, cout, cin * taps, st);
+}
+
+// 3x3 layer over MaxPool2d(2, 2)(in), in = the un-pooled [Hs, Ws, cin] map (enc_im2col_pooled_kernel)
+void enc_conv_gemm_pooled(const float* in, float* xcol, const float* w, const float* b, float* out, int Hs, int Ws, int cin, int cout, hipStream_t st) {
+  const int H = Hs / 2, W = Ws / 2;
+  const long nx = (long)H * W * cin * 9;
+  hipLaunchKernelGGL(enc_im2col_pooled_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, in, xcol, Hs, Ws, cin);
+  enc_gemm_nt(true, xcol, cin * 9, w, cin * 9, b, out, cout, H * W, cout, cin * 9, st);
 }
 
 // MaxPool2d(2,2), floor mode
@@ -313,13 +336,11 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
   enc_chw_conv1(img, wt[0], w[1], a, b, H * W, st);             // NCHW -> pixel-major + conv1
   conv<9, true>(b, wt[1], w[3], a, H, W, 3, 64, st);            // conv2 + relu2
   enc_conv_gemm(9, a, xc, w[4], w[5], b, H, W, 64, 64, st);     // conv3 + relu3 (fp32 MFMA GEMM over the patch matrix)
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * 64 + 255) / 256), dim3(256), 0, st, b, a, H, W, 64);
   const int H2 = H / 2, W2 = W / 2;
-  enc_conv_gemm(9, a, xc, w[6], w[7], b, H2, W2, 64, 128, st);  // conv4 + relu4
-  enc_conv_gemm(9, b, xc, w[8], w[9], a, H2, W2, 128, 128, st); // conv5 + relu5
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(((H2 / 2) * (W2 / 2) * 128 + 255) / 256), dim3(256), 0, st, a, b, H2, W2, 128);
+  enc_conv_gemm_pooled(b, xc, w[6], w[7], a, H, W, 64, 128, st);        // max-pool + conv4 + relu4 (the pooled map lives in the patch matrix only)
+  enc_conv_gemm(9, a, xc, w[8], w[9], b, H2, W2, 128, 128, st);         // conv5 + relu5
   const int H4 = H2 / 2, W4 = W2 / 2;
-  enc_conv_gemm(9, b, xc, w[10], w[11], a, H4, W4, 128, 128, st);   // conv6 + relu6
+  enc_conv_gemm_pooled(b, xc, w[10], w[11], a, H2, W2, 128, 128, st);   // max-pool + conv6 + relu6
   hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((32 * 32 * 128 + 255) / 256), dim3(256), 0, st, a, b, H4, W4, 128, 32);
   enc_conv_gemm(1, b, nullptr, w[12], w[13], out, 32, 32, 128, 64, st);   // conv7 + relu7
   return check_launch("encoder_forward");

@@ -16,6 +16,7 @@ void enc_conv(int taps, bool act, const float* in, const float* wt, const float*
 void enc_transpose_weights(const float* w, float* wt, int cout, int cin, int taps, hipStream_t st);
 void enc_transpose_weights_all(const float* const* w, float* const* wt, const int* cout, const int* cin, const int* taps, hipStream_t st);
 void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st);
+void enc_conv_gemm_pooled(const float* in, float* xcol, const float* w, const float* b, float* out, int Hs, int Ws, int cin, int cout, hipStream_t st);
 void enc_chw_conv1(const float* img, const float* wt, const float* b, float* a0, float* y1, int HW, hipStream_t st);
 void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st);
 void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st);
@@ -33,10 +34,10 @@ static EncLayout enc_layout(int H, int W) {
   EncLayout L;
   L.H = H; L.W = W; L.H2 = H / 2; L.W2 = W / 2; L.H4 = L.H2 / 2; L.W4 = L.W2 / 2;
   const size_t n0 = (size_t)H * W, n2 = (size_t)L.H2 * L.W2, n4 = (size_t)L.H4 * L.W4;
-  size_t o = 0;
+  size_t o = 0;                                       // (p3 / p5: the pooled maps are not materialised any more -- they live in x4 / x6 only)
   L.a0 = o; o += n0 * 3;   L.y1 = o; o += n0 * 3;   L.y2 = o; o += n0 * 64;  L.y3 = o; o += n0 * 64;
-  L.p3 = o; o += n2 * 64;  L.y4 = o; o += n2 * 128; L.y5 = o; o += n2 * 128;
-  L.p5 = o; o += n4 * 128; L.y6 = o; o += n4 * 128; L.p6 = o; o += (size_t)1024 * 128;
+  L.p3 = o;                L.y4 = o; o += n2 * 128; L.y5 = o; o += n2 * 128;
+  L.p5 = o;                L.y6 = o; o += n4 * 128; L.p6 = o; o += (size_t)1024 * 128;
   L.x3 = o; o += n0 * 576; L.x4 = o; o += n2 * 576; L.x5 = o; o += n2 * 1152; L.x6 = o; o += n4 * 1152;
   L.end = o;
   return L;
@@ -88,11 +89,9 @@ int launch_encoder_forward_train(const float* img, int H, int W, const float* co
   enc_conv(9, true, s + L.y1, wt[1], w[3], s + L.y2, H, W, 3, 64, st);
   // cin >= 64: fp32 MFMA GEMMs over the patch matrices (encoder.hip), which stay in `saved` for the weight gradients
   enc_conv_gemm(9, s + L.y2, s + L.x3, w[4], w[5], s + L.y3, H, W, 64, 64, st);
-  enc_maxpool2(s + L.y3, s + L.p3, H, W, 64, st);
-  enc_conv_gemm(9, s + L.p3, s + L.x4, w[6], w[7], s + L.y4, L.H2, L.W2, 64, 128, st);
+  enc_conv_gemm_pooled(s + L.y3, s + L.x4, w[6], w[7], s + L.y4, H, W, 64, 128, st);            // max-pool + conv4: the pooled map exists only inside x4
   enc_conv_gemm(9, s + L.y4, s + L.x5, w[8], w[9], s + L.y5, L.H2, L.W2, 128, 128, st);
-  enc_maxpool2(s + L.y5, s + L.p5, L.H2, L.W2, 128, st);
-  enc_conv_gemm(9, s + L.p5, s + L.x6, w[10], w[11], s + L.y6, L.H4, L.W4, 128, 128, st);
+  enc_conv_gemm_pooled(s + L.y5, s + L.x6, w[10], w[11], s + L.y6, L.H2, L.W2, 128, 128, st);   // max-pool + conv6
   enc_adaptive_avgpool(s + L.y6, s + L.p6, L.H4, L.W4, 128, 32, st);
   enc_conv_gemm(1, s + L.p6, nullptr, w[12], w[13], out, 32, 32, 128, 64, st);
   return check_launch("encoder_forward_train");
@@ -286,11 +285,11 @@ int launch_encoder_backward(int H, int W, const float* const* w, const void* sav
   hipLaunchKernelGGL(enc_act_grad_kernel, dim3((unsigned)((1024L * 64 + 255) / 256)), dim3(256), 0, st, d_out, out, g[6], 1024L * 64);
   conv_bwd<1>(g[6], s + L.p6, w[12], B, grads[12], grads[13], ga, nullptr, 32, 32, 128, 64, st, nullptr, wt[6]);                  // conv7 -> d p6
   hipLaunchKernelGGL(enc_avgpool_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, ga, g[5], L.H4, L.W4, 128, 32, s + L.y6);   // -> g of conv6
-  conv_bwd<9>(g[5], s + L.p5, w[10], B, grads[10], grads[11], ga, nullptr, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);             // conv6 -> d p5
+  conv_bwd<9>(g[5], nullptr, w[10], B, grads[10], grads[11], ga, nullptr, L.H4, L.W4, 128, 128, st, s + L.x6, wt[5]);             // conv6 -> d p5
   if ((L.H2 | L.W2) & 1) (void)hipMemsetAsync(g[4], 0, (size_t)n2 * 128 * sizeof(float), st);   // (an odd row / column lies in no pooling window)
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n4 * 128 + 255) / 256), dim3(256), 0, st, s + L.y5, ga, g[4], L.H2, L.W2, 128, 1);   // -> g of conv5
   conv_bwd<9>(g[4], s + L.y4, w[8], B, grads[8], grads[9], g[3], s + L.y4, L.H2, L.W2, 128, 128, st, s + L.x5, wt[4]);             // conv5 -> g of conv4
-  conv_bwd<9>(g[3], s + L.p3, w[6], B, grads[6], grads[7], gb, nullptr, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);                 // conv4 -> d p3
+  conv_bwd<9>(g[3], nullptr, w[6], B, grads[6], grads[7], gb, nullptr, L.H2, L.W2, 64, 128, st, s + L.x4, wt[3]);                 // conv4 -> d p3
   if ((H | W) & 1) (void)hipMemsetAsync(g[2], 0, (size_t)n0 * 64 * sizeof(float), st);
   hipLaunchKernelGGL(enc_maxpool2_bwd_kernel, dim3((n2 * 64 + 255) / 256), dim3(256), 0, st, s + L.y3, gb, g[2], H, W, 64, 1);           // -> g of conv3
   conv_bwd<9>(g[2], s + L.y2, w[4], B, grads[4], grads[5], g[1], s + L.y2, H, W, 64, 64, st, s + L.x3, wt[2]);                     // conv3 -> g of conv2
