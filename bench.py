@@ -766,37 +766,73 @@ def main():
         style = torch.rand(1024, 64, generator=torch.Generator().manual_seed(0)).to(dev).view(1, 32, 32, 64).permute(0, 3, 1, 2)
         z_steps, u_steps = torch.linspace(0, 1, NC, device=dev), torch.linspace(0, 1, NI, device=dev)  # rendering.py:160, :27
 
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        # event pairs around the render launch of every step (warm-up steps included: the warm-up runs the IDENTICAL host path, so the
+        # first hipEventCreate / hipEventRecord, their code pages and torch's lazy event pool are paid before the timed region -- on a
+        # cold box the round-4 line lost 11 ms = 0.56 ms per step to exactly that), one more event at the end of every
+        # step, and a host stamp after every enqueue: the line carries the per-step device and host times it was computed from
+        n_ev = a.warmup + a.steps
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        host_stamp = [0.0] * n_ev
 
-        def step(i=None):
-            if i is not None:
+        r4_warmup = os.environ.get("CRNERF_BENCH_R4_WARMUP") == "1"   # diagnosis only: warm-up steps record no events, as bench.py did up to round 4
+
+        def step(i):
+            quiet = r4_warmup and i < a.warmup
+            if not quiet:
                 ev[i][0].record()
             out = ops.render_rays(pc, pf, rays, NC, NI, z_steps=z_steps, u=u_steps, precision=a.precision)
-            if i is not None:
+            if not quiet:
                 ev[i][1].record()
             feat = out["feature_fine"]
             if use_dist:
-                return decode_sharded(net, feat, style, gather=True, equal_shards=True, exchange=exchange, check_exchange=False)   # checked once after the timed region
-            return net(feat.t().reshape(1, 64, *grid_hw), style)
+                rgb = decode_sharded(net, feat, style, gather=True, equal_shards=True, exchange=exchange, check_exchange=False)   # checked once after the timed region
+            else:
+                rgb = net(feat.t().reshape(1, 64, *grid_hw), style)
+            if not quiet:
+                ev[i][2].record()
+            host_stamp[i] = time.perf_counter()
+            return rgb
 
         def fence():
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(a.warmup):
-            last_rgb = step()
+        import gc
+        for i in range(a.warmup):
+            last_rgb = step(i)
+        gc.collect()
+        gc.disable()        # a generation-2 collection of torch's heap is a ~10 ms host pause: exposed if it lands on the first steps, before work is queued
         fence()
         t0 = time.perf_counter()
-        for i in range(a.steps):
+        for i in range(a.warmup, n_ev):
             last_rgb = step(i)
+        t_enq = time.perf_counter()
         fence()
         dt = time.perf_counter() - t0
+        gc.enable()
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+        tev = ev[a.warmup:]
+        kern_each = [s.elapsed_time(e) for s, e, _ in tev]
+        step_each = [s.elapsed_time(d) for s, _, d in tev]                      # render launch .. end of the decode, on the device
+        gap_each = [tev[i][2].elapsed_time(tev[i + 1][0]) for i in range(len(tev) - 1)]   # device idle between two steps (host-starved if > ~0.01)
+        hs = [t0] + host_stamp[a.warmup:]
+        host_each = [(hs[i + 1] - hs[i]) * 1e3 for i in range(len(hs) - 1)]    # host time to enqueue one step
+
+        def _stats(v):
+            v2 = sorted(v)
+            return {"min": v2[0], "median": v2[len(v2) // 2], "max": v2[-1]} if v2 else None
+        timing = {"step_ms_each": [round(x, 4) for x in step_each], "kernel_ms_each": [round(x, 4) for x in kern_each],
+                  "device_gap_ms_each": [round(x, 4) for x in gap_each], "host_enqueue_ms_each": [round(x, 4) for x in host_each],
+                  "step_ms": _stats(step_each), "kernel_ms": _stats(kern_each), "device_gap_ms": _stats(gap_each), "host_enqueue_ms": _stats(host_each),
+                  "host_enqueue_total_ms": (t_enq - t0) * 1e3, "wall_ms": dt * 1e3, "device_span_ms": tev[0][0].elapsed_time(tev[-1][2]),
+                  "note": "HIP events on the launch stream (render start / render end / decode end of every timed step) and perf_counter stamps after "
+                          "every enqueue; wall_ms = the contract's barrier-to-barrier time; wall_ms - device_span_ms = launch latency of the first "
+                          "step + the final synchronize"}
+        kern_ms = sum(kern_each) / a.steps
         rgb_sums = None
         if use_dist and test_backend:      # test hook only: every rank must hold the same gathered image
             mine = torch.tensor([float(last_rgb.double().sum()), float(last_rgb.shape[-1])], dtype=torch.float64, device=dev)
@@ -841,6 +877,7 @@ def main():
                          "traffic_source": (None if traffic is None else "profiles/render_rays_hbm_bytes.json: a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                                           "pass over this command (profiles/README.md), not measured in this run"),
                          "kernel_ms": kern_ms, "flops_per_launch": flops},
+            "timing": timing,
         }
         if world == 1 and not a.no_cpu_baseline:
             # untimed legs; the headline line above must be printed whatever happens in them
@@ -851,6 +888,7 @@ def main():
             try:
                 line["parity"], line["extra"] = evidence(a, dev, rays, rays_np, st_c, st_f, grid_hw, style, z_steps, u_steps, Args)
 
+                line["extra"]["step_ms_each"], line["extra"]["host_enqueue_ms_each"] = timing["step_ms_each"], timing["host_enqueue_ms_each"]
                 for kx in ("f32x3_kernel", "f32h2_kernel"):
                     if not bf16 and kx in line["extra"]:
                         line["extra"][kx]["speedup_vs_fp32_mfma_kernel"] = kern_ms / line["extra"][kx]["kernel_ms"]

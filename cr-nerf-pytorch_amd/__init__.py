@@ -28,7 +28,12 @@ def set_precision(precision):
     the h2 core's making reaches the caller (include/crnerf.h "auto"), or "bf16_hc": bf16 with an fp32-accurate COARSE pass ("auto" arithmetic on the
     coarse network's 25 % of the points, the fine network on the bf16 matrix cores: the fine depths then follow the fp32 reference;
     models/rendering.py::_render_bf16_accurate_coarse).  A `precision=` keyword to render_rays_cross_ray / batched_inference /
-    NeRF_sigma.forward overrides it per call.  Training (grad mode) always runs fp32."""
+    NeRF_sigma.forward overrides it per call.
+    Training (grad mode) does not read this setting: its default is "auto" for the forward and the data gradient (fp32-accurate two-piece fp16
+    splits on the fp16 matrix cores, f32x3 where the h2 core refuses) and bf16x3 for the weight gradients (three-piece bf16 splits) -- every
+    product fp32-ACCURATE (float64 distance of the fp32 MFMA), none bit-for-bit the reference's fp32 arithmetic.  Opt out with
+    autograd.set_training_forward_precision("f32") / CRNERF_TRAIN_FWD=f32 and autograd.set_wgrad_precision("f32") / CRNERF_WGRAD_F32=1
+    (every product on the fp32 matrix cores); autograd.set_training_precision("bf16") is the opt-in mixed-precision mode."""
     global _precision
     from .ops import _is_auto, _is_bf16, _is_h2, _is_x3
     _precision = "bf16_hc" if precision in ("bf16_hc", "bf16+h2c") else "auto" if _is_auto(precision) else "f32h2" if _is_h2(precision) else ("f32x3" if _is_x3(precision) else ("bf16" if _is_bf16(precision) else "f32"))

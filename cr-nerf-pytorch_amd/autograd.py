@@ -452,7 +452,7 @@ class CompositeFn(torch.autograd.Function):
 # engine None for the parameters, keeps the gradients, and ONE callback at the end of the backward pass sums them with multi-tensor adds and
 # writes / accumulates .grad.  Not for torch.autograd.grad() callers, parameter hooks or DDP's reducer: those need AccumulateGrad to run.
 _DEFER_ON = [False]
-_DEFERRED = {"pending": {}, "scheduled": False}
+_DEFERRED = {"pending": {}, "task": None}       # "task": id of the backward pass (graph task) whose end-of-pass callback is queued
 
 
 class deferred_param_grads:
@@ -463,23 +463,37 @@ class deferred_param_grads:
 
     def __enter__(self):
         self.prev, _DEFER_ON[0] = _DEFER_ON[0], self.on
+        if self.on and torch._C._current_graph_task_id() < 0:
+            reset_deferred()                 # a forward is starting and no backward is running: whatever is pending belongs to a backward that died
 
     def __exit__(self, *exc):
         _DEFER_ON[0] = self.prev
 
 
+def reset_deferred():
+    """Drop gradients a backward pass left behind when it raised before its end-of-pass callback ran (the engine discards the callback with the
+    failed pass).  Nothing of the failed pass reaches .grad -- what torch does with a node that raised."""
+    _DEFERRED["pending"], _DEFERRED["task"] = {}, None
+
+
 def _defer(params, grads):
+    # The callback belongs to ONE backward pass: the engine drops it when a later node of that pass raises (HIP error, OOM, KeyboardInterrupt).  The
+    # queued state is therefore keyed to the graph task's id, not kept as a sticky flag: a new pass finds another id, discards what the dead pass
+    # left (its gradients must not leak into this one's) and queues its own callback.
+    task = torch._C._current_graph_task_id()
+    if _DEFERRED["task"] != task:
+        _DEFERRED["pending"], _DEFERRED["task"] = {}, task
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
     pend = _DEFERRED["pending"]
     for p, g in zip(params, grads):
         pend.setdefault(id(p), (p, []))[1].append(g)
-    if not _DEFERRED["scheduled"]:
-        _DEFERRED["scheduled"] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
 
 
 def _flush_deferred():
     pend = _DEFERRED["pending"]
-    _DEFERRED["pending"], _DEFERRED["scheduled"] = {}, False
+    _DEFERRED["pending"], _DEFERRED["task"] = {}, None
+    if not pend:
+        return
     with torch.no_grad():
         total = {pid: gs[0] for pid, (_, gs) in pend.items()}
         for k in range(1, max(len(gs) for _, gs in pend.values())):       # use k + 1 of every parameter that has one: one multi-tensor add
@@ -497,9 +511,9 @@ def _leaf_of(t):
     """The Parameter a tensor handed to a node stands for: itself, or the leaf it is a same-size view of (conv weights travel as [cout, cin] views
     of their [cout, cin, 1, 1] parameters); None: anything else keeps going through the engine."""
     if t.is_leaf:
-        return t
+        return t if t.requires_grad else None          # a frozen Parameter is a leaf too: AccumulateGrad never gives it a .grad, neither may the deferral
     base = t._base if t._is_view() else None
-    return base if (base is not None and base.is_leaf and base.numel() == t.numel() and base.is_contiguous() and t.is_contiguous()) else None
+    return base if (base is not None and base.is_leaf and base.requires_grad and base.numel() == t.numel() and base.is_contiguous() and t.is_contiguous()) else None
 
 
 def _param_grads(ctx, params, grads):

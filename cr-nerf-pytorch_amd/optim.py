@@ -9,7 +9,8 @@ buffers that share offsets -- `p.data` becomes a view, nothing else about the mo
 
 Same update as `torch.optim.Adam` (amsgrad / maximize / capturable off): tests/test_gpu_optim.py steps both on the same
 gradients.  A parameter whose `.grad` is None is skipped; its step count is the group's (torch keeps one per parameter --
-they only differ for a parameter that misses steps, which no module of this pipeline does).
+they only differ for a parameter that misses steps, which no module of this pipeline does; `load_state_dict` therefore REFUSES an
+optimiser state whose parameters of one group hold different step counts instead of resuming it with the wrong bias correction).
 """
 import ctypes
 import math
@@ -47,6 +48,8 @@ class _FlatGroup:
         for p in params:
             if not p.is_cuda or p.dtype != torch.float32 or p.device != dev:
                 raise TypeError("crnerf_amd.FlatAdam: parameters must be fp32 tensors of one GPU (got %s on %s); there is no CPU path" % (p.dtype, p.device))
+        if len({id(p) for p in params}) != len(params):
+            raise ValueError("crnerf_amd.FlatAdam: a parameter appears more than once in a group (torch.optim.Optimizer warns about the same)")
         self.params = list(params)
         self.offsets, total = [], 0
         for p in params:
@@ -126,6 +129,9 @@ class FlatAdam(torch.optim.Optimizer):
                 loss = closure()
         lib, stream = _lib.load(), _lib.stream_ptr()
         for group, fg in zip(self.param_groups, self._groups):
+            if fg.flat.device.index != torch.cuda.current_device():      # stream_ptr() is the CURRENT device's stream
+                raise RuntimeError("crnerf_amd.FlatAdam: the parameters live on %s but the current device is cuda:%d; step() enqueues on the "
+                                   "current device's stream -- wrap the call in torch.cuda.device(...)" % (fg.flat.device, torch.cuda.current_device()))
             fg.t += 1
             beta1, beta2 = group["betas"]
             step_size = group["lr"] / (1.0 - beta1 ** fg.t)

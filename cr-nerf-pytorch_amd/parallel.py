@@ -167,7 +167,7 @@ class _HipKernels:
 
 
 def decode_sharded(net, feature_local, style_feature, group=None, gather=True, kernels=None, equal_shards=False, exchange=None,
-                   check_exchange=16):
+                   check_exchange=True):
     """Cross-ray decode of a ray-sharded feature grid.
 
     net: style_net; feature_local: this rank's [R_local,64] block of feature_fine (pixel-major, rank
@@ -180,9 +180,10 @@ def decode_sharded(net, feature_local, style_feature, group=None, gather=True, k
     all-reduce(64 floats) -> Gram of the centred conv chain -> all-reduce(1024 floats) -> fc / fold /
     apply on the local pixels -> all-gather of RGB.  exchange: a PeerExchange built on the same group carries the two
     reductions instead of RCCL (default None = RCCL).  check_exchange: with a PeerExchange, exchange.check() -- one device
-    synchronisation; a peer that timed out raises there instead of leaving the exchange out of step -- True: after every call;
-    an int n (default 16): after the first and then every n-th call on that exchange (a timed-out reduction hands back NaN images
-    until then); False: never, the caller checks where it synchronises anyway."""
+    synchronisation; a peer that timed out raises there instead of leaving the exchange out of step -- True (default): after every
+    call; an int n: after the first and then every n-th call on that exchange (a timed-out reduction hands back NaN images until then --
+    for latency-critical inference loops only, never where the image feeds a loss); False: never, the caller checks where it
+    synchronises anyway."""
     k = kernels or _HipKernels()
     dev = feature_local.device
     n_local = feature_local.shape[0]

@@ -144,7 +144,20 @@ class TrainingSystem:
         # the modules a step calls several times (enc_a x3, decoder x3, enc_cont x2) sum their parameter gradients in ONE multi-tensor add at the
         # end of backward instead of one AccumulateGrad add per tensor and use (autograd.deferred_param_grads).  Off where torch DDP may be
         # listening on AccumulateGrad (a process group exists and this system does not shard rays itself); set the attribute to override.
-        self.fused_grad_accumulation = (ray_parallel_group is not False) or not (torch.distributed.is_available() and torch.distributed.is_initialized())
+        # Decided at every training_step (a process group created, or the modules wrapped in DDP, AFTER this constructor must still
+        # switch it off); assign True / False to `fused_grad_accumulation` to override.
+        self._ray_parallel_requested = ray_parallel_group is not False
+        self._fused_grad_override = None
+
+    @property
+    def fused_grad_accumulation(self):
+        if self._fused_grad_override is not None:
+            return self._fused_grad_override
+        return self._ray_parallel_requested or not (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+    @fused_grad_accumulation.setter
+    def fused_grad_accumulation(self, on):
+        self._fused_grad_override = None if on is None else bool(on)
 
     def parameters(self):
         return [p for m in self.models_to_train for p in m.parameters()]

@@ -304,3 +304,75 @@ def test_get_scheduler_mirrors_the_reference_factory():
     hp.lr_scheduler, hp.warmup_epochs = "cosine", 2
     with pytest.raises(NotImplementedError, match="GradualWarmupScheduler"):
         optim.get_scheduler(hp, opt)
+
+
+class _DeferringNode(torch.autograd.Function):
+    """A multi-use node in the style of autograd.DecoderFn, on CPU: hands its parameter gradient to the deferral."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from crnerf_amd import autograd as AG
+        ctx.save_for_backward(x, w)
+        ctx.defer, ctx.leaves = AG._DEFER_ON[0], ([AG._leaf_of(w)] if AG._DEFER_ON[0] else None)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        from crnerf_amd import autograd as AG
+        x, w = ctx.saved_tensors
+        return (g * w,) + AG._param_grads(ctx, [w], [g * x])
+
+
+class _RaisingNode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError("HIP error stand-in")
+
+
+def test_deferred_gradients_survive_a_backward_that_raised():
+    """the engine drops the end-of-pass callback of a backward that raises; the next healthy backward must still deliver .grad,
+    and nothing of the dead pass may leak into it."""
+    from crnerf_amd import autograd as AG
+    w = torch.nn.Parameter(torch.full((3,), 2.0))
+    x = torch.arange(3.0, requires_grad=True)
+    with AG.deferred_param_grads(True):
+        y = _DeferringNode.apply(_RaisingNode.apply(x), w)     # backward: the deferring node runs first, then the raising one
+    with pytest.raises(RuntimeError, match="stand-in"):
+        y.sum().backward()
+    assert w.grad is None
+    for _ in range(2):                                         # with and without re-entering the context in between
+        y = None
+        with AG.deferred_param_grads(True):
+            y = _DeferringNode.apply(x, w)
+        w.grad = None
+        y.sum().backward()
+        assert torch.equal(w.grad, torch.arange(3.0))          # this pass's gradient only
+        assert not AG._DEFERRED["pending"] and AG._DEFERRED["task"] is None
+    # a node built before the failure, run again without re-entering the context (retain_graph): the stale state is keyed to the dead pass
+    with AG.deferred_param_grads(True):
+        y = _DeferringNode.apply(_RaisingNode.apply(x), w)
+        y2 = _DeferringNode.apply(x, w)
+    with pytest.raises(RuntimeError):
+        y.sum().backward()
+    w.grad = None
+    y2.sum().backward()
+    assert torch.equal(w.grad, torch.arange(3.0))
+
+
+def test_deferred_gradients_leave_frozen_parameters_alone():
+    """a frozen Parameter is a leaf; AccumulateGrad never gives it a .grad and neither may the deferral (FlatAdam would train it)."""
+    from crnerf_amd import autograd as AG
+    frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+    conv = torch.nn.Parameter(torch.ones(3, 1, 1, 1), requires_grad=False)
+    assert AG._leaf_of(frozen) is None and AG._leaf_of(conv.view(3, 1)) is None
+    x = torch.arange(3.0, requires_grad=True)
+    with AG.deferred_param_grads(True):
+        y = _DeferringNode.apply(x, frozen)
+    y.sum().backward()
+    assert frozen.grad is None and torch.equal(x.grad, torch.ones(3))
+    live = torch.nn.Parameter(torch.ones(3, 1, 1, 1))
+    assert AG._leaf_of(live) is live and AG._leaf_of(live.view(3, 1)) is live
