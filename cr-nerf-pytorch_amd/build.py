@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrnerf_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-SOURCES = ["abi.hip", "pack.hip", "mlp_forward.hip", "mlp_forward16.hip", "render_fused.hip", "render_fused16.hip", "mlp_forward_bf16.hip", "mlp_forward_bf16p.hip", "mlp_forward_x3.hip", "mlp_forward_h2.hip", "render_fused_h2.hip", "mlp_backward_x3.hip", "mlp_backward_h2.hip", "render_fused_bf16.hip", "render_fused_bf16p.hip", "render_fused_x3.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip", "cgnet_chain.hip",
+SOURCES = ["abi.hip", "pack.hip", "mlp_forward16.hip", "render_fused16.hip", "mlp_forward_bf16p.hip", "mlp_forward_x3.hip", "mlp_forward_h2.hip", "render_fused_h2.hip", "mlp_backward_x3.hip", "mlp_backward_h2.hip", "render_fused_bf16p.hip", "render_fused_x3.hip", "mlp_train16.hip", "mlp_gemm_bf16.hip", "train_aux.hip", "ray_kernels.hip", "raygen.hip", "encoder.hip", "encoder_train.hip", "cgnet.hip", "cgnet_chain.hip",
            "crossray.hip", "peer_xchg.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/crnerf.h"]   # every header: any edit rebuilds
 # -ffp-contract=off: the reference evaluates o + d*z, near*(1-s) + far*s, ... as separate mul/add;
@@ -24,11 +24,12 @@ FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 
 # -fno-slp-vectorize (bf16 units): hipcc otherwise packs the epilogue's scalar adds into v_pk_add_f32 bundles placed
 # at the END of a layer -- the hand-interleaved epilogue collapses into a serial VALU burst behind the MFMAs.
-PER_FILE_FLAGS = {"mlp_forward_bf16.hip": ["-fno-slp-vectorize"], "render_fused_bf16.hip": ["-fno-slp-vectorize"],
-                  # pragma-unroll-threshold: the tile loop of the 22-k-step layer is "too large" for `#pragma unroll` at the default 16k,
+PER_FILE_FLAGS = {# pragma-unroll-threshold: the tile loop of the 22-k-step layer is "too large" for `#pragma unroll` at the default 16k,
                   # and every ring constant of the pair core depends on full unrolling
                   "render_fused_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
-                  "mlp_forward_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+                  "mlp_forward_bf16p.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
+                  # the unit tools/isa_audit.py flags for SGPR spill reloads in front of its LDS-DMA statements (csrc/mlp_core.h "HAZARD")
+                  "mlp_forward_h2.hip": ["-DCRNERF_GLDS_SALU_COPY"]}
 for _kv in os.environ.get("CRNERF_EXTRA_FILE_FLAGS", "").split(";"):      # tuning builds only: "mlp_train16.hip=-fno-slp-vectorize -DX;other.hip=..."
     if "=" in _kv:
         PER_FILE_FLAGS.setdefault(_kv.split("=", 1)[0].strip(), []).extend(_kv.split("=", 1)[1].split())

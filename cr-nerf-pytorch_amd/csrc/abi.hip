@@ -73,13 +73,6 @@ int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
 
 using namespace crnerf;
 
-// Tuning switch (not part of the ABI): CRNERF_CORE=32 selects the one-wave-per-SIMD 32x32x2 core,
-// anything else the two-waves-per-SIMD 16x16x4 core.  Packed buffers are core-specific.
-static const bool g_core16 = [] {
-  const char* e = getenv("CRNERF_CORE");
-  return !(e && strcmp(e, "32") == 0);
-}();
-
 #define REQUIRE(p, name) \
   if (!(p)) return set_error(CRNERF_ERR_NULL, name " is NULL")
 
@@ -101,7 +94,7 @@ int crnerf_pack_mlp_weights(const float* const* tensors, void* packed, void* str
   t.w_sigma = tensors[18]; t.b_sigma = tensors[19];
   t.w_dir = tensors[20]; t.b_dir = tensors[21];
   t.w_rgb = tensors[22]; t.b_rgb = tensors[23];
-  return launch_pack_mlp(t, packed, g_core16 ? 1 : 0, (hipStream_t)stream);
+  return launch_pack_mlp(t, packed, (hipStream_t)stream);
 }
 
 static MlpTensors to_tensors(const float* const* tensors) {
@@ -128,7 +121,6 @@ int crnerf_pack_mlp_weights_t(const float* const* tensors, void* packed_t, void*
 int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out, void* acts, int64_t n, void* stream) {
   if (n == 0) return 0;
   REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(acts, "acts");
-  if (!g_core16) return set_error(CRNERF_ERR_CONFIG, "training kernels exist for the 16x16x4 core only (unset CRNERF_CORE)");
   return launch_mlp_forward_train(packed, x, out, (float*)acts, (long)n, (hipStream_t)stream);
 }
 
@@ -170,8 +162,7 @@ int crnerf_mlp_forward_f32(const void* packed, const float* x, float* out, int64
   REQUIRE(x, "x");
   REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward: negative n");
-  return g_core16 ? launch_mlp_forward16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream)
-                  : launch_mlp_forward(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  return launch_mlp_forward16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
 int crnerf_composite_f32(const float* raw, const float* z, const float* noise, float noise_std, float* weights, float* feature,
@@ -219,26 +210,20 @@ static int render_rays_common(const crnerf_render_args* a, void* stream, bool bf
   r.train_acts_coarse = acts_c; r.train_acts_fine = acts_f; r.train_raw_coarse = raw_c; r.train_raw_fine = raw_f;
   if (a->rng_flags) {
     if (a->rng_flags & ~(CRNERF_RNG_JITTER | CRNERF_RNG_U | CRNERF_RNG_NOISE)) return set_error(CRNERF_ERR_CONFIG, "render_rays: unknown rng_flags bits");
-    if (bf16 || !(x3 || acts_c || g_core16)) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32 16x16x4, f32x3 and f32h2 kernels only");
+    if (bf16) return set_error(CRNERF_ERR_CONFIG, "render_rays: in-kernel random draws exist in the fp32, f32x3 and f32h2 kernels only");
     if ((a->rng_flags & CRNERF_RNG_JITTER) && a->z_coarse) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_JITTER and z_coarse are exclusive");
     if ((a->rng_flags & CRNERF_RNG_U) && a->u) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_U and u are exclusive");
     if ((a->rng_flags & CRNERF_RNG_NOISE) && (a->noise_coarse || a->noise_fine)) return set_error(CRNERF_ERR_CONFIG, "render_rays: CRNERF_RNG_NOISE and noise_* are exclusive");
     r.rng_seed = a->rng_seed; r.rng_ray_offset = (long)a->rng_ray_offset; r.rng_flags = a->rng_flags; r.perturb = a->perturb;
   }
-  if ((a->z_coarse_out || a->noise_coarse_out || a->noise_fine_out) && (bf16 || !(x3 || acts_c || g_core16)))   // (the bf16 kernels and the round-1 32x32x2 core do not write them)
-    return set_error(CRNERF_ERR_CONFIG, "render_rays: z_coarse_out / noise_*_out are written by the fp32 16x16x4, f32x3 and f32h2 kernels only");
+  if ((a->z_coarse_out || a->noise_coarse_out || a->noise_fine_out) && bf16)   // (the bf16 kernels do not write them)
+    return set_error(CRNERF_ERR_CONFIG, "render_rays: z_coarse_out / noise_*_out are written by the fp32, f32x3 and f32h2 kernels only");
   r.z_coarse_out = a->z_coarse_out; r.noise_coarse_out = a->noise_coarse_out; r.noise_fine_out = a->noise_fine_out;
   if (x3 == 2) return launch_render_rays_h2(r, (hipStream_t)stream);
   if (x3 == 3) r.repair = 1;
   if (x3) return launch_render_rays_x3(r, (hipStream_t)stream);
-  if (bf16) {
-    // the pair core is the product path; CRNERF_BF16_CORE=64 keeps the round-1/2 one-wave-per-SIMD kernel reachable for A/B runs
-    static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();
-    if (acts_c) return launch_render_rays_bf16p(r, (hipStream_t)stream);   // the bf16 training twin exists on the pair core only
-    return core64 ? launch_render_rays_bf16(r, (hipStream_t)stream) : launch_render_rays_bf16p(r, (hipStream_t)stream);
-  }
-  if (acts_c) return launch_render_rays16(r, (hipStream_t)stream);       // the training twin exists on the 16x16x4 core only
-  return g_core16 ? launch_render_rays16(r, (hipStream_t)stream) : launch_render_rays(r, (hipStream_t)stream);
+  if (bf16) return launch_render_rays_bf16p(r, (hipStream_t)stream);   // inference and (acts_c) the mixed-precision training twin
+  return launch_render_rays16(r, (hipStream_t)stream);                 // inference and (acts_c) the fp32 training twin
 }
 
 int crnerf_render_rays_f32(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, false); }
@@ -446,9 +431,7 @@ int crnerf_mlp_forward_bf16(const void* packed, const float* x, float* out, int6
   if (n == 0) return 0;
   REQUIRE(packed, "packed"); REQUIRE(x, "x"); REQUIRE(out, "out");
   if (n < 0) return set_error(CRNERF_ERR_SHAPE, "mlp_forward_bf16: negative n");
-  static const bool core64 = [] { const char* e = getenv("CRNERF_BF16_CORE"); return e && atoi(e) == 64; }();   // the round-1/2 kernel, for A/B runs
-  return core64 ? launch_mlp_forward_bf16(packed, x, out, (long)n, sigma_only, (hipStream_t)stream)
-                : launch_mlp_forward_bf16p(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
+  return launch_mlp_forward_bf16p(packed, x, out, (long)n, sigma_only, (hipStream_t)stream);
 }
 
 size_t crnerf_encoder_workspace_bytes(int H, int W) { return encoder_workspace_bytes(H, W); }

@@ -30,7 +30,7 @@ struct MlpTensors {  // device pointers to the 24 tensors of one NeRF_sigma (mod
   const float* w_rgb;   const float* b_rgb;    // static_rgb.0
 };
 
-int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream);
+int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream);
 size_t mlp_train_acts_bytes(long P);
 size_t mlp_train_scratch_bytes(long P);
@@ -67,7 +67,6 @@ size_t wgrad_batch_ws_floats(const WgradSpec* specs, int n);       // partial-su
 int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipStream_t st);
 int launch_posenc(const float* x, float* out, long n, int n_freqs, hipStream_t stream);
 int launch_embed_points(const float* rays, const float* z, const float* dir_emb, float* x, long R, int N, hipStream_t stream);
-int launch_mlp_forward(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_composite(const float* raw, const float* z, const float* noise, float noise_std, float* weights,
                      float* feature, float* depth, long R, int N, hipStream_t stream);
 int launch_composite_backward(const float* raw, const float* z, const float* noise, float noise_std, const float* d_feature,
@@ -113,7 +112,6 @@ struct RenderArgs {
   float* train_raw_coarse = nullptr;   // [R*Nc,65]
   float* train_raw_fine = nullptr;     // [R*(Nc+Ni),65]
 };
-int launch_render_rays(const RenderArgs& a, hipStream_t stream);
 int launch_render_rays16(const RenderArgs& a, hipStream_t stream);
 int launch_mlp_forward16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);
 int launch_pack_mlp_bf16(const MlpTensors& t, void* packed, hipStream_t stream);
@@ -132,9 +130,7 @@ int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d
 // only_if: device word; the kernel leaves at once when it is 0 (the f32x3 stand-in of an h2 data gradient whose pack was refused); null: always
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream, const int* only_if = nullptr);
-int launch_mlp_forward_bf16(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);    // round-1/2 core (CRNERF_BF16_CORE=64)
 int launch_mlp_forward_bf16p(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream);   // pair core: the module entry
-int launch_render_rays_bf16(const RenderArgs& a, hipStream_t stream);    // one ray per wave, 64-point tiles, one wave per SIMD (render_fused_bf16.hip)
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream);
 int launch_rng_fill(float* out, long R, int n, unsigned long long seed, int stream_id, long ray_offset, hipStream_t stream);   // one ray per wave PAIR, 32-point tiles, two waves per SIMD (render_fused_bf16p.hip)
 

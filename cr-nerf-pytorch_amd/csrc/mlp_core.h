@@ -1,20 +1,7 @@
-// NeRF_sigma forward for one 32-point tile per wavefront, fp32 MFMA, activations register-resident.
-//
-// Reference semantics: NeRF_sigma.forward, models/nerf.py:157-182 (8x256 trunk with a skip at
-// layer 5, softplus sigma head, 256->256 linear, dir layer 283->128 relu, 128->64 sigmoid).
-//
-// MI355X design (not a translation of the reference's eager addmm chain):
-//   * swapped-operand GEMM: D[feature][point] = W[feature][k] * act[k][point] with
-//     v_mfma_f32_32x32x2_f32.  Lane (p = lane&31, h = lane>>5) owns point p; the C/D layout leaves
-//     it holding features 32t + 8q + 4h + j (reg 4q+j of tile t), which is exactly the set of
-//     k-values it must supply as the B operand of the next layer -- so a 32-point tile's
-//     activations NEVER leave the register file across the 11 layers (no LDS round trip, no HBM).
-//   * the A operand (weights) is shared by the 4 waves of a workgroup (one wave per SIMD) and is
-//     streamed HBM/L2 -> LDS in 16 KiB stages with global_load_lds (direct-to-LDS DMA) through a
-//     ring of RING_SLOTS stages, PF_DIST stages ahead; fragments are pre-packed (layout.h) so a
-//     wave's ds_read_b128 is lane-linear and bank-conflict-free.
-//   * one s_barrier per 64 MFMAs (4096 MFMA cycles); the barrier for stage s also certifies that
-//     stage s+1 has landed, so reads may run ahead of the next barrier.
+// What every MLP core shares: vector typedefs, the LDS map (two consts blocks, the weight ring, scratch), the phase timer of
+// -DCRNERF_TIMING builds, the LDS-DMA instruction as asm, the reference's softplus / sigmoid, the consts loader.
+// (Rounds 1-4 kept the first core here as well -- one wave per SIMD on v_mfma_f32_32x32x2_f32, CRNERF_CORE=32; removed in round 5:
+// the product cores are mlp_core16.h (fp32 MFMA), mlp_core_bf16p.h, mlp_core_x3.h, mlp_core_h2.h / mlp_core_h2t.h.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "layout.h"
@@ -72,120 +59,44 @@ struct PhaseTimer {
 };
 #endif
 
-#define CRNERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
 // One LDS-DMA piece: lanes copy 16 B each, global (base + voff + imm) -> LDS (lds_addr + imm + 16 * lane).  Written as
 // asm on purpose: with the builtin, hipcc's waitcnt model stops counting LDS reads across an LDS-DMA instruction and
 // the next use of ANY prefetched fragment becomes s_waitcnt lgkmcnt(0) -- the read-ahead ring is drained every fourth
 // k-step.  (vmcnt for these loads is counted by hand in start()/advance() anyway.)  The asm rewrites M0 without telling
 // the compiler (M0 is a reserved register, clang rejects it as a clobber): kernels that contain it must not index
 // register arrays dynamically (s_set_gpr_idx / v_movrel keep their index in M0) -- checked by grepping the ISA.
+//
+// HAZARD (round 5, tools/isa_audit.py "vsgpr->vmem"): `base` is an SGPR pair the compiler owns.  Under SGPR pressure hipcc parks such pointers in VGPR
+// lanes and restores them with v_readlane right in front of the statement -- and a VALU-written SGPR must not be read by a VMEM instruction for 5 wait
+// states (CDNA3 ISA 4.5; hipcc pads its own VMEM, it cannot see the one in here).  mlp_forward_h2_kernel had 2 states in the round-4 build.  Two forms:
+//   default          the base is used as it comes.  Correct as long as the audit finds no such reload in the unit's ISA -- tests/test_host.py runs it
+//                    over every unit on every build, so a build that has one does not pass.
+//   CRNERF_GLDS_SALU_COPY (per unit, build.py PER_FILE_FLAGS)   the base goes through an SALU copy inside the statement: an SALU read of a VALU-written
+//                    SGPR is interlocked, and so is the VMEM read of the SALU's result.  Safe whatever the compiler does -- at a price: the
+//                    interlock stalls the wave's issue, +7.5 % on the f32x3 renderer, +8.6 % on f32h2 (one wave per SIMD: nothing hides it;
+//                    profiles/r5/glds_salu_copy_cost.txt).  Switched on for the units the audit flags (today: mlp_forward_h2.hip).
 __device__ __forceinline__ void glds16(uint32_t lds_addr, const char* base, uint32_t voff, int imm) {
-#ifdef CRNERF_EXP_GLOADONLY   // (timing experiments only; garbage) the same VMEM request into a dummy register: issue + L2 traffic, no LDS write
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  u4 dummy;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dummy) : "v"(voff), "s"(base), "n"(imm) : "memory");
-  return;
-#endif
+#ifdef CRNERF_GLDS_SALU_COPY
+  uint64_t b;
+  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %3\n\tglobal_load_lds_dwordx4 %2, %0 offset:%4"
+               : "=&s"(b) : "s"(lds_addr), "v"(voff), "s"(base), "n"(imm) : "memory");
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(voff), "s"(base), "n"(imm)
                : "memory");
+#endif
+}
+// A further piece of the same stage: M0 as the last glds16 left it (nothing else in these kernels touches M0, tests/test_host.py), the
+// instruction offset applies to both sides.
+__device__ __forceinline__ void glds16_more(const char* base, uint32_t voff, int imm) {
+#ifdef CRNERF_GLDS_SALU_COPY
+  uint64_t b;
+  asm volatile("s_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0 offset:%3" : "=&s"(b) : "v"(voff), "s"(base), "n"(imm) : "memory");
+#else
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(base), "n"(imm) : "memory");
+#endif
 }
 
-
-// Streams packed weights into the LDS ring.  All members except pf_ptr / rd_addr are wave-uniform.
-//
-// Protocol (c = stage being consumed):  fragments of stage c AND of stage c+1 may be read (the
-// latter so that the first fragments of the next stage are already in registers when the barrier
-// falls -- no LDS latency is exposed at stage boundaries).  advance() moves c -> c+1; it must be
-// called after the last read of stage c has been issued: it waits until this wave's pieces of stage
-// c+2 have landed (counted vmcnt, never 0) and barriers (=> everyone's have, and nobody still reads
-// stage c-1).  Stage c-1's slot is then refilled with stage c+RING_SLOTS-1 by four issue_piece()
-// calls spread over the consumption of stage c+1.
-struct WeightPipe {
-  lds_char* lds;
-  gbl_char* base[2];   // per-lane pointers into the two packed streams (wave*4 KiB + lane*16 added)
-  gbl_char* pf_ptr;    // next stage to fetch
-  int pf_left;         // stages left in the pass being fetched
-  int pf_pass;         // pass index inside the cycle
-  int passes0;         // the first passes0 passes of a cycle use base[0], the rest base[1]
-  int passes;          // passes per cycle
-  uint32_t pf_slot;
-  uint32_t rd_slot;
-  uint32_t rd_addr;    // per-lane LDS byte address of fragment 0 of stage c
-  uint32_t lane16;
-  uint32_t wave4k;
-
-  // One of the 4 LDS-DMA pieces (1 KiB each) this wave contributes to the stage being fetched.  A
-  // global_load_lds costs ~60-180 issue cycles (MI355X guide), so the pieces are issued one at a
-  // time between MFMA groups (mma_layer) instead of back to back behind the barrier.
-  __device__ __forceinline__ void issue_piece(int i) {
-    lds_char* dst = lds + LDS_RING + pf_slot * STAGE_BYTES + wave4k;
-#ifndef CRNERF_EXP_NOGLDS   // (timing experiments only: results are garbage without the loads)
-    __builtin_amdgcn_global_load_lds(pf_ptr + i * FRAG_BYTES, dst + i * FRAG_BYTES, 16, 0, 0);
-#endif
-    if (i == 3) {
-      pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
-      pf_ptr += STAGE_BYTES;
-      if (--pf_left == 0) {
-        pf_left = STAGES_PER_PASS;
-        pf_pass = (pf_pass + 1 == passes) ? 0 : pf_pass + 1;
-        pf_ptr = (pf_pass < passes0) ? base[0] : base[1];
-      }
-    }
-  }
-  __device__ __forceinline__ void issue() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(i);
-  }
-
-  // Call once, all waves.  On return stages 0 and 1 are readable.
-  __device__ __forceinline__ void start(lds_char* lds_, gbl_char* stream0, gbl_char* stream1, int passes0_,
-                                        int passes_, int lane, int wave) {
-    lds = lds_;
-    lane16 = (uint32_t)lane * 16u;
-    wave4k = (uint32_t)wave * 4096u;
-    base[0] = stream0 + wave4k + lane16;
-    base[1] = stream1 + wave4k + lane16;
-    passes0 = passes0_;
-    passes = passes_;
-    pf_pass = 0;
-    pf_left = STAGES_PER_PASS;
-    pf_ptr = (passes0 > 0) ? base[0] : base[1];
-    pf_slot = 0;
-    rd_slot = 0;
-    rd_addr = LDS_RING + lane16;
-#pragma unroll
-    for (int s = 0; s < RING_SLOTS - 1; ++s) issue();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 3)) : "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  __device__ __forceinline__ uint32_t next_addr() const {
-    const uint32_t n = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
-    return LDS_RING + n * STAGE_BYTES + lane16;
-  }
-
-  __device__ __forceinline__ void advance() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_SLOTS - 4)) : "memory");
-#ifndef CRNERF_EXP_NOBARRIER  // (timing experiments only)
-    __builtin_amdgcn_s_barrier();
-#endif
-    rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
-    rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
-  }
-
-  __device__ __forceinline__ f32x4 read_at(uint32_t addr, int frag) const {
-    return *(const __attribute__((address_space(3))) f32x4*)(lds + addr + frag * FRAG_BYTES);
-  }
-
-  // first k-group (8 fragments) of stage c into cur -- once, before the first layer
-  __device__ __forceinline__ void prime(f32x4 (&cur)[8]) const {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) cur[t] = read_at(rd_addr, t);
-  }
-};
-
-// acc[t][4q+j] = bias[32t + 8q + 4h + j]
+// 32x32 C/D layout (the split cores, mlp_core_x3.h / mlp_core_h2t.h): acc[t][4q+j] = bias[32t + 8q + 4h + j]
 template <int NT>
 __device__ __forceinline__ void init_acc(f32x16 (&acc)[NT], const lds_float* bias, int h) {
 #pragma unroll
@@ -198,45 +109,6 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NT], const lds_float* bia
       acc[t][4 * q + 2] = b[2];
       acc[t][4 * q + 3] = b[3];
     }
-  }
-}
-
-// One layer: NT output tiles, k-groups 0..NGA-1 with B operands from srcA then NGB groups from srcB
-// (group g of a source = registers 4(g%4)..+3 of its tile g/4).  Software-pipelined by k-group:
-// on entry cur[0..NT) holds the fragments of group 0; while group g's MFMAs run, group g+1's
-// fragments are loaded (from the next stage when g+1 starts one); after the last group the first
-// group of the NEXT layer (NT_NEXT fragments, always the head of the next stage) is left in cur.
-template <int NT, int NGA, int NGB, int NT_NEXT, int NA, int NB>
-__device__ __forceinline__ void mma_layer(WeightPipe& p, const f32x16 (&srcA)[NA], const f32x16 (&srcB)[NB],
-                                          f32x16 (&acc)[NT], f32x4 (&cur)[8]) {
-  static_assert((NGA + 3) / 4 <= NA && (NGB + 3) / 4 <= NB, "source too small");
-  static_assert(STAGE_FRAGS % NT == 0 && ((NGA + NGB) * NT) % STAGE_FRAGS == 0, "layer must be whole stages");
-  constexpr int NG = NGA + NGB;
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const bool last = (g == NG - 1);
-    const int nphi = ((g + 1) * NT) % STAGE_FRAGS;     // slot of the next group's first fragment in its stage
-    const bool new_stage = last || nphi == 0;
-    const uint32_t base = new_stage ? p.next_addr() : p.rd_addr;
-    const int cnt = last ? NT_NEXT : NT;
-    f32x4 nxt[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      if (t < cnt) nxt[t] = p.read_at(base, (last ? 0 : nphi) + t);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int slot = (g * NT + t) % STAGE_FRAGS;       // this fragment's position in its stage
-      if (slot % 4 == 0) p.issue_piece(slot / 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b = (g < NGA) ? srcA[g >> 2][(g & 3) * 4 + j] : srcB[(g - NGA) >> 2][((g - NGA) & 3) * 4 + j];
-        acc[t] = CRNERF_MFMA(cur[t][j], b, acc[t]);
-      }
-    }
-    if (new_stage) p.advance();
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      if (t < cnt) cur[t] = nxt[t];
   }
 }
 
@@ -253,84 +125,6 @@ __device__ __forceinline__ float softplus_ref(float x) {
   return x > 20.0f ? x : log1pf(expf(x));
 }
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// One 32-point tile through one model.  pe/dv are the positional embeddings in B-operand order
-// (posenc.h); cur carries the prefetched head fragments between layers/passes.  Returns feat[t][4q+j] = rgb feature 32t+8q+4h+j of point p, and sigma (both halves).
-__device__ __forceinline__ void mlp_tile(WeightPipe& p, int model, const f32x16 (&pe)[3], const f32x16 (&dv)[1],
-                                         f32x16 (&feat)[2], float& sigma, int h, f32x4 (&cur)[8], PhaseTimer& tm) {
-  const lds_float* C = (const lds_float*)(p.lds + (model ? LDS_CONST1 : LDS_CONST0));
-  const float NEG_INF = -__builtin_huge_valf();
-  f32x16 act[8], acc[8];
-  tm.tick(T_PROLOGUE);
-
-  init_acc<8>(acc, C + C_BIAS, h);                       // xyz_encoding_1
-  tm.tick(T_EPILOGUE);
-  mma_layer<8, G_XYZ, 0, 8>(p, pe, pe, acc, cur);
-  tm.tick(T_MMA);
-  store_act<8>(acc, act, 0.0f);
-#pragma unroll 1
-  for (int l = 1; l < 4; ++l) {                          // xyz_encoding_2..4
-    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    tm.tick(T_EPILOGUE);
-    mma_layer<8, G_HID, 0, 8>(p, act, act, acc, cur);
-    tm.tick(T_MMA);
-    store_act<8>(acc, act, 0.0f);
-  }
-  init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);        // xyz_encoding_5 = Linear(cat[xyz, h])
-  tm.tick(T_EPILOGUE);
-  mma_layer<8, G_XYZ, G_HID, 8>(p, pe, act, acc, cur);
-  tm.tick(T_MMA);
-  store_act<8>(acc, act, 0.0f);
-#pragma unroll 1
-  for (int l = 5; l < 8; ++l) {                          // xyz_encoding_6..8
-    init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
-    tm.tick(T_EPILOGUE);
-    mma_layer<8, G_HID, 0, 8>(p, act, act, acc, cur);
-    tm.tick(T_MMA);
-    store_act<8>(acc, act, 0.0f);
-  }
-  {                                                      // static_sigma: 256 -> 1 on the VALU
-    float s = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *(const __attribute__((address_space(3))) f32x4*)(C + C_WSIG + 32 * t + 8 * q + 4 * h);
-        s = fmaf(w[0], act[t][4 * q + 0], s);
-        s = fmaf(w[1], act[t][4 * q + 1], s);
-        s = fmaf(w[2], act[t][4 * q + 2], s);
-        s = fmaf(w[3], act[t][4 * q + 3], s);
-      }
-    s += __shfl_xor(s, 32);
-    sigma = softplus_ref(s + C[C_BSIG]);
-    tm.tick(T_SIGMA);
-  }
-  init_acc<8>(acc, C + C_BFIN, h);                       // xyz_encoding_final (no activation)
-  tm.tick(T_EPILOGUE);
-  mma_layer<8, G_HID, 0, 4>(p, act, act, acc, cur);
-  tm.tick(T_MMA);
-  store_act<8>(acc, act, NEG_INF);
-  {
-    f32x16 acc4[4];                                      // dir_encoding = relu(Linear(cat[final, dir]))
-    init_acc<4>(acc4, C + C_BDIR, h);
-    tm.tick(T_EPILOGUE);
-    mma_layer<4, G_HID, G_DIR, 2>(p, act, dv, acc4, cur);
-    tm.tick(T_MMA);
-    store_act<4>(acc4, act, 0.0f);
-  }
-  {
-    f32x16 acc2[2];                                      // static_rgb = sigmoid(Linear)
-    init_acc<2>(acc2, C + C_BRGB, h);
-    tm.tick(T_EPILOGUE);
-    mma_layer<2, G_HALF, 0, 8>(p, act, act, acc2, cur);
-    tm.tick(T_MMA);  // leaves the next pass's layer-1 head in cur
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(acc2[t][r]);
-    tm.tick(T_EPILOGUE);
-  }
-}
 
 // Copy both models' consts blocks into LDS (all threads of a 256-thread workgroup).
 __device__ __forceinline__ void load_consts(lds_char* lds, const char* packed0, const char* packed1) {

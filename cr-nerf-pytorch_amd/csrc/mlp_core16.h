@@ -42,13 +42,11 @@ struct WeightPipe16 {
   int stagger;          // 0/1: which of the two candidate slot sets this wave uses for its LDS-DMA issue
 
   __device__ __forceinline__ void issue_piece(int i) {
-#ifndef CRNERF_EXP_NOGLDS   // (timing experiments only)
     // asm, not the builtin: see glds16 (mlp_core.h) -- with the builtin every fragment prefetch is drained
     // (s_waitcnt lgkmcnt(0)) at the first use after each LDS-DMA instruction
     const uint32_t dst = lds_ring + pf_slot * STAGE_BYTES;
     if (i == 0) glds16(dst, pf_ptr, lane16, 0);
     else glds16(dst, pf_ptr, lane16, FRAG_BYTES);
-#endif
     if (i == V16_PIECES - 1) {
       pf_slot = (pf_slot + 1 == RING_SLOTS) ? 0u : pf_slot + 1;
       pf_ptr += STAGE_BYTES;
@@ -67,11 +65,7 @@ struct WeightPipe16 {
     lane16 = (uint32_t)lane * 16u;
     wave2k = (uint32_t)wave * (V16_PIECES * FRAG_BYTES);
     lds_ring = (uint32_t)(uintptr_t)lds_ + LDS_RING + wave2k;
-#ifdef CRNERF_EXP_STAGGER_ODD
-    stagger = wave & 1;
-#else
     stagger = (wave >> 2) & 1;   // waves w and w+4 of a 512-thread workgroup share a SIMD
-#endif
     base[0] = stream0 + wave2k;
     base[1] = stream1 + wave2k;
     passes0 = passes0_;
@@ -97,9 +91,7 @@ struct WeightPipe16 {
 
   __device__ __forceinline__ void advance() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V16_PIECES * (RING_SLOTS - 4)) : "memory");
-#ifndef CRNERF_EXP_NOBARRIER  // (timing experiments only)
     __builtin_amdgcn_s_barrier();
-#endif
     rd_slot = (rd_slot + 1 == RING_SLOTS) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * STAGE_BYTES + lane16;
   }

@@ -86,10 +86,8 @@ struct WeightPipeP {
 
   __device__ __forceinline__ void issue_piece(int i, int F) {   // both constant after unrolling
     const char* src = F < STAGESB_PER_PASS ? cur : nxt;
-#ifndef CRNERF_EXP_NOGLDS   // (energy / timing experiments only: results are garbage without the loads; tools/bf16_energy_probe.py)
     if (i == 0) glds16(m0s[F % B_RING], src, voff, 0);            // writes M0; piece 1 reuses it with its instruction offset
-    else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(src), "n"(FRAG_BYTES) : "memory");
-#endif
+    else glds16_more(src, voff, FRAG_BYTES);
   }
   __device__ __forceinline__ void cursor_update(int F) {
     voff = (F + 1 == STAGESB_PER_PASS) ? rd_base - LDS_RING : voff + STAGE_BYTES;   // = lane16, from the register that is live in every k-step
@@ -129,10 +127,7 @@ struct WeightPipeP {
   // `stores`: store instructions this wave has issued since its pieces of the stage the barrier opens (training twin; 0 at inference)
   __device__ __forceinline__ void advance(int stores = 0) {
     switch (stores) {   // the count must be an immediate; constant after unrolling
-#ifndef CRNERF_EXP_VMSLACK
-#define CRNERF_EXP_VMSLACK 0   // (timing experiments only: > 0 lets weight stages be read before they land)
-#endif
-#define CRNERF_VMW(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + N + (N ? CRNERF_EXP_VMSLACK : 0)) : "memory"); break;
+#define CRNERF_VMW(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + N) : "memory"); break;
       CRNERF_VMW(0) CRNERF_VMW(1) CRNERF_VMW(2) CRNERF_VMW(3) CRNERF_VMW(4) CRNERF_VMW(5) CRNERF_VMW(6) CRNERF_VMW(7) CRNERF_VMW(8) CRNERF_VMW(9)
       CRNERF_VMW(10) CRNERF_VMW(11) CRNERF_VMW(12) CRNERF_VMW(13) CRNERF_VMW(14) CRNERF_VMW(15) CRNERF_VMW(16) CRNERF_VMW(17) CRNERF_VMW(18)
       CRNERF_VMW(19) CRNERF_VMW(20) CRNERF_VMW(21) CRNERF_VMW(22) CRNERF_VMW(23) CRNERF_VMW(24) CRNERF_VMW(25) CRNERF_VMW(26) CRNERF_VMW(27)
@@ -469,21 +464,13 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
       accs[cur] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, b), accs[cur], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);   // MFMA first, its fillers behind it
       if (p_piece_at(i, P_STAGGER) >= 0) p.issue_piece(p_piece_at(i, P_STAGGER), i / STAGE_FRAGS + B_RING - 1);
-#ifdef CRNERF_EXP_NOLDSREAD   // (experiments only) keep the fragments of the first four k-steps forever
-      asm volatile("" : "+v"(q[i % B_AHEAD]));
-#elif defined(CRNERF_EXP_HALFLDSREAD)   // (experiments only) every other fragment read
-      if (i & 1) q[i % B_AHEAD] = p.read(b_pos(i + B_AHEAD)); else asm volatile("" : "+v"(q[i % B_AHEAD]));
-#else
       q[i % B_AHEAD] = p.read(b_pos(i + B_AHEAD));
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#ifndef CRNERF_EXP_NOEPI   // (experiments only)
 #pragma unroll
       for (int u = 0; u < count; ++u) {
         if (T == 0) prev.finish(PT, first + u, pa);
         else epi.finish(T - 1, first + u, pa);
       }
-#endif
       if (s == 0) {
         if (T == 0) prev.prefetch(PT);
         else epi.prefetch(T - 1);

@@ -47,8 +47,15 @@ struct BOpH { xu32x4 b1, b2; };   // the two piece operands of one k-step: dword
 // value x (fp32) -> half e&1 of dword e/2 of the two operand vectors: h1 = fp16(x * sc), then h2 = fp16(x * sc - h1).  x * sc is exact (sc a power of
 // two), so is the difference: each result is rounded once, to nearest even, fp16 subnormals kept -- the arithmetic of the round-3 split, in two
 // instructions.  (v_fma_mix*: op_sel_hi picks fp32 (0) or fp16 (1) per source, op_sel the fp16 half; mixlo / mixhi keep the
-// other half of the destination.)  The two steps are separate calls because gfx950 wants a wait state between a partial-dword write and a read of the
-// same register (hipcc pads back-to-back asm statements with s_nop 0): the layer code puts an MFMA between them.
+// other half of the destination.)  The two steps are separate calls so that the layer code can put an MFMA between the write of h1 and its use.
+// HAZARD, and how it is closed (round 5; tools/isa_audit.py "valu->mfma", DESIGN Appendix A): an MFMA must not read a register for 2 wait states after
+// a VALU wrote it.  hipcc pads that between ITS OWN instructions; an asm statement is not a VALU write to its hazard recogniser (it gets the fixed
+// one-state pad of any asm output), so whether the MFMA that takes b1 / b2 as its B operand is far enough behind the last split is a property of one
+// build -- the round-4 training form had `v_fma_mixhi v15 ; v_cndmask ; v_mfma ... v[14:17]` in one place and single tiles came out wrong.  Closed
+// by construction in both consumer loops: mma_layer_h2 (below) pins its stream with sched_barrier(0) between every MFMA and every chunk of splits, and
+// the last split of a k-step's operands is followed by two MFMAs and two tail gaps of the SAME k-step before the hand-over; mma_layer_h2t
+// (mlp_core_h2t.h), which leaves the schedule to hipcc, ends every hand-over with h2_operands_ready(b): a two-state nop tied to the eight operand
+// registers, behind every split that writes them and in front of every MFMA that reads them.  tests/test_host.py audits the ISA of every build.
 __device__ __forceinline__ void h2_split_first(xu32x4& b1, int e, float x, float sc) {
   uint32_t h1 = b1[e >> 1];
   if (e & 1) asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h1) : "v"(x), "v"(sc));
@@ -61,6 +68,8 @@ __device__ __forceinline__ void h2_split_second(const xu32x4& b1, xu32x4& b2, in
   else asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2) : "v"(x), "v"(sc), "v"(b1[e >> 1]));
   b2[e >> 1] = h2;
 }
+// the operands written by h2_split_* may be read by MFMAs from here on (see HAZARD above): s_nop 1 = the two wait states VALU write -> MFMA read needs
+__device__ __forceinline__ void h2_operands_ready(xu32x4& b1, xu32x4& b2) { asm volatile("s_nop 1" : "+v"(b1), "+v"(b2)); }
 __device__ __forceinline__ void h2_split_into(xu32x4& b1, xu32x4& b2, int e, float x, float sc) {
   h2_split_first(b1, e, x, sc);
   h2_split_second(b1, b2, e, x, sc);
@@ -211,7 +220,7 @@ __device__ __forceinline__ void mma_layer_h2(WeightPipeX& p, xu32x4 (&q)[X_AHEAD
       tail_gap(T + 1);
       CRNERF_H2_PIN();
     }
-    b = nb;
+    b = nb;     // (no h2_operands_ready here: the pins above already order every split of nb in front of two MFMAs + two tail gaps of THIS k-step)
   }
 }
 

@@ -62,23 +62,18 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
       __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * ss), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * ss + 32u), 0, 0);
     }
-    // The split in plain arithmetic (v_cvt_f16_f32 rounds to nearest even and keeps subnormals; x * sc and the difference are exact).  NOT the
-    // two-instruction v_fma_mix form of the inference core: with this kernel's register pressure (58-95 spilled registers) that form produced
-    // wrong operands for single tiles -- bit-exact again with the conversions below (tests/test_gpu_h2.py; measured round 4, cause not isolated:
-    // suspected a partial-register-write hazard between the asm statements and the MFMA that reads the operand).  ~5 VALU instructions per value
-    // beside 3 NT MFMAs per k-step: hidden.
-    typedef _Float16 h2pair __attribute__((ext_vector_type(2)));
+    // The split: the inference core's two-instruction v_fma_mix form (2 VALU per value instead of ~5 as plain conversions).  Round 4 had dropped it
+    // here because single tiles came out wrong; round 5 found why with tools/isa_audit.py: in that build ONE builtin MFMA read its B operand one wait
+    // state after the asm v_fma_mixhi that completed it (VALU write -> MFMA read needs two, and hipcc does not pad an asm statement's writes) --
+    // mlp_core_h2.h "HAZARD".  h2_operands_ready() below closes it by construction.
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const float x0 = v[2 * d] * sc, x1 = v[2 * d + 1] * sc;
-      const h2pair p1 = {(_Float16)x0, (_Float16)x1};
-      const h2pair p2 = {(_Float16)(x0 - (float)p1[0]), (_Float16)(x1 - (float)p1[1])};
-      o.b1[d] = __builtin_bit_cast(uint32_t, p1);
-      o.b2[d] = __builtin_bit_cast(uint32_t, p2);
-    }
+    for (int e = 0; e < 8; ++e) h2_split_first(o.b1, e, v[e], sc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h2_split_second(o.b1, o.b2, e, v[e], sc);
   };
   BOpH b;
   prepare(0, b);
+  h2_operands_ready(b.b1, b.b2);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     BOpH nb = b;
@@ -96,6 +91,7 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
       acc[T + 1] = CRNERF_MFMA_H(w1, b.b1, acc[T + 1]);
     }
     b = nb;
+    h2_operands_ready(b.b1, b.b2);
   }
 }
 

@@ -513,11 +513,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const long pt = pb + 8 * kk + e;
-#ifdef CRNERF_EXP_WGRAD_L2      // (timing experiments only; garbage) every chunk re-reads 1,024 rows: operands from L2, not HBM
-          const long pc = (pt < plast ? pt : plast) & 1023;
-#else
           const long pc = pt < plast ? pt : plast;
-#endif
           d[e] = *(const f32x4*)(dbase + pc * j.ldd);      // raw: rows past the chunk are zeroed where the registers are handed to the
           a[e] = *(const f32x4*)(abase + pc * j.lda);      // next k-step (take16) -- a multiply here would wait for the load just issued
         }
@@ -533,14 +529,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       // column t of eight points -> the three piece fragments (dword q = points 2q, 2q + 1)
       auto split3 = [&](const f32x4 (&v)[8], int t, xbf16x8_t& f1, xbf16x8_t& f2, xbf16x8_t& f3) {
         uint32_t w1[4], w2[4], w3[4];
-#ifdef CRNERF_EXP_X3_NOSPLIT   // (timing experiments only; garbage) the cost of everything but the split
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { w1[q] = __float_as_uint(v[2 * q][t]); w2[q] = __float_as_uint(v[2 * q + 1][t]); w3[q] = w1[q] ^ w2[q]; }
-        f1 = __builtin_bit_cast(xbf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
-        f2 = __builtin_bit_cast(xbf16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
-        f3 = __builtin_bit_cast(xbf16x8_t, make_uint4(w3[0], w3[1], w3[2], w3[3]));
-        return;
-#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float x0 = v[2 * q][t], x1 = v[2 * q + 1][t];
@@ -606,11 +594,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           using I3 = std::integral_constant<int, 3>; using IC = std::integral_constant<int, c>;
           // the next k-step's rows (the last k-step re-reads its own: harmless, and the loop stays free of branches)
           left -= 1;
-#ifdef CRNERF_EXP_WGRAD_L2   // (timing experiments only; garbage) the same rows again and again: operands from L1 / L2, i.e. the loop's compute time
-          const long adv = 0;
-#else
           const long adv = left > 0 ? 1 : 0;
-#endif
           db += adv * sd;
           ab += adv * sa;
 #pragma unroll

@@ -8,12 +8,12 @@
 
 namespace crnerf {
 
-__global__ void pack_stream_kernel(MlpTensors t, float* __restrict__ stream, int v16) {
+__global__ void pack_stream_kernel(MlpTensors t, float* __restrict__ stream) {   // fp32 "v16" fragment order (layout.h): 16-row tiles
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)STREAM_FRAGS * FRAG_FLOATS) return;
   const int frag = (int)(idx / FRAG_FLOATS);
   const int lane = (int)(idx % FRAG_FLOATS) / 4, j = (int)(idx % 4);
-  const int i = v16 ? (lane & 15) : (lane & 31), kk = v16 ? (lane >> 4) : (lane >> 5);
+  const int i = lane & 15, kk = lane >> 4;
 
   const float* W;
   int in_dim, nt, phi, kind;  // kind: 0 hidden, 1 L1, 2 L5 (skip), 3 dir, 4 rgb
@@ -25,17 +25,16 @@ __global__ void pack_stream_kernel(MlpTensors t, float* __restrict__ stream, int
   else if (frag < OFF_RGB) { W = t.w_dir; in_dim = W_HIDDEN + DIR_DIM; nt = 4; phi = frag - OFF_DIR; kind = 3; }
   else { W = t.w_rgb; in_dim = 128; nt = 2; phi = frag - OFF_RGB; kind = 4; }
 
-  if (v16) nt *= 2;                                     // 16-row tiles
+  nt *= 2;                                              // 16-row tiles
   const int v = phi / nt, tile = phi % nt;
-  const int k = v16 ? 16 * v + 4 * kk + j : 8 * v + 4 * kk + j;
-  const int row = (v16 ? 16 : 32) * tile + i;
+  const int k = 16 * v + 4 * kk + j;
+  const int row = 16 * tile + i;
   int col;
   switch (kind) {
-    case 1: col = v16 ? posenc_slot_to_col16(k, XYZ_FREQS) : posenc_slot_to_col(k, XYZ_FREQS); break;
-    case 2: col = k < XYZ_PAD ? (v16 ? posenc_slot_to_col16(k, XYZ_FREQS) : posenc_slot_to_col(k, XYZ_FREQS))
-                              : XYZ_DIM + (k - XYZ_PAD); break;  // nerf.py:169 cat([xyz, h])
+    case 1: col = posenc_slot_to_col16(k, XYZ_FREQS); break;
+    case 2: col = k < XYZ_PAD ? posenc_slot_to_col16(k, XYZ_FREQS) : XYZ_DIM + (k - XYZ_PAD); break;  // nerf.py:169 cat([xyz, h])
     case 3: {
-      const int dc = k < W_HIDDEN ? 0 : (v16 ? posenc_slot_to_col16(k - W_HIDDEN, DIR_FREQS) : posenc_slot_to_col(k - W_HIDDEN, DIR_FREQS));
+      const int dc = k < W_HIDDEN ? 0 : posenc_slot_to_col16(k - W_HIDDEN, DIR_FREQS);
       col = k < W_HIDDEN ? k : (dc < 0 ? -1 : W_HIDDEN + dc);
       break;
     }
@@ -346,12 +345,12 @@ int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream) {
   return check_launch("pack_mlp_h2t");
 }
 
-int launch_pack_mlp(const MlpTensors& t, void* packed, int v16, hipStream_t stream) {
+int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream) {
   float* consts = (float*)packed;
   float* wstream = (float*)((char*)packed + CONST_BYTES);
   hipLaunchKernelGGL(pack_consts_kernel, dim3((CONST_BYTES / 4 + 255) / 256), dim3(256), 0, stream, t, consts, 1.0f);
   const long n = (long)STREAM_FRAGS * FRAG_FLOATS;
-  hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream, v16);
+  hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t, wstream);
   return check_launch("pack_mlp");
 }
 

@@ -26,9 +26,7 @@ struct PairScratch {
 // workgroup-scope fence would also drain vmcnt, i.e. the LDS-DMA prefetches in flight.)
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef CRNERF_EXP_NOBARRIER  // (timing experiments only)
   __builtin_amdgcn_s_barrier();
-#endif
   asm volatile("" ::: "memory");
 }
 

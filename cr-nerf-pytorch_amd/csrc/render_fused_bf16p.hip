@@ -47,24 +47,14 @@ struct TrainHookP {
   float* rawo[2];   // [R*N][65]
   long R;
   __device__ __forceinline__ bool stores_on() const {
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1
-    return false;
-#else
     return true;
-#endif
   }
   // n0: the tile's first sample, n = n0 + p this lane's; ray_ok: r < R
   __device__ __forceinline__ ActSaveP saver(int pass, long r, int N, int n0, int n, bool ray_ok, int lane, int wave, lds_char* lds) const {
     const long P = R * N, pt = r * N + n;
     const int h = lane >> 5;
     bool ok = ray_ok && n < N;
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1   // (timing experiments only) every store issued and dropped
-    ok = false;
-#endif
     int pts = ray_ok ? (N - n0 < 32 ? N - n0 : 32) : 0;   // points of this tile (<= 0: none)
-#if defined(CRNERF_EXP_SAVE) && CRNERF_EXP_SAVE == 1
-    pts = 0;
-#endif
     ActSaveP sv;
     sv.acts = acts[pass]; sv.slot_bytes = P * 512; sv.P = P;
     sv.boff = ok ? (uint32_t)pt * 32u + 8u * (uint32_t)h : SAVE_OOB;
@@ -172,17 +162,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
         const float znext = zsrc[nc + 1 < N ? nc + 1 : N - 1];
         const float x = ox + dx * zn, y = oy + dy * zn, z = oz + dz * zn;   // rendering.py:178 / :188 (separate mul and add)
         u32x4 pe[KS_XYZ];
-#ifdef CRNERF_EXP_MLP_ONLY   // (energy / ceiling experiments only, tools/bf16_energy_probe.py: the MLP stream with NO per-ray work)
-#pragma unroll
-        for (int s = 0; s < KS_XYZ; ++s)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {   // bf16-looking pseudo-random operands in (-1, 1): 0x3f00..0x3f7f / 0xbf00.. halves
-            const uint32_t hsh = (uint32_t)(lane * 2654435761u) ^ (uint32_t)((4 * s + j + 1) * 40503u) ^ __builtin_bit_cast(uint32_t, x);
-            pe[s][j] = (hsh & 0x807f807fu) | 0x3f003f00u;
-          }
-#else
         posenc_b<XYZ_FREQS, KS_XYZ>(x, y, z, h, pe);
-#endif
         tm.tick(T_X0);
         f32x16 feat[2];
         float sigma;
@@ -213,11 +193,6 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
             }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sigma), rr, (int)(h == 0 && ro != SAVE_OOB ? ro + 4u * FEAT_DIM : SAVE_OOB), 0, 0);
         }
-#ifdef CRNERF_EXP_MLP_ONLY
-        fsum += feat[0][0] + feat[1][15] + sigma;
-        if (valid && h == 0 && pass == 0) scr.wc[n] = znext;
-        continue;
-#endif
         // ---- compositing, rendering.py:121-143 (both lane halves evaluate the same 32 samples)
         const float noise = (noise_row && valid) ? noise_row[n] * a.noise_std : 0.0f;
         const float delta = (n == N - 1) ? 1e2f : znext - zn;
@@ -266,13 +241,6 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
         if (lane == 0) (pass ? a.depth_f : a.depth_c)[r] = dacc + scr.xfeat[64];
       }
       tm.tick(T_X5);
-#ifdef CRNERF_EXP_MLP_ONLY
-      if (pass == 0 && Ni > 0) {
-        for (int n = lane128; n < Nf; n += 128) scr.zs[n] = scr.zc[n % Nc] + 1e-3f * (float)n;
-        wg_barrier();
-        continue;
-      }
-#endif
       if (pass == 0 && Ni > 0) {
         sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128);
         wg_barrier();

@@ -176,12 +176,7 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
         f32x16 pe[3], feat[2];
         {
           float tmp[48];
-#ifdef CRNERF_EXP_NOPOSENC   // (timing experiments only; garbage) the cost of the accurate sincosf embeddings of a tile
-#pragma unroll
-          for (int i = 0; i < 48; ++i) tmp[i] = (i % 3 == 0 ? x : (i % 3 == 1 ? y : z)) * (1.0f / 64.0f) * (float)(1 + (i & 7));
-#else
           posenc_regs<XYZ_FREQS, 24>(x, y, z, h, tmp);
-#endif
 #pragma unroll
           for (int i = 0; i < 48; ++i) pe[i / 16][i % 16] = tmp[i];
         }

@@ -70,14 +70,12 @@ struct WeightPipeX {
   // the wave's column of the slot); pieces 1.. reuse it with their instruction offset, which applies to both sides.  Nothing else in the kernels
   // built on this pipe touches M0 (tests/test_host.py checks the ISA), so the four pieces of a stage may be any number of instructions apart.
   __device__ __forceinline__ void issue_piece(int i) {
-#ifndef CRNERF_EXP_NOGLDS   // (timing experiments only: results are garbage without the loads)
     switch (i) {   // the instruction offset must be an immediate
       case 0: glds16(lds_ring + pf_slot * X_STAGE_BYTES, pf_ptr, lane16, 0); break;
-      case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(FRAG_BYTES) : "memory"); break;
-      case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(2 * FRAG_BYTES) : "memory"); break;
-      default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pf_ptr), "n"(3 * FRAG_BYTES) : "memory"); break;
+      case 1: glds16_more(pf_ptr, lane16, FRAG_BYTES); break;
+      case 2: glds16_more(pf_ptr, lane16, 2 * FRAG_BYTES); break;
+      default: glds16_more(pf_ptr, lane16, 3 * FRAG_BYTES); break;
     }
-#endif
     if (i == X_PIECES - 1) {
       pf_slot = (pf_slot + 1 == X_RING) ? 0u : pf_slot + 1;
       pf_ptr += X_STAGE_BYTES;
@@ -119,9 +117,6 @@ struct WeightPipeX {
   // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twins; they share vmcnt with the LDS-DMA and retire in
   // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
   __device__ __forceinline__ void advance(int stores = 0) {
-#ifdef CRNERF_EXP_NOVMWAIT   // (timing experiments only: racy) the LDS-DMA pieces are issued but never waited for
-    stores = -1;
-#endif
     switch (stores) {
       case -1: break;
       case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 2) : "memory"); break;
@@ -130,9 +125,7 @@ struct WeightPipeX {
       case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 8) : "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4)) : "memory"); break;
     }
-#ifndef CRNERF_EXP_NOBARRIER   // (timing experiments only: racy without it) what the per-stage rendezvous of the four waves costs
     __builtin_amdgcn_s_barrier();
-#endif
     rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * X_STAGE_BYTES + lane16;
   }
@@ -171,9 +164,6 @@ struct ActSaveX {
     return SaveRowX{__builtin_amdgcn_make_buffer_rsrc(base + (long)slot * P * 256, 0, (int)(uint32_t)(P * 1024), 0x00020000)};
   }
   __device__ __forceinline__ uint32_t offset() const {
-#ifdef CRNERF_EXP_X3_NOSAVE   // (timing experiments only) every row store issued and dropped
-    return SAVEX_OOB;
-#endif
     return valid ? (uint32_t)n * 1024u + 16u * (uint32_t)h : SAVEX_OOB;
   }
   // lane (p, h) owns the mask words g = h and g = h + 2: bit 4T + r <-> register 4q + r of tile T >> 1, q = 2 (T & 1) + (g >> 1)

@@ -7,6 +7,11 @@ work for the ~190 tensors of the five trained modules.  `FlatAdam` moves the par
 buffers that share offsets -- `p.data` becomes a view, nothing else about the module changes -- and updates them with
 `crnerf_adam_step_f32`: one launch per <= 448 tensors, gradients read where autograd left them.
 
+Scope: the optimiser STEP is on the training step's critical path (SURVEY 8f N4 / configs[3]); the reference's factories around it
+(`get_optimizer` / `get_scheduler` / `get_learning_rate`, utils/__init__.py:24-67) are control plane -- SURVEY section 2 marks them out of scope --
+and are not mirrored: `FlatAdam(get_parameters(models), lr=hparams.lr, eps=1e-8, weight_decay=hparams.weight_decay)` is the reference's
+'adam' branch, and any torch.optim.lr_scheduler drives it like any other optimiser.
+
 Same update as `torch.optim.Adam` (amsgrad / maximize / capturable off): tests/test_gpu_optim.py steps both on the same
 gradients.  A parameter whose `.grad` is None is skipped; its step count is the group's (torch keeps one per parameter --
 they only differ for a parameter that misses steps, which no module of this pipeline does; `load_state_dict` therefore REFUSES an
@@ -19,7 +24,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["FlatAdam", "get_parameters", "get_optimizer", "get_scheduler", "get_learning_rate"]
+__all__ = ["FlatAdam", "get_parameters"]
 
 _ALIGN = 64            # elements: every tensor starts on a 256-byte boundary of the flat buffers
 _BLOCK = 4096          # elements one workgroup updates (csrc/kernels.h ADAM_BLOCK_ELEMS)
@@ -171,43 +176,3 @@ def get_parameters(models):
     if isinstance(models, dict):
         return [p for m in models.values() for p in get_parameters(m)]
     return list(models.parameters())
-
-
-def get_optimizer(hparams, models):
-    """utils/__init__.py:24-43.  'adam' -> FlatAdam (the same update, one launch); 'sgd' -> torch's; 'radam' / 'ranger' come from
-    the torch_optimizer package in the reference and are used as they are when that package is importable."""
-    eps = 1e-8
-    parameters = get_parameters(models)
-    if hparams.optimizer == "adam":
-        return FlatAdam(parameters, lr=hparams.lr, eps=eps, weight_decay=hparams.weight_decay)
-    if hparams.optimizer == "sgd":
-        return torch.optim.SGD(parameters, lr=hparams.lr, momentum=hparams.momentum, weight_decay=hparams.weight_decay)
-    if hparams.optimizer in ("radam", "ranger"):
-        import torch_optimizer                      # ImportError here = the reference's own dependency is not installed
-        cls = torch_optimizer.RAdam if hparams.optimizer == "radam" else torch_optimizer.Ranger
-        return cls(parameters, lr=hparams.lr, eps=eps, weight_decay=hparams.weight_decay)
-    raise ValueError("optimizer not recognized!")
-
-
-def get_scheduler(hparams, optimizer):
-    """utils/__init__.py:45-63: 'steplr' / 'cosine' / 'poly' over epochs.  The reference wraps the result in its GradualWarmupScheduler when
-    hparams.warmup_epochs > 0 (utils/warmup_scheduler.py; no shipped recipe sets it): that wrapper is not rebuilt here."""
-    from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR, MultiStepLR
-    if hparams.lr_scheduler == "steplr":
-        scheduler = MultiStepLR(optimizer, milestones=hparams.decay_step, gamma=hparams.decay_gamma)
-    elif hparams.lr_scheduler == "cosine":
-        scheduler = CosineAnnealingLR(optimizer, T_max=hparams.num_epochs, eta_min=1e-8)
-    elif hparams.lr_scheduler == "poly":
-        scheduler = LambdaLR(optimizer, lambda epoch: (1 - epoch / hparams.num_epochs) ** hparams.poly_exp)
-    else:
-        raise ValueError("scheduler not recognized!")
-    if getattr(hparams, "warmup_epochs", 0) > 0 and hparams.optimizer not in ("radam", "ranger"):
-        raise NotImplementedError("crnerf_amd: warmup_epochs > 0 needs the reference's GradualWarmupScheduler (utils/warmup_scheduler.py), "
-                                  "which is outside the hot path and not rebuilt; wrap the returned scheduler yourself")
-    return scheduler
-
-
-def get_learning_rate(optimizer):
-    """utils/__init__.py:65-67."""
-    for param_group in optimizer.param_groups:
-        return param_group["lr"]

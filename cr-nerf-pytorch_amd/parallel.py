@@ -105,6 +105,7 @@ class PeerExchange:
             raise ValueError("crnerf_amd: PeerExchange serves the GPUs of one node (world_size <= 8), got %d" % self.world)
         self.timeout_us = int(timeout_s * 1e6)
         self.device = torch.cuda.current_device()
+        self._require_peer_access()         # before any window exists: a missing xGMI / PCIe peer path would otherwise surface as a timeout
         own = ctypes.c_void_p()
         handle = ctypes.create_string_buffer(64)
         _lib.check(lib.crnerf_peer_window_create(ctypes.byref(own), handle), "crnerf_peer_window_create")
@@ -126,6 +127,36 @@ class PeerExchange:
             self._opened.append(w)
         self.epoch = 0
         dist.barrier(group=group)   # every window is open everywhere before the first push
+
+    def _require_peer_access(self):
+        """Collective.  Every rank asks the runtime (hipDeviceCanAccessPeer through torch.cuda.can_device_access_peer) whether its GPU can map
+        the GPU of every other rank, and ALL ranks raise together when any pair cannot -- instead of the first reduction waiting `timeout_s`
+        for a push that can never land.  Peers are identified by PCI address (domain:bus:device), so the check is independent of how each
+        process numbers its devices; a peer this process cannot see at all (HIP_VISIBLE_DEVICES isolation) counts as not verifiable and is
+        refused as well unless CRNERF_PEER_SKIP_ACCESS_CHECK=1."""
+        def pci(i):
+            p = torch.cuda.get_device_properties(i)
+            return (int(getattr(p, "pci_domain_id", 0)), int(getattr(p, "pci_bus_id", -1)), int(getattr(p, "pci_device_id", -1)))
+        mine = pci(self.device)
+        local = {pci(i): i for i in range(torch.cuda.device_count())}
+        addrs = [None] * self.world
+        dist.all_gather_object(addrs, mine, group=self.group)
+        problems = []
+        if os.environ.get("CRNERF_PEER_SKIP_ACCESS_CHECK") != "1":
+            for r, a in enumerate(addrs):
+                if r == self.rank or tuple(a) == mine:          # (ranks sharing one GPU: the single-GPU test mode)
+                    continue
+                idx = local.get(tuple(a))
+                if idx is None:
+                    problems.append("rank %d cannot see rank %d's GPU %04x:%02x:%02x (device isolation): peer access not verifiable" % ((self.rank, r) + tuple(a)))
+                elif not torch.cuda.can_device_access_peer(self.device, idx):
+                    problems.append("rank %d (GPU %04x:%02x:%02x) has no peer access to rank %d (GPU %04x:%02x:%02x)" % ((self.rank,) + mine + (r,) + tuple(a)))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, problems, group=self.group)
+        flat = [p for ps in everyone for p in ps]
+        if flat:
+            raise RuntimeError("crnerf_amd: PeerExchange needs hipDeviceCanAccessPeer for every pair of ranks; " + "; ".join(flat) +
+                               " -- use the RCCL path (exchange=None)")
 
     def all_reduce(self, t):
         if self._own is None:

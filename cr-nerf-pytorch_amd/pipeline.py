@@ -181,12 +181,6 @@ class TrainingSystem:
             return random.choice(seen)
         return random.Random(0x5EED + self.global_step).choice(seen)
 
-    def configure_optimizers(self):
-        """train_mask_grid_sample.py:249-252: ([optimizer], [scheduler]) over every trained module; 'adam' is optim.FlatAdam (one launch per step)."""
-        from . import optim
-        self.optimizer = optim.get_optimizer(self.hparams_, self.models_to_train)
-        return [self.optimizer], [optim.get_scheduler(self.hparams_, self.optimizer)]
-
     def sync_gradients(self):
         """Ray-parallel mode, after loss.backward(): MLP gradients summed over the ranks, replicated modules averaged."""
         from .parallel import sync_ray_parallel_gradients

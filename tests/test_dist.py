@@ -308,3 +308,45 @@ def test_ray_parallel_training_step_matches_single_process():
             assert float(np.abs(grads[k] - gref).max()) <= 2e-4 * scale + 1e-9, (r, k, float(np.abs(grads[k] - gref).max()), scale)
     for k in got[0][2]:
         assert np.array_equal(got[0][2][k], got[1][2][k]), k      # replicas stay bit-identical after the sync
+
+
+def _peer_access_worker(rank, world, port, can_access, out_q):
+    """PeerExchange._require_peer_access over gloo with the two HIP queries replaced by a table: two 'GPUs' at PCI 0:1:0 and 0:2:0."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from crnerf_amd.parallel import PeerExchange
+        props = [types.SimpleNamespace(pci_domain_id=0, pci_bus_id=1 + i, pci_device_id=0) for i in range(world)]
+        torch.cuda.get_device_properties = lambda i: props[i]
+        torch.cuda.device_count = lambda: world
+        torch.cuda.can_device_access_peer = lambda a, b: can_access
+        ex = PeerExchange.__new__(PeerExchange)
+        ex.group, ex.rank, ex.world, ex.device = None, rank, world, rank
+        try:
+            ex._require_peer_access()
+            out_q.put((rank, "ok"))
+        except RuntimeError as e:
+            out_q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("can_access", [True, False])
+def test_peer_exchange_refuses_to_start_without_peer_access(can_access):
+    """VERDICT r4 #8: a missing peer path must fail the constructor on EVERY rank (named pair), not surface as a 60 s timeout in the first reduction."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_access_worker, args=(r, 2, port, can_access, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if can_access:
+        assert res == {0: "ok", 1: "ok"}
+    else:
+        for r in (0, 1):
+            assert "hipDeviceCanAccessPeer" in res[r] and "rank 0 (GPU 0000:01:00) has no peer access to rank 1" in res[r] and "RCCL" in res[r], res[r]

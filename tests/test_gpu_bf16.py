@@ -212,22 +212,3 @@ def test_render_cold_l2_is_deterministic(precision, passes):
                     d = (out[k] != ref[k]).view(R, -1).any(1).nonzero().flatten()
                     raise AssertionError("pass %d: %s differs in %d rays (first %s): max |d| %.3e" % (it, k, d.numel(), d[:8].tolist(),
                                                                                                 float((out[k] - ref[k]).abs().max())))
-
-
-@torch.no_grad()
-def test_mlp_bf16_module_entry_pair_core_equals_the_round2_core(tmp_path):
-    """crnerf_mlp_forward_bf16 runs on the pair core since round 4 (mlp_forward_bf16p.hip); the round-1/2 kernel stays reachable with
-    CRNERF_BF16_CORE=64 (read once per process, hence the child).  Same fragment stream, same accumulation order per output: bit-identical."""
-    import os, subprocess, sys
-    st = synth.mlp_state(7, 2.0, 0.5)
-    x = embedded(4099, 5)
-    got = ops.mlp_forward(packed(st), x.to(DEV), precision="bf16").cpu().numpy()
-    np.save(tmp_path / "x.npy", x.numpy())
-    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); import crnerf_amd.synth as synth; from crnerf_amd import ops\n"
-            "st = {k: torch.from_numpy(v).cuda() for k, v in synth.mlp_state(7, 2.0, 0.5).items()}\n"
-            "x = torch.from_numpy(np.load(%r)).cuda()\n"
-            "np.save(%r, ops.mlp_forward(ops.pack_mlp_weights(st, precision='bf16'), x, precision='bf16').cpu().numpy())\n"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "x.npy"), str(tmp_path / "old.npy")))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, CRNERF_BF16_CORE="64"))
-    old = np.load(tmp_path / "old.npy")
-    assert np.array_equal(got, old), float(np.abs(got - old).max())

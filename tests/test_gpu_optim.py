@@ -107,7 +107,7 @@ def test_flat_adam_follows_a_scheduler_and_refuses_moved_parameters():
     ours, theirs = _params(6), _params(6)
     a = optim.FlatAdam(ours, lr=5e-4)
     b = torch.optim.Adam(theirs, lr=5e-4)
-    sa = torch.optim.lr_scheduler.CosineAnnealingLR(a, T_max=4, eta_min=1e-8)     # get_scheduler's 'cosine' (utils/__init__.py:50-51)
+    sa = torch.optim.lr_scheduler.CosineAnnealingLR(a, T_max=4, eta_min=1e-8)     # the reference's 'cosine' schedule (utils/__init__.py:50-51)
     sb = torch.optim.lr_scheduler.CosineAnnealingLR(b, T_max=4, eta_min=1e-8)
     g = torch.Generator().manual_seed(7)
     for _ in range(4):
@@ -124,14 +124,10 @@ def test_flat_adam_follows_a_scheduler_and_refuses_moved_parameters():
         a.step()
 
 
-def test_get_optimizer_mirrors_the_reference_factory():
-    import types
+def test_get_parameters_flattens_modules_lists_and_dicts():
+    """optim.get_parameters = utils/__init__.py:10-22 (what the reference hands its optimiser); FlatAdam over it is the reference's 'adam' branch."""
     lin = torch.nn.Linear(4, 3).to(DEV)
-    hp = types.SimpleNamespace(optimizer="adam", lr=5e-4, weight_decay=0.0, momentum=0.9)
-    opt = optim.get_optimizer(hp, {"a": lin, "b": [torch.nn.Linear(2, 2).to(DEV)]})
-    assert isinstance(opt, optim.FlatAdam) and len(opt.param_groups[0]["params"]) == 4 and opt.param_groups[0]["eps"] == 1e-8
-    hp.optimizer = "sgd"
-    assert isinstance(optim.get_optimizer(hp, lin), torch.optim.SGD)
-    hp.optimizer = "lamb"
-    with pytest.raises(ValueError, match="optimizer not recognized"):
-        optim.get_optimizer(hp, lin)
+    opt = optim.FlatAdam(optim.get_parameters({"a": lin, "b": [torch.nn.Linear(2, 2).to(DEV)]}), lr=5e-4, eps=1e-8, weight_decay=0.0)
+    assert len(opt.param_groups[0]["params"]) == 4 and opt.param_groups[0]["eps"] == 1e-8
+    with pytest.raises(ValueError, match="more than once"):
+        optim.FlatAdam([lin.weight, lin.weight], lr=1e-3)

@@ -426,33 +426,6 @@ def test_reference_call_signature_end_to_end(golden):
     close(models["fine"](x), O.mlp_forward(O.to_torch(st_f), x.cpu()), atol=3e-5, rtol=1e-5)
 
 
-def test_alternate_core32_still_matches(golden):
-    """CRNERF_CORE=32 selects the one-wave-per-SIMD 32x32x2 core (kept for A/B measurements); the env var is
-    read at library load, so it is exercised in a fresh interpreter."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import crnerf_amd.synth as synth\n"
-        "from crnerf_amd import ops\n"
-        "g = dict(np.load(%r))\n"
-        "C = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
-        "pk = lambda s: ops.pack_mlp_weights({k: C(v) for k, v in s.items()})\n"
-        "sc = synth.mlp_state(int(g['seed_coarse']), float(g['gain']), float(g['sigma_bias']))\n"
-        "sf = synth.mlp_state(int(g['seed_fine']), float(g['gain']), float(g['sigma_bias']))\n"
-        "with torch.no_grad():\n"
-        "    out = ops.render_rays(pk(sc), pk(sf), C(g['rays']), 64, 128, z_steps=C(g['z_steps_64']), u=C(g['u_steps_128']))\n"
-        "d = float((out['feature_coarse'].cpu() - torch.from_numpy(g['c64_f128__feature_coarse'])).abs().max())\n"
-        "w = float((out['weights_coarse'].cpu() - torch.from_numpy(g['c64_f128__weights_coarse'])).abs().max())\n"
-        "assert d < 1e-5 and w < 3e-6, (d, w)\n"
-        "print('core32 ok', d, w)\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-         os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_render.npz"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRNERF_CORE="32"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
 # ------------------------------------------------------------------ backward twins (training)
 @pytest.mark.parametrize("N,with_extras", [(64, False), (192, True), (1, False), (65, True), (300, True)])
 def test_composite_backward_vs_autograd_oracle(N, with_extras):
@@ -507,9 +480,51 @@ def test_mlp_backward_vs_autograd_oracle(n, gain):
         assert err <= tol, "%s: max|d| %.3e > %.3e (|ref|max %.3e)" % (name, err, tol, float(ref.abs().max()))
 
 
-def test_training_step_gradients_vs_autograd_oracle(golden):
+@pytest.mark.parametrize("core", ["h2", "x3"])
+def test_split_core_backward_vs_autograd_oracle(core):
+    """crnerf_mlp_backward_{h2,x3}_f32 (data gradient on the fp16 / bf16 matrix cores) + the bf16x3 weight gradients -- the kernels of the
+    training default -- held DIRECTLY to torch autograd through oracle.cpu_ref.mlp_forward (n = 400, gain 2), at the fp32 twin's own bar
+    (test_mlp_backward_vs_autograd_oracle), not to the fp32 HIP twin."""
+    n, gain = 400, 2.0
+    st = synth.mlp_state(13, gain, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32))
+    d_out[::7] *= 1e-6
+    w = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+    ref_out = O.mlp_forward(w, x)
+    (ref_out * d_out).sum().backward()
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        close(out, ref_out.detach(), atol=3e-5, rtol=1e-5)
+        pack_t = ops.pack_mlp_weights_t_h2(dev_state) if core == "h2" else ops.pack_mlp_weights_t_x3(dev_state)
+        grads = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="bf16x3", dgrad_h2=core == "h2", dgrad_x3=core == "x3")
+    for name, gq in zip(ops.MLP_TENSOR_NAMES, grads):
+        ref = w[name].grad
+        err = float((gq.cpu() - ref).abs().max())
+        tol = 2e-4 * float(ref.abs().max()) + 1e-5
+        assert bool(torch.isfinite(gq).all()) and err <= tol, "%s: max|d| %.3e > %.3e (|ref|max %.3e)" % (name, err, tol, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "auto"])
+def test_training_step_gradients_vs_autograd_oracle(mode):
     """A training-style step on the reference-signature modules (grad mode, perturb/noise inputs fixed):
-    render -> decode coarse+fine -> MSE; parameter gradients against torch autograd through the oracle."""
+    render -> decode coarse+fine -> MSE; parameter gradients against torch autograd through the oracle -- in "f32" (every product on the
+    fp32 matrix cores) and in "auto", the training default (h2 forward / data gradient, bf16x3 weight gradients): both are fp32-accurate
+    and held to 2e-4 of each tensor's largest gradient entry (smoke() measures 3.5e-6 on the same kind of step)."""
+    from crnerf_amd import autograd as AG
+    AG.set_training_forward_precision(mode)
+    AG.set_wgrad_precision("f32" if mode == "f32" else None)
+    try:
+        _training_step_gradients_vs_autograd_oracle()
+    finally:
+        AG.set_training_forward_precision(None)
+        AG.set_wgrad_precision(None)
+
+
+def _training_step_gradients_vs_autograd_oracle():
     from crnerf_amd.models.linearStyleTransfer import style_net
     from crnerf_amd.models.nerf import NeRF_sigma, PosEmbedding
     from crnerf_amd.models.rendering import render_rays_cross_ray
@@ -564,13 +579,13 @@ def test_training_step_gradients_vs_autograd_oracle(golden):
                 continue
             g, r_ = p.grad.cpu(), ref[name].grad
             r_ = r_.reshape(g.shape)
-            tol = 5e-3 * float(r_.abs().max()) + 1e-7
+            tol = 2e-4 * float(r_.abs().max()) + 1e-7
             assert float((g - r_).abs().max()) <= tol, "%s %s: %.3e > %.3e" % (what, name, float((g - r_).abs().max()), tol)
     check(models["coarse"].named_parameters(), wc, "coarse")
     check(models["fine"].named_parameters(), wf, "fine")
     check(models["decoder"].named_parameters(), wd, "decoder")
     gs, rs = style.grad.cpu(), style_ref.grad
-    assert float((gs - rs).abs().max()) <= 5e-3 * float(rs.abs().max()) + 1e-7
+    assert float((gs - rs).abs().max()) <= 2e-4 * float(rs.abs().max()) + 1e-7
 
 
 # ------------------------------------------------------------------ next rows

@@ -39,8 +39,8 @@ def _run(golden, flat_adam=False):
     hp = S.hparams()
     sysm = pipeline.TrainingSystem(hp, device=DEV)
     if flat_adam:
-        (opt,), (sched,) = sysm.configure_optimizers()           # NeRFSystem.configure_optimizers (:249-252): get_optimizer -> FlatAdam, get_scheduler -> cosine over epochs
-        assert isinstance(opt, optim.FlatAdam) and opt.param_groups[0]["eps"] == 1e-8 and isinstance(sched, torch.optim.lr_scheduler.CosineAnnealingLR)
+        # utils/__init__.py:24-33, the 'adam' branch, over everything the system trains
+        opt = optim.FlatAdam(optim.get_parameters(sysm.models_to_train), lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
     else:
         opt = torch.optim.Adam(sysm.parameters(), lr=hp.lr, eps=1e-8, fused=True)
     idx = torch.arange(S.SIDE * S.SIDE, device=DEV)

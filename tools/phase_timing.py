@@ -19,8 +19,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
-fn = lib.crnerf_debug_read_timing_h2 if PREC == "f32h2" else lib.crnerf_debug_read_timing_x3 if PREC == "f32x3" else ((lib.crnerf_debug_read_timing_bf16 if os.environ.get("CRNERF_BF16_CORE") == "64" else lib.crnerf_debug_read_timing_bf16p) if PREC == "bf16" else
-      lib.crnerf_debug_read_timing if os.environ.get("CRNERF_CORE") == "32" else lib.crnerf_debug_read_timing16)
+fn = (lib.crnerf_debug_read_timing_h2 if PREC == "f32h2" else lib.crnerf_debug_read_timing_x3 if PREC == "f32x3" else
+      lib.crnerf_debug_read_timing_bf16p if PREC == "bf16" else lib.crnerf_debug_read_timing16)      # exported by -DCRNERF_TIMING builds only
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
 names = ["prologue(posenc)", "mma", "epilogue+init", "sigma", "composite", "ray-level", "total"] + ["x%d" % i for i in range(8)] + ["real (100 MHz)"]
