@@ -10,7 +10,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrnerf_hip.so")
+# CRNERF_LIB_PATH: a tuning build of the same library (tools/variants.py) -- never a different backend; a path that does not exist raises at load
+LIB_PATH = os.environ.get("CRNERF_LIB_PATH") or os.path.join(_HERE, "libcrnerf_hip.so")
 
 EXPORTS = [
     "crnerf_abi_version", "crnerf_last_error", "crnerf_packed_mlp_bytes", "crnerf_pack_mlp_weights",

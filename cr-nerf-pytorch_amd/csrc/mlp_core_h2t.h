@@ -22,6 +22,8 @@
 namespace crnerf {
 inline namespace xcore_h2 {
 
+constexpr int H2T_ROW_BURST = 4;   // k-steps whose row pieces leave together (mma_layer_h2t)
+
 // One layer: NT output tiles; k-steps 0..NSA-1 take their B operands from srcA (registers 8(s%2) .. +7 of tile s/2), the following NSB from srcB.
 // q always holds the next X_AHEAD fragments of the STREAM.  SAVEA / SAVEB: the source is saved while it is walked (rowA / rowB = the slot's rows,
 // voff = this lane's byte offset; unconditional raw-buffer stores, see ActSaveX).  sc: the lane's operand scale (see above).
@@ -31,6 +33,20 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
   static_assert((NSA + 1) / 2 <= NA && (NSB + 1) / 2 <= NB, "source too small");
   constexpr int NS = NSA + NSB;
   static_assert(((NS * NT * 2) % X_STAGE_FRAGS) == 0 && ((NS * NT * 2) % X_AHEAD) == 0 && NT % 2 == 0, "layer: whole stages, whole queue turns, tile pairs");
+  // Row stores leave in BURSTS of G = 4 k-steps' pieces: 8 stores = 256 contiguous bytes per point, issued by the prepare() of the group's first
+  // k-step (the layer's whole source sits in registers, so WHEN a piece leaves is free to choose).  Round 5, profiles/r5/row_store_experiments.txt:
+  // the kernel is bound by how fast the L2 can drain these rows to HBM -- with every store landing in an L2-resident window the twin runs at its
+  // no-store speed (4.27 ms per 2^20 points against 6.35), half the store INSTRUCTIONS change nothing, non-temporal stores double the time (the L2's
+  // merging of the 32-byte pieces is essential) -- and that drain is faster when a line's pieces arrive together: two stores per k-step (rounds 3-4)
+  // 6.28 ms, G = 2: 5.85, G = 4: 5.68, G = 8: 5.76, G = 16: 5.88; one contiguous 8 KB block per wave and burst (tile-blocked rows): no better.
+  constexpr int G = H2T_ROW_BURST;
+  auto part_len = [&](int ks) { return ks < NSA ? NSA : NSB; };
+  auto part_idx = [&](int ks) { return ks < NSA ? ks : ks - NSA; };
+  auto stores_at = [&](int ks) {     // store instructions issued by prepare(ks)
+    if (!(ks < NSA ? SAVEA : SAVEB) || part_idx(ks) % G != 0) return 0;
+    const int left = part_len(ks) - part_idx(ks);
+    return 2 * (left < G ? left : G);
+  };
   // consume one fragment of the stream: returns it, refills the queue, keeps the ring going (f = the fragment's index in the layer)
   auto take = [&](int f) {
     const int slot = f % X_STAGE_FRAGS;
@@ -44,7 +60,7 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
       // (the stores of k-step ks are issued by prepare(ks), in front of the take() of fragment (ks - 1) NT 2; k-step 0's in front of the layer)
       const int fp = f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP);   // the fragment whose take() issued that piece
       for (int ks = 0; ks < NS; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && (ks == 0 ? fp < 0 : ((ks - 1) * NT * 2 > fp && (ks - 1) * NT * 2 <= f))) st += 2;
+        if (ks == 0 ? fp < 0 : ((ks - 1) * NT * 2 > fp && (ks - 1) * NT * 2 <= f)) st += stores_at(ks);
       p.advance(st);
     }
     return w;
@@ -55,12 +71,21 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
     const int ss = s < NSA ? s : s - NSA;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = s < NSA ? srcA[s < NSA ? ss >> 1 : 0][8 * (ss & 1) + e] : srcB[s < NSA ? 0 : ss >> 1][8 * (ss & 1) + e];
-    if (s < NSA ? SAVEA : SAVEB) {
+    if ((s < NSA ? SAVEA : SAVEB) && ss % G == 0) {
       const SaveRowX& row = s < NSA ? rowA : rowB;
-      const xu32x4 lo = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-      const xu32x4 hi = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-      __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * ss), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * ss + 32u), 0, 0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (ss + g < (s < NSA ? NSA : NSB)) {
+          const int t = ss + g;
+          float w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = s < NSA ? srcA[s < NSA ? t >> 1 : 0][8 * (t & 1) + e] : srcB[s < NSA ? 0 : t >> 1][8 * (t & 1) + e];
+          const xu32x4 lo = {__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3])};
+          const xu32x4 hi = {__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(lo, row.rs, (int)(voff + 64u * t), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(hi, row.rs, (int)(voff + 64u * t + 32u), 0, 0);
+        }
+      }
     }
     // The split: the inference core's two-instruction v_fma_mix form (2 VALU per value instead of ~5 as plain conversions).  Round 4 had dropped it
     // here because single tiles came out wrong; round 5 found why with tools/isa_audit.py: in that build ONE builtin MFMA read its B operand one wait
