@@ -627,7 +627,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
 
     hp = HP()
     torch.manual_seed(0)
-    sysm = pipeline.TrainingSystem(hp, device=dev, ray_parallel_group=None if use_dist and world > 1 else False)
+    sysm = pipeline.TrainingSystem(hp, device=dev, ray_parallel_group=None if use_dist else False)   # (also with ONE rank under the launcher: the collectives are then issued and timed over RCCL)
     sysm.models["coarse"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(1, 2.0, 0.5).items()})
     sysm.models["fine"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.mlp_state(2, 2.0, 0.5).items()})
     sysm.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
@@ -647,7 +647,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
         opt.zero_grad(set_to_none=True)
         loss, _, _ = sysm.training_step(batch)
         loss.backward()
-        if use_dist and world > 1:
+        if use_dist:
             sysm.sync_gradients()
         opt.step()
         return loss.detach()

@@ -123,9 +123,10 @@ struct WeightPipeX {
       case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 4) : "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 6) : "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 8) : "memory"); break;
-      // (Larger allowances are NOT taken, although the layers' counts are right: with up to 20 stores allowed the x3 repair kernel came out
-      // different from the x3 twin -- round 5, deterministic -- i.e. with many stores in flight the counter does not retire strictly in issue
-      // order against the LDS-DMA loads; at <= 8 the three stages of look-ahead cover it.  A window that holds more waits for all of them.)
+      // (Larger allowances are NOT taken: with the layers' own counts allowed -- up to 20 in the two-tile layers -- the x3 repair kernel came out
+      // different from the x3 twin, deterministically (round 5, tests/test_gpu_h2.py).  Not isolated which assumption breaks there: the count of
+      // the short layers, or that the counter retires stores and LDS-DMA loads in issue order when many stores are in flight.  At <= 8 -- rounds
+      // 3-4, cold-L2 suite green -- three stages of look-ahead lie between a piece's issue and its first read.  A window with more waits for all.)
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4)) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
