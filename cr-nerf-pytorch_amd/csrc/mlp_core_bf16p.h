@@ -159,7 +159,7 @@ struct WeightPipeP {
 // Rows leave through LDS in whole cache lines.  Stored straight from the registers a row piece is 32 contiguous bytes per point and
 // instruction (two lanes per point), a 128-byte line is completed by four instructions of two different tiles, ~1 us apart: 2.76 ms per
 // 2^20 points against 1.17 ms for the inference kernel (2.25 TB/s of saved state), and the same stores aimed at whole lines -- eight points
-// x 128 bytes per instruction -- 2.16 ms (tools/mixed_fwd_bench.py with -DCRNERF_EXP_SAVE=5).  So a wave parks the 64-byte pieces of two
+// x 128 bytes per instruction -- 2.16 ms (a round-3 tuning build).  So a wave parks the 64-byte pieces of two
 // consecutive tiles in a private 32 x (128 + 16)-byte LDS block (ds_write_b128, conflict-free with the 16-byte row pad) and reads them back
 // transposed: lane l takes bytes 16(l & 7).. of row 8e + (l >> 3), four instructions e = 0..3 per tile pair, each writing eight full lines.
 // Every piece of that traffic rides in the MFMA loop of the following tiles (mma_layer_p: LDS writes in k-steps 9 / 11, activity bits in

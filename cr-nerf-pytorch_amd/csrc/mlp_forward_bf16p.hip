@@ -1,6 +1,6 @@
 // Stand-alone NeRF_sigma forward on the bf16 PAIR core (mlp_core_bf16p.h: 32-point tiles, two waves per SIMD): x[P,120] fp32 (already embedded)
 // -> out[P,65] fp32, in the mixed-precision semantics of include/crnerf.h "bf16".  Module-level entry (NeRF_sigma.__call__, models/nerf.py:157-182);
-// round 4: crnerf_mlp_forward_bf16 moved here from the round-1/2 core (mlp_forward_bf16.hip, kept behind CRNERF_BF16_CORE=64 for A/B runs) --
+// round 4: crnerf_mlp_forward_bf16 moved here from the round-1/2 core (mlp_forward_bf16.hip; removed in round 5) --
 // the two cores' outputs are bit-identical (tests/test_gpu_bf16.py).  The production path is the fused renderer, render_fused_bf16p.hip.
 #include <hip/hip_runtime.h>
 #include "kernels.h"

@@ -10,7 +10,7 @@
 
 namespace crnerf {
 
-// B-operand register rho of half h holds padded slot 8(rho/4) + 4h + rho%4 (layout.h posenc_slot_to_col; as mlp_forward.hip)
+// B-operand register rho of half h holds padded slot 8(rho/4) + 4h + rho%4 (layout.h posenc_slot_to_col)
 template <int F, int NREG>
 __device__ __forceinline__ void gather_embedded_x3(const float* __restrict__ row, int h, bool valid, float* dst) {
 #pragma unroll

@@ -553,7 +553,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         // Row addresses are a uniform base (SGPR pair, advanced per k-step) plus eight per-lane byte offsets computed once -- no 64-bit
         // multiplies in the loop.  Two k-steps per trip so that the double-buffered pieces are compile-time registers.  Same products, same
         // accumulation order per accumulator as the loop below: same bits.  Measured (2^20 points, 13 jobs, profiles/r4/): 9.1 -> 7.1 ms; a
-        // 256 x 256 job 550-645 us = 3.3-3.8 TB/s of operand rows, against 480 us with the rows served from L1 / L2 (CRNERF_EXP_WGRAD_L2: the
+        // 256 x 256 job 550-645 us = 3.3-3.8 TB/s of operand rows, against 480 us with the rows served from L1 / L2 (a round-4 tuning build that re-read 1,024 rows per chunk: the
         // stream's own time, ~3,600 cycles per k-step for 3,072 of MFMA) -- the kernel now sits where its matrix stream and its HBM rows cost
         // about the same, and what is left is the part of the row latency one k-step of prefetch (all the registers allow) does not cover.
         const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;

@@ -1,6 +1,6 @@
 // Stand-alone (un-fused) per-ray kernels: alpha compositing over a materialised [R,N,65] tensor and
 // sample_pdf + merge.  They back the C-ABI test entry points and the general-N fallback path; the
-// production path is render_fused.hip.  Both are HBM-bandwidth kernels: one ray per wavefront,
+// production path is render_fused16.hip.  Both are HBM-bandwidth kernels: one ray per wavefront,
 // coalesced 260-B sample rows, wave-prefix transmittance.
 // Reference: models/rendering.py:116-143 (compositing), :7-46 + :183-187 (sample_pdf, merge).
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // Fused volumetric renderer on the v16 core (mlp_core16.h): two wavefronts per SIMD.
-// Same contract as render_fused.hip (render_rays_cross_ray, models/rendering.py:50-196).
+// Contract: render_rays_cross_ray, models/rendering.py:50-196 (coarse pass, sample_pdf + merge, fine pass; outputs per A0 of SURVEY 8a).
 //
 // Work decomposition: workgroup = 8 waves = 4 rays; a ray belongs to a PAIR of waves (A = even wave,
 // B = odd wave).  The ray's samples are walked in 32-sample steps; in step k wave A owns samples

@@ -1,4 +1,4 @@
-// "f32x3" fused volumetric renderer: render_fused.hip's kernel on the x3 core (mlp_core_x3.h: fp32-accurate products from three-piece bf16
+// "f32x3" fused volumetric renderer: the one-ray-per-wave renderer (round 1's render_fused.hip structure) on the x3 core (mlp_core_x3.h: fp32-accurate products from three-piece bf16
 // splits on the bf16 matrix cores); everything around the MLP is the same fp32 code.
 // Fused volumetric renderer: the whole of render_rays_cross_ray (models/rendering.py:50-196) for
 // one ray per wavefront in ONE launch -- coarse depths, positional encoding, coarse NeRF_sigma,

@@ -1,12 +1,8 @@
-"""Tuning tool (GPU box): the f32x3 renderer, its training twin and the fp32 training twin on one ray chunk (5,460 rays x (64+64)).  -DCRNERF_EXP_X3_NOSAVE
-(CRNERF_EXTRA_FLAGS) drops every row store: measured 8.22 -> 7.11 ms per 2^20 points (inference 6.26; the rest is the relu-bit / raw-row work and spill reloads)."""
+"""Tuning tool (GPU box): the f32x3 renderer, its training twin and the fp32 training twin on one ray chunk (5,460 rays x (64+64)).  Variant libraries from tools/variants.py are selected with
+CRNERF_LIB_PATH (profiles/r5/row_store_experiments.txt)."""
 import os, subprocess, sys, time
 ROOT = "/root/repo" if os.path.isdir("/root/repo/tools") else os.getcwd()
 sys.path.insert(0, ROOT)
-flags = os.environ.get("CRNERF_EXTRA_FLAGS")
-if flags:
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
-    print("flags:", flags)
 import numpy as np, torch
 import crnerf_amd.synth as synth
 from crnerf_amd import ops
