@@ -124,17 +124,10 @@ struct WeightPipeP {
     // positions in 64 VGPRs outside the tile loop instead of using the ds_read offset field
     asm volatile("" : "+v"(rd_base));
   }
-  // `stores`: store instructions this wave has issued since its pieces of the stage the barrier opens (training twin; 0 at inference)
-  __device__ __forceinline__ void advance(int stores = 0) {
-    switch (stores) {   // the count must be an immediate; constant after unrolling
-#define CRNERF_VMW(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + N) : "memory"); break;
-      CRNERF_VMW(0) CRNERF_VMW(1) CRNERF_VMW(2) CRNERF_VMW(3) CRNERF_VMW(4) CRNERF_VMW(5) CRNERF_VMW(6) CRNERF_VMW(7) CRNERF_VMW(8) CRNERF_VMW(9)
-      CRNERF_VMW(10) CRNERF_VMW(11) CRNERF_VMW(12) CRNERF_VMW(13) CRNERF_VMW(14) CRNERF_VMW(15) CRNERF_VMW(16) CRNERF_VMW(17) CRNERF_VMW(18)
-      CRNERF_VMW(19) CRNERF_VMW(20) CRNERF_VMW(21) CRNERF_VMW(22) CRNERF_VMW(23) CRNERF_VMW(24) CRNERF_VMW(25) CRNERF_VMW(26) CRNERF_VMW(27)
-      CRNERF_VMW(28) CRNERF_VMW(29) CRNERF_VMW(30) CRNERF_VMW(31) CRNERF_VMW(32)
-#undef CRNERF_VMW
-      default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    }
+  // the wait counts LDS-DMA pieces only (two of this wave's may be in flight per open stage pair); row stores of the training twin share the counter
+  // and are waited for with them -- see xcore_pipe.h advance() for why the per-window store allowance of rounds 3-4 is gone (0.7 % of the mixed step)
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   __device__ __forceinline__ u32x4 read(int pos) const {
@@ -166,13 +159,12 @@ struct WeightPipeP {
 // 10 / 12, the read -> store chain in k-steps 13, 15, 1, 3, 5): a store wave-instruction holds the CU's store path ~64 cycles, see ActSaver
 // in mlp_train16.h.
 //
-// Stores and the weight ring share vmcnt (gfx9 has no separate store counter; VMEM operations retire in issue order).  The ring's barrier in
-// stage c must know that this wave's LDS-DMA pieces of stage c + 1 have landed; they were issued in stage c - 2, and everything issued after
-// them may stay in flight: the four pieces of stages c + 2 and c + 3 -- vmcnt(4) at inference -- PLUS every store issued since.  So every
-// store of the training twin is UNCONDITIONAL -- a raw-buffer store whose resource ends at the pass' last row; lanes without a point (tail
-// of a ray, rays past R) carry an out-of-range offset and the hardware drops them -- which makes the number of stores between any two
-// points of the tile's static schedule a compile-time constant, and the barrier waits vmcnt(4 + that number) (p_store_window below).  Stores
-// the model does not know (compositing outputs between tiles) only make the wait stricter.
+// Stores and the weight ring share vmcnt (gfx9 has no separate store counter).  The ring's barrier in stage c must know that this wave's LDS-DMA
+// pieces of stage c + 1 have landed; they were issued in stage c - 2, and the four pieces of stages c + 2 and c + 3 issued after them may stay in
+// flight: vmcnt(4).  Every store issued since is waited for as well (rounds 3-4 counted them into the wait -- compile-time store windows --, which
+// presumes that stores and LDS-DMA loads retire in issue order against each other; round 5 dropped that, xcore_pipe.h advance(): 0.7 % of the
+// mixed step).  The stores stay UNCONDITIONAL raw-buffer stores (lanes without a point carry an out-of-range offset and the hardware drops them):
+// no branch in the tile's static schedule.
 constexpr uint32_t SAVE_OOB = 0xF0000000u;     // offset of a lane that stores nothing (>= every resource size; + instruction offsets stays < 2^32)
 constexpr int SAVE_FLAGS = 0x00020000;         // buffer resource word 3 (gfx9: DATA_FORMAT_32), raw buffer: stride 0, range check on the byte offset
 constexpr int SAVE_TILE_BURST = 8 + 9;         // between two tiles: the raw output row (8 x 16 B + sigma) and the embedded input (8 x 16 B)
@@ -309,43 +301,12 @@ constexpr PStoreTable p_make_stores() {   // n[i]: store instructions issued in 
 }
 constexpr PStoreTable P_STORES = p_make_stores();
 constexpr int p_stores_at(int i) { return P_STORES.n[i]; }
-constexpr int p_second_piece_step(int stage, int stagger) {   // k-step that issues piece 1 of the stage fetched during `stage`
-  return stage * STAGE_FRAGS + (stage == STAGESB_PER_PASS - 1 ? 2 + stagger : 5 + 2 * stagger);
-}
-// stores issued after this wave's pieces of stage c + 1 (issued in stage c - 2, possibly of the previous tile) up to the barrier of stage c
-constexpr int p_store_window(int i_barrier, int stagger) {
-  const int c = i_barrier / STAGE_FRAGS;
-  int n = 0;
-  if (c >= 2) {
-    for (int i = p_second_piece_step(c - 2, stagger); i <= i_barrier; ++i) n += p_stores_at(i);
-  } else {
-    for (int i = p_second_piece_step(c - 2 + STAGESB_PER_PASS, stagger); i < STREAMB_USED; ++i) n += p_stores_at(i);
-    n += SAVE_TILE_BURST;
-    for (int i = 0; i <= i_barrier; ++i) n += p_stores_at(i);
-  }
-  return n;
-}
 constexpr int p_store_total() {
   int n = 0;
   for (int i = 0; i < STREAMB_USED; ++i) n += p_stores_at(i);
   return n;
 }
 static_assert(P_STORES.ok && p_store_total() == 9 * 16 + 8 + 8 * 4 + 2, "store schedule: 38 tile pairs x 4 line stores, activity dwords 8 x 4 + dir 2");
-constexpr int p_store_window_max() {
-  int m = 0;
-  for (int i = 0; i < STREAMB_USED; ++i)
-    if (b_advance_at(i) && p_store_window(i, P_STAGGER) > m) m = p_store_window(i, P_STAGGER);
-  return m;
-}
-static_assert(4 + p_store_window_max() <= 36, "vmcnt is a 6-bit counter; WeightPipeP::advance spells out the immediates up to 4 + 32");
-struct PWindowTable { int v[STAGESB_PER_PASS]; };
-constexpr PWindowTable p_make_windows() {   // per stage: the store window of its barrier (a table, so that the unrolled tile loop folds it to an immediate)
-  PWindowTable t{};
-  for (int i = 0; i < STREAMB_USED; ++i)
-    if (b_advance_at(i)) t.v[i / STAGE_FRAGS] = p_store_window(i, P_STAGGER);
-  return t;
-}
-constexpr PWindowTable P_WINDOWS = p_make_windows();
 
 // ---- epilogues, one point group: quarter qc (0..7) = accumulator registers 2qc, 2qc+1 -> dword qc&3 of k-step
 // 2T + (qc>>2) of the next layer's B operand.  The accumulators live in ARCHITECTURAL registers here (gfx950 MFMA takes
@@ -494,7 +455,7 @@ __device__ __forceinline__ void mma_layer_p(WeightPipeP& p, const u32x4 (&srcA)[
         const lds_float* nb = (T + 1 < NT) ? bias : next_bias;
         load_bias_into(accs[cur ^ 1], nb, (T + 1 < NT) ? T + 1 : 0, h, s - (NS - 2));
       }
-      if (b_advance_at(i)) p.advance(SV::on ? P_WINDOWS.v[i / STAGE_FRAGS] : 0);
+      if (b_advance_at(i)) p.advance();
       if (b_cursor_at(i)) p.cursor_update(i / STAGE_FRAGS + B_RING - 1);
       __builtin_amdgcn_sched_barrier(0);
     }

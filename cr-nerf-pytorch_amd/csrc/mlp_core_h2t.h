@@ -40,29 +40,13 @@ __device__ __forceinline__ void mma_layer_h2t(WeightPipeX& p, const f32x16 (&src
   // merging of the 32-byte pieces is essential) -- and that drain is faster when a line's pieces arrive together: two stores per k-step (rounds 3-4)
   // 6.28 ms, G = 2: 5.85, G = 4: 5.68, G = 8: 5.76, G = 16: 5.88; one contiguous 8 KB block per wave and burst (tile-blocked rows): no better.
   constexpr int G = H2T_ROW_BURST;
-  auto part_len = [&](int ks) { return ks < NSA ? NSA : NSB; };
-  auto part_idx = [&](int ks) { return ks < NSA ? ks : ks - NSA; };
-  auto stores_at = [&](int ks) {     // store instructions issued by prepare(ks)
-    if (!(ks < NSA ? SAVEA : SAVEB) || part_idx(ks) % G != 0) return 0;
-    const int left = part_len(ks) - part_idx(ks);
-    return 2 * (left < G ? left : G);
-  };
   // consume one fragment of the stream: returns it, refills the queue, keeps the ring going (f = the fragment's index in the layer)
   auto take = [&](int f) {
     const int slot = f % X_STAGE_FRAGS;
     const xu32x4 w = q[f % X_AHEAD];
     if (slot % (X_STAGE_FRAGS / X_PIECES) == 0) p.issue_piece(slot / (X_STAGE_FRAGS / X_PIECES));
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
-    if (slot == X_STAGE_FRAGS - 1) {
-      // row stores issued since this wave's pieces of the stage the barrier certifies (mma_layer_x3 has the derivation): a lower bound
-      constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
-      int st = 0;
-      // (the stores of k-step ks are issued by prepare(ks), in front of the take() of fragment (ks - 1) NT 2; k-step 0's in front of the layer)
-      const int fp = f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP);   // the fragment whose take() issued that piece
-      for (int ks = 0; ks < NS; ++ks)
-        if (ks == 0 ? fp < 0 : ((ks - 1) * NT * 2 > fp && (ks - 1) * NT * 2 <= f)) st += stores_at(ks);
-      p.advance(st);
-    }
+    if (slot == X_STAGE_FRAGS - 1) p.advance();
     return w;
   };
   // the operands of k-step s: written BEFORE the MFMAs of k-step s - 1, so the split and the two row stores sit in their shadow

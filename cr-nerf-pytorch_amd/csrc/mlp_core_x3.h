@@ -69,20 +69,7 @@ __device__ __forceinline__ void mma_layer_x3(WeightPipeX& p, const f32x16 (&srcA
     const xu32x4 w = q[f % X_AHEAD];
     if (slot % (X_STAGE_FRAGS / X_PIECES) == 0) p.issue_piece(slot / (X_STAGE_FRAGS / X_PIECES));
     q[f % X_AHEAD] = p.read_slot(slot + X_AHEAD);
-    if (slot == X_STAGE_FRAGS - 1) {
-      // row stores issued since this wave's pieces of the stage the barrier certifies (stage c + 2, whose last piece went out in the take() of
-      // fragment X_STAGE_FRAGS (c - X_RING + 4) + last piece slot): the k-steps of THIS layer that start behind it, up to f -- a lower bound
-      // (the previous layer's are ignored)
-      constexpr int LASTP = (X_PIECES - 1) * (X_STAGE_FRAGS / X_PIECES);
-      int st = 0;
-      // (the stores of k-step ks are issued by prepare(ks), in front of the take() of fragment (ks - 1) NT XNP; k-step 0's in front of the layer.
-      // Round 4: the count used ks NT XNP and was two stores too high in a layer's last k-step -- this wave's last two pieces of the certified
-      // stage could then still be in flight at the barrier; never observed, three stages of slack)
-      const int fp = f - (X_STAGE_FRAGS * (X_RING - 3) - 1 - LASTP);   // the fragment whose take() issued that piece
-      for (int ks = 0; ks < NSA + NSB; ++ks)
-        if ((ks < NSA ? SAVEA : SAVEB) && (ks == 0 ? fp < 0 : ((ks - 1) * NT * XNP > fp && (ks - 1) * NT * XNP <= f))) st += 2;
-      p.advance(st);
-    }
+    if (slot == X_STAGE_FRAGS - 1) p.advance();
     return w;
   };
   // the split of k-step s + 1 is written BEFORE the MFMAs of k-step s (it does not depend on them): its ~50 VALU instructions and the two

@@ -114,21 +114,14 @@ struct WeightPipeX {
     const uint32_t n = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     return LDS_RING + n * X_STAGE_BYTES + lane16;
   }
-  // stores: store instructions this wave has issued since its pieces of stage c + 2 (training twins; they share vmcnt with the LDS-DMA and retire in
-  // order, so they may stay in flight on top of the two stages of pieces) -- a compile-time lower bound, see mma_layer_x3
-  __device__ __forceinline__ void advance(int stores = 0) {
-    switch (stores) {
-      case -1: break;
-      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 2) : "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 4) : "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 6) : "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4) + 8) : "memory"); break;
-      // (Larger allowances are NOT taken: with the layers' own counts allowed -- up to 20 in the two-tile layers -- the x3 repair kernel came out
-      // different from the x3 twin, deterministically (round 5, tests/test_gpu_h2.py).  Not isolated which assumption breaks there: the count of
-      // the short layers, or that the counter retires stores and LDS-DMA loads in issue order when many stores are in flight.  At <= 8 -- rounds
-      // 3-4, cold-L2 suite green -- three stages of look-ahead lie between a piece's issue and its first read.  A window with more waits for all.)
-      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4)) : "memory"); break;
-    }
+  // The wait counts LDS-DMA pieces only: three stages of them may be in flight.  Row stores of the training twins share the counter, so a window
+  // that holds stores waits for those as well.  Rounds 3-4 allowed up to 8 of a window's stores on top (their counts are compile-time constants);
+  // that is sound only if stores and LDS-DMA loads retire in issue order against EACH OTHER, and round 5 has a counter-example at larger
+  // allowances (the x3 repair kernel differed from the x3 twin with the two-tile layers' 20 allowed).  With the plain wait only the order of
+  // loads among themselves matters.  What the allowance was worth once the rows leave in bursts: 0.2 % on the x3 twin, 0.7 % on the h2 twin,
+  // 1.5 % on the h2 backward (profiles/r5/row_store_experiments.txt).
+  __device__ __forceinline__ void advance() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X_PIECES * (X_RING - 4)) : "memory");
     __builtin_amdgcn_s_barrier();
     rd_slot = (rd_slot + 1 == X_RING) ? 0u : rd_slot + 1;
     rd_addr = LDS_RING + rd_slot * X_STAGE_BYTES + lane16;
@@ -162,8 +155,7 @@ struct NoSaveX {
 struct ActSaveX {
   static constexpr bool on = true;
   float* base; long P; long n; bool valid; int h;
-  // row stores are UNCONDITIONAL raw-buffer stores (lanes without a point carry an out-of-range offset), so that their number between two
-  // points of a layer's code is a compile-time constant the ring's vmcnt can allow for (mma_layer_x3)
+  // row stores are UNCONDITIONAL raw-buffer stores (lanes without a point carry an out-of-range offset): no branch in the layer's unrolled stream
   __device__ __forceinline__ SaveRowX row(int slot) const {
     return SaveRowX{__builtin_amdgcn_make_buffer_rsrc(base + (long)slot * P * 256, 0, (int)(uint32_t)(P * 1024), 0x00020000)};
   }
