@@ -811,14 +811,16 @@ def main():
             last_rgb = step(i)
         gc.collect()
         gc.disable()        # a generation-2 collection of torch's heap is a ~10 ms host pause: exposed if it lands on the first steps, before work is queued
-        fence()
-        t0 = time.perf_counter()
-        for i in range(a.warmup, n_ev):
-            last_rgb = step(i)
-        t_enq = time.perf_counter()
-        fence()
-        dt = time.perf_counter() - t0
-        gc.enable()
+        try:
+            fence()
+            t0 = time.perf_counter()
+            for i in range(a.warmup, n_ev):
+                last_rgb = step(i)
+            t_enq = time.perf_counter()
+            fence()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
