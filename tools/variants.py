@@ -18,7 +18,9 @@ def main(name, extra, units):
     spec = importlib.util.spec_from_file_location("crnerf_build_v", os.path.join(PKG, "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    b.build(verbose=False)                                   # the shipped objects are current
+    with open(b.STAMP) as f:                                 # the shipped objects must be current (run build.py first; several variants may then be
+        if f.read().strip() != b._digest():                  # built in parallel -- this script never rebuilds the shipped library itself)
+            raise SystemExit("cr-nerf-pytorch_amd/build.py first: the shipped library is older than its sources")
     objdir = os.path.join(PKG, "build_" + name)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.join(PKG, "variants"), exist_ok=True)
