@@ -55,6 +55,12 @@ def test_bench_n_ranks_prints_one_valid_json_line(n):
     for name in ("allreduce_channel_sums_64f", "allreduce_gram_1024f", "allgather_rgb_12B_per_pixel"):
         assert times[name]["calls"] == 6 and times[name]["ms_per_call"] > 0, times      # 2 warm-up + 4 timed steps
     assert j["roofline"]["traffic_source"] is None or "not measured in this run" in j["roofline"]["traffic_source"]
+    # round 5: the line shows where a step's time went -- per timed step the device span, the render kernel, the idle gap to the next step and
+    # the host's enqueue time (a slow driver-side line can be told from a slow kernel)
+    t = j["timing"]
+    assert len(t["step_ms_each"]) == 4 and len(t["kernel_ms_each"]) == 4 and len(t["host_enqueue_ms_each"]) == 4 and len(t["device_gap_ms_each"]) == 3
+    assert all(k <= s_ for k, s_ in zip(t["kernel_ms_each"], t["step_ms_each"])) and t["device_span_ms"] <= t["wall_ms"] + 1e-3
+    assert abs(sum(t["kernel_ms_each"]) / 4 - j["roofline"]["kernel_ms"]) < 1e-3 and j["meets"].startswith("north_star")
 
 
 def _json_line(out):
