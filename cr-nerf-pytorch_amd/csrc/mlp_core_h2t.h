@@ -143,10 +143,15 @@ __device__ __forceinline__ void mlp_tile_h2t(WeightPipeX& p, int model, const f3
   sv.template masks<8>(0, act);
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {                            // xyz_encoding_2..4 (their input h_l is saved in slot l - 1 on the way)
+    tm.tick(T_X7);
     init_acc<8>(acc, C + C_BIAS + l * W_HIDDEN, h);
+    tm.tick(T_X0);
     mma_layer_h2t<8, KS_HID, 0, SAVE, false>(p, act, act, acc, q, 1.0f, sv.row(l - 1), SaveRowX{}, vo);
+    tm.tick(T_X1);
     finish_act_h2t<8>(acc, act, 0.0f, amax);
+    tm.tick(T_X2);
     sv.template masks<8>(l, act);
+    tm.tick(T_X3);
   }
   init_acc<8>(acc, C + C_BIAS + 4 * W_HIDDEN, h);          // xyz_encoding_5 = Linear(cat[xyz, h])
   mma_layer_h2t<8, KS_XYZ, KS_HID, false, SAVE>(p, pe, act, acc, q, 1.0f, SaveRowX{}, sv.row(3), vo);

@@ -3,9 +3,11 @@ per-phase cycle breakdown of wave 0 / block 0 (shader clock)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-env = dict(os.environ, CRNERF_EXTRA_FLAGS="-DCRNERF_TIMING " + os.environ.get("CRNERF_EXTRA_FLAGS", ""))
-subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], env=env, stdout=subprocess.DEVNULL)
-print("flags:", env["CRNERF_EXTRA_FLAGS"])
+TRAIN = os.environ.get("CRNERF_PHASE_TRAIN") == "1"      # the training twin of the kernel (train=True) instead of the inference kernel
+if not os.environ.get("CRNERF_LIB_PATH"):                  # (a -DCRNERF_TIMING variant from tools/variants.py needs no rebuild on the box)
+    env = dict(os.environ, CRNERF_EXTRA_FLAGS="-DCRNERF_TIMING " + os.environ.get("CRNERF_EXTRA_FLAGS", ""))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], env=env, stdout=subprocess.DEVNULL)
+    print("flags:", env["CRNERF_EXTRA_FLAGS"])
 import torch
 import crnerf_amd.synth as synth
 from crnerf_amd import ops, _lib
@@ -15,7 +17,7 @@ PREC = os.environ.get("CRNERF_PRECISION", "f32")   # bf16 -> the bf16 fused kern
 pc, pf = ops.pack_mlp_weights(C(synth.mlp_state(1, 3.0, 1.0)), precision=PREC), ops.pack_mlp_weights(C(synth.mlp_state(2, 3.0, 1.0)), precision=PREC)
 rays = torch.from_numpy(synth.rays(1024)).to(dev)
 for _ in range(3):
-    ops.render_rays(pc, pf, rays, 64, 128, precision=PREC)
+    ops.render_rays(pc, pf, rays, 64, 128, precision=PREC, train=TRAIN)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
@@ -35,5 +37,5 @@ elif PREC == "bf16":
     print("ideal matrix-pipe cycles per SIMD: %d (9664 MFMA x 32 cycles; pair core: two waves of 4 x 1208 each)" % (4 * 2416 * 32))
 else:
     print("ideal matrix-pipe cycles per SIMD: %d (8 steps x 9664 MFMA x 64 cycles-equivalent)" % (8 * 9664 * 64))
-if not os.environ.get("CRNERF_KEEP_BUILD"):   # restore the production build
+if not os.environ.get("CRNERF_KEEP_BUILD") and not os.environ.get("CRNERF_LIB_PATH"):   # restore the production build
     subprocess.check_call([sys.executable, os.path.join(ROOT, "cr-nerf-pytorch_amd", "build.py"), "--force"], stdout=subprocess.DEVNULL)
