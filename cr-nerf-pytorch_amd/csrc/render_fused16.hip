@@ -42,11 +42,11 @@ struct TrainHook {
   float* rawo[2];   // [R*N][65]
   long R;
   __device__ __forceinline__ ActSaver saver(int pass, long r, int N, int n, bool ok, int g) const {
-    return ActSaver{acts[pass], R * N, r * N + n, ok, g};
+    return ActSaver{pass ? acts[1] : acts[0], R * N, r * N + n, ok, g};
   }
   __device__ __forceinline__ void raw(int pass, long r, int N, int n, bool ok, int g, const f32x4 (&feat)[4], float sigma) const {
     if (!ok) return;
-    float* o = rawo[pass] + (r * N + n) * OUT_DIM;
+    float* o = (pass ? rawo[1] : rawo[0]) + (r * N + n) * OUT_DIM;
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll

@@ -56,7 +56,7 @@ struct TrainHookP {
     bool ok = ray_ok && n < N;
     int pts = ray_ok ? (N - n0 < 32 ? N - n0 : 32) : 0;   // points of this tile (<= 0: none)
     ActSaveP sv;
-    sv.acts = acts[pass]; sv.slot_bytes = P * 512; sv.P = P;
+    sv.acts = pass ? acts[1] : acts[0]; sv.slot_bytes = P * 512; sv.P = P;
     sv.boff = ok ? (uint32_t)pt * 32u + 8u * (uint32_t)h : SAVE_OOB;
     sv.toff = (uint32_t)(r * N + n0 + (lane >> 3)) * 512u + 16u * (uint32_t)(lane & 7);
     sv.rowlim = pts - (lane >> 3);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
         if constexpr (HOOK::on) {   // raw MLP output row (rgb features after the sigmoid, sigma after the softplus): what compositing consumes.
           // 8 x 16 B + sigma, unconditional (SAVE_TILE_BURST); rows are 260 B apart: dword-aligned 16-byte stores
           const long P = hook.R * N;
-          const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(hook.rawo[pass], 0, (int)(uint32_t)(P * (OUT_DIM * 4)), SAVE_FLAGS);
+          const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pass ? hook.rawo[1] : hook.rawo[0], 0, (int)(uint32_t)(P * (OUT_DIM * 4)), SAVE_FLAGS);
           const uint32_t ro = (valid && ray_ok && hook.stores_on()) ? (uint32_t)(r * N + n) * (uint32_t)(OUT_DIM * 4) + 16u * (uint32_t)h : SAVE_OOB;
 #pragma unroll
           for (int t = 0; t < 2; ++t)

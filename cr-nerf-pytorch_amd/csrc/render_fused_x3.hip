@@ -61,10 +61,12 @@ struct TrainHookX {
   float* acts[2];   // [10][R*N][256] + masks, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
   float* rawo[2];   // [R*N][65]
   long R;
-  __device__ __forceinline__ ActSaveX saver(int pass, long r, int N, int n, bool ok, int h) const { return ActSaveX{acts[pass], R * N, r * N + n, ok, h}; }
+  // (pass ? [1] : [0], not [pass]: a dynamic index into a by-value kernel argument goes through private memory, the pointer comes back in a VGPR
+  // and hipcc wraps EVERY row store in a readfirstlane waterfall loop -- twelve instructions and a branch per store; round 5, found in the ISA)
+  __device__ __forceinline__ ActSaveX saver(int pass, long r, int N, int n, bool ok, int h) const { return ActSaveX{pass ? acts[1] : acts[0], R * N, r * N + n, ok, h}; }
   __device__ __forceinline__ void raw(int pass, long r, int N, int n, bool ok, int h, const f32x16 (&feat)[2], float sigma) const {
     if (!ok) return;
-    float* o = rawo[pass] + (r * N + n) * OUT_DIM;
+    float* o = (pass ? rawo[1] : rawo[0]) + (r * N + n) * OUT_DIM;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
