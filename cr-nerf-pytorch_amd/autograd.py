@@ -71,7 +71,8 @@ def set_wgrad_precision(precision=None):
     the 256 x 256 blocks is split into three bf16 pieces in registers and a product is the sum of the six leading piece products (fp32
     accumulation; the dropped terms are one fp32 rounding), so that third of the MLP work runs at the rate of its operand reads with none
     of the bf16 mode's rounding noise.  Forward, loss, data gradients, biases and all other tensors are unchanged."""
-    _WGRAD_BF16[0] = None if precision is None else (2 if str(precision).lower() in ("bf16x3", "x3") else (1 if ops._is_bf16(precision) else 0))
+    _WGRAD_BF16[0] = None if precision is None else (3 if str(precision).lower() in ("f16x2", "h2") else 2 if str(precision).lower() in ("bf16x3", "x3") else
+                                                     (1 if ops._is_bf16(precision) else 0))
 
 
 _TRAIN_BF16 = [False]
@@ -147,16 +148,19 @@ def get_training_bf16():
     return _TRAIN_BF16[0] or os.environ.get("CRNERF_TRAIN_BF16", "") not in ("", "0")
 
 
-def get_wgrad_bf16():
-    """0: exact fp32 MFMA; 1: bf16-rounded operands; 2: three-piece bf16 split (fp32-accurate)."""
+def get_wgrad_bf16(h2=False):
+    """0: exact fp32 MFMA; 1: bf16-rounded operands; 2: three-piece bf16 split (fp32-accurate); 3: two-piece fp16 split of the full blocks
+    (fp32-accurate, h2 data gradient only: `h2` says whether the caller runs it -- without it 3 means 2)."""
     import os
     if _WGRAD_BF16[0] is not None:
-        return int(_WGRAD_BF16[0])
+        return int(_WGRAD_BF16[0]) if h2 else min(int(_WGRAD_BF16[0]), 2)
     if os.environ.get("CRNERF_WGRAD_F32", "") not in ("", "0"):
         return 0
     if os.environ.get("CRNERF_WGRAD_BF16X3", "") not in ("", "0"):
         return 2
-    return 1 if os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0") else 2
+    if os.environ.get("CRNERF_WGRAD_BF16", "") not in ("", "0"):
+        return 1
+    return 3 if h2 else 2
 
 
 def set_training_recompute(flag=True):
@@ -254,7 +258,7 @@ class FusedRenderFn(torch.autograd.Function):
             x3, h2 = mode == "f32x3", mode in ("f32h2", "auto")
             packed_t = ops.pack_mlp_weights_t_h2(states[m]) if h2 else (ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]))
             net = ops.pack_mlp_weights_t_x3(states[m]) if mode == "auto" else None      # "auto": the f32x3 data gradient stands by (device-side range flag)
-            grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(), dgrad_x3=x3, dgrad_h2=h2,
+            grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(h2), dgrad_x3=x3, dgrad_h2=h2,
                                       fallback_t_x3=net)
             del x, d_raw
         if getattr(ctx, "defer", False):

@@ -330,8 +330,8 @@ int crnerf_pack_mlp_weights_t_h2(const float* const* tensors, void* packed, void
 int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts,
                                void* scratch, float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
-  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: unknown flag bits");
-  if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: the two weight-gradient modes are exclusive");
+  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3 | CRNERF_BWD_WGRAD_F16X2)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: unknown flag bits");
+  if ((flags & (flags - 1)) != 0) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: the weight-gradient modes are exclusive");
   REQUIRE(packed_t_h2, "packed_t_h2"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
   REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
   for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)

@@ -39,7 +39,7 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags = 0, const void* packedT_x3 = nullptr, const void* packedT_h2 = nullptr);
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
-                      long P, hipStream_t stream, int wb);
+                      long P, hipStream_t stream, int wb, const uint32_t* dmax = nullptr);
 // mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs; activations, deltas and the embedded input travel as bf16
 size_t gemm_packed_bytes();
 size_t mlp_train_mixed_acts_bytes(long P);
@@ -59,9 +59,10 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
 size_t wgrad_workspace_floats(long P, int M, int N);
 // bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16 = 0);
+          hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr);
 // several such products in ONE launch + ONE reduction (small batches: a launch per job is mostly ramp-up and drain); at most 16 jobs
-struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; };
+// bf16: 0 fp32 operands, 1 bf16-rounded, 2 "bf16x3", 3 "f16x2" (full tiles; dmax = the bits of max |D| over the tensor, see wgrad_h2_kernel)
+struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; const uint32_t* dmax = nullptr; };
 float wgrad_job_weight(int M, int N);                              // per-point cost of a job relative to a full 256 x 256 block
 size_t wgrad_batch_ws_floats(const WgradSpec* specs, int n);       // partial-sum workspace the plan for these jobs needs
 int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipStream_t st);
@@ -125,8 +126,10 @@ int pack_h2_status(const void* packed, hipStream_t stream);
 int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_h2(const RenderArgs& a, hipStream_t stream);
 int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream);
+// dmax: null, or ACT_SLOTS words the kernel raises (atomic max) to the bits of the largest |delta| it stored in every slot (slots 1..8: what the
+// f16x2 weight gradients range their delta operands with, mlp_train16.hip wgrad_h2_kernel); the caller zeroes them
 int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
-                        hipStream_t stream);
+                        hipStream_t stream, uint32_t* dmax = nullptr);
 // only_if: device word; the kernel leaves at once when it is 0 (the f32x3 stand-in of an h2 data gradient whose pack was refused); null: always
 int launch_mlp_dgrad_x3(const void* packedT_x3, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream, const int* only_if = nullptr);

@@ -23,14 +23,16 @@ __device__ __forceinline__ void zero_acc_h(f32x16 (&acc)[NT]) {
 // The operand scale of this lane's point and the factor that undoes it together with the weights' 2^8: sc = 2^(134 - e), e = the biased exponent
 // of the point's largest |delta| (clamped to [32, 254]: below 2^-95 the entries keep sc = 2^102 and simply use less of fp16's range; a zero
 // vector stays zero).  Both are exact powers of two.
+// slot_max: an LDS word that collects the largest |delta| of the whole tensor for the weight gradients (see the kernel's last lines), or null
 template <int NT>
-__device__ __forceinline__ void point_scale_h(const f32x16 (&d)[NT], float& sc, float& inv) {
+__device__ __forceinline__ void point_scale_h(const f32x16 (&d)[NT], float& sc, float& inv, lds_uint* slot_max = nullptr) {
   float m = 0.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, fabsf(d[t][r])), fabsf(d[t][r + 1]));
   m = fmaxf(m, __shfl_xor(m, 32));
+  if (slot_max) __hip_atomic_fetch_max(slot_max, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // m >= 0: its bits order like its value
   int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
   e = e < 32 ? 32 : (e > 254 ? 254 : e);
   sc = __uint_as_float((uint32_t)(261 - e) << 23);     // 2^(134 - e)
@@ -58,7 +60,7 @@ __device__ __forceinline__ void finish_delta_h(const f32x16 (&acc)[NT], f32x16 (
 
 __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __restrict__ packedT, const float* __restrict__ out, const float* __restrict__ d_out,
                                                                  const float* __restrict__ acts, float* __restrict__ deltas, float* __restrict__ d_rgb,
-                                                                 float* __restrict__ d_sig, long P, int iters) {
+                                                                 float* __restrict__ d_sig, long P, int iters, uint32_t* __restrict__ dmax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* lds = (lds_char*)smem;
   const int lane = threadIdx.x & 63;
@@ -67,6 +69,14 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
   load_consts(lds, packedT, packedT);   // the consts block carries the sigma-head weights (unscaled)
   const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
   if (__float_as_uint(C[H2_FLAG_WORD]) != 0u) return;   // a weight is outside fp16's range: the f32x3 data gradient runs instead (launch_mlp_backward)
+  // the largest |delta| per slot, collected per workgroup in the (unused) second consts block and raised into dmax[] once at the end: the range
+  // words of the f16x2 weight gradients (mlp_train16.hip wgrad_h2_kernel).  Every delta row but slots 0 and 9 leaves right behind a point_scale_h
+  // of exactly its values, so the maximum costs one LDS atomic per lane and layer.
+  lds_uint* smax = dmax ? (lds_uint*)(lds + LDS_CONST1) : nullptr;
+  if (dmax) {
+    if (threadIdx.x < ACT_SLOTS) smax[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   WeightPipeX pipe;
   pipe.set_stream_frags(STREAMHT_FRAGS);
   pipe.start(lds, packedT + CONST_BYTES, packedT + CONST_BYTES, 1, 1, lane, wave);
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
     mma_layer_h2t<8, 128 / 16, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(9), SaveRowX{}, vo);
     finish_delta_h<8, false>(acc, dl, inv, 0ull, 0ull);
     zero_acc_h<8>(acc);                               // through xyz_encoding_final^T, + sigma head -> h8 (relu)
-    point_scale_h<8>(dl, sc, inv);
+    point_scale_h<8>(dl, sc, inv, smax ? smax + 8 : nullptr);
     mma_layer_h2t<8, KS_HID, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(8), SaveRowX{}, vo);
 #pragma unroll
     for (int t = 0; t < 8; ++t)                       // (the sigma-head term joins AFTER the accumulator is scaled back: dsp need not fit the deltas' scale)
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                    // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2; delta_l leaves on the way
       zero_acc_h<8>(acc);
-      point_scale_h<8>(dl, sc, inv);
+      point_scale_h<8>(dl, sc, inv, smax ? smax + l : nullptr);
       mma_layer_h2t<8, KS_HID, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(l), SaveRowX{}, vo);
       unsigned long long m0 = b0[0], m1 = b1[0];      // words of slot l - 1 by selects: a dynamic register index would go through M0, which the
 #pragma unroll                                        // LDS-DMA asm (glds16) rewrites behind the compiler's back
@@ -164,10 +174,14 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (dmax) {
+    __syncthreads();
+    if (threadIdx.x < ACT_SLOTS && smax[threadIdx.x] != 0u) atomicMax(dmax + threadIdx.x, smax[threadIdx.x]);
+  }
 }
 
 int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
-                        hipStream_t stream) {
+                        hipStream_t stream, uint32_t* dmax) {
   if (P <= 0) return 0;
   if ((unsigned long long)P * 1024ull >= (unsigned long long)SAVEX_OOB)
     return set_error(-2, "mlp_backward_h2: more than 3.9 M points per call (the delta rows are addressed with 32-bit offsets)");
@@ -175,7 +189,7 @@ int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (int rc = ensure_dynamic_lds((const void*)mlp_backward_h2_kernel, LDS_SCRATCH_X, "mlp_backward_h2_kernel")) return rc;
-  hipLaunchKernelGGL(mlp_backward_h2_kernel, dim3(grid), dim3(256), LDS_SCRATCH_X, stream, (const char*)packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
+  hipLaunchKernelGGL(mlp_backward_h2_kernel, dim3(grid), dim3(256), LDS_SCRATCH_X, stream, (const char*)packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, iters, dmax);
   return check_launch("mlp_backward_h2_kernel");
 }
 

@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) uint32_t lds_uint;
 typedef const __attribute__((address_space(1))) char gbl_char;
 
 constexpr int RING_SLOTS = 6;   // stages c-1 (being refilled), c (read), c+1 (read ahead), c+2 (certified), c+3, c+4 (in flight)

@@ -203,6 +203,7 @@ struct WgradJob {
   float* bias_partial;                 // [nchunk][M] column sums of D (bias gradient) or null
   long P; int chunk;
   int bf16;                            // != 0: the full 256 x 256 tiles multiply bf16-rounded operands (fp32 accumulate), see wgrad_kernel
+  const uint32_t* dmax;                // wgrad_h2_kernel: the bits of max |D| over the whole tensor (written by the h2 data gradient), or null
 };
 
 __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32: a -> low half, b -> high half
@@ -451,8 +452,33 @@ __device__ __forceinline__ void split_all(const float __attribute__((ext_vector_
   static_for<11>([&](auto K) { split_stage<decltype(K)::value, T>(v, w, r, u); });
 }
 
-// X3: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3) -- see the full-tile branch below
-template <bool X3 = false>
+// The two-piece fp16 split of column T of eight fp32 rows (the h2 core's arithmetic, mlp_core_h2.h h2_split_*): h1 = fp16(x * s), h2 = fp16(x * s - h1),
+// one v_fma_mix per half -- four micro-stages of four independent instructions (one per point pair; dword q = points 2q low, 2q + 1 high).
+template <int K, int T>
+__device__ __forceinline__ void split_stage_h(const float __attribute__((ext_vector_type(4))) (&v)[8], uint32_t (&w)[2][4], float s) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (K == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(w[0][q]) : "v"(v[2 * q][T]), "v"(s));
+    else if constexpr (K == 1) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(w[0][q]) : "v"(v[2 * q + 1][T]), "v"(s));
+    else if constexpr (K == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(w[1][q]) : "v"(v[2 * q][T]), "v"(s), "v"(w[0][q]));
+    else asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(w[1][q]) : "v"(v[2 * q + 1][T]), "v"(s), "v"(w[0][q]));
+  }
+}
+template <int T>
+__device__ __forceinline__ void split_all_h(const float __attribute__((ext_vector_type(4))) (&v)[8], uint32_t (&w)[2][4], float s) {
+  static_for<4>([&](auto K) { split_stage_h<decltype(K)::value, T>(v, w, s); });
+}
+// m[0..3] = max(m, |eight values of two rows|): four independent v_max3_f32 (one slot of the stream)
+__device__ __forceinline__ void max_slot(float (&m)[4], const float __attribute__((ext_vector_type(4)))& r0, const float __attribute__((ext_vector_type(4)))& r1) {
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m[0]) : "v"(r0[0]), "v"(r0[1]));
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m[1]) : "v"(r0[2]), "v"(r0[3]));
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m[2]) : "v"(r1[0]), "v"(r1[1]));
+  asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m[3]) : "v"(r1[2]), "v"(r1[3]));
+}
+
+// MODE 1: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3); MODE 2: the "f16x2" form of the full tiles with bf16x3 behind it -- see the
+// full-tile branch below
+template <int MODE = 0>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the wave's tile origin lives in SGPRs
   const int i = lane & 31, kk = lane >> 5;
@@ -498,7 +524,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
     const float* dbase = j.D + m0 + 4 * i;
     const float* abase = j.A + n0 + 4 * i;
     const long plast = p1 - 1;
-    if constexpr (X3) {
+    if constexpr (MODE != 0) {
       // ---- opt-in "bf16x3" (CRNERF_BWD_WGRAD_BF16X3): fp32-ACCURATE products on the bf16 matrix cores.  Every fp32 operand is split in
       // registers into three bf16 pieces, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (8 + 8 + 8 mantissa
       // bits: the split is exact up to the last bit or two), and a product d * a is the sum of the SIX leading piece products
@@ -544,6 +570,107 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       };
       const bool do_bias3 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum3 = {0.0f, 0.0f, 0.0f, 0.0f};
+      bool done_h = false;
+      if constexpr (MODE == 2) {
+        if (j.dmax && ((p1 - p0) & 31) == 0 && p1 > p0) {
+          // ---- "f16x2" (the default behind the h2 data gradient, launch_mlp_backward): the same stream with every operand split into TWO fp16 pieces,
+          // x * s = h1 + h2 (11 + 11 mantissa bits, the h2 core's split: one v_fma_mix per half), and a product formed from the THREE leading piece
+          // products d2 a1 + d1 a2 + d1 a1 on v_mfma_f32_32x32x16_f16 -- half the MFMAs and a third of the split work of bf16x3 (measured with a
+          // tuning build that issued half the MFMAs, profiles/r5/wgrad_half_work.txt: the thirteen jobs of a backward 7.4 -> 6.1-6.3 ms per 2^20
+          // points), what is dropped is d2 a2 <= 2^-22 of the product.  fp16 has five exponent bits, so the operands need a range: activations go
+          // in as they are (the h2 forward's own limit, |a| < 65504), deltas under ONE power of two per tensor, s = 2^(140 - e) with e the exponent
+          // of the tensor's largest |delta| (j.dmax, written by the h2 data gradient's workgroups: max s |delta| in [2^13, 2^14)); a delta 2^-38 of
+          // that maximum still lands on a piece bit.  The accumulators run in the scaled domain and are scaled back (exactly) before they leave.
+          // Nothing is trusted: the stream keeps the largest |a| and |delta| it has seen (v_max3 in its spare slots), and a wave that saw an operand
+          // leave fp16's range -- rows of a ray the forward had to repair, a stale or missing range word -- throws its sums away and runs its chunk
+          // again on the bf16x3 stream below: same result as wgrad_x3_kernel, bit for bit.
+          typedef _Float16 xh16x8_t __attribute__((ext_vector_type(8)));
+          uint32_t eb = (__builtin_nontemporal_load(j.dmax) >> 23) & 0xffu;
+          eb = __builtin_amdgcn_readfirstlane(eb < 32u ? 32u : (eb > 254u ? 254u : eb));
+          const float sd = __uint_as_float((267u - eb) << 23);            // 2^(140 - e): the largest scaled delta in [2^13, 2^14)
+          const float sinv = __uint_as_float((eb - 13u) << 23);           // 1 / sd
+          const float one = 1.0f;
+          const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
+          uint32_t vd[8], va[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { vd[e] = (uint32_t)(8 * kk + e) * rowd + 16u * i; va[e] = (uint32_t)(8 * kk + e) * rowa + 16u * i; }
+          const char* db = (const char*)(j.D + m0) + p0 * (long)rowd;
+          const char* ab = (const char*)(j.A + n0) + p0 * (long)rowa;
+          const long sd_b = 16L * rowd, sa_b = 16L * rowa;
+          f32x4 draw[2][8], araw[8];
+          uint32_t Ah[2][4][2][4], Dh[3][2][4];                          // piece dwords: [buffer][column][piece][dword], [set][piece][dword]
+          float amx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dmx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          long left = (p1 - p0) / 16;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { draw[0][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
+          split_all_h<0>(araw, Ah[0][0], one); split_all_h<1>(araw, Ah[0][1], one); split_all_h<2>(araw, Ah[0][2], one); split_all_h<3>(araw, Ah[0][3], one);
+          split_all_h<0>(draw[0], Dh[0], sd);
+          max_slot(amx, araw[0], araw[1]); max_slot(amx, araw[2], araw[3]); max_slot(amx, araw[4], araw[5]); max_slot(amx, araw[6], araw[7]);
+          auto fragh = [](const uint32_t (&w)[4]) { return __builtin_bit_cast(xh16x8_t, make_uint4(w[0], w[1], w[2], w[3])); };
+          // One phase = the 12 MFMAs of delta column A against the four activation columns of buffer C (every accumulator: d2 a1, d1 a2, d1 a1, the
+          // four accumulators taking turns); behind MFMA g rides micro-stage g of split X (g < 4), g - 4 of split Y (g < 8), or one slot of the tail
+          // (two bias rows, two range slots), and a scheduling fence.
+          auto phase = [&](auto A_, auto DS_, auto C_, auto&& x_stage, auto&& y_stage, auto&& tail) {
+            constexpr int a = decltype(A_)::value, ds = decltype(DS_)::value, c = decltype(C_)::value;
+            static_for<12>([&](auto G) {
+              constexpr int g = decltype(G)::value, pp = g / 4, b = g % 4;
+              constexpr int dp = pp == 0 ? 1 : 0, ap = pp == 1 ? 1 : 0;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fragh(Dh[ds][dp]), fragh(Ah[c][b][ap]), acc[a][b], 0, 0, 0);
+              if constexpr (g < 4) x_stage(G);
+              else if constexpr (g < 8) y_stage(std::integral_constant<int, g - 4>{});
+              else tail(std::integral_constant<int, g - 8>{});
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          };
+          auto kstep = [&](auto CUR) {
+            constexpr int c = decltype(CUR)::value, n = 1 - c;
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>; using IC = std::integral_constant<int, c>;
+            left -= 1;
+            const long adv = left > 0 ? 1 : 0;
+            db += adv * sd_b;
+            ab += adv * sa_b;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { draw[n][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+            // the same rotation as the bf16x3 k-step: delta pieces through three sets, the next k-step's activation rows first touched in phase 1
+            phase(I0{}, I0{}, IC{}, [&](auto K) { split_stage_h<decltype(K)::value, 1>(draw[c], Dh[1], sd); },
+                  [&](auto K) { split_stage_h<decltype(K)::value, 2>(draw[c], Dh[2], sd); },
+                  [&](auto R) { constexpr int r = decltype(R)::value; if constexpr (r < 2) bsum3 += draw[c][r]; else max_slot(dmx, draw[c][2 * (r - 2)], draw[c][2 * (r - 2) + 1]); });
+            phase(I1{}, I1{}, IC{}, [&](auto K) { split_stage_h<decltype(K)::value, 0>(araw, Ah[n][0], one); },
+                  [&](auto K) { split_stage_h<decltype(K)::value, 1>(araw, Ah[n][1], one); },
+                  [&](auto R) { constexpr int r = decltype(R)::value; if constexpr (r < 2) bsum3 += draw[c][2 + r]; else max_slot(amx, araw[2 * (r - 2)], araw[2 * (r - 2) + 1]); });
+            phase(I2{}, I2{}, IC{}, [&](auto K) { split_stage_h<decltype(K)::value, 3>(draw[c], Dh[1], sd); },
+                  [&](auto K) { split_stage_h<decltype(K)::value, 2>(araw, Ah[n][2], one); },
+                  [&](auto R) { constexpr int r = decltype(R)::value; if constexpr (r < 2) bsum3 += draw[c][4 + r]; else max_slot(dmx, draw[c][4 + 2 * (r - 2)], draw[c][4 + 2 * (r - 2) + 1]); });
+            phase(I3{}, I1{}, IC{}, [&](auto K) { split_stage_h<decltype(K)::value, 3>(araw, Ah[n][3], one); },
+                  [&](auto K) { split_stage_h<decltype(K)::value, 0>(draw[n], Dh[0], sd); },
+                  [&](auto R) { constexpr int r = decltype(R)::value; if constexpr (r < 2) bsum3 += draw[c][6 + r]; else max_slot(amx, araw[4 + 2 * (r - 2)], araw[4 + 2 * (r - 2) + 1]); });
+          };
+          while (left > 0) {
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+          }
+          const float am = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3])), dm = fmaxf(fmaxf(dmx[0], dmx[1]), fmaxf(dmx[2], dmx[3])) * sd;
+          const bool in_range = am < 65504.0f && dm < 65504.0f;          // (an Inf or a NaN among the operands fails it too)
+          if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) acc[a][b] *= sinv;
+            done_h = true;
+          } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            bsum3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+        }
+      }
+      if (!done_h) {
       if (((p1 - p0) & 31) == 0 && p1 > p0) {
         // ---- the stream for whole pairs of k-steps (every chunk but a ragged last one), placed by hand, because one wave per SIMD hides nothing by
         // itself: hipcc's schedule of the loop below is [~530 VALU: addresses, splits] then [96 MFMAs] in clumps -- 2.8 us per k-step where the
@@ -649,6 +776,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
         take16(pb + 16);
+      }
       }
       }
       if (do_bias3) {
@@ -793,21 +921,23 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
   // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
   const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, X3>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, MODE != 0>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
   CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
   CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
 }
 
 
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body(j, blockIdx.x, blockIdx.y, blockIdx.z); }
-__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(WgradJob j) { wgrad_body<true>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body<0>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(WgradJob j) { wgrad_body<1>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256, 1) void wgrad_h2_kernel(WgradJob j) { wgrad_body<2>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Every weight gradient of one NeRF_sigma backward in ONE launch: at the reference's 1,024-ray batches a per-layer launch is
 // ~256 workgroups of 256 points each -- fourteen ramp-ups and drains per model, and a [256 chunks][256][256] partial-sum slab
 // per layer that costs as much HBM traffic as the operands.  Batched, the jobs share the chip (a job's workgroups are laid
 // out consecutively, the big jobs first), so a chunk can be ~9x longer and the partial sums ~9x smaller.
 constexpr int WG_MAX_JOBS = 16;
+constexpr int WG_RANGE_WORDS = 64;   // launch_mlp_backward: one word per delta slot (max |delta| bits, ACT_SLOTS used), a 256-byte line of the scratch
 struct WgradBatch {
   WgradJob job[WG_MAX_JOBS];
   int first[WG_MAX_JOBS + 1];   // first flat block of job k; first[njobs] = grid size
@@ -815,7 +945,7 @@ struct WgradBatch {
   int my[WG_MAX_JOBS];          // row blocks (ceil(M / 256))
   int njobs;
 };
-template <bool X3>
+template <int MODE>
 __device__ __forceinline__ void wgrad_batch_body(const WgradBatch& b) {
   int k = 0;
 #pragma unroll 1
@@ -823,10 +953,11 @@ __device__ __forceinline__ void wgrad_batch_body(const WgradBatch& b) {
   k = __builtin_amdgcn_readfirstlane(k);
   const int local = (int)blockIdx.x - b.first[k];
   const int bx = local % b.nchunk[k], rest = local / b.nchunk[k];
-  wgrad_body<X3>(b.job[k], bx, rest % b.my[k], rest / b.my[k]);
+  wgrad_body<MODE>(b.job[k], bx, rest % b.my[k], rest / b.my[k]);
 }
-__global__ __launch_bounds__(256, 1) void wgrad_batch_kernel(WgradBatch b) { wgrad_batch_body<false>(b); }
-__global__ __launch_bounds__(256, 1) void wgrad_x3_batch_kernel(WgradBatch b) { wgrad_batch_body<true>(b); }
+__global__ __launch_bounds__(256, 1) void wgrad_batch_kernel(WgradBatch b) { wgrad_batch_body<0>(b); }
+__global__ __launch_bounds__(256, 1) void wgrad_x3_batch_kernel(WgradBatch b) { wgrad_batch_body<1>(b); }
+__global__ __launch_bounds__(256, 1) void wgrad_h2_batch_kernel(WgradBatch b) { wgrad_batch_body<2>(b); }
 
 struct ReduceJob { const float* partial; const float* bias_partial; float* dst; float* db; int nchunk, M, N, ldc; };
 struct ReduceBatch { ReduceJob job[WG_MAX_JOBS]; int first[WG_MAX_JOBS + 1]; int njobs; };
@@ -885,12 +1016,13 @@ size_t wgrad_workspace_floats(long P, int M, int N) {
 }
 
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16) {
+          hipStream_t st, int bf16, const uint32_t* dmax) {
   const int chunk = wg_chunk(P);
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
-  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 == 2 ? 0 : bf16};   // bf16x3: its own kernel (wgrad_body<true>)
-  if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
+  if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  else if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);
   return 0;
@@ -906,7 +1038,7 @@ size_t mlp_train_scratch_bytes(long P) {
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
   size_t wsf = nchunk * (size_t)(256 * 256 + 256);                 // per-layer launches (CRNERF_WGRAD_BATCH=0)
   if (wgrad_batch_workspace_floats() > wsf) wsf = wgrad_batch_workspace_floats();   // the batched launch keeps every job's partial sums
-  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + wsf * 4;
+  return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + WG_RANGE_WORDS * 4 + wsf * 4;   // deltas | d_rgb | d_sig | range words | partial sums
 }
 
 static int launch_core(const void* fn, int grid, size_t shmem) {
@@ -968,13 +1100,15 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
   b.njobs = r.njobs = n;
   int blocks = 0, rblocks = 0;
   float* w = ws;
-  bool x3 = false;
+  bool x3 = false, h2 = false;
   for (int q = 0; q < n; ++q) {
     const WgradSpec& sp = specs[order[q]];
     const int nc = nchunk[order[q]];
     float* bws = w + (size_t)nc * sp.M * sp.N;
     x3 = x3 || sp.bf16 == 2;
-    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16 == 2 ? 0 : sp.bf16};
+    h2 = h2 || sp.bf16 == 3;
+    b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16 >= 2 ? 0 : sp.bf16,
+                        sp.bf16 == 3 ? sp.dmax : nullptr};
     b.first[q] = blocks;
     b.nchunk[q] = nc;
     b.my[q] = (sp.M + 255) / 256;
@@ -987,7 +1121,8 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
   b.first[n] = blocks;
   r.first[n] = rblocks;
   if ((size_t)(w - ws) > ws_floats) return set_error(-3, "wgrad batch: workspace too small");
-  if (x3) hipLaunchKernelGGL(wgrad_x3_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+  if (h2) hipLaunchKernelGGL(wgrad_h2_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+  else if (x3) hipLaunchKernelGGL(wgrad_x3_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
   else hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblocks), dim3(256), 0, st, r);
   return 0;
@@ -1001,9 +1136,11 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
 // (profiles/r3/pmc_train_sq.txt): matrix pipe busy 85.6 % of the kernel's cycles at a shader clock of 2.07 GHz -- the 2.4 TB/s of
 // operand traffic costs clock, not issue slots; 0.856 x 2.07 / 2.4 = the measured 74 % of the 157.3 TFLOP/s figure.)
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
-                      long P, hipStream_t stream, int wb) {
+                      long P, hipStream_t stream, int wb, const uint32_t* dmax) {
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
+  auto R = [&](int slot) { return dmax ? dmax + slot : nullptr; };   // the range word of delta slot `slot` (wb == 3: the f16x2 full tiles)
+  if (wb == 3 && !dmax) wb = 2;
   // batched below 2^18 points (the reference's 1,024-ray batches: 8.24 -> 8.02 ms per step, 56 launches -> 4); beyond that a
   // per-layer launch of 256 equal workgroups is already one even wave over the chip and the batched launch's mixed job lengths
   // only add a tail (16,384-ray step: 103 ms per layer, 108 ms batched).  CRNERF_WGRAD_BATCH=0 / 1 forces either.
@@ -1017,12 +1154,12 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     for (int l = 1; l < 8; ++l) {
       if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169
         sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P};
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P, R(4)};
       } else {
-        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P};
+        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P, R(l)};
       }
     }
-    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P};                                  // xyz_encoding_final
+    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P, R(8)};                            // xyz_encoding_final
     sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0, P};                                         // static_sigma
     sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P};                         // dir_encoding: cat([final, dir])
     sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P};
@@ -1035,12 +1172,12 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
       wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb);
-      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb);
+      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb, R(4));
     } else {
-      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb);
+      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb, R(l));
     }
   }
-  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb);            // xyz_encoding_final
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8));      // xyz_encoding_final
   wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
   wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb);  // dir_encoding: cat([final, dir])
   wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb);
@@ -1051,17 +1188,22 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
 // grads: 24 device pointers in crnerf.h tensor order, each overwritten with the gradient of sum(out * d_out)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags, const void* packedT_x3, const void* packedT_h2) {
-  const int wb = (flags & 2) ? 2 : (flags & 1);   // CRNERF_BWD_WGRAD_BF16X3 / CRNERF_BWD_WGRAD_BF16
+  int wb = (flags & 4) ? 3 : ((flags & 2) ? 2 : (flags & 1));   // CRNERF_BWD_WGRAD_F16X2 (h2 data gradient only, checked by the caller) / _BF16X3 / _BF16
   if (P <= 0) return 0;
   float* deltas = (float*)scratch;
   float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
   float* d_sig = d_rgb + (size_t)P * FEAT_DIM;
-  float* ws = d_sig + P;
+  uint32_t* dmax = (uint32_t*)(d_sig + P);          // the delta tensors' range words (h2 data gradient -> f16x2 weight gradients)
+  float* ws = d_sig + P + WG_RANGE_WORDS;
   const long groups = (P + 127) / 128;
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (packedT_h2) {   // crnerf_mlp_backward_h2_f32: the data gradient on the h2 core (mlp_backward_h2.hip), same scratch layout
-    if (int rc = launch_mlp_dgrad_h2(packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, stream)) return rc;
+    // CRNERF_BWD_WGRAD_F16X2: the full tiles of the weight gradients on the two-piece fp16 form (wgrad_h2_kernel), ranged by the
+    // largest |delta| of every tensor, which the data gradient's workgroups leave in dmax (zero = nothing known: the kernel falls back by itself)
+    const bool h2w = wb == 3;
+    if (h2w && hipMemsetAsync(dmax, 0, WG_RANGE_WORDS * 4, stream) != hipSuccess) return set_error(-1, "mlp_backward: hipMemsetAsync(range words) failed");
+    if (int rc = launch_mlp_dgrad_h2(packedT_h2, out, d_out, acts, deltas, d_rgb, d_sig, P, stream, h2w ? dmax : nullptr)) return rc;
     if (packedT_x3)   // its safety net: the same deltas on the scale-free core, only when the h2 pack carries the range flag (device-side test)
       if (int rc = launch_mlp_dgrad_x3(packedT_x3, out, d_out, acts, deltas, d_rgb, d_sig, P, stream, (const int*)packedT_h2 + H2_FLAG_WORD)) return rc;
   } else if (packedT_x3) {   // crnerf_mlp_backward_x3_f32: the data gradient on the x3 core (mlp_backward_x3.hip), same scratch layout
@@ -1071,7 +1213,8 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
     hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
     if (int rc = check_launch("mlp_backward16_kernel")) return rc;
   }
-  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb);
+  if (wb == 3 && !packedT_h2) wb = 2;
+  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb, wb == 3 ? dmax : nullptr);
 }
 
 }  // namespace crnerf

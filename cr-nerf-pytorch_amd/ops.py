@@ -265,10 +265,15 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
     (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
     CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
-    cores.  Data gradients, biases and everything else exact fp32."""
+    cores; 3 / "f16x2" (dgrad_h2 only) = CRNERF_BWD_WGRAD_F16X2 -- the same with the full 256 x 256 blocks from two-piece fp16 splits (three
+    piece products, the h2 core's arithmetic; bf16x3 takes over by itself where an operand leaves fp16's range).  Data gradients as the dgrad_*
+    arguments say; biases and everything else exact fp32."""
     lib = _lib.load()
     x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
     n = x.shape[0]
+    f16x2 = wgrad_bf16 in (3, "f16x2", "h2")
+    if f16x2 and not dgrad_h2:
+        raise ValueError("crnerf_amd: f16x2 weight gradients take their delta ranges from the h2 data gradient (dgrad_h2=True)")
     grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
     scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
     # dgrad_x3 / dgrad_h2: the data gradient on the x3 / h2 core; packed_t is then a pack_mlp_weights_t_x3 / pack_mlp_weights_t_h2 pack
@@ -282,7 +287,7 @@ def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False
     head = (ctypes.c_void_p(packed_t.data_ptr()),) + ((ctypes.c_void_p(fallback_t_x3.data_ptr() if fallback_t_x3 is not None else None),) if dgrad_h2 else ())
     _lib.check(fn(*head, _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
                   ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
-                  _lib.ptr_array(grads, "grad"), n, 2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0),
+                  _lib.ptr_array(grads, "grad"), n, 4 if f16x2 else (2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0)),
                   _lib.stream_ptr()), name)
     return grads
 

@@ -92,6 +92,13 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
  * block of the eleven nn.Linear (static_sigma: only when the jobs share one batched launch, n <= 2^18); bias gradients, data gradients
  * and everything else: the exact fp32 path.  Exclusive with CRNERF_BWD_WGRAD_BF16. */
 #define CRNERF_BWD_WGRAD_BF16X3 2
+/* CRNERF_BWD_WGRAD_F16X2 (crnerf_mlp_backward_h2_f32 only; exclusive with the two above): CRNERF_BWD_WGRAD_BF16X3 with the full 256 x 256 blocks
+ * -- eight of the thirteen products of a backward -- formed from TWO fp16 pieces per operand and three piece products (what is dropped is <= 2^-22
+ * of a product: the h2 core's arithmetic): half the matrix instructions.  Activations go in unscaled (fp16's range is the h2 forward's own limit),
+ * a delta tensor under one power of two taken from its largest entry, which the h2 data gradient of the same call leaves in the scratch.  A
+ * workgroup that meets an operand outside fp16's range (rows of a ray the forward had to repair; the f32x3 stand-in ran and left no range) redoes
+ * its chunk of points as CRNERF_BWD_WGRAD_BF16X3 would have, bit for bit. */
+#define CRNERF_BWD_WGRAD_F16X2 4
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream);
 

@@ -508,6 +508,90 @@ def test_split_core_backward_vs_autograd_oracle(core):
         assert bool(torch.isfinite(gq).all()) and err <= tol, "%s: max|d| %.3e > %.3e (|ref|max %.3e)" % (name, err, tol, float(ref.abs().max()))
 
 
+def _backward_case(n, seed=13, gain=2.0):
+    st = synth.mlp_state(seed, gain, 0.5)
+    rng = np.random.default_rng(n)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32))
+    d_out[::7] *= 1e-6
+    return st, x, d_out
+
+
+def test_f16x2_weight_gradients_vs_autograd_oracle():
+    """CRNERF_BWD_WGRAD_F16X2 (the weight gradients of the training default: two-piece fp16 splits of the full 256 x 256 blocks, ranged by the
+    largest |delta| the h2 data gradient saw) against torch autograd through oracle.cpu_ref.mlp_forward at the fp32 twin's own bar, on deltas
+    that span twelve decades (every seventh point 1e-6 of the rest, the whole batch then scaled 1e-6 / 1 / 1e+6: the range word has to follow)."""
+    n = 1184                                   # whole 32-point pairs of k-steps in every chunk but a ragged last one
+    st, x, d_out = _backward_case(n)
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        pack_t = ops.pack_mlp_weights_t_h2(dev_state)
+    for scale in (1.0, 1e-6, 1e6):
+        w = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+        (O.mlp_forward(w, x) * (d_out * scale)).sum().backward()
+        with torch.no_grad():
+            grads = ops.mlp_backward(pack_t, x.to(DEV), out, (d_out * scale).to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
+        for name, gq in zip(ops.MLP_TENSOR_NAMES, grads):
+            ref = w[name].grad
+            err = float((gq.cpu() - ref).abs().max())
+            tol = 2e-4 * float(ref.abs().max()) + 1e-5 * scale
+            assert bool(torch.isfinite(gq).all()) and err <= tol, "scale %g, %s: max|d| %.3e > %.3e" % (scale, name, err, tol)
+
+
+def test_f16x2_weight_gradients_are_as_accurate_as_bf16x3():
+    """Against a float64 evaluation of the same products (the device's own deltas and activations: D^T A per layer), the two-piece fp16 form and the
+    three-piece bf16 form sit at the same distance -- both are fp32-accurate; fp16's eleven-bit pieces lose nothing a reader of the fp32 result
+    would see."""
+    n = 4096
+    st, x, d_out = _backward_case(n, seed=29)
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        pack_t = ops.pack_mlp_weights_t_h2(dev_state)
+        g2 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
+        g3 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="bf16x3", dgrad_h2=True)
+    w = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in st.items()}
+    (O.mlp_forward(w, x.double()) * d_out.double()).sum().backward()
+    for k, name in enumerate(ops.MLP_TENSOR_NAMES):
+        ref = w[name].grad
+        top = float(ref.abs().max())
+        e2, e3 = float((g2[k].cpu().double() - ref).abs().max()) / top, float((g3[k].cpu().double() - ref).abs().max()) / top
+        assert e2 <= max(2.0 * e3, 2e-6), "%s: f16x2 %.3e vs bf16x3 %.3e of the largest entry" % (name, e2, e3)
+        if name.startswith("xyz_encoding_") and name.endswith("weight") and name not in ("xyz_encoding_1.0.weight",):
+            assert not torch.equal(g2[k], g3[k]), name + ": the f16x2 kernel did not run"
+
+
+def test_f16x2_weight_gradients_fall_back_bit_for_bit():
+    """Operands outside fp16's range -- what the saved rows of a ray the forward had to repair may hold (here: two activation columns set to 7e4 and
+    1e5).  A wave that meets one redoes its chunk on the bf16x3 stream: every tensor equals the bf16x3 call's bit for bit, and nothing is Inf / NaN
+    (fp16(7e4) is Inf: a result kept from the fp16 stream would be)."""
+    n = 2048
+    st, x, d_out = _backward_case(n, seed=31)
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        pack_t = ops.pack_mlp_weights_t_h2(dev_state)
+        rows = acts.view(torch.float32)[: 10 * n * 256].view(10, n, 256)
+        rows[:8, :, 5] = 7.0e4                      # one column in either half of every hidden activation, all points: every wave of every full
+        rows[:8, :, 133] = 1.0e5                    # block (128 activation columns each) meets a value fp16 cannot hold
+        g2 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
+        g3 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="bf16x3", dgrad_h2=True)
+    for k, name in enumerate(ops.MLP_TENSOR_NAMES):
+        assert bool(torch.isfinite(g2[k]).all()), name
+        assert torch.equal(g2[k], g3[k]), "%s: max|d| %.3e" % (name, float((g2[k] - g3[k]).abs().max()))
+
+
+def test_f16x2_weight_gradients_need_the_h2_data_gradient():
+    st, x, d_out = _backward_case(64)
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        with pytest.raises(ValueError, match="h2 data gradient"):
+            ops.mlp_backward(ops.pack_mlp_weights_t_x3(dev_state), x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_x3=True)
+
+
 @pytest.mark.parametrize("mode", ["f32", "auto"])
 def test_training_step_gradients_vs_autograd_oracle(mode):
     """A training-style step on the reference-signature modules (grad mode, perturb/noise inputs fixed):

@@ -52,6 +52,8 @@ print("forward, f32x3 (inference kernel)  %7.2f ms" % (t_fx * 1e3))
 packed_th = ops.pack_mlp_weights_t_h2(st)
 t_bh, _ = timed(lambda: ops.mlp_backward(packed_th, x, out, d_out, acts, wgrad_bf16=2, dgrad_h2=True))
 print("backward, h2 data gradient + bf16x3 weight gradients   %7.2f ms" % (t_bh * 1e3))
+t_bh2, _ = timed(lambda: ops.mlp_backward(packed_th, x, out, d_out, acts, wgrad_bf16="f16x2", dgrad_h2=True))
+print("backward, h2 data gradient + f16x2 weight gradients    %7.2f ms" % (t_bh2 * 1e3))
 ph = ops.pack_mlp_weights_h2(st)
 t_fh, _ = timed(lambda: ops.mlp_forward_h2(ph, x))
 print("forward, f32h2 (inference kernel)  %7.2f ms" % (t_fh * 1e3))
