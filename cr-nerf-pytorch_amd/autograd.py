@@ -55,8 +55,12 @@ _WGRAD_BF16 = [None]
 
 
 def set_wgrad_precision(precision=None):
-    """How the weight gradients of NeRF_sigma's 256 x 256 blocks are formed.  None: the default -- "bf16x3" since round 4 (CRNERF_WGRAD_F32=1 /
-    CRNERF_WGRAD_BF16=1 in the environment choose the others).  Why bf16x3 is the default: it is fp32-accurate -- against a float64 evaluation the
+    """How the weight gradients of NeRF_sigma's 256 x 256 blocks are formed.  None: the default -- "f16x2" behind the h2 data gradient (training
+    forward "auto" / "f32h2": the arithmetic of that core -- two fp16 pieces per operand, three piece products, 22 mantissa bits -- on the eight full
+    256 x 256 blocks, the delta operands ranged by the largest |delta| of each tensor, which the data gradient leaves behind; a wave that meets an
+    operand outside fp16's range redoes its chunk as bf16x3 would have.  tests/test_gpu_parity.py::test_f16x2_*: same distance to a float64
+    evaluation as bf16x3; 65,536-ray train.sh step 210-214 -> 200 ms), "bf16x3" everywhere else (CRNERF_WGRAD_F32=1 / CRNERF_WGRAD_BF16=1 /
+    CRNERF_WGRAD_BF16X3=1 in the environment choose the others).  Why bf16x3 took over from f32 in round 4: it is fp32-accurate -- against a float64 evaluation the
     split path and the fp32 matrix cores sit at the SAME distance on every tensor (tests/test_gpu_train_fused.py::
     test_wgrad_bf16x3_is_as_accurate_as_the_fp32_matrix_cores) -- and faster: the weight gradient is the third of the training MLP work whose
     operands come from HBM (2 KB per point and layer); the fp32-MFMA kernel sits at 75 % of its peak there for reasons that are NOT power (an
@@ -70,7 +74,8 @@ def set_wgrad_precision(precision=None):
     "bf16x3": fp32-ACCURATE weight gradients on the bf16 matrix cores (CRNERF_BWD_WGRAD_BF16X3, include/crnerf.h): every fp32 operand of
     the 256 x 256 blocks is split into three bf16 pieces in registers and a product is the sum of the six leading piece products (fp32
     accumulation; the dropped terms are one fp32 rounding), so that third of the MLP work runs at the rate of its operand reads with none
-    of the bf16 mode's rounding noise.  Forward, loss, data gradients, biases and all other tensors are unchanged."""
+    of the bf16 mode's rounding noise.  Forward, loss, data gradients, biases and all other tensors are unchanged.
+    "f16x2": CRNERF_BWD_WGRAD_F16X2 (include/crnerf.h) where the h2 data gradient runs, "bf16x3" elsewhere."""
     _WGRAD_BF16[0] = None if precision is None else (3 if str(precision).lower() in ("f16x2", "h2") else 2 if str(precision).lower() in ("bf16x3", "x3") else
                                                      (1 if ops._is_bf16(precision) else 0))
 

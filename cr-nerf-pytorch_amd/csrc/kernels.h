@@ -126,8 +126,8 @@ int pack_h2_status(const void* packed, hipStream_t stream);
 int launch_mlp_forward_h2(const void* packed, const float* x, float* out, long P, int sigma_only, hipStream_t stream, int repair);
 int launch_render_rays_h2(const RenderArgs& a, hipStream_t stream);
 int launch_pack_mlp_h2t(const MlpTensors& t, void* packed, hipStream_t stream);
-// dmax: null, or ACT_SLOTS words the kernel raises (atomic max) to the bits of the largest |delta| it stored in every slot (slots 1..8: what the
-// f16x2 weight gradients range their delta operands with, mlp_train16.hip wgrad_h2_kernel); the caller zeroes them
+// dmax: null, or ACT_SLOTS + 1 words the kernel raises (atomic max) to the bits of the largest |delta| it stored in every slot and in d_rgb (what
+// the f16x2 weight gradients range their delta operands with, mlp_train16.hip wgrad_h2_kernel); the caller zeroes them
 int launch_mlp_dgrad_h2(const void* packedT_h2, const float* out, const float* d_out, const float* acts, float* deltas, float* d_rgb, float* d_sig, long P,
                         hipStream_t stream, uint32_t* dmax = nullptr);
 // only_if: device word; the kernel leaves at once when it is 0 (the f32x3 stand-in of an h2 data gradient whose pack was refused); null: always

@@ -23,7 +23,8 @@ __device__ __forceinline__ void zero_acc_h(f32x16 (&acc)[NT]) {
 // The operand scale of this lane's point and the factor that undoes it together with the weights' 2^8: sc = 2^(134 - e), e = the biased exponent
 // of the point's largest |delta| (clamped to [32, 254]: below 2^-95 the entries keep sc = 2^102 and simply use less of fp16's range; a zero
 // vector stays zero).  Both are exact powers of two.
-// slot_max: an LDS word that collects the largest |delta| of the whole tensor for the weight gradients (see the kernel's last lines), or null
+// slot_max: this LANE's LDS word for the largest |delta| of the tensor (see the kernel's last lines; one word per lane and slot: sixty-four lanes
+// raising ONE word serialise in the LDS and held up the other waves' weight reads -- the data gradient ran 19 % longer), or null
 template <int NT>
 __device__ __forceinline__ void point_scale_h(const f32x16 (&d)[NT], float& sc, float& inv, lds_uint* slot_max = nullptr) {
   float m = 0.0f;
@@ -32,7 +33,7 @@ __device__ __forceinline__ void point_scale_h(const f32x16 (&d)[NT], float& sc, 
 #pragma unroll
     for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, fabsf(d[t][r])), fabsf(d[t][r + 1]));
   m = fmaxf(m, __shfl_xor(m, 32));
-  if (slot_max) __hip_atomic_fetch_max(slot_max, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // m >= 0: its bits order like its value
+  if (slot_max) { const uint32_t b = __float_as_uint(m); *slot_max = *slot_max > b ? *slot_max : b; }   // m >= 0: its bits order like its value
   int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
   e = e < 32 ? 32 : (e > 254 ? 254 : e);
   sc = __uint_as_float((uint32_t)(261 - e) << 23);     // 2^(134 - e)
@@ -69,13 +70,15 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
   load_consts(lds, packedT, packedT);   // the consts block carries the sigma-head weights (unscaled)
   const lds_float* C = (const lds_float*)(lds + LDS_CONST0);
   if (__float_as_uint(C[H2_FLAG_WORD]) != 0u) return;   // a weight is outside fp16's range: the f32x3 data gradient runs instead (launch_mlp_backward)
-  // the largest |delta| per slot, collected per workgroup in the (unused) second consts block and raised into dmax[] once at the end: the range
-  // words of the f16x2 weight gradients (mlp_train16.hip wgrad_h2_kernel).  Every delta row but slots 0 and 9 leaves right behind a point_scale_h
-  // of exactly its values, so the maximum costs one LDS atomic per lane and layer.
-  lds_uint* smax = dmax ? (lds_uint*)(lds + LDS_CONST1) : nullptr;
-  if (dmax) {
-    if (threadIdx.x < ACT_SLOTS) smax[threadIdx.x] = 0u;
-    __syncthreads();
+  // the largest |delta| per slot, collected per lane in the (unused) second consts block -- 11 slots x 256 lanes = its 11 KB exactly -- and raised
+  // into dmax[] once at the end: the range words of the f16x2 weight gradients (mlp_train16.hip wgrad_h2_kernel).  Every delta row but slot 0
+  // leaves right behind a point_scale_h of exactly its values, so the maximum costs one LDS read-max-write per lane and layer.  Slots 0..9: the
+  // delta rows; slot 10: d_rgb.
+  static_assert(WG_RANGE_USED * 256 * 4 <= CONST_BYTES, "range words: one per lane and slot in the second consts block");
+  lds_uint* smax = dmax ? (lds_uint*)(lds + LDS_CONST1) + threadIdx.x : nullptr;
+  if (dmax) {                                         // (load_consts, which filled the block, ends with a barrier)
+#pragma unroll
+    for (int sl = 0; sl < WG_RANGE_USED; ++sl) smax[sl * 256] = 0u;
   }
   WeightPipeX pipe;
   pipe.set_stream_frags(STREAMHT_FRAGS);
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
     {  // through static_rgb^T -> dir_encoding output (relu)
       f32x16 acc4[4];
       zero_acc_h<4>(acc4);
-      point_scale_h<2>(drgb, sc, inv);
+      point_scale_h<2>(drgb, sc, inv, smax ? smax + ACT_SLOTS * 256 : nullptr);   // slot 10: d_rgb
       mma_layer_h2t<4, FEAT_DIM / 16, 0>(pipe, drgb, drgb, acc4, q, sc);
       finish_delta_h<4, true>(acc4, dl, inv, b0[9], b1[9]);
     }
@@ -133,12 +136,12 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
       f32x16 d4[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) d4[t] = dl[t];
-      point_scale_h<4>(d4, sc, inv);
+      point_scale_h<4>(d4, sc, inv, smax ? smax + 9 * 256 : nullptr);
     }
     mma_layer_h2t<8, 128 / 16, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(9), SaveRowX{}, vo);
     finish_delta_h<8, false>(acc, dl, inv, 0ull, 0ull);
     zero_acc_h<8>(acc);                               // through xyz_encoding_final^T, + sigma head -> h8 (relu)
-    point_scale_h<8>(dl, sc, inv, smax ? smax + 8 : nullptr);
+    point_scale_h<8>(dl, sc, inv, smax ? smax + 8 * 256 : nullptr);
     mma_layer_h2t<8, KS_HID, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(8), SaveRowX{}, vo);
 #pragma unroll
     for (int t = 0; t < 8; ++t)                       // (the sigma-head term joins AFTER the accumulator is scaled back: dsp need not fit the deltas' scale)
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                    // through xyz_encoding_{l+1}^T -> h_l (relu); l+1 = 8..2; delta_l leaves on the way
       zero_acc_h<8>(acc);
-      point_scale_h<8>(dl, sc, inv, smax ? smax + l : nullptr);
+      point_scale_h<8>(dl, sc, inv, smax ? smax + l * 256 : nullptr);
       mma_layer_h2t<8, KS_HID, 0, true, false>(pipe, dl, dl, acc, q, sc, dsv.row(l), SaveRowX{}, vo);
       unsigned long long m0 = b0[0], m1 = b1[0];      // words of slot l - 1 by selects: a dynamic register index would go through M0, which the
 #pragma unroll                                        // LDS-DMA asm (glds16) rewrites behind the compiler's back
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
       finish_delta_h<8, true>(acc, dl, inv, m0, m1);
     }
     {   // the first layer's deltas: nothing left to hide them behind
+      if (smax) { float s0, i0; point_scale_h<8>(dl, s0, i0, smax); }   // (only the range word is used)
       const SaveRowX r0 = dsv.row(0);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -176,7 +180,12 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_h2_kernel(const char* __r
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (dmax) {
     __syncthreads();
-    if (threadIdx.x < ACT_SLOTS && smax[threadIdx.x] != 0u) atomicMax(dmax + threadIdx.x, smax[threadIdx.x]);
+    if (threadIdx.x < WG_RANGE_USED) {
+      const lds_uint* col = (const lds_uint*)(lds + LDS_CONST1) + threadIdx.x * 256;
+      uint32_t b = 0u;
+      for (int t = 0; t < 256; ++t) b = col[t] > b ? col[t] : b;
+      if (b != 0u) atomicMax(dmax + threadIdx.x, b);
+    }
   }
 }
 

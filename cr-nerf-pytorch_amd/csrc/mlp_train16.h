@@ -9,6 +9,7 @@ namespace crnerf {
 
 constexpr int ACT_SLOTS = 10;   // h1..h8, final, dir_act(128 used)
 constexpr int ACT_W = 256;
+constexpr int WG_RANGE_USED = ACT_SLOTS + 1;   // range words of a backward (launch_mlp_backward): max |delta| bits per delta slot, then d_rgb's
 
 // relu-activity bits of the saved activations: masks[slot][point][g] = 64 bits, bit 4T + r <-> feature 16T + 4g + r.
 // The backward-data kernel reads these 32 B per point and layer (all ten layers in ONE load batch per tile) instead of

@@ -212,7 +212,27 @@ __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {   // v_cvt_p
   return __builtin_bit_cast(uint32_t, v);
 }
 
-template <int MT, int NT, bool X3 = false>
+// packed two-piece fp16 split of a point pair (low half x0, high half x1): w1 = fp16(x s), w2 = fp16(x s - w1) -- the arithmetic of split_stage_h
+// below, left to hipcc's scheduler.  An MFMA may read the results only behind pieces_ready() (two wait states after the last VALU write: hipcc does
+// not count an asm statement as one -- mlp_core_h2.h "HAZARD").
+__device__ __forceinline__ void split_pair_h(float x0, float x1, float s, uint32_t& w1, uint32_t& w2) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(w1) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(w1) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(w2) : "v"(x0), "v"(s), "v"(w1));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(w2) : "v"(x1), "v"(s), "v"(w1));
+}
+typedef _Float16 wh16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void pieces_ready(wh16x8_t& a, wh16x8_t& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+// the scale of a delta tensor's fp16 pieces from its range word (see the full-tile f16x2 branch of wgrad_body): s = 2^(140 - e), inv = 1 / s
+__device__ __forceinline__ void delta_scale_h(const uint32_t* dmax, float& s, float& inv) {
+  uint32_t eb = (__builtin_nontemporal_load(dmax) >> 23) & 0xffu;
+  eb = __builtin_amdgcn_readfirstlane(eb < 32u ? 32u : (eb > 254u ? 254u : eb));
+  s = __uint_as_float((267u - eb) << 23);
+  inv = __uint_as_float((eb - 13u) << 23);
+}
+
+// MODE: 0 fp32 / single-piece bf16 (j.bf16), 1 bf16x3, 2 f16x2 where the job carries a range word (bf16x3 otherwise and as its fallback)
+template <int MT, int NT, int MODE = 0>
 __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&acc)[4][4], int m0, int n0, long p0, long p1, int i, int kk,
                                                     bool bias_wave, int bx, int bz) {
   // k-steps (2 points each) per iteration = prefetch depth: the small blocks are bandwidth-bound, keep more rows in flight
@@ -224,6 +244,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
   for (int t = 0; t < NT; ++t) { const int c = n0 + 32 * t + i; acol[t] = c < j.N ? c : j.N - 1; amask[t] = c < j.N ? 1.0f : 0.0f; }
   const long plast = p1 - 1;
+  constexpr bool X3 = MODE != 0;
   if (j.bf16 || X3) {
     // opt-in mixed precision (CRNERF_BWD_WGRAD_BF16), narrow blocks: the same dword-per-lane operand loads, eight points per lane
     // and k-step of 16 points, rounded to bf16 in registers and multiplied on v_mfma_f32_32x32x16_bf16 (see the full-tile path in
@@ -249,6 +270,82 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
     float bs16[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) bs16[t] = 0.0f;
+    bool done_h = false;
+    if constexpr (MODE == 2) {
+      if (j.dmax) {
+        // CRNERF_BWD_WGRAD_F16X2 on the narrow blocks: two-piece fp16 splits, three MFMAs per tile; range, scale and the bf16x3 fallback as in the
+        // full-tile branch of wgrad_body
+        float sdl, sinv;
+        delta_scale_h(j.dmax, sdl, sinv);
+        const float one = 1.0f;
+        float amx = 0.0f, dmx = 0.0f;
+        fetch16(p0, dcu, acu);
+        for (long pb = p0; pb < p1; pb += 16) {
+          fetch16(pb + 16, dnx, anx);
+          wh16x8_t a1[NT], a2[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            uint32_t w1[4], w2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              split_pair_h(acu[2 * q][t], acu[2 * q + 1][t], one, w1[q], w2[q]);
+              amx = fmaxf(fmaxf(amx, fabsf(acu[2 * q][t])), fabsf(acu[2 * q + 1][t]));
+            }
+            a1[t] = __builtin_bit_cast(wh16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+            a2[t] = __builtin_bit_cast(wh16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+            pieces_ready(a1[t], a2[t]);
+          }
+#pragma unroll
+          for (int a = 0; a < MT; ++a) {
+            uint32_t w1[4], w2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              split_pair_h(dcu[2 * q][a], dcu[2 * q + 1][a], sdl, w1[q], w2[q]);
+              dmx = fmaxf(fmaxf(dmx, fabsf(dcu[2 * q][a])), fabsf(dcu[2 * q + 1][a]));
+            }
+            wh16x8_t d1 = __builtin_bit_cast(wh16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+            wh16x8_t d2 = __builtin_bit_cast(wh16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+            pieces_ready(d1, d2);
+            if (do_bias16) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) bs16[a] += dcu[e][a];
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+              f32x16 c = acc[a][b];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(d2, a1[b], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, a2[b], c, 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d1, a1[b], c, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) dcu[e][t] = dnx[e][t];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acu[e][t] = anx[e][t];
+          }
+        }
+        const bool in_range = amx < 65504.0f && dmx * sdl < 65504.0f;
+        if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] *= sinv;
+          done_h = true;
+        } else {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) {
+            bs16[a] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+          }
+        }
+      }
+    }
+    if (!done_h) {
     fetch16(p0, dcu, acu);
     for (long pb = p0; pb < p1; pb += 16) {
       fetch16(pb + 16, dnx, anx);
@@ -332,6 +429,7 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
 #pragma unroll
         for (int t = 0; t < NT; ++t) acu[e][t] = anx[e][t];
       }
+    }
     }
     if (do_bias16) {
 #pragma unroll
@@ -585,10 +683,8 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           // leave fp16's range -- rows of a ray the forward had to repair, a stale or missing range word -- throws its sums away and runs its chunk
           // again on the bf16x3 stream below: same result as wgrad_x3_kernel, bit for bit.
           typedef _Float16 xh16x8_t __attribute__((ext_vector_type(8)));
-          uint32_t eb = (__builtin_nontemporal_load(j.dmax) >> 23) & 0xffu;
-          eb = __builtin_amdgcn_readfirstlane(eb < 32u ? 32u : (eb > 254u ? 254u : eb));
-          const float sd = __uint_as_float((267u - eb) << 23);            // 2^(140 - e): the largest scaled delta in [2^13, 2^14)
-          const float sinv = __uint_as_float((eb - 13u) << 23);           // 1 / sd
+          float sd, sinv;                                                 // 2^(140 - e): the largest scaled delta in [2^13, 2^14); 1 / sd
+          delta_scale_h(j.dmax, sd, sinv);
           const float one = 1.0f;
           const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
           uint32_t vd[8], va[8];
@@ -921,7 +1017,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
   // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
   const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, MODE != 0>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, MODE>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
   CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
   CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
@@ -1150,10 +1246,10 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     WgradSpec sp[WG_MAX_JOBS];
     int n = 0;
     const float W_FULL = 1.0f, W_EMB = 0.52f, W_DIR = 0.66f, W_DIRE = 0.19f, W_RGB = 0.26f, W_SIG = 0.26f;   // measured per-point cost relative to a full block (profiles/r3/train_1024_before_ordered.txt)
-    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P};                               // xyz_encoding_1
+    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P, R(0)};                         // xyz_encoding_1
     for (int l = 1; l < 8; ++l) {
       if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P, R(4)};
         sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P, R(4)};
       } else {
         sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P, R(l)};
@@ -1161,17 +1257,17 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     }
     sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P, R(8)};                            // xyz_encoding_final
     sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0, P};                                         // static_sigma
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P};                         // dir_encoding: cat([final, dir])
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P};
-    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb, P};                          // static_rgb
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P, R(9)};                   // dir_encoding: cat([final, dir])
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P, R(9)};
+    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb, P, R(ACT_SLOTS)};            // static_rgb
     if (int rc = wgrad_batch(sp, n, ws, wgrad_batch_workspace_floats(), stream)) return rc;
     return check_launch("mlp_backward wgrad (batched)");
   }
   // xyz_encoding_1: input x[:, :93]
-  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb);
+  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb, R(0));
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
-      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb);
+      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb, R(4));
       wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb, R(4));
     } else {
       wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb, R(l));
@@ -1179,9 +1275,9 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
   }
   wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8));      // xyz_encoding_final
   wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
-  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb);  // dir_encoding: cat([final, dir])
-  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb);
-  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb);   // static_rgb
+  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb, R(9));  // dir_encoding: cat([final, dir])
+  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb, R(9));
+  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb, R(ACT_SLOTS));   // static_rgb
   return check_launch("mlp_backward wgrad");
 }
 

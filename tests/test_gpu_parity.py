@@ -574,13 +574,24 @@ def test_f16x2_weight_gradients_fall_back_bit_for_bit():
         out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
         pack_t = ops.pack_mlp_weights_t_h2(dev_state)
         rows = acts.view(torch.float32)[: 10 * n * 256].view(10, n, 256)
-        rows[:8, :, 5] = 7.0e4                      # one column in either half of every hidden activation, all points: every wave of every full
-        rows[:8, :, 133] = 1.0e5                    # block (128 activation columns each) meets a value fp16 cannot hold
+        rows[:, :, 5::64] = 7.0e4                   # a column in every 32-wide tile of every saved activation, all points: every wave of every job
+        rows[:, :, 37::64] = 1.0e5                  # that reads activations meets a value fp16 cannot hold
         g2 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
         g3 = ops.mlp_backward(pack_t, x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="bf16x3", dgrad_h2=True)
+    kept = 0
     for k, name in enumerate(ops.MLP_TENSOR_NAMES):
         assert bool(torch.isfinite(g2[k]).all()), name
-        assert torch.equal(g2[k], g3[k]), "%s: max|d| %.3e" % (name, float((g2[k] - g3[k]).abs().max()))
+        a, b = g2[k], g3[k]
+        # the blocks that multiply the embedded INPUT (in range by construction) keep their fp16 result: close to, not equal to, bf16x3's
+        emb = {"xyz_encoding_1.0.weight": slice(0, 93), "xyz_encoding_5.0.weight": slice(0, 93), "dir_encoding.0.weight": slice(256, 283)}.get(name)
+        if emb is not None:
+            close(a[:, emb], b[:, emb].cpu(), atol=2e-5 * float(b.abs().max()), rtol=0)
+            kept += int(not torch.equal(a[:, emb], b[:, emb]))
+            keep = torch.ones(a.shape[1], dtype=torch.bool)
+            keep[emb] = False
+            a, b = a[:, keep], b[:, keep]
+        assert torch.equal(a, b), "%s: max|d| %.3e" % (name, float((a - b).abs().max()))
+    assert kept == 3, "the narrow blocks did not run on the fp16 form"
 
 
 def test_f16x2_weight_gradients_need_the_h2_data_gradient():
