@@ -612,7 +612,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
     from crnerf_amd import autograd as AG, optim as crnerf_optim, pipeline
     exact = a.train_precision == "f32"
     AG.set_training_forward_precision("f32" if exact else "auto")
-    AG.set_wgrad_precision("f32" if exact else "bf16x3")
+    AG.set_wgrad_precision("f32" if exact else None)   # None: the default behind the h2 data gradient = f16x2 (bf16x3 as its in-launch fallback)
     from crnerf_amd.datasets.phototourism_mask_grid_sample import GridSampleBatcher
     R = a.train_rays
     side = int(R ** 0.5)
@@ -655,13 +655,13 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
     dt, last = timed_steps(a, step, use_dist, dist, dev)
     pts = R * (nc + nc + ni)
     achieved = 3 * pts * FLOP_PER_POINT / dt * a.steps / 1e12 / world      # per GPU: algorithmic fp32 FLOPs of forward + data gradient + weight gradient
-    # auto: what the matrix cores are ISSUED -- forward 3.02 x (two fp16 pieces, three MFMAs per product), data gradient 3 x, weight gradient 6 x
-    # (three bf16 pieces) the algorithmic FLOPs of their third of the step
-    issued = achieved if exact else achieved * (3.02 + 3.0 + 6.0) / 3.0
+    # auto: what the matrix cores are ISSUED -- forward 3.02 x, data gradient 3 x, weight gradient 3 x (two fp16 pieces per operand, three MFMAs per
+    # product, all three) the algorithmic FLOPs of their third of the step
+    issued = achieved if exact else achieved * (3.02 + 3.0 + 3.0) / 3.0
     peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_BF16_MFMA_TFLOPS
     line = {"metric": "rays/sec (64+64 samples, training step: fwd + bwd + Adam)", "value": R * a.steps / dt, "unit": "rays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if exact else "f32h2 / bf16x3 (fp32 operands split into fp16 / bf16 pieces, fp32 accumulation)", "data": "synthetic",
+            "dtype": "f32" if exact else "f32h2 / f16x2 (fp32 operands split into two fp16 pieces, three MFMAs per product, fp32 accumulation)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: ONE %d-ray grid-sample training batch (%dx%d grid, transient mask, encode_a / encode_c / "
                                    "encode_random) x (%d+%d) split over %d rank(s): rays sharded, feature rows all-gathered, decoder / encoders / mask "
                                    "network replicated, one flat gradient all-reduce; --train-precision %s" % (R, side, side, nc, ni, world, a.train_precision),
@@ -669,12 +669,13 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
                        "train_precision": a.train_precision},
             "roofline": {"bound": "mfma",
                          "kernel": ("render_rays_train16_kernel + mlp_backward16_kernel + wgrad_kernel" if exact else
-                                    "render_rays_train_h2_kernel + mlp_backward_h2_kernel + wgrad_x3_batch_kernel"),
+                                    "render_rays_train_h2_kernel + mlp_backward_h2_kernel + wgrad_h2_kernel"),
                          "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": None, "traffic_source": None,
                          "fp32_work_tflops": achieved,
                          "note": "whole step per GPU: the MLP work of this rank's rays / step time (decoder, encoders, mask network and Adam included in the "
-                                 "time).  f32: 3 x the forward's algorithmic FLOPs on the fp32 MFMA.  auto: the ISSUED fp16 / bf16 MFMA work (12.02 x the "
-                                 "forward's algorithmic FLOPs) against the nominal 2.5 PFLOP/s; fp32_work_tflops = the algorithmic fp32 work"},
+                                 "time).  f32: 3 x the forward's algorithmic FLOPs on the fp32 MFMA.  auto: the ISSUED fp16 MFMA work (9.02 x the "
+                                 "forward's algorithmic FLOPs) against the nominal 2.5 PFLOP/s -- the three big kernels of that step are bound by their activation / "
+                                 "delta rows in HBM, not by the matrix cores (DESIGN 3.5); fp32_work_tflops = the algorithmic fp32 work"},
             "loss": float(last), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
     if use_dist and world > 1:
         chk = torch.tensor([float(last), float(sum(p.detach().double().sum() for p in sysm.parameters()))], dtype=torch.float64, device=dev)

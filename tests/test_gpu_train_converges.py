@@ -23,7 +23,7 @@ def test_training_system_learns_the_scene_like_the_reference(golden, mode):
     from crnerf_amd import autograd as AG
     mode, _, flat = mode.partition("+")         # "+FlatAdam": the optimiser step as one HIP launch (crnerf_amd/optim.py) instead of torch's multi-tensor Adam
     AG.set_training_forward_precision(mode)
-    AG.set_wgrad_precision("f32" if mode == "f32" else "bf16x3")   # "auto": h2 forward / data gradient with the x3 safety net, bf16x3 weight gradients
+    AG.set_wgrad_precision("f32" if mode == "f32" else ("bf16x3" if mode == "f32x3" else None))   # "auto": the defaults -- h2 forward / data gradient with the x3 safety net, f16x2 weight gradients
     try:
         _run(golden, bool(flat))
     finally:
