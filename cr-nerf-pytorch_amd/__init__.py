@@ -30,7 +30,8 @@ def set_precision(precision):
     models/rendering.py::_render_bf16_accurate_coarse).  A `precision=` keyword to render_rays_cross_ray / batched_inference /
     NeRF_sigma.forward overrides it per call.
     Training (grad mode) does not read this setting: its default is "auto" for the forward and the data gradient (fp32-accurate two-piece fp16
-    splits on the fp16 matrix cores, f32x3 where the h2 core refuses) and bf16x3 for the weight gradients (three-piece bf16 splits) -- every
+    splits on the fp16 matrix cores, f32x3 where the h2 core refuses) and f16x2 for the weight gradients (the same two-piece form, ranged per
+    delta tensor; bf16x3 -- three-piece bf16 splits -- inside the same launch where an operand leaves fp16's range) -- every
     product fp32-ACCURATE (float64 distance of the fp32 MFMA), none bit-for-bit the reference's fp32 arithmetic.  Opt out with
     autograd.set_training_forward_precision("f32") / CRNERF_TRAIN_FWD=f32 and autograd.set_wgrad_precision("f32") / CRNERF_WGRAD_F32=1
     (every product on the fp32 matrix cores); autograd.set_training_precision("bf16") is the opt-in mixed-precision mode."""
