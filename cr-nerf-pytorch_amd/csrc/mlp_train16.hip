@@ -575,7 +575,8 @@ __device__ __forceinline__ void max_slot(float (&m)[4], const float __attribute_
 }
 
 // MODE 1: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3); MODE 2: the "f16x2" form of the full tiles with bf16x3 behind it -- see the
-// full-tile branch below
+// full-tile branch below; MODE 4: MODE 2 for jobs without a full tile, compiled without that branch (wgrad_h2_narrow_kernel: half the registers,
+// two workgroups per CU)
 template <int MODE = 0>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the wave's tile origin lives in SGPRs
@@ -614,7 +615,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  if (mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
+  if (MODE != 4 && mt == 4 && nt == 4 && m0 + 128 <= j.M && n0 + 128 <= j.N && (j.ldd & 3) == 0 && (j.lda & 3) == 0) {
     // ---- full 128x128 wave tile (every 256-wide layer): branch-free stream.  Column mapping: MFMA tile t, lane i <->
     // column 4i + t, so a lane's four operands of a point are ONE 16-byte load (512 contiguous bytes per half-wave) and
     // the whole k-step is 2 x global_load_dwordx4 + 16 MFMAs.  (The guarded generic loop below puts a branch around
@@ -1017,7 +1018,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
   // tiles, MT in {1,2,4}, NT in {1,2,3,4} chosen once per wave; loads are unconditional (clamped row / column, zero mask),
   // so no control flow sits between a prefetch and the MFMAs that hide it
   const int MTs = mt <= 1 ? 1 : (mt == 2 ? 2 : 4), NTs = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt == 3 ? 3 : 4));
-#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, MODE>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
+#define CRNERF_WG(MT, NT) if (MTs == MT && NTs == NT) { wgrad_partial_tiles<MT, NT, MODE == 4 ? 2 : MODE>(j, acc, m0, n0, p0, p1, i, kk, bias_wave, bx, bz); return; }
   CRNERF_WG(1, 1) CRNERF_WG(1, 2) CRNERF_WG(1, 3) CRNERF_WG(1, 4) CRNERF_WG(2, 1) CRNERF_WG(2, 2) CRNERF_WG(2, 3) CRNERF_WG(2, 4)
   CRNERF_WG(4, 1) CRNERF_WG(4, 2) CRNERF_WG(4, 3) CRNERF_WG(4, 4)
 #undef CRNERF_WG
@@ -1027,6 +1028,9 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body<0>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(WgradJob j) { wgrad_body<1>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 __global__ __launch_bounds__(256, 1) void wgrad_h2_kernel(WgradJob j) { wgrad_body<2>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
+// The smallest jobs (128 x 27, 64 x 128: one or two accumulator tiles per wave) compiled for 256 registers: two workgroups share a CU, each on half a
+// chunk -- twice the row bytes in flight per CU, which is what bounds these jobs (wgrad()).
+__global__ __launch_bounds__(256, 2) void wgrad_h2_narrow_kernel(WgradJob j) { wgrad_body<4>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Every weight gradient of one NeRF_sigma backward in ONE launch: at the reference's 1,024-ray batches a per-layer launch is
 // ~256 workgroups of 256 points each -- fourteen ramp-ups and drains per model, and a [256 chunks][256][256] partial-sum slab
@@ -1113,11 +1117,16 @@ size_t wgrad_workspace_floats(long P, int M, int N) {
 
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
           hipStream_t st, int bf16, const uint32_t* dmax) {
-  const int chunk = wg_chunk(P);
+  // at most two accumulator tiles per wave (dir_encoding's direction block, static_rgb): wgrad_h2_narrow_kernel, two workgroups per CU on half chunks
+  // (measured per 2^19 points: 139 -> 93 and 142 -> 119 us; the 93-column embedding blocks gain nothing from it, dir_encoding's 4 x 2 tiles spill in 256 registers)
+  const bool narrow = bf16 == 3 && M <= 128 && N <= 128;
+  int chunk = wg_chunk(P);
+  if (narrow) { chunk = (chunk / 2 + 31) / 32 * 32; if (chunk < 128) chunk = 128; }   // (2 x nchunk x (M N + M) stays inside the workspace of a full block)
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
   WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
-  if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  if (narrow) hipLaunchKernelGGL(wgrad_h2_narrow_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  else if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);

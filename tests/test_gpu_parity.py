@@ -594,6 +594,44 @@ def test_f16x2_weight_gradients_fall_back_bit_for_bit():
     assert kept == 3, "the narrow blocks did not run on the fp16 form"
 
 
+def test_f16x2_weight_gradients_per_layer_launches_match_the_batched_launch():
+    """Beyond 2^18 points every weight-gradient job is its own launch (wgrad_h2_kernel, wgrad_h2_narrow_kernel for the two smallest) instead of one
+    batched launch: the same arithmetic over other chunks of points.  Forced here at a small size (CRNERF_WGRAD_BATCH=0 is read once per process, so
+    the per-layer leg runs in a child process) and compared tensor by tensor: fp32 summation-order distance, nothing more."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    n = 2500                                                       # ragged last chunk included
+    st, x, d_out = _backward_case(n, seed=37)
+    dev_state = {k: C(v) for k, v in st.items()}
+    with torch.no_grad():
+        out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+        g_batched = ops.mlp_backward(ops.pack_mlp_weights_t_h2(dev_state), x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import crnerf_amd.synth as synth
+from crnerf_amd import ops
+from test_gpu_parity import _backward_case, C, DEV
+st, x, d_out = _backward_case(%d, seed=37)
+dev_state = {k: C(v) for k, v in st.items()}
+with torch.no_grad():
+    out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev_state), x.to(DEV))
+    g = ops.mlp_backward(ops.pack_mlp_weights_t_h2(dev_state), x.to(DEV), out, d_out.to(DEV), acts, wgrad_bf16="f16x2", dgrad_h2=True)
+np.savez(sys.argv[1], *[t.cpu().numpy() for t in g])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), n)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "g.npz")
+        env = dict(os.environ, CRNERF_WGRAD_BATCH="0")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        per_layer = np.load(path)
+        for k, name in enumerate(ops.MLP_TENSOR_NAMES):
+            a, b = torch.from_numpy(per_layer["arr_%d" % k]), g_batched[k].cpu()
+            assert bool(torch.isfinite(a).all()), name
+            assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()) + 1e-9, "%s: max|d| %.3e of %.3e" % (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_f16x2_weight_gradients_need_the_h2_data_gradient():
     st, x, d_out = _backward_case(64)
     dev_state = {k: C(v) for k, v in st.items()}
