@@ -37,6 +37,7 @@ EXPORTS = [
     "crnerf_cgnet_param_count", "crnerf_cgnet_bn_count", "crnerf_cgnet_arena_bytes", "crnerf_cgnet_forward_train_f32", "crnerf_cgnet_backward_f32",
     "crnerf_peer_window_bytes", "crnerf_peer_window_create", "crnerf_peer_window_open", "crnerf_peer_window_close", "crnerf_peer_window_destroy",
     "crnerf_peer_window_status", "crnerf_peer_allreduce_f32",
+    "crnerf_cus_per_xcd", "crnerf_stream_create_cu_share", "crnerf_stream_destroy",
 ]
 
 _c_fp = ctypes.c_void_p  # device float*
@@ -222,6 +223,9 @@ def load():
             "crnerf_peer_window_destroy": (ctypes.c_int, [vp]),
             "crnerf_peer_window_status": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
             "crnerf_peer_allreduce_f32": (ctypes.c_int, [vp, i32, pp, i32, i32, ctypes.c_uint32, i64, vp]),
+            "crnerf_cus_per_xcd": (ctypes.c_int, []),
+            "crnerf_stream_create_cu_share": (ctypes.c_int, [pp, i32, i32]),
+            "crnerf_stream_destroy": (ctypes.c_int, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not match include/crnerf.h

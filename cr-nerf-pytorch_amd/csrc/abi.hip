@@ -37,6 +37,32 @@ int num_cus() {
   return cached[dev];
 }
 
+// CU-share streams (include/crnerf.h).  The CU mask of hipExtStreamCreateWithCUMask is indexed in the driver's logical CU order, which on a
+// multi-XCD part interleaves the XCDs (bit b = CU b / n_xcd of XCD b % n_xcd): a contiguous range of logical CUs of EVERY XCD is then the
+// bit range [first * n_xcd, (first + count) * n_xcd).  n_xcd = 8 on gfx950 (256 CUs = 8 x 32).
+static const int N_XCD = 8;
+extern "C" int crnerf_cus_per_xcd(void) { return num_cus() / N_XCD; }
+extern "C" int crnerf_stream_create_cu_share(void** stream, int first, int count) {
+  if (!stream) return set_error(-1, "stream_create_cu_share: stream is NULL");
+  const int per = num_cus() / N_XCD;
+  if (first < 0 || count <= 0 || first + count > per) return set_error(-3, "stream_create_cu_share: [first, first + count) must lie inside crnerf_cus_per_xcd()");
+  uint32_t mask[16] = {0};
+  for (int b = first * N_XCD; b < (first + count) * N_XCD; ++b) mask[b >> 5] |= 1u << (b & 31);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((num_cus() + 31) / 32), mask);
+  if (e != hipSuccess) {
+    static thread_local char msg[160];
+    snprintf(msg, sizeof msg, "stream_create_cu_share: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return set_error(-1, msg);
+  }
+  *stream = (void*)st;
+  return 0;
+}
+extern "C" int crnerf_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : set_error(-1, "stream_destroy: hipStreamDestroy failed");
+}
+
 unsigned int* sched_slot(const void* symbol) {
   static std::mutex mu;
   static int cursor = 0;
@@ -124,6 +150,25 @@ int crnerf_mlp_forward_train_f32(const void* packed, const float* x, float* out,
   return launch_mlp_forward_train(packed, x, out, (float*)acts, (long)n, (hipStream_t)stream);
 }
 
+// Flag and pointer checks shared by the three crnerf_mlp_backward_*_f32 entries.  `modes`: the weight-gradient modes this entry accepts (exclusive);
+// CRNERF_BWD_PHASE_DGRAD / _WGRAD choose which half runs and with it which pointers are read.
+static int check_backward_args(const char* who, int flags, int modes, const void* packed_t, const float* x, const float* out, const float* d_out,
+                               const void* acts, const void* scratch, float* const* grads) {
+  static thread_local char msg[160];
+  const int phases = CRNERF_BWD_PHASE_DGRAD | CRNERF_BWD_PHASE_WGRAD;
+  if (flags & ~(modes | phases)) { snprintf(msg, sizeof msg, "%s: unknown flag bits", who); return set_error(CRNERF_ERR_CONFIG, msg); }
+  const int m = flags & modes;
+  if ((m & (m - 1)) != 0) { snprintf(msg, sizeof msg, "%s: the weight-gradient modes are exclusive", who); return set_error(CRNERF_ERR_CONFIG, msg); }
+  const bool dgrad = (flags & phases) != CRNERF_BWD_PHASE_WGRAD, wgrad = (flags & phases) != CRNERF_BWD_PHASE_DGRAD;
+  const char* missing = !acts ? "acts" : !scratch ? "scratch" : (dgrad && !packed_t) ? "packed_t" : (dgrad && !out) ? "out" : (dgrad && !d_out) ? "d_out" :
+                        (wgrad && !x) ? "x" : (wgrad && !grads) ? "grads" : nullptr;
+  if (missing) { snprintf(msg, sizeof msg, "%s: %s is NULL", who, missing); return set_error(CRNERF_ERR_NULL, msg); }
+  if (wgrad)
+    for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
+      if (!grads[i]) { snprintf(msg, sizeof msg, "%s: a gradient pointer is NULL", who); return set_error(CRNERF_ERR_NULL, msg); }
+  return 0;
+}
+
 int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                             float* const* grads, int64_t n, void* stream) {
   return crnerf_mlp_backward_ex_f32(packed_t, x, out, d_out, acts, scratch, grads, n, 0, stream);
@@ -132,12 +177,7 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
-  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: unknown flag bits");
-  if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_ex: the two weight-gradient modes are exclusive");
-  REQUIRE(packed_t, "packed_t"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
-  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
-  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
-    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward: a gradient pointer is NULL");
+  if (int rc = check_backward_args("mlp_backward_ex", flags, CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3, packed_t, x, out, d_out, acts, scratch, grads)) return rc;
   return launch_mlp_backward(packed_t, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags);
 }
 
@@ -309,12 +349,7 @@ int crnerf_pack_mlp_weights_t_x3(const float* const* tensors, void* packed, void
 int crnerf_mlp_backward_x3_f32(const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
-  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_x3: unknown flag bits");
-  if ((flags & CRNERF_BWD_WGRAD_BF16) && (flags & CRNERF_BWD_WGRAD_BF16X3)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_x3: the two weight-gradient modes are exclusive");
-  REQUIRE(packed_t_x3, "packed_t_x3"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
-  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
-  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
-    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_x3: a gradient pointer is NULL");
+  if (int rc = check_backward_args("mlp_backward_x3", flags, CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3, packed_t_x3, x, out, d_out, acts, scratch, grads)) return rc;
   return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, packed_t_x3);
 }
 
@@ -330,13 +365,11 @@ int crnerf_pack_mlp_weights_t_h2(const float* const* tensors, void* packed, void
 int crnerf_mlp_backward_h2_f32(const void* packed_t_h2, const void* packed_t_x3, const float* x, const float* out, const float* d_out, const void* acts,
                                void* scratch, float* const* grads, int64_t n, int flags, void* stream) {
   if (n == 0) return 0;
-  if (flags & ~(CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3 | CRNERF_BWD_WGRAD_F16X2)) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: unknown flag bits");
-  if ((flags & (flags - 1)) != 0) return set_error(CRNERF_ERR_CONFIG, "mlp_backward_h2: the weight-gradient modes are exclusive");
-  REQUIRE(packed_t_h2, "packed_t_h2"); REQUIRE(x, "x"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(acts, "acts");
-  REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
-  for (int i = 0; i < CRNERF_MLP_TENSORS; ++i)
-    if (!grads[i]) return set_error(CRNERF_ERR_NULL, "mlp_backward_h2: a gradient pointer is NULL");
-  return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, packed_t_x3, packed_t_h2);
+  if (int rc = check_backward_args("mlp_backward_h2", flags, CRNERF_BWD_WGRAD_BF16 | CRNERF_BWD_WGRAD_BF16X3 | CRNERF_BWD_WGRAD_F16X2, packed_t_h2, x, out, d_out, acts,
+                                   scratch, grads)) return rc;
+  // a PHASE_WGRAD call carries no packs; the non-null marker keeps the f16x2 mode (its range words are in the scratch)
+  const void* h2 = packed_t_h2 ? packed_t_h2 : (const void*)scratch;
+  return launch_mlp_backward(nullptr, x, out, d_out, (const float*)acts, scratch, grads, (long)n, (hipStream_t)stream, flags, packed_t_x3, h2);
 }
 
 size_t crnerf_packed_mlp_x3_bytes(void) { return PACKEDX_BYTES; }

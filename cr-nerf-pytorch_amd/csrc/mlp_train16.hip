@@ -1294,6 +1294,8 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags, const void* packedT_x3, const void* packedT_h2) {
   int wb = (flags & 4) ? 3 : ((flags & 2) ? 2 : (flags & 1));   // CRNERF_BWD_WGRAD_F16X2 (h2 data gradient only, checked by the caller) / _BF16X3 / _BF16
+  // CRNERF_BWD_PHASE_DGRAD / _WGRAD (include/crnerf.h): one half of the backward per call, so that the caller can put the halves on two streams
+  const bool do_dgrad = (flags & 24) != 16, do_wgrad = (flags & 24) != 8;
   if (P <= 0) return 0;
   float* deltas = (float*)scratch;
   float* d_rgb = deltas + (size_t)ACT_SLOTS * P * ACT_W;
@@ -1303,7 +1305,8 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   const long groups = (P + 127) / 128;
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
-  if (packedT_h2) {   // crnerf_mlp_backward_h2_f32: the data gradient on the h2 core (mlp_backward_h2.hip), same scratch layout
+  if (!do_dgrad) {
+  } else if (packedT_h2) {   // crnerf_mlp_backward_h2_f32: the data gradient on the h2 core (mlp_backward_h2.hip), same scratch layout
     // CRNERF_BWD_WGRAD_F16X2: the full tiles of the weight gradients on the two-piece fp16 form (wgrad_h2_kernel), ranged by the
     // largest |delta| of every tensor, which the data gradient's workgroups leave in dmax (zero = nothing known: the kernel falls back by itself)
     const bool h2w = wb == 3;
@@ -1318,7 +1321,8 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
     hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packedT, out, d_out, acts, deltas, d_rgb, d_sig, P, iters);
     if (int rc = check_launch("mlp_backward16_kernel")) return rc;
   }
-  if (wb == 3 && !packedT_h2) wb = 2;
+  if (!do_wgrad) return 0;
+  if (wb == 3 && !packedT_h2) wb = 2;                 // (a PHASE_WGRAD call of the h2 entry arrives with a non-null marker: abi.hip)
   return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb, wb == 3 ? dmax : nullptr);
 }
 

@@ -261,35 +261,55 @@ def pack_mlp_weights_t_h2(state):
     return out
 
 
-def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False, dgrad_h2=False, fallback_t_x3=None):
+BWD_PHASE_DGRAD, BWD_PHASE_WGRAD = 8, 16      # CRNERF_BWD_PHASE_* (include/crnerf.h)
+
+
+def mlp_backward(packed_t, x, out, d_out, acts, wgrad_bf16=False, dgrad_x3=False, dgrad_h2=False, fallback_t_x3=None, phase=None, scratch=None, grads=None):
     """Gradients of sum(out * d_out) w.r.t. the 24 tensors, in MLP_TENSOR_NAMES order.  wgrad_bf16: True / 1 = CRNERF_BWD_WGRAD_BF16
     (include/crnerf.h) -- the weight gradients of every Linear except static_sigma from bf16-rounded operands; 2 / "x3" =
     CRNERF_BWD_WGRAD_BF16X3 -- fp32-accurate weight gradients of the 256 x 256 blocks from three-piece bf16 splits on the bf16 matrix
     cores; 3 / "f16x2" (dgrad_h2 only) = CRNERF_BWD_WGRAD_F16X2 -- the same with the full 256 x 256 blocks from two-piece fp16 splits (three
     piece products, the h2 core's arithmetic; bf16x3 takes over by itself where an operand leaves fp16's range).  Data gradients as the dgrad_*
-    arguments say; biases and everything else exact fp32."""
+    arguments say; biases and everything else exact fp32.
+    phase: None = the whole backward; "dgrad" = CRNERF_BWD_PHASE_DGRAD (returns the scratch tensor that holds the deltas; x may be None);
+    "wgrad" = CRNERF_BWD_PHASE_WGRAD on `scratch` (the tensor a "dgrad" call returned; packed_t / out / d_out may be None) -- the two halves may
+    be enqueued on different streams, ordered by the caller (autograd.FusedRenderFn)."""
     lib = _lib.load()
-    x, out, d_out = _f32c(x, "x"), _f32c(out, "out"), _f32c(d_out, "d_out")
-    n = x.shape[0]
+    do_d, do_w = phase != "wgrad", phase != "dgrad"
+    if phase not in (None, "dgrad", "wgrad"):
+        raise ValueError("crnerf_amd: mlp_backward phase is None, 'dgrad' or 'wgrad', got %r" % (phase,))
+    x = _f32c(x, "x") if (do_w or x is not None) else None
+    out, d_out = (_f32c(out, "out"), _f32c(d_out, "d_out")) if do_d else (None, None)
+    n = x.shape[0] if x is not None else out.shape[0]
+    dev = x.device if x is not None else out.device
     f16x2 = wgrad_bf16 in (3, "f16x2", "h2")
     if f16x2 and not dgrad_h2:
         raise ValueError("crnerf_amd: f16x2 weight gradients take their delta ranges from the h2 data gradient (dgrad_h2=True)")
-    grads = [torch.empty(s, dtype=torch.float32, device=x.device) for s in MLP_TENSOR_SHAPES]
-    scratch = torch.empty(lib.crnerf_mlp_train_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+    if do_w and grads is None:
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in MLP_TENSOR_SHAPES]
+    need = lib.crnerf_mlp_train_scratch_bytes(n)
+    if scratch is None:
+        if phase == "wgrad":
+            raise ValueError("crnerf_amd: mlp_backward(phase='wgrad') needs the scratch of the 'dgrad' call")
+        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    elif scratch.numel() < need or not scratch.is_contiguous() or scratch.dtype != torch.uint8:
+        raise ValueError("crnerf_amd: mlp_backward scratch must be a contiguous uint8 tensor of >= %d bytes" % need)
     # dgrad_x3 / dgrad_h2: the data gradient on the x3 / h2 core; packed_t is then a pack_mlp_weights_t_x3 / pack_mlp_weights_t_h2 pack
     fn, name, want = ((lib.crnerf_mlp_backward_h2_f32, "crnerf_mlp_backward_h2_f32", lib.crnerf_packed_mlp_t_h2_bytes()) if dgrad_h2 else
                       (lib.crnerf_mlp_backward_x3_f32, "crnerf_mlp_backward_x3_f32", lib.crnerf_packed_mlp_t_x3_bytes()) if dgrad_x3 else
                       (lib.crnerf_mlp_backward_ex_f32, "crnerf_mlp_backward_ex_f32", lib.crnerf_packed_mlp_t_bytes()))
-    if packed_t.numel() != want:
+    if do_d and packed_t.numel() != want:
         raise ValueError("crnerf_amd: %s needs a %d-byte transposed pack, got %d" % (name, want, packed_t.numel()))
     if fallback_t_x3 is not None and (not dgrad_h2 or fallback_t_x3.numel() != lib.crnerf_packed_mlp_t_x3_bytes()):
         raise ValueError("crnerf_amd: fallback_t_x3 is the pack_mlp_weights_t_x3 safety net of dgrad_h2")
-    head = (ctypes.c_void_p(packed_t.data_ptr()),) + ((ctypes.c_void_p(fallback_t_x3.data_ptr() if fallback_t_x3 is not None else None),) if dgrad_h2 else ())
-    _lib.check(fn(*head, _lib.dev_ptr(x), _lib.dev_ptr(out), _lib.dev_ptr(d_out),
+    nul = ctypes.c_void_p(None)
+    head = (ctypes.c_void_p(packed_t.data_ptr()) if do_d else nul,) + ((ctypes.c_void_p(fallback_t_x3.data_ptr() if (fallback_t_x3 is not None and do_d) else None),) if dgrad_h2 else ())
+    flags = 4 if f16x2 else (2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0))
+    flags |= BWD_PHASE_DGRAD if phase == "dgrad" else (BWD_PHASE_WGRAD if phase == "wgrad" else 0)
+    _lib.check(fn(*head, _lib.dev_ptr(x) if x is not None else nul, _lib.dev_ptr(out) if do_d else nul, _lib.dev_ptr(d_out) if do_d else nul,
                   ctypes.c_void_p(acts.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
-                  _lib.ptr_array(grads, "grad"), n, 4 if f16x2 else (2 if wgrad_bf16 in (2, "x3", "bf16x3") else (1 if wgrad_bf16 else 0)),
-                  _lib.stream_ptr()), name)
-    return grads
+                  _lib.ptr_array(grads, "grad") if do_w else None, n, flags, _lib.stream_ptr()), name)
+    return scratch if phase == "dgrad" else grads
 
 
 def pack_mlp_weights_mixed(state):

@@ -99,6 +99,13 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
  * workgroup that meets an operand outside fp16's range (rows of a ray the forward had to repair; the f32x3 stand-in ran and left no range) redoes
  * its chunk of points as CRNERF_BWD_WGRAD_BF16X3 would have, bit for bit. */
 #define CRNERF_BWD_WGRAD_F16X2 4
+/* Phases (crnerf_mlp_backward_h2_f32 / _x3_f32 / _ex_f32; neither bit or both = the whole backward in one call).  CRNERF_BWD_PHASE_DGRAD: the data
+ * gradient only -- the layer deltas, d_rgb, d_sig and (F16X2) the delta range words are left in `scratch`; `x` and `grads` are not touched and may be
+ * NULL.  CRNERF_BWD_PHASE_WGRAD: the weight / bias gradients only, from a `scratch` that a PHASE_DGRAD call with the same n, acts and weight-gradient
+ * mode has filled; packed_t_* / out / d_out are not read and may be NULL.  The two halves may run on different streams (the caller orders them with an
+ * event): the weight gradients of one ray chunk read rows at the HBM read rate while the data gradient of the next writes its rows -- DESIGN 3.5. */
+#define CRNERF_BWD_PHASE_DGRAD 8
+#define CRNERF_BWD_PHASE_WGRAD 16
 int crnerf_mlp_backward_ex_f32(const void* packed_t, const float* x, const float* out, const float* d_out, const void* acts, void* scratch,
                                float* const* grads, int64_t n, int flags, void* stream);
 
@@ -356,6 +363,14 @@ int crnerf_crossray_decode_sharded_f32(const float* content, int64_t HW_local, c
  * wait, sum in rank order (bit-identical on all ranks).  `windows` = HOST array of world_size device pointers, windows[rank] = own.
  * `epoch` = 1, 2, 3, ... the same on all ranks for the same reduction, +1 per call.  A peer that does not arrive within
  * timeout_us leaves NaN in `data` and 1 + its rank in the window's status word (crnerf_peer_window_status; synchronises). */
+/* ---- streams that own a share of the GPU's compute units.  The training backward runs its write-bound data gradient and its read-bound weight
+ * gradients side by side (CRNERF_BWD_PHASE_*); every such kernel takes a whole CU per workgroup (512 registers per wave), so "side by side"
+ * means a partition of the CUs, which HIP offers per stream.  crnerf_stream_create_cu_share: a stream whose kernels run on a fraction of every XCD's
+ * CUs -- those with index (within the XCD's logical numbering) in [first, first + count) out of crnerf_cus_per_xcd().  Destroy with
+ * crnerf_stream_destroy (synchronises the stream).  Any entry point of this library takes such a stream as its `stream` argument. */
+int crnerf_cus_per_xcd(void);
+int crnerf_stream_create_cu_share(void** stream, int first, int count);
+int crnerf_stream_destroy(void* stream);
 #define CRNERF_PEER_MAX_RANKS 8
 #define CRNERF_PEER_MAX_FLOATS 1024
 #define CRNERF_PEER_HANDLE_BYTES 64
