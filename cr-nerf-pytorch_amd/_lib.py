@@ -28,7 +28,7 @@ EXPORTS = [
     "crnerf_packed_mlp_h2_bytes", "crnerf_pack_mlp_weights_h2", "crnerf_mlp_forward_f32h2", "crnerf_render_rays_f32h2",
     "crnerf_render_rays_f32x3_repair", "crnerf_mlp_forward_f32x3_repair",
     "crnerf_render_rays_train_f32h2", "crnerf_render_rays_train_f32x3_repair", "crnerf_packed_mlp_t_h2_bytes", "crnerf_pack_mlp_weights_t_h2", "crnerf_mlp_backward_h2_f32", "crnerf_pack_mlp_weights_h2_async", "crnerf_pack_h2_status",
-    "crnerf_packed_mlp_x3_bytes", "crnerf_pack_mlp_weights_x3", "crnerf_mlp_forward_f32x3", "crnerf_render_rays_f32x3", "crnerf_render_rays_train_f32x3", "crnerf_packed_mlp_t_x3_bytes", "crnerf_pack_mlp_weights_t_x3", "crnerf_mlp_backward_x3_f32", "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16",
+    "crnerf_packed_mlp_x3_bytes", "crnerf_pack_mlp_weights_x3", "crnerf_mlp_forward_f32x3", "crnerf_render_rays_f32x3", "crnerf_render_rays_train_f32x3", "crnerf_packed_mlp_t_x3_bytes", "crnerf_pack_mlp_weights_t_x3", "crnerf_mlp_backward_x3_f32", "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16", "crnerf_render_rays_bf16_fine",
     "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32", "crnerf_adam_max_tensors", "crnerf_adam_step_f32",
@@ -156,6 +156,7 @@ def load():
             "crnerf_render_rays_train_f32": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp, vp, vp, vp, vp]),
             "crnerf_render_rays_train_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp, vp, vp, vp, vp]),
             "crnerf_render_rays_bf16": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
+            "crnerf_render_rays_bf16_fine": (ctypes.c_int, [ctypes.POINTER(RenderArgs), vp]),
             "crnerf_packed_mlp_h2_bytes": (ctypes.c_size_t, []),
             "crnerf_pack_mlp_weights_h2": (ctypes.c_int, [pp, vp, vp]),
             "crnerf_mlp_forward_f32h2": (ctypes.c_int, [vp, vp, vp, i64, i32, vp]),

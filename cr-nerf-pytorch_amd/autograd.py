@@ -203,7 +203,14 @@ class FusedRenderFn(torch.autograd.Function):
             if mod is not None and hasattr(mod, "invalidate_packed"):
                 mod.invalidate_packed()      # an optimiser step follows (see MlpFn)
         mode = get_training_forward_mode()
-        packed = [_pack_for_training(mode, st) for st in states]
+        # one set of packs per render call, shared by its ray chunks (fused_render_with_grad; round 6: eight chunks of a 65,536-ray step packed
+        # the same weights eight times, forward and transposed: ~130 launches and 0.7 ms)
+        shared = cfg.get("shared")
+        packed = shared.get(("fwd", mode)) if shared is not None else None
+        if packed is None:
+            packed = [_pack_for_training(mode, st) for st in states]
+            if shared is not None:
+                shared[("fwd", mode)] = packed
         recompute = get_training_recompute()
         ctx.mode = _effective_mode(mode, packed)   # the backward follows the forward's core
         out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
@@ -235,8 +242,16 @@ class FusedRenderFn(torch.autograd.Function):
         keep, params = saved[:ctx.n_keep], saved[ctx.n_keep:]
         rays, z_fine = keep[0], keep[1]
         states = [dict(zip(ops.MLP_TENSOR_NAMES, params[24 * m:24 * m + 24])) for m in range(ctx.n_models)]
+        shared = cfg.get("shared")
+
+        def cached(key, make):     # the transposed packs of a step's weights: made by the first chunk's backward, used by all of them
+            if shared is None:
+                return make()
+            if key not in shared:
+                shared[key] = make()
+            return shared[key]
         if ctx.recompute:
-            packed = [_pack_for_training(ctx.mode, st) for st in states]
+            packed = cached(("fwd", ctx.mode), lambda: [_pack_for_training(ctx.mode, st) for st in states])
             out = ops.render_rays(packed[0], packed[1] if Ni > 0 else None, rays, Nc, Ni, use_disp=cfg["use_disp"], view_dir=cfg["view_dir"],
                                   z_coarse=cfg["z_coarse"], u=cfg["u"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
                                   noise_std=cfg["noise_std"], train=True, rng=cfg.get("rng"), z_steps=cfg.get("z_steps"),
@@ -261,8 +276,9 @@ class FusedRenderFn(torch.autograd.Function):
             x = _embed_points(rays, z, cfg["view_dir"])
             mode = getattr(ctx, "mode", "f32")   # a split-core forward brings the data gradient on the same core with it (set_training_forward_precision)
             x3, h2 = mode == "f32x3", mode in ("f32h2", "auto")
-            packed_t = ops.pack_mlp_weights_t_h2(states[m]) if h2 else (ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m]))
-            net = ops.pack_mlp_weights_t_x3(states[m]) if mode == "auto" else None      # "auto": the f32x3 data gradient stands by (device-side range flag)
+            packed_t = cached(("t", "h2" if h2 else "x3" if x3 else "f32", m),
+                              lambda: ops.pack_mlp_weights_t_h2(states[m]) if h2 else (ops.pack_mlp_weights_t_x3(states[m]) if x3 else ops.pack_mlp_weights_t(states[m])))
+            net = cached(("t", "x3", m), lambda: ops.pack_mlp_weights_t_x3(states[m])) if mode == "auto" else None      # "auto": the f32x3 data gradient stands by (device-side range flag)
             grads += ops.mlp_backward(packed_t, x, raw.view(-1, 65), d_raw.view(-1, 65), acts, wgrad_bf16=get_wgrad_bf16(h2), dgrad_x3=x3, dgrad_h2=h2,
                                       fallback_t_x3=net)
             del x, d_raw
@@ -415,12 +431,16 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
     params = list(ops.mlp_params(coarse)) + (list(ops.mlp_params(fine)) if Ni > 0 else [])
     step = max(4, ((1 << 20) // (Nc + Ni)) // 4 * 4)
     parts = []
+    # packs of this call's weights, made once and shared by the chunks' nodes (forward packs, and the transposed ones their backward makes); the
+    # dict dies with the graph.  The weights cannot change between this forward and its backward without autograd objecting to the saved
+    # parameters -- except through p.data writes that bypass the version counter (FlatAdam): do not step the optimiser between the two.
+    shared = {} if R > step else None
     for lo in range(0, R, step):
         hi = min(R, lo + step)
         sl = lambda t: None if t is None else t[lo:hi].contiguous()  # noqa: E731
         cfg = {"Nc": Nc, "Ni": Ni, "use_disp": use_disp, "view_dir": sl(view_dir), "z_coarse": sl(z_coarse),
                "u": (u_steps if u is None else sl(u)) if Ni > 0 else None, "noise_c": sl(noise_c), "noise_f": sl(noise_f),
-               "noise_std": float(noise_std), "modules": (coarse, fine)}
+               "noise_std": float(noise_std), "modules": (coarse, fine), "shared": shared}
         if rng is not None:
             cfg["rng"] = dict(rng, ray_offset=int(rng.get("ray_offset", 0)) + lo)
             cfg["z_steps"] = z_steps          # the reference's torch.linspace table (rendering.py:160): the jitter is formed from it in-kernel
@@ -461,7 +481,7 @@ class CompositeFn(torch.autograd.Function):
 # engine None for the parameters, keeps the gradients, and ONE callback at the end of the backward pass sums them with multi-tensor adds and
 # writes / accumulates .grad.  Not for torch.autograd.grad() callers, parameter hooks or DDP's reducer: those need AccumulateGrad to run.
 _DEFER_ON = [False]
-_DEFERRED = {"pending": {}, "task": None}       # "task": id of the backward pass (graph task) whose end-of-pass callback is queued
+_DEFERRED = {}       # graph-task id -> {id(param): (param, [gradients])}: one entry per backward pass that has deferred something and not finished yet
 
 
 class deferred_param_grads:
@@ -482,25 +502,26 @@ class deferred_param_grads:
 def reset_deferred():
     """Drop gradients a backward pass left behind when it raised before its end-of-pass callback ran (the engine discards the callback with the
     failed pass).  Nothing of the failed pass reaches .grad -- what torch does with a node that raised."""
-    _DEFERRED["pending"], _DEFERRED["task"] = {}, None
+    _DEFERRED.clear()
 
 
 def _defer(params, grads):
     # The callback belongs to ONE backward pass: the engine drops it when a later node of that pass raises (HIP error, OOM, KeyboardInterrupt).  The
-    # queued state is therefore keyed to the graph task's id, not kept as a sticky flag: a new pass finds another id, discards what the dead pass
-    # left (its gradients must not leak into this one's) and queues its own callback.
+    # queued state is therefore keyed to the graph task's id, one dict per pass: a nested or re-entrant backward (torch.utils.checkpoint with
+    # use_reentrant=True, a .backward() inside a Function.backward) has its own id, its own dict and its own callback, and leaves the outer pass's
+    # pending gradients alone (ADVICE r5: a single slot made the inner pass discard them).  What a dead pass left behind is dropped when the next
+    # forward starts (deferred_param_grads.__enter__) -- never by another pass.
     task = torch._C._current_graph_task_id()
-    if _DEFERRED["task"] != task:
-        _DEFERRED["pending"], _DEFERRED["task"] = {}, task
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
-    pend = _DEFERRED["pending"]
+    pend = _DEFERRED.get(task)
+    if pend is None:
+        pend = _DEFERRED[task] = {}
+        torch.autograd.Variable._execution_engine.queue_callback(lambda task=task: _flush_deferred(task))
     for p, g in zip(params, grads):
         pend.setdefault(id(p), (p, []))[1].append(g)
 
 
-def _flush_deferred():
-    pend = _DEFERRED["pending"]
-    _DEFERRED["pending"], _DEFERRED["task"] = {}, None
+def _flush_deferred(task):
+    pend = _DEFERRED.pop(task, None)
     if not pend:
         return
     with torch.no_grad():

@@ -277,6 +277,25 @@ int crnerf_rng_fill_f32(float* out, int64_t n_rays, int n, uint64_t seed, int st
 
 int crnerf_render_rays_bf16(const crnerf_render_args* a, void* stream) { return render_rays_common(a, stream, true); }
 
+int crnerf_render_rays_bf16_fine(const crnerf_render_args* a, void* stream) {
+  REQUIRE(a, "args");
+  if (a->n_rays == 0) return 0;
+  if (a->n_rays < 0) return set_error(CRNERF_ERR_SHAPE, "render_rays_bf16_fine: negative n_rays");
+  if (a->n_importance <= 0) return set_error(CRNERF_ERR_CONFIG, "render_rays_bf16_fine: n_importance must be > 0");
+  REQUIRE(a->packed_fine, "packed_fine"); REQUIRE(a->rays, "rays"); REQUIRE(a->weights_coarse, "weights_coarse (input)");
+  REQUIRE(a->weights_fine, "weights_fine"); REQUIRE(a->feature_fine, "feature_fine"); REQUIRE(a->depth_fine, "depth_fine");
+  if (a->rng_flags || a->z_coarse_out || a->noise_coarse_out || a->noise_fine_out)
+    return set_error(CRNERF_ERR_CONFIG, "render_rays_bf16_fine: no in-kernel random draws in the bf16 kernels");
+  RenderArgs r;
+  r.packed_coarse = a->packed_fine; r.packed_fine = a->packed_fine; r.rays = a->rays; r.view_dir = a->view_dir;
+  r.z_coarse = a->z_coarse; r.z_steps = a->z_steps; r.u = a->u; r.u_stride = (long)a->u_stride; r.noise_coarse = nullptr; r.noise_fine = a->noise_fine;
+  r.noise_std = a->noise_std; r.use_disp = a->use_disp; r.R = (long)a->n_rays; r.Nc = a->n_samples; r.Ni = a->n_importance;
+  r.weights_coarse = a->weights_coarse; r.feature_coarse = nullptr; r.depth_coarse = nullptr;
+  r.weights_fine = a->weights_fine; r.feature_fine = a->feature_fine; r.depth_fine = a->depth_fine; r.z_fine = a->z_fine;
+  r.fine_only = 1;
+  return launch_render_rays_bf16p(r, (hipStream_t)stream);
+}
+
 size_t crnerf_packed_mlp_mixed_bytes(void) { return gemm_packed_bytes(); }
 size_t crnerf_mlp_train_mixed_acts_bytes(int64_t n) { return mlp_train_mixed_acts_bytes((long)n); }
 size_t crnerf_mlp_train_mixed_scratch_bytes(int64_t n) { return mlp_train_mixed_scratch_bytes((long)n); }

@@ -56,7 +56,7 @@ int launch_generate_rays(const float* intr4_host, const float* c2w_host, int H, 
 size_t encoder_workspace_bytes(int H, int W);
 int launch_encoder_forward(const float* img, int H, int W, const float* const* w, void* workspace, float* out, hipStream_t st);
 // dst[m*ldc + n] = sum_p D[p][m] * A[p][n] (and db[m] = sum_p D[p][m] when db != null); ws: wgrad_workspace_floats()
-size_t wgrad_workspace_floats(long P, int M, int N);
+size_t wgrad_workspace_floats(long P, int M, int N, int bf16 = 0);   // bf16: the mode wgrad() will be called with (3 = f16x2: narrow jobs run on half chunks)
 // bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
           hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr);
@@ -107,6 +107,8 @@ struct RenderArgs {
   float* noise_fine_out = nullptr;
   // crnerf_render_rays_f32x3_repair: only ray quads whose feature_coarse / feature_fine hold a NaN are rendered (again)
   int repair = 0;
+  // crnerf_render_rays_bf16_fine: weights_coarse is an INPUT (rendered by another core); sample_pdf + merge + the fine pass only
+  int fine_only = 0;
   // training twin (crnerf_render_rays_train_f32; all null for inference): saved activations + raw MLP outputs per pass
   void* train_acts_coarse = nullptr;   // crnerf_mlp_train_acts_bytes(R*Nc)
   void* train_acts_fine = nullptr;     // crnerf_mlp_train_acts_bytes(R*(Nc+Ni))

@@ -1109,8 +1109,14 @@ static int wg_chunk(long P) {
 }
 
 // dW (and, when db != null, the bias gradient of the same delta) for one (delta, input-block) pair
-size_t wgrad_workspace_floats(long P, int M, int N) {
-  const int chunk = wg_chunk(P);
+// the chunk length wgrad() gives a job: f16x2 jobs of at most two accumulator tiles per wave run on wgrad_h2_narrow_kernel, two workgroups per CU on half chunks
+static int wgrad_job_chunk(long P, int M, int N, int bf16) {
+  int chunk = wg_chunk(P);
+  if (bf16 == 3 && M <= 128 && N <= 128) { chunk = (chunk / 2 + 31) / 32 * 32; if (chunk < 128) chunk = 128; }
+  return chunk;
+}
+size_t wgrad_workspace_floats(long P, int M, int N, int bf16) {
+  const int chunk = wgrad_job_chunk(P, M, N, bf16);     // (the narrow f16x2 jobs write up to twice the partial-sum slabs of a full chunk)
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
   return nchunk * ((size_t)M * N + M);
 }
@@ -1120,8 +1126,7 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
   // at most two accumulator tiles per wave (dir_encoding's direction block, static_rgb): wgrad_h2_narrow_kernel, two workgroups per CU on half chunks
   // (measured per 2^19 points: 139 -> 93 and 142 -> 119 us; the 93-column embedding blocks gain nothing from it, dir_encoding's 4 x 2 tiles spill in 256 registers)
   const bool narrow = bf16 == 3 && M <= 128 && N <= 128;
-  int chunk = wg_chunk(P);
-  if (narrow) { chunk = (chunk / 2 + 31) / 32 * 32; if (chunk < 128) chunk = 128; }   // (2 x nchunk x (M N + M) stays inside the workspace of a full block)
+  const int chunk = wgrad_job_chunk(P, M, N, bf16);     // (narrow: 2 x nchunk x (M N + M) stays inside the workspace of a full block; wgrad_workspace_floats(.., 3) sizes it)
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
   WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)

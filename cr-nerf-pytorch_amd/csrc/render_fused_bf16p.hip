@@ -25,6 +25,7 @@ struct RenderParamsP {
   long R; int Nc, Ni, iters;
   unsigned int* sched;   // null: static quad -> workgroup map (iters passes); else {next-quad counter, finished-workgroup counter}
   float* weights_c; float* feature_c; float* depth_c; float* weights_f; float* feature_f; float* depth_f; float* z_fine;
+  const float* wc_in;    // render_rays_bf16p_fine_kernel: the coarse pass's weights [R, Nc], computed elsewhere (crnerf_render_rays_bf16_fine)
 };
 
 constexpr int LDS_DIR_P = LDS_SCRATCH_P + 4 * PAIR_BYTES;        // 8 waves x 64 B: the ray's direction embedding as B operands
@@ -89,7 +90,10 @@ __device__ __forceinline__ float fold32(float (&v)[32], int p) {
   return v[0];
 }
 
-template <class HOOK>
+// FINE_ONLY (crnerf_render_rays_bf16_fine, precision "bf16_hc"): the coarse pass has been rendered by another core (fp32-accurate, so that the fine
+// depths are the fp32 reference's); its weights come in through a.wc_in, the kernel runs sample_pdf + merge on them and the FINE pass only --
+// packed0 == packed1 == the fine model, the ring starts on model 1 and never leaves it.
+template <class HOOK, bool FINE_ONLY = false>
 __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, const HOOK& hook) {
 #ifdef CRNERF_TIMING
   if (threadIdx.x == 0 && blockIdx.x < 1024) crnerf_wg_times_p[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -111,7 +115,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
   lds_char* dirbuf = lds + LDS_DIR_P + wave * 64;
 
   WeightPipeP pipe;
-  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, 0, lane, wave, HOOK::on);
+  pipe.start(lds, a.packed0 + CONST_BYTES, a.packed1 + CONST_BYTES, FINE_ONLY ? 1 : 0, lane, wave, HOOK::on);
   u32x4 q[B_AHEAD];
   pipe.prime(q);
   tm.tick(T_RAYLEVEL);
@@ -141,11 +145,22 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
     }
     for (int n = lane128; n < Nc; n += 128)
       scr.zc[n] = a.z_coarse ? a.z_coarse[r * Nc + n] : coarse_depth(near, far, a.z_steps ? a.z_steps[n] : linspace01(n, Nc), a.use_disp);
+    if constexpr (FINE_ONLY) {
+      for (int n = lane128; n < Nc; n += 128) scr.wc[n] = a.wc_in[r * Nc + n];
+    }
     wg_barrier();
 
     const int npass = Ni > 0 ? 2 : 1;
 #pragma unroll 1
-    for (int pass = 0; pass < npass; ++pass) {
+    for (int pass = FINE_ONLY ? 1 : 0; pass < npass; ++pass) {
+      if constexpr (FINE_ONLY) {   // what follows the coarse pass in the full kernel (below), on the weights that came in
+        sample_pdf_pair(scr, Nc, Ni, a.u ? a.u + r * a.u_stride : nullptr, lane, lane128);
+        wg_barrier();
+        merge_sort_pair(scr, Nc, Ni, lane128);
+        wg_barrier();
+        if (a.z_fine && ray_ok)
+          for (int n = lane128; n < Nf; n += 128) a.z_fine[r * Nf + n] = scr.zs[n];
+      }
       const int N = pass ? Nf : Nc;
       const lds_float* zsrc = pass ? scr.zs : scr.zc;
       const float* noise_row = pass ? (a.noise_f ? a.noise_f + r * Nf : nullptr) : (a.noise_c ? a.noise_c + r * Nc : nullptr);
@@ -167,7 +182,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
         f32x16 feat[2];
         float sigma;
         // the model of the tile after this one: same pass, the fine pass, or the next ray's coarse pass
-        const int next_model = k + 1 < steps ? pass : (pass + 1 < npass ? 1 : 0);
+        const int next_model = FINE_ONLY ? 1 : (k + 1 < steps ? pass : (pass + 1 < npass ? 1 : 0));
         auto sv = hook.saver(pass, r, N, 64 * k + 32 * half, n, ray_ok, lane, wave, lds);
         if constexpr (HOOK::on) {   // the embedded input as the MLP multiplies it: xyz k-steps 0..5, dir k-steps 6, 7 (32 B per point and k-step);
           const __amdgpu_buffer_rsrc_t xr = sv.xb();                        // unconditional stores, counted in SAVE_TILE_BURST (mlp_core_bf16p.h)
@@ -270,6 +285,7 @@ __device__ __forceinline__ void render_rays_bf16p_body(const RenderParamsP& a, c
 
 __global__ __launch_bounds__(512, 2) void render_rays_bf16p_kernel(RenderParamsP a) { render_rays_bf16p_body(a, NoHookP()); }
 __global__ __launch_bounds__(512, 2) void render_rays_train_bf16p_kernel(RenderParamsP a, TrainHookP hook) { render_rays_bf16p_body(a, hook); }
+__global__ __launch_bounds__(512, 2) void render_rays_bf16p_fine_kernel(RenderParamsP a) { render_rays_bf16p_body<NoHookP, true>(a, NoHookP()); }
 
 int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
   if (a.R <= 0) return 0;
@@ -285,6 +301,14 @@ int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
   k.R = a.R; k.Nc = a.Nc; k.Ni = a.Ni;
   k.weights_c = a.weights_coarse; k.feature_c = a.feature_coarse; k.depth_c = a.depth_coarse;
   k.weights_f = a.weights_fine; k.feature_f = a.feature_fine; k.depth_f = a.depth_fine; k.z_fine = a.z_fine;
+  k.wc_in = nullptr;
+  if (a.fine_only) {   // crnerf_render_rays_bf16_fine: weights_coarse is an INPUT, the fine model runs alone
+    if (a.Ni <= 0 || !a.packed_fine || !a.weights_coarse) return set_error(-3, "render_rays_bf16_fine: needs N_importance > 0, the fine model and weights_coarse");
+    if (a.train_acts_coarse) return set_error(-3, "render_rays_bf16_fine: no training twin");
+    k.packed0 = k.packed1 = (const char*)a.packed_fine;
+    k.wc_in = a.weights_coarse;
+    k.weights_c = k.feature_c = k.depth_c = nullptr;
+  }
   const long quads = (a.R + 3) / 4;
   const int cus = num_cus();
   const int grid = (int)(quads < cus ? quads : cus);   // one workgroup per CU, persistent over ray quads
@@ -299,6 +323,11 @@ int launch_render_rays_bf16p(const RenderArgs& a, hipStream_t stream) {
     if (int rc = ensure_dynamic_lds((const void*)render_rays_train_bf16p_kernel, LDS_TOTAL_TRAIN_P, "render_rays_train_bf16p_kernel")) return rc;
     hipLaunchKernelGGL(render_rays_train_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_TRAIN_P, stream, k, h);
     return check_launch("render_rays_train_bf16p_kernel");
+  }
+  if (a.fine_only) {
+    if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16p_fine_kernel, LDS_TOTAL_P, "render_rays_bf16p_fine_kernel")) return rc;
+    hipLaunchKernelGGL(render_rays_bf16p_fine_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k);
+    return check_launch("render_rays_bf16p_fine_kernel");
   }
   if (int rc = ensure_dynamic_lds((const void*)render_rays_bf16p_kernel, LDS_TOTAL_P, "render_rays_bf16p_kernel")) return rc;
   hipLaunchKernelGGL(render_rays_bf16p_kernel, dim3(grid), dim3(512), LDS_TOTAL_P, stream, k);

@@ -77,25 +77,19 @@ def _render_unfused(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u,
     return out
 
 
-def _render_bf16_accurate_coarse(coarse, fine, rays, Nc, Ni, use_disp, view_dir, noise_c, noise_f, noise_std, chunk):
+def _render_bf16_accurate_coarse(coarse, fine, rays, Nc, Ni, use_disp, view_dir, noise_c, noise_f, noise_std, chunk, want_z_fine=False):
     """precision="bf16_hc" (inference, perturb = 0): the COARSE pass in fp32 accuracy on the fp16 matrix cores (precision "auto": f32h2 with the
     f32x3 safety net; 25 % of the points), the FINE pass on the bf16 matrix cores.  Why: bf16's end-to-end pixel error on a trained checkpoint is
     sampling sensitivity -- bf16 coarse weights move the fine depths (weights_fine rel-L2 2.8e-2, tests/test_gpu_trained_ckpt.py) -- so with
     fp32-accurate coarse weights the fine depths are the fp32 reference's and what is left is the fine network's own bf16 rounding.
-    Un-fused: fused coarse render -> sample_pdf + merge -> embed -> bf16 MLP -> compositing, the same HIP kernels as _render_unfused."""
-    R = rays.shape[0]
+    Two fused launches (+ the repair kernel that leaves at once): the coarse-only render on the h2 core, then crnerf_render_rays_bf16_fine --
+    sample_pdf, merge, embedding, fine MLP and compositing in one kernel on the coarse weights (round 6; rounds 4-5 ran five un-fused calls with
+    the [P,120] embeddings and [P,65] raw rows through HBM: 297 ms per 800 x 800 frame)."""
     z_steps, u_steps = _linspace_tables(Nc, Ni, rays.device)
     out = ops.render_rays(coarse.packed_weights("auto"), None, rays, Nc, 0, use_disp=use_disp, view_dir=view_dir, z_steps=z_steps,
                           noise_coarse=noise_c, noise_std=float(noise_std), precision="auto")
-    near, far = rays[:, 6:7], rays[:, 7:8]
-    z_coarse = (near * (1 - z_steps) + far * z_steps) if not use_disp else 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)   # rendering.py:161-165
-    z_fine = ops.sample_pdf_merge(z_coarse.expand(R, Nc).contiguous(), out["weights_coarse"], Ni, u=u_steps)
-    demb = ops.posenc((view_dir if view_dir is not None else rays[:, 3:6]).contiguous(), 4)
-    N = Nc + Ni
-    rstep = max(max(int(chunk), 1 << 20) // N, 1)
-    raw = torch.cat([ops.mlp_forward(fine.packed_weights("bf16"), ops.embed_points(rays[i:i + rstep], z_fine[i:i + rstep], demb[i:i + rstep]), precision="bf16")
-                     for i in range(0, R, rstep)], 0)
-    out["weights_fine"], out["feature_fine"], out["depth_fine"] = ops.composite(raw.view(R, N, 65), z_fine, noise_f, noise_std)
+    out.update(ops.render_rays_bf16_fine(fine.packed_weights("bf16"), rays, out["weights_coarse"], Nc, Ni, use_disp=use_disp, view_dir=view_dir,
+                                         z_steps=z_steps, u=u_steps, noise_fine=noise_f, noise_std=float(noise_std), want_z_fine=want_z_fine))
     return out
 
 

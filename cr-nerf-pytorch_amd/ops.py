@@ -593,6 +593,41 @@ def render_rays(packed_coarse, packed_fine, rays, n_samples, n_importance, use_d
     return out
 
 
+def render_rays_bf16_fine(packed_fine_bf16, rays, weights_coarse, n_samples, n_importance, use_disp=False, view_dir=None, z_coarse=None, z_steps=None, u=None,
+                          noise_fine=None, noise_std=0.0, want_z_fine=False):
+    """crnerf_render_rays_bf16_fine: sample_pdf + z merge on `weights_coarse` [R,Nc] (rendered by another core, e.g. render_rays(..., n_importance=0,
+    precision="auto")) and the fine model on the bf16 matrix cores, fused -- {"weights_fine", "feature_fine", "depth_fine"[, "z_fine"]}."""
+    lib = _lib.load()
+    _check_packed(packed_fine_bf16, True)
+    rays, weights_coarse = _f32c(rays, "rays"), _f32c(weights_coarse, "weights_coarse")
+    R, dev = rays.shape[0], rays.device
+    Nc, Ni = int(n_samples), int(n_importance)
+    if rays.dim() != 2 or rays.shape[1] != 8 or tuple(weights_coarse.shape) != (R, Nc) or Ni <= 0:
+        raise ValueError("render_rays_bf16_fine: rays [R,8], weights_coarse [R,%d] and n_importance > 0 expected, got %s / %s / %d"
+                         % (Nc, tuple(rays.shape), tuple(weights_coarse.shape), Ni))
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    out = {"weights_fine": new(R, Nc + Ni), "feature_fine": new(R, 64), "depth_fine": new(R)}
+    if want_z_fine:
+        out["z_fine"] = new(R, Nc + Ni)
+    if R == 0:
+        return out
+    keep = [t if t is None else _f32c(t, n) for t, n in ((view_dir, "view_dir"), (z_coarse, "z_coarse"), (z_steps, "z_steps"), (u, "u"), (noise_fine, "noise_fine"))]
+    a = _lib.RenderArgs()
+    a.packed_fine = packed_fine_bf16.data_ptr()
+    a.rays = rays.data_ptr()
+    a.u_stride = 0 if (u is None or u.dim() == 1) else Ni
+    for field, t in zip(("view_dir", "z_coarse", "z_steps", "u", "noise_fine"), keep):
+        setattr(a, field, t.data_ptr() if t is not None else None)
+    a.noise_std = float(noise_std)
+    a.use_disp = int(bool(use_disp))
+    a.n_rays, a.n_samples, a.n_importance = R, Nc, Ni
+    a.weights_coarse = weights_coarse.data_ptr()                    # INPUT of this entry point
+    for k in ("weights_fine", "feature_fine", "depth_fine", "z_fine"):
+        setattr(a, k, out[k].data_ptr() if k in out else None)
+    _lib.check(lib.crnerf_render_rays_bf16_fine(ctypes.byref(a), _lib.stream_ptr()), "crnerf_render_rays_bf16_fine")
+    return out
+
+
 def _repair_args(a, repair):
     """The argument block of the h2 render with the x3 packs in place of the h2 ones (crnerf_render_rays_f32x3_repair)."""
     if repair is None:

@@ -221,6 +221,13 @@ int crnerf_pack_mlp_weights_bf16(const float* const* tensors, void* packed_bf16,
 int crnerf_mlp_forward_bf16(const void* packed_bf16, const float* x, float* out, int64_t n, int sigma_only, void* stream);
 /* render_rays_cross_ray, models/rendering.py:50-196, fully fused; args->packed_{coarse,fine} are bf16 packs. */
 int crnerf_render_rays_bf16(const crnerf_render_args* args, void* stream);
+/* The FINE half of render_rays_cross_ray on the bf16 matrix cores (models/rendering.py:183-194: sample_pdf on the coarse weights, the z merge, the
+ * fine model over the N_samples + N_importance merged depths, compositing) for a coarse pass rendered elsewhere -- precision "bf16_hc" renders it
+ * with crnerf_render_rays_f32h2 / _f32x3_repair (n_importance = 0), so that the fine DEPTHS are the fp32 reference's and only the fine network's
+ * own products are bf16.  args->weights_coarse [R, n_samples] is READ; args->packed_fine is a bf16 pack; packed_coarse, feature_coarse and
+ * depth_coarse are ignored (may be NULL); z_coarse / z_steps / u / noise_fine as in crnerf_render_rays_bf16; writes weights_fine, feature_fine,
+ * depth_fine and (optional) z_fine.  Nothing per point goes through HBM. */
+int crnerf_render_rays_bf16_fine(const crnerf_render_args* args, void* stream);
 
 /* Training twin of crnerf_render_rays_bf16 for the opt-in mixed-precision training mode (no counterpart in the reference): the same
  * fused launch on the bf16 matrix cores that additionally keeps, per pass, what crnerf_mlp_backward_mixed_ex_f32(..., CRNERF_MIXED_ACTS_FUSED)

@@ -212,3 +212,40 @@ def test_render_cold_l2_is_deterministic(precision, passes):
                     d = (out[k] != ref[k]).view(R, -1).any(1).nonzero().flatten()
                     raise AssertionError("pass %d: %s differs in %d rays (first %s): max |d| %.3e" % (it, k, d.numel(), d[:8].tolist(),
                                                                                                 float((out[k] - ref[k]).abs().max())))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("R,Nc,Ni,use_disp", [(257, 64, 128, False), (5, 48, 40, True), (64, 256, 256, False), (1, 3, 1, False)])
+def test_render_rays_bf16_fine_is_the_fine_half_of_the_fused_renderer(R, Nc, Ni, use_disp):
+    """crnerf_render_rays_bf16_fine (round 6, precision "bf16_hc"): sample_pdf + merge + the fine pass on coarse weights that come IN.  Fed the
+    fused bf16 renderer's own weights_coarse it must reproduce that renderer's fine outputs bit for bit (the same code on the same inputs) --
+    ragged ray counts, ragged tile counts, use_disp, per-ray noise and u included."""
+    st_c, st_f = synth.mlp_state(21, 2.0, 0.5), synth.mlp_state(22, 2.0, 0.5)
+    pc, pf = packed(st_c), packed(st_f)
+    rays = C(synth.rays(R, seed=R))
+    g = torch.Generator().manual_seed(R)
+    u = torch.rand(R, Ni, generator=g).to(DEV)
+    noise_f = torch.randn(R, Nc + Ni, generator=g).to(DEV)
+    kw = dict(use_disp=use_disp, z_steps=torch.linspace(0, 1, Nc, device=DEV), u=u, noise_fine=noise_f, noise_std=0.5)
+    full = ops.render_rays(pc, pf, rays, Nc, Ni, want_z_fine=True, precision="bf16", **kw)
+    fine = ops.render_rays_bf16_fine(pf, rays, full["weights_coarse"], Nc, Ni, want_z_fine=True, **kw)
+    for k in ("z_fine", "weights_fine", "feature_fine", "depth_fine"):
+        assert torch.equal(fine[k], full[k]), k
+    # ... and on other coarse weights (the h2 core's, as "bf16_hc" feeds it) its depths are sample_pdf_merge's on those weights, bit for bit
+    hc = ops.render_rays(ops.pack_mlp_weights_auto({k: C(v) for k, v in st_c.items()}), None, rays, Nc, 0, precision="auto", use_disp=use_disp,
+                         z_steps=kw["z_steps"])
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    zs = kw["z_steps"]
+    z_coarse = (near * (1 - zs) + far * zs) if not use_disp else 1 / (1 / near * (1 - zs) + 1 / far * zs)
+    fine2 = ops.render_rays_bf16_fine(pf, rays, hc["weights_coarse"], Nc, Ni, want_z_fine=True, **kw)
+    assert torch.equal(fine2["z_fine"], ops.sample_pdf_merge(z_coarse.expand(R, Nc).contiguous(), hc["weights_coarse"], Ni, u=u))
+    assert bool(torch.isfinite(fine2["feature_fine"]).all())
+
+
+def test_render_rays_bf16_fine_refuses_what_it_cannot_do():
+    pf = packed(synth.mlp_state(22, 1.0))
+    rays = C(synth.rays(8, seed=0))
+    with pytest.raises(ValueError, match="n_importance > 0"):
+        ops.render_rays_bf16_fine(pf, rays, torch.zeros(8, 64, device=DEV), 64, 0)
+    with pytest.raises(ValueError, match="weights_coarse"):
+        ops.render_rays_bf16_fine(pf, rays, torch.zeros(8, 32, device=DEV), 64, 16)

@@ -540,3 +540,49 @@ def test_train_auto_gradients_through_repaired_rays():
         # (2e-2: the two steps differ in their data gradients -- h2 against x3 -- and a 1e-7 difference of a coarse weight moves a fine depth, see
         # test_gpu_train_fused.py's "auto" bar; measured 2e-3 on a bias, whose sum is the same fp32 code in both)
         assert float((gau[k] - gx3[k]).norm() / (gx3[k].norm() + 1e-30)) <= 2e-2, (k, float((gau[k] - gx3[k]).norm() / (gx3[k].norm() + 1e-30)))
+
+
+@pytest.mark.parametrize("core,wmode", [("h2", "f16x2"), ("h2", 2), ("x3", 2), ("f32", 0)])
+def test_backward_phases_are_the_halves_of_the_one_call_backward(core, wmode):
+    """CRNERF_BWD_PHASE_DGRAD / _WGRAD (round 6): the data gradient and the weight gradients as two calls over one scratch -- on one stream and with
+    the weight gradients on a CU-share stream behind an event (crnerf_stream_create_cu_share) -- give the one-call backward's gradients bit for bit."""
+    import ctypes
+    from crnerf_amd import _lib
+    n = 70000
+    st = synth.mlp_state(13, 2.0, 0.5)
+    rng = np.random.default_rng(3)
+    x = torch.cat([O.posenc(torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)), 15),
+                   O.posenc(torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)), 4)], 1).to(DEV)
+    d_out = torch.from_numpy(rng.normal(size=(n, 65)).astype(np.float32)).to(DEV)
+    dev = {k: C(v) for k, v in st.items()}
+    out, acts = ops.mlp_forward_train(ops.pack_mlp_weights(dev), x)
+    pk = ops.pack_mlp_weights_t_h2(dev) if core == "h2" else ops.pack_mlp_weights_t_x3(dev) if core == "x3" else ops.pack_mlp_weights_t(dev)
+    kw = dict(wgrad_bf16=wmode, dgrad_h2=core == "h2", dgrad_x3=core == "x3")
+    whole = ops.mlp_backward(pk, x, out, d_out, acts, **kw)
+    scratch = ops.mlp_backward(pk, None, out, d_out, acts, phase="dgrad", **kw)
+    halves = ops.mlp_backward(None, x, None, None, acts, phase="wgrad", scratch=scratch, **kw)
+    for name, a, b in zip(ops.MLP_TENSOR_NAMES, halves, whole):
+        assert torch.equal(a, b), name
+    # the weight gradients on a stream that owns a quarter of every XCD's CUs, ordered behind the data gradient by an event
+    lib = _lib.load()
+    per = lib.crnerf_cus_per_xcd()
+    assert per >= 4
+    h = ctypes.c_void_p()
+    _lib.check(lib.crnerf_stream_create_cu_share(ctypes.byref(h), per // 4, per // 4), "crnerf_stream_create_cu_share")
+    try:
+        side = torch.cuda.ExternalStream(h.value)
+        scratch2 = ops.mlp_backward(pk, None, out, d_out, acts, phase="dgrad", **kw)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            shared = ops.mlp_backward(None, x, None, None, acts, phase="wgrad", scratch=scratch2, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        for name, a, b in zip(ops.MLP_TENSOR_NAMES, shared, whole):
+            assert torch.equal(a, b), name
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.crnerf_stream_destroy(h), "crnerf_stream_destroy")
+    assert lib.crnerf_stream_create_cu_share(ctypes.byref(h), per, 1) != 0          # a share outside the XCD is refused
+    with pytest.raises(ValueError, match="scratch"):
+        ops.mlp_backward(None, x, None, None, acts, phase="wgrad", **kw)

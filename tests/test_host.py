@@ -386,7 +386,7 @@ def test_deferred_gradients_survive_a_backward_that_raised():
         w.grad = None
         y.sum().backward()
         assert torch.equal(w.grad, torch.arange(3.0))          # this pass's gradient only
-        assert not AG._DEFERRED["pending"] and AG._DEFERRED["task"] is None
+        assert not AG._DEFERRED                                # this pass's dict is gone; the dead pass's went when the forward started
     # a node built before the failure, run again without re-entering the context (retain_graph): the stale state is keyed to the dead pass
     with AG.deferred_param_grads(True):
         y = _DeferringNode.apply(_RaisingNode.apply(x), w)
@@ -396,6 +396,44 @@ def test_deferred_gradients_survive_a_backward_that_raised():
     w.grad = None
     y2.sum().backward()
     assert torch.equal(w.grad, torch.arange(3.0))
+
+
+class _NestedBackwardNode(torch.autograd.Function):
+    """Runs a whole inner backward pass (its own graph task, with deferring nodes of its own) inside its backward -- what
+    torch.utils.checkpoint(use_reentrant=True) does."""
+
+    @staticmethod
+    def forward(ctx, x, w_inner):
+        ctx.w_inner = w_inner
+        ctx.save_for_backward(x)
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from crnerf_amd import autograd as AG
+        (x,) = ctx.saved_tensors
+        with torch.enable_grad():
+            xi = x.detach().requires_grad_(True)
+            with AG.deferred_param_grads(True):
+                yi = _DeferringNode.apply(xi, ctx.w_inner)
+            yi.sum().backward()                                 # inner pass: own graph task id, own pending dict, own callback
+        return g, None
+
+
+def test_deferred_gradients_survive_a_nested_backward():
+    """a nested / re-entrant backward has its own graph task id; with ONE pending slot it silently discarded what the outer pass had
+    already deferred.  Pending gradients are kept per task: both passes deliver."""
+    from crnerf_amd import autograd as AG
+    w_outer = torch.nn.Parameter(torch.full((3,), 2.0))
+    w_inner = torch.nn.Parameter(torch.full((3,), 5.0))
+    x = torch.arange(3.0, requires_grad=True)
+    with AG.deferred_param_grads(True):
+        # backward order: the outer deferring node first (its gradient is pending), then the node that runs the inner pass
+        y = _DeferringNode.apply(_NestedBackwardNode.apply(x, w_inner), w_outer)
+    y.sum().backward()
+    assert torch.equal(w_outer.grad, torch.arange(3.0))        # the outer pass's deferred gradient arrived
+    assert torch.equal(w_inner.grad, torch.arange(3.0))        # so did the inner pass's
+    assert not AG._DEFERRED
 
 
 def test_deferred_gradients_leave_frozen_parameters_alone():
