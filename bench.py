@@ -837,8 +837,9 @@ def main():
             dt = time.perf_counter() - t0
             # the same steps through the C-ABI wrapper alone (ops.render_rays: what rounds 1-5 timed), outside the contract's timed region
             td0 = time.perf_counter()
-            for i in range(a.warmup, n_ev):
-                step(i, direct=True)
+            if not use_dist:                       # (N = 1 only: under torch.distributed these steps would add collectives to the record)
+                for i in range(a.warmup, n_ev):
+                    step(i, direct=True)
             td_enq = time.perf_counter()
             fence()
             dt_direct = time.perf_counter() - td0
@@ -863,7 +864,7 @@ def main():
                   "step_ms": _stats(step_each), "kernel_ms": _stats(kern_each), "device_gap_ms": _stats(gap_each), "host_enqueue_ms": _stats(host_each),
                   "host_enqueue_total_ms": (t_enq - t0) * 1e3, "wall_ms": dt * 1e3, "device_span_ms": tev[0][0].elapsed_time(tev[-1][2]),
                   "timed_through": "crnerf_amd.models.rendering.render_rays_cross_ray (the reference's signature, eval.py:39-52) + style_net.forward",
-                  "direct_c_abi": {"ms_per_step": dt_direct / a.steps * 1e3, "host_enqueue_ms_per_step": (td_enq - td0) / a.steps * 1e3,
+                  "direct_c_abi": None if use_dist else {"ms_per_step": dt_direct / a.steps * 1e3, "host_enqueue_ms_per_step": (td_enq - td0) / a.steps * 1e3,
                                    "note": "the same steps through ops.render_rays (the ctypes wrapper of crnerf_render_rays_*: what rounds 1-5 timed), "
                                            "run after the timed region"},
                   "gc": "gc.collect() + gc.disable() around the timed region (a generation-2 collection is a ~10 ms host pause; a training loop that "

@@ -34,12 +34,23 @@ int launch_pack_mlp(const MlpTensors& t, void* packed, hipStream_t stream);
 int launch_pack_mlpT(const MlpTensors& t, void* packed, hipStream_t stream);
 size_t mlp_train_acts_bytes(long P);
 size_t mlp_train_scratch_bytes(long P);
+// The saved state's RANGE WORD (round 6): behind the rows and relu bits of a pass's P points sits one 256-byte line whose first word
+// holds the bits of the largest |operand| -- activations and embedded inputs -- the h2 forward twin multiplied in this pass (every workgroup raises
+// it with an atomic max; Inf = a point left fp16's range).  The f16x2 weight gradients take the power of two of their ACTIVATION operand from it
+// (mlp_train16.hip act_scale_h); 0 = not tracked (the fp32 / f32x3 twins wrote the rows): scale 1, as up to round 5.  Every producer of saved rows
+// zeroes it first (zero_acts_range).
+constexpr size_t ACTS_RANGE_BYTES = 256;
+__host__ __device__ inline size_t acts_rows_bytes(long P) { return (size_t)10 * P * 256 * 4 + (size_t)10 * P * 32; }
+__host__ __device__ inline uint32_t* acts_range_word(const void* acts, long P) { return (uint32_t*)((char*)acts + acts_rows_bytes(P)); }
+inline int zero_acts_range(void* acts, long P, hipStream_t st) {
+  return hipMemsetAsync(acts_range_word(acts, P), 0, ACTS_RANGE_BYTES, st) == hipSuccess ? 0 : set_error(-1, "saved state: hipMemsetAsync(range word) failed");
+}
 int launch_mlp_forward_train(const void* packed, const float* x, float* out, float* acts, long P, hipStream_t stream);
 // flags: bit 0 = weight gradients of every Linear except static_sigma from bf16-rounded operands (CRNERF_BWD_WGRAD_BF16, include/crnerf.h)
 int launch_mlp_backward(const void* packedT, const float* x, const float* out, const float* d_out, const float* acts, void* scratch,
                         float* const* grads, long P, hipStream_t stream, int flags = 0, const void* packedT_x3 = nullptr, const void* packedT_h2 = nullptr);
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
-                      long P, hipStream_t stream, int wb, const uint32_t* dmax = nullptr);
+                      long P, hipStream_t stream, int wb, const uint32_t* dmax = nullptr, const uint32_t* amax = nullptr);
 // mixed-precision training twins (mlp_gemm_bf16.hip): per-layer bf16-MFMA GEMMs; activations, deltas and the embedded input travel as bf16
 size_t gemm_packed_bytes();
 size_t mlp_train_mixed_acts_bytes(long P);
@@ -59,10 +70,11 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
 size_t wgrad_workspace_floats(long P, int M, int N, int bf16 = 0);   // bf16: the mode wgrad() will be called with (3 = f16x2: narrow jobs run on half chunks)
 // bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr);
+          hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr, const uint32_t* amax = nullptr);
 // several such products in ONE launch + ONE reduction (small batches: a launch per job is mostly ramp-up and drain); at most 16 jobs
 // bf16: 0 fp32 operands, 1 bf16-rounded, 2 "bf16x3", 3 "f16x2" (full tiles; dmax = the bits of max |D| over the tensor, see wgrad_h2_kernel)
-struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; const uint32_t* dmax = nullptr; };
+struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; const uint32_t* dmax = nullptr;
+                   const uint32_t* amax = nullptr; };   // amax: the saved state's range word (acts_range_word) or null -- the f16x2 activation scale
 float wgrad_job_weight(int M, int N);                              // per-point cost of a job relative to a full 256 x 256 block
 size_t wgrad_batch_ws_floats(const WgradSpec* specs, int n);       // partial-sum workspace the plan for these jobs needs
 int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipStream_t st);

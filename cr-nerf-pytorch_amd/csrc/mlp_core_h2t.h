@@ -209,6 +209,7 @@ __device__ __forceinline__ void mlp_tile_h2t(WeightPipeX& p, int model, const f3
 #pragma unroll
       for (int r = 0; r < 16; ++r) feat[t][r] = sigmoid_ref(acc2[t][r] * H2_INV);
   }
+  sv.note_range(p.lds, amax);   // the pass's largest |operand| so far: what the f16x2 weight gradients scale their activation operand with
   {   // an operand left fp16's range somewhere in this point's MLP: NaN out, not a finite wrong answer
     float am = fmaxf(amax, __shfl_xor(amax, 32));
     if (!(am < H2_ACT_LIMIT)) {

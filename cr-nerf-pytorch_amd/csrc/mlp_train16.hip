@@ -204,6 +204,7 @@ struct WgradJob {
   long P; int chunk;
   int bf16;                            // != 0: the full 256 x 256 tiles multiply bf16-rounded operands (fp32 accumulate), see wgrad_kernel
   const uint32_t* dmax;                // wgrad_h2_kernel: the bits of max |D| over the whole tensor (written by the h2 data gradient), or null
+  const uint32_t* amax;                // wgrad_h2_kernel: the saved state's range word (bits of the h2 forward's largest |operand|, kernels.h), or null
 };
 
 __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32: a -> low half, b -> high half
@@ -229,6 +230,21 @@ __device__ __forceinline__ void delta_scale_h(const uint32_t* dmax, float& s, fl
   eb = __builtin_amdgcn_readfirstlane(eb < 32u ? 32u : (eb > 254u ? 254u : eb));
   s = __uint_as_float((267u - eb) << 23);
   inv = __uint_as_float((eb - 13u) << 23);
+}
+
+// the scale of the ACTIVATION operand's fp16 pieces (round 6): s = 2^(14 - e) with e the exponent of the largest |operand| the h2 forward
+// multiplied in this pass (amax: the saved state's range word), so that the largest scaled activation sits in [2^14, 2^15) and an activation
+// 2^-39 of it still lands on a piece bit.  Up to round 5 activations went in unscaled: below 2^-14 a piece is an fp16 subnormal, so an activation of
+// 2^-10 kept 15 bits and a column of uniformly small activations (or a scene in small coordinates) lost what the bound promised.  No word, a
+// word of zero (the fp32 / f32x3 twins wrote the rows) or Inf (a point left fp16's range in the forward): scale 1.  Whatever the word says, the
+// stream's own range watch decides whether the chunk's sums stand.
+__device__ __forceinline__ void act_scale_h(const uint32_t* amax, float& s, float& inv) {
+  uint32_t eb = amax ? (__builtin_nontemporal_load(amax) >> 23) & 0xffu : 0u;
+  eb = __builtin_amdgcn_readfirstlane(eb);
+  if (eb == 0u || eb == 255u) { s = 1.0f; inv = 1.0f; return; }
+  eb = eb < 103u ? 103u : (eb > 165u ? 165u : eb);          // 2^-24 <= max < 2^39: s in [2^-24, 2^38]
+  s = __uint_as_float((268u - eb) << 23);                   // 2^(141 - eb): max * s in [2^14, 2^15)
+  inv = __uint_as_float((eb - 14u) << 23);
 }
 
 // MODE: 0 fp32 / single-piece bf16 (j.bf16), 1 bf16x3, 2 f16x2 where the job carries a range word (bf16x3 otherwise and as its fallback)
@@ -275,9 +291,9 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
       if (j.dmax) {
         // CRNERF_BWD_WGRAD_F16X2 on the narrow blocks: two-piece fp16 splits, three MFMAs per tile; range, scale and the bf16x3 fallback as in the
         // full-tile branch of wgrad_body
-        float sdl, sinv;
+        float sdl, sinv, one, ainv;                       // (`one`: the activation operand's scale -- 1 up to round 5, act_scale_h since)
         delta_scale_h(j.dmax, sdl, sinv);
-        const float one = 1.0f;
+        act_scale_h(j.amax, one, ainv);
         float amx = 0.0f, dmx = 0.0f;
         fetch16(p0, dcu, acu);
         for (long pb = p0; pb < p1; pb += 16) {
@@ -326,12 +342,12 @@ __device__ __forceinline__ void wgrad_partial_tiles(const WgradJob& j, f32x16 (&
             for (int t = 0; t < NT; ++t) acu[e][t] = anx[e][t];
           }
         }
-        const bool in_range = amx < 65504.0f && dmx * sdl < 65504.0f;
+        const bool in_range = amx * one < 65504.0f && dmx * sdl < 65504.0f;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
 #pragma unroll
           for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[a][b] *= sinv;
+            for (int b = 0; b < NT; ++b) acc[a][b] = (acc[a][b] * ainv) * sinv;     // two exact power-of-two factors, one after the other (their product may leave fp32's range)
           done_h = true;
         } else {
 #pragma unroll
@@ -677,16 +693,17 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           // products d2 a1 + d1 a2 + d1 a1 on v_mfma_f32_32x32x16_f16 -- half the MFMAs and a third of the split work of bf16x3 (measured with a
           // tuning build that issued half the MFMAs, profiles/r5/wgrad_half_work.txt: the thirteen jobs of a backward 7.4 -> 6.1-6.3 ms per 2^20
           // points), what is dropped is d2 a2 <= 2^-22 of the product.  fp16 has five exponent bits, so the operands need a range: activations go
-          // in as they are (the h2 forward's own limit, |a| < 65504), deltas under ONE power of two per tensor, s = 2^(140 - e) with e the exponent
+          // in under the power of two of the pass's largest |operand| (act_scale_h: the h2 forward's range word; without one as they are, the h2
+          // forward's own limit being |a| < 65504), deltas under ONE power of two per tensor, s = 2^(140 - e) with e the exponent
           // of the tensor's largest |delta| (j.dmax, written by the h2 data gradient's workgroups: max s |delta| in [2^13, 2^14)); a delta 2^-38 of
           // that maximum still lands on a piece bit.  The accumulators run in the scaled domain and are scaled back (exactly) before they leave.
           // Nothing is trusted: the stream keeps the largest |a| and |delta| it has seen (v_max3 in its spare slots), and a wave that saw an operand
           // leave fp16's range -- rows of a ray the forward had to repair, a stale or missing range word -- throws its sums away and runs its chunk
           // again on the bf16x3 stream below: same result as wgrad_x3_kernel, bit for bit.
           typedef _Float16 xh16x8_t __attribute__((ext_vector_type(8)));
-          float sd, sinv;                                                 // 2^(140 - e): the largest scaled delta in [2^13, 2^14); 1 / sd
-          delta_scale_h(j.dmax, sd, sinv);
-          const float one = 1.0f;
+          float sd, sinv, one, ainv;                                      // 2^(140 - e): the largest scaled delta in [2^13, 2^14); 1 / sd; `one`: the
+          delta_scale_h(j.dmax, sd, sinv);                                // activation operand's scale (1 up to round 5, act_scale_h since) and its inverse
+          act_scale_h(j.amax, one, ainv);
           const uint32_t rowd = (uint32_t)j.ldd * 4u, rowa = (uint32_t)j.lda * 4u;
           uint32_t vd[8], va[8];
 #pragma unroll
@@ -748,13 +765,13 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
           }
-          const float am = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3])), dm = fmaxf(fmaxf(dmx[0], dmx[1]), fmaxf(dmx[2], dmx[3])) * sd;
+          const float am = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3])) * one, dm = fmaxf(fmaxf(dmx[0], dmx[1]), fmaxf(dmx[2], dmx[3])) * sd;
           const bool in_range = am < 65504.0f && dm < 65504.0f;          // (an Inf or a NaN among the operands fails it too)
           if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-              for (int b = 0; b < 4; ++b) acc[a][b] *= sinv;
+              for (int b = 0; b < 4; ++b) acc[a][b] = (acc[a][b] * ainv) * sinv;     // two exact power-of-two factors, one after the other
             done_h = true;
           } else {
 #pragma unroll
@@ -1122,14 +1139,14 @@ size_t wgrad_workspace_floats(long P, int M, int N, int bf16) {
 }
 
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16, const uint32_t* dmax) {
+          hipStream_t st, int bf16, const uint32_t* dmax, const uint32_t* amax) {
   // at most two accumulator tiles per wave (dir_encoding's direction block, static_rgb): wgrad_h2_narrow_kernel, two workgroups per CU on half chunks
   // (measured per 2^19 points: 139 -> 93 and 142 -> 119 us; the 93-column embedding blocks gain nothing from it, dir_encoding's 4 x 2 tiles spill in 256 registers)
   const bool narrow = bf16 == 3 && M <= 128 && N <= 128;
   const int chunk = wgrad_job_chunk(P, M, N, bf16);     // (narrow: 2 x nchunk x (M N + M) stays inside the workspace of a full block; wgrad_workspace_floats(.., 3) sizes it)
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
-  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr, bf16 == 3 ? amax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
   if (narrow) hipLaunchKernelGGL(wgrad_h2_narrow_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
@@ -1142,7 +1159,7 @@ int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float*
 // lengths, few enough that the partial sums stay ~100 MB whatever the batch size
 static int wgrad_batch_blocks() { static const int per_cu = [] { const char* e = getenv("CRNERF_WGRAD_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }(); return per_cu * num_cus(); }
 static size_t wgrad_batch_workspace_floats() { return (size_t)(wgrad_batch_blocks() + WG_MAX_JOBS) * (256 * 256 + 256); }
-size_t mlp_train_acts_bytes(long P) { return (size_t)ACT_SLOTS * P * ACT_W * sizeof(float) + (size_t)ACT_SLOTS * P * 32; }   // activations + relu bits
+size_t mlp_train_acts_bytes(long P) { return acts_rows_bytes(P) + ACTS_RANGE_BYTES; }   // activations + relu bits + the range word's line (kernels.h)
 size_t mlp_train_scratch_bytes(long P) {
   const int chunk = wg_chunk(P);
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
@@ -1161,6 +1178,7 @@ int launch_mlp_forward_train(const void* packed, const float* x, float* out, flo
   const int cus = num_cus();
   const int grid = (int)(groups < cus ? groups : cus), iters = (int)((groups + grid - 1) / grid);
   if (int rc = launch_core((const void*)mlp_forward_train16_kernel, grid, LDS_SCRATCH)) return rc;
+  if (int rc = zero_acts_range(acts, P, stream)) return rc;        // the fp32 twin tracks no range
   hipLaunchKernelGGL(mlp_forward_train16_kernel, dim3(grid), dim3(512), LDS_SCRATCH, stream, (const char*)packed, x, out, acts, P, iters);
   return check_launch("mlp_forward_train16_kernel");
 }
@@ -1218,7 +1236,7 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
     x3 = x3 || sp.bf16 == 2;
     h2 = h2 || sp.bf16 == 3;
     b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16 >= 2 ? 0 : sp.bf16,
-                        sp.bf16 == 3 ? sp.dmax : nullptr};
+                        sp.bf16 == 3 ? sp.dmax : nullptr, sp.bf16 == 3 ? sp.amax : nullptr};
     b.first[q] = blocks;
     b.nchunk[q] = nc;
     b.my[q] = (sp.M + 255) / 256;
@@ -1246,7 +1264,7 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
 // (profiles/r3/pmc_train_sq.txt): matrix pipe busy 85.6 % of the kernel's cycles at a shader clock of 2.07 GHz -- the 2.4 TB/s of
 // operand traffic costs clock, not issue slots; 0.856 x 2.07 / 2.4 = the measured 74 % of the 157.3 TFLOP/s figure.)
 int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, const float* d_rgb, const float* d_sig, float* ws, float* const* grads,
-                      long P, hipStream_t stream, int wb, const uint32_t* dmax) {
+                      long P, hipStream_t stream, int wb, const uint32_t* dmax, const uint32_t* amax) {
   auto A = [&](int slot) { return acts + (size_t)slot * P * ACT_W; };
   auto D = [&](int slot) { return deltas + (size_t)slot * P * ACT_W; };
   auto R = [&](int slot) { return dmax ? dmax + slot : nullptr; };   // the range word of delta slot `slot` (wb == 3: the f16x2 full tiles)
@@ -1260,38 +1278,38 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     WgradSpec sp[WG_MAX_JOBS];
     int n = 0;
     const float W_FULL = 1.0f, W_EMB = 0.52f, W_DIR = 0.66f, W_DIRE = 0.19f, W_RGB = 0.26f, W_SIG = 0.26f;   // measured per-point cost relative to a full block (profiles/r3/train_1024_before_ordered.txt)
-    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P, R(0)};                         // xyz_encoding_1
+    sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P, R(0), amax};                         // xyz_encoding_1
     for (int l = 1; l < 8; ++l) {
       if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P, R(4)};
-        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P, R(4)};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], W_EMB, wb, P, R(4), amax};
+        sp[n++] = WgradSpec{D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, W_FULL, wb, P, R(4), amax};
       } else {
-        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P, R(l)};
+        sp[n++] = WgradSpec{D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], W_FULL, wb, P, R(l), amax};
       }
     }
-    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P, R(8)};                            // xyz_encoding_final
+    sp[n++] = WgradSpec{D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], W_FULL, wb, P, R(8), amax};                            // xyz_encoding_final
     sp[n++] = WgradSpec{d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], W_SIG, 0, P};                                         // static_sigma
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P, R(9)};                   // dir_encoding: cat([final, dir])
-    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P, R(9)};
-    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb, P, R(ACT_SLOTS)};            // static_rgb
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], W_DIR, wb, P, R(9), amax};                   // dir_encoding: cat([final, dir])
+    sp[n++] = WgradSpec{D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, W_DIRE, wb, P, R(9), amax};
+    sp[n++] = WgradSpec{d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], W_RGB, wb, P, R(ACT_SLOTS), amax};            // static_rgb
     if (int rc = wgrad_batch(sp, n, ws, wgrad_batch_workspace_floats(), stream)) return rc;
     return check_launch("mlp_backward wgrad (batched)");
   }
   // xyz_encoding_1: input x[:, :93]
-  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb, R(0));
+  wgrad(D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], P, ws, stream, wb, R(0), amax);
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {  // xyz_encoding_5: cat([xyz, h4])            nerf.py:168-169
-      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb, R(4));
-      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb, R(4));
+      wgrad(D(4), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[8], XYZ_DIM + 256, grads[9], P, ws, stream, wb, R(4), amax);
+      wgrad(D(4), ACT_W, 256, A(3), ACT_W, 256, grads[8] + XYZ_DIM, XYZ_DIM + 256, nullptr, P, ws, stream, wb, R(4), amax);
     } else {
-      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb, R(l));
+      wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb, R(l), amax);
     }
   }
-  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8));      // xyz_encoding_final
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8), amax);      // xyz_encoding_final
   wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
-  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb, R(9));  // dir_encoding: cat([final, dir])
-  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb, R(9));
-  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb, R(ACT_SLOTS));   // static_rgb
+  wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb, R(9), amax);  // dir_encoding: cat([final, dir])
+  wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb, R(9), amax);
+  wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb, R(ACT_SLOTS), amax);   // static_rgb
   return check_launch("mlp_backward wgrad");
 }
 
@@ -1328,7 +1346,7 @@ int launch_mlp_backward(const void* packedT, const float* x, const float* out, c
   }
   if (!do_wgrad) return 0;
   if (wb == 3 && !packedT_h2) wb = 2;                 // (a PHASE_WGRAD call of the h2 entry arrives with a non-null marker: abi.hip)
-  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb, wb == 3 ? dmax : nullptr);
+  return launch_mlp_wgrads(x, acts, deltas, d_rgb, d_sig, ws, grads, P, stream, wb, wb == 3 ? dmax : nullptr, wb == 3 ? acts_range_word(acts, P) : nullptr);
 }
 
 }  // namespace crnerf

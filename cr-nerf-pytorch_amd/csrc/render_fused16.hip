@@ -269,6 +269,9 @@ int launch_render_rays16(const RenderArgs& a, hipStream_t stream) {
     if (a.Ni > 0 && (!a.train_acts_fine || !a.train_raw_fine)) return set_error(-1, "render_rays_train: fine buffers are NULL");
     if (!a.train_raw_coarse) return set_error(-1, "render_rays_train: raw_coarse is NULL");
     TrainHook h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
+    if (int rc = zero_acts_range(a.train_acts_coarse, a.R * a.Nc, stream)) return rc;     // the fp32 twin tracks no operand range (kernels.h)
+    if (a.Ni > 0)
+      if (int rc = zero_acts_range(a.train_acts_fine, a.R * (a.Nc + a.Ni), stream)) return rc;
     const bool rngk = a.rng_flags != 0 || a.z_coarse_out;
     const void* fn = rngk ? (const void*)render_rays_train16_rng_kernel : (const void*)render_rays_train16_kernel;
     if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_train16_kernel")) return rc;

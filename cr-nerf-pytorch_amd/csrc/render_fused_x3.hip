@@ -53,17 +53,38 @@ struct RenderParamsX {
 
 // What the training twin adds (crnerf_render_rays_train_f32x3): every tile's layer activations + relu bits in the layout of the fp32 training
 // twins (ActSaveX, mlp_core_x3.h) and its raw MLP output row, per pass -- the fp32 backward twins read them unchanged.
+// LDS behind the four waves' ray scratch: one word per lane and pass, the running maximum |operand| of the h2 training twin (TrainHookX::publish_range)
+constexpr int LDS_RANGE_X = LDS_SCRATCH_X + 4 * SCRATCH_BYTES;
+constexpr int LDS_RANGE_BYTES = 2 * 256 * 4;
+static_assert(LDS_RANGE_X + LDS_RANGE_BYTES <= 160 * 1024, "LDS budget of the training twin");
 struct NoHookX {
+  static constexpr bool on = false;
+  __device__ __forceinline__ void publish_range(lds_char*, int, int, int) const {}
   __device__ __forceinline__ NoSaveX saver(int, long, int, int, bool, int) const { return NoSaveX(); }
   __device__ __forceinline__ void raw(int, long, int, int, bool, int, const f32x16 (&)[2], float) const {}
 };
 struct TrainHookX {
+  static constexpr bool on = true;
   float* acts[2];   // [10][R*N][256] + masks, pass 0 = coarse (N = Nc), pass 1 = fine (N = Nc+Ni)
   float* rawo[2];   // [R*N][65]
   long R;
   // (pass ? [1] : [0], not [pass]: a dynamic index into a by-value kernel argument goes through private memory, the pointer comes back in a VGPR
   // and hipcc wraps EVERY row store in a readfirstlane waterfall loop -- twelve instructions and a branch per store; round 5, found in the ISA)
-  __device__ __forceinline__ ActSaveX saver(int pass, long r, int N, int n, bool ok, int h) const { return ActSaveX{pass ? acts[1] : acts[0], R * N, r * N + n, ok, h}; }
+  __device__ __forceinline__ ActSaveX saver(int pass, long r, int N, int n, bool ok, int h) const {
+    return ActSaveX{pass ? acts[1] : acts[0], R * N, r * N + n, ok, h, (uint32_t)(LDS_RANGE_X + 4 * ((pass ? 256 : 0) + (int)threadIdx.x))};
+  }
+  // the workgroup's largest |operand| per pass (the lanes' LDS words, raised tile by tile by mlp_tile_h2t) into the saved state's range word
+  __device__ __forceinline__ void publish_range(lds_char* lds, int Nc, int Nf, int npass) const {
+#if CRNERF_X_NP == 2
+    __syncthreads();
+    if ((int)threadIdx.x < npass) {
+      const __attribute__((address_space(3))) uint32_t* w = (const __attribute__((address_space(3))) uint32_t*)(lds + LDS_RANGE_X) + 256 * threadIdx.x;
+      uint32_t b = 0u;
+      for (int t = 0; t < 256; ++t) b = w[t] > b ? w[t] : b;
+      if (b != 0u) atomicMax(acts_range_word(threadIdx.x ? acts[1] : acts[0], R * (threadIdx.x ? Nf : Nc)), b);
+    }
+#endif
+  }
   __device__ __forceinline__ void raw(int pass, long r, int N, int n, bool ok, int h, const f32x16 (&feat)[2], float sigma) const {
     if (!ok) return;
     float* o = (pass ? rawo[1] : rawo[0]) + (r * N + n) * OUT_DIM;
@@ -111,6 +132,12 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
 #endif
   RayScratch scr;
   scr.bind(lds + LDS_SCRATCH_X + wave * SCRATCH_BYTES);
+#if CRNERF_X_NP == 2
+  if constexpr (HOOK::on) {   // this lane's two range words (its own: no barrier needed before it raises them)
+    __attribute__((address_space(3))) uint32_t* w = (__attribute__((address_space(3))) uint32_t*)(lds + LDS_RANGE_X) + threadIdx.x;
+    w[0] = 0u; w[256] = 0u;
+  }
+#endif
 
   const int tiles_c = (Nc + 31) >> 5, tiles_f = Ni > 0 ? (Nf + 31) >> 5 : 0;
   WeightPipeX pipe;
@@ -215,6 +242,7 @@ __device__ __forceinline__ void render_rays_x3_body(const RenderParamsX a, const
   }
   tm.flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  hook.publish_range(lds, Nc, Nf, Ni > 0 ? 2 : 1);
 }
 
 __global__ __launch_bounds__(256, 1) void render_rays_x3_kernel(RenderParamsX a) { render_rays_x3_body<false>(a, NoHookX()); }
@@ -252,10 +280,16 @@ int launch_render_rays_x3(const RenderArgs& a, hipStream_t stream) {
     if ((unsigned long long)a.R * (unsigned)(a.Nc + a.Ni) * 1024ull >= (unsigned long long)SAVEX_OOB)
       return set_error(-2, "render_rays_train_f32x3: more than 3.9 M sample points per pass and call (the saved rows are addressed with 32-bit offsets)");
     TrainHookX h{{(float*)a.train_acts_coarse, (float*)a.train_acts_fine}, {a.train_raw_coarse, a.train_raw_fine}, a.R};
+    if (!a.repair) {   // the range words of both passes start at zero (the repair launch leaves what the h2 twin raised: kernels.h acts_range_word)
+      if (int rc = zero_acts_range(a.train_acts_coarse, a.R * a.Nc, stream)) return rc;
+      if (a.Ni > 0)
+        if (int rc = zero_acts_range(a.train_acts_fine, a.R * (a.Nc + a.Ni), stream)) return rc;
+    }
     const void* fn = rngk ? (const void*)render_rays_train_x3_rng_kernel : (const void*)render_rays_train_x3_kernel;
-    if (int rc = ensure_dynamic_lds(fn, shmem, "render_rays_train_x3_kernel")) return rc;
-    if (rngk) hipLaunchKernelGGL(render_rays_train_x3_rng_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
-    else hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem, stream, k, h);
+    const size_t shmem_t = shmem + LDS_RANGE_BYTES;      // + the h2 twin's per-lane range words (x3: unused)
+    if (int rc = ensure_dynamic_lds(fn, shmem_t, "render_rays_train_x3_kernel")) return rc;
+    if (rngk) hipLaunchKernelGGL(render_rays_train_x3_rng_kernel, dim3(grid), dim3(256), shmem_t, stream, k, h);
+    else hipLaunchKernelGGL(render_rays_train_x3_kernel, dim3(grid), dim3(256), shmem_t, stream, k, h);
     return check_launch("render_rays_train_x3_kernel");
   }
   const void* fn = rngk ? (const void*)render_rays_x3_rng_kernel : (const void*)render_rays_x3_kernel;

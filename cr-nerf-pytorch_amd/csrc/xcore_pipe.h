@@ -151,10 +151,17 @@ struct NoSaveX {
   template <int NT>
   __device__ __forceinline__ void masks(int, const f32x16 (&)[NT]) const {}
   __device__ __forceinline__ void mask_words(int, int, uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void note_range(lds_char*, float) const {}
 };
 struct ActSaveX {
   static constexpr bool on = true;
   float* base; long P; long n; bool valid; int h;
+  uint32_t range_lds = 0;     // LDS byte offset of this lane's range word for this pass (h2 training twin), 0: none
+  // the h2 training form's largest |operand| of the tile (an Inf when the point left fp16's range): kept as a running maximum in the lane's own LDS
+  // word -- one ds_max per tile, no register lives across the MLP; positive floats order like their bit patterns
+  __device__ __forceinline__ void note_range(lds_char* lds, float amax) const {
+    if (range_lds) __hip_atomic_fetch_max((__attribute__((address_space(3))) uint32_t*)(lds + range_lds), __float_as_uint(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   // row stores are UNCONDITIONAL raw-buffer stores (lanes without a point carry an out-of-range offset): no branch in the layer's unrolled stream
   __device__ __forceinline__ SaveRowX row(int slot) const {
     return SaveRowX{__builtin_amdgcn_make_buffer_rsrc(base + (long)slot * P * 256, 0, (int)(uint32_t)(P * 1024), 0x00020000)};

@@ -94,8 +94,12 @@ int crnerf_mlp_backward_f32(const void* packed_t, const float* x, const float* o
 #define CRNERF_BWD_WGRAD_BF16X3 2
 /* CRNERF_BWD_WGRAD_F16X2 (crnerf_mlp_backward_h2_f32 only; exclusive with the two above): CRNERF_BWD_WGRAD_BF16X3 with the full 256 x 256 blocks
  * -- eight of the thirteen products of a backward -- formed from TWO fp16 pieces per operand and three piece products (what is dropped is <= 2^-22
- * of a product: the h2 core's arithmetic): half the matrix instructions.  Activations go in unscaled (fp16's range is the h2 forward's own limit),
- * a delta tensor under one power of two taken from its largest entry, which the h2 data gradient of the same call leaves in the scratch.  A
+ * of a product: the h2 core's arithmetic): half the matrix instructions.  Both operands go in under ONE power of two per tensor group: a delta
+ * tensor under 2^(13 - e) of its largest entry, which the h2 data gradient of the same call leaves in the scratch; the activation / embedded-input
+ * operand under 2^(14 - e) of the largest |operand| of the whole pass, which crnerf_render_rays_train_f32h2 leaves behind the saved rows (the
+ * "range word": the last 256 bytes of crnerf_mlp_train_acts_bytes(n); zero when the fp32 / f32x3 twin wrote the rows -- the operand then goes
+ * in unscaled and values below 2^-14 keep fewer than 22 bits, an ABSOLUTE piece error of 2^-25).  With the word an operand 2^-39 of the pass's
+ * largest still lands on a piece bit; what is dropped is then <= 2^-22 of a product relative to the largest operands of its tensor, not more.  A
  * workgroup that meets an operand outside fp16's range (rows of a ray the forward had to repair; the f32x3 stand-in ran and left no range) redoes
  * its chunk of points as CRNERF_BWD_WGRAD_BF16X3 would have, bit for bit. */
 #define CRNERF_BWD_WGRAD_F16X2 4

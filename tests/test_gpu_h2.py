@@ -586,3 +586,55 @@ def test_backward_phases_are_the_halves_of_the_one_call_backward(core, wmode):
     assert lib.crnerf_stream_create_cu_share(ctypes.byref(h), per, 1) != 0          # a share outside the XCD is refused
     with pytest.raises(ValueError, match="scratch"):
         ops.mlp_backward(None, x, None, None, acts, phase="wgrad", **kw)
+
+
+@torch.no_grad()
+def test_f16x2_weight_gradients_keep_small_activation_columns():
+    """up to round 5 the activation operand of the f16x2 weight gradients went in unscaled -- below 2^-14 an fp16 piece is a
+    subnormal, so a column of uniformly small activations (here: 64 units of xyz_encoding_3 scaled by 2^-12, and the raw coordinate columns of a
+    scene in small units) kept 13-15 bits instead of 22, invisible to every test that measures errors against the tensor's LARGEST entry.  Since
+    round 6 the h2 forward twin leaves the pass's largest |operand| behind the saved rows (the range word) and the weight gradients scale the
+    activation operand by the power of two that puts it in [2^14, 2^15).  Checked per COLUMN against a float64 evaluation, next to bf16x3 (which has
+    fp32's exponent and no such floor): the f16x2 result must be as good, column by column."""
+    R, Nc = 96, 64
+    st = synth.mlp_state(41, 1.5, 0.5)
+    st["xyz_encoding_3.0.weight"][:64] *= np.float32(2.0 ** -12)
+    st["xyz_encoding_3.0.bias"][:64] *= np.float32(2.0 ** -12)
+    rays_np = synth.rays(R, seed=5)
+    rays_np[:, 0:3] *= np.float32(0.01)          # a scene in small units: |xyz| ~ 0.02, the three raw-coordinate columns of the embedding are small
+    rays_np[:, 6] = 0.5
+    rays_np[:, 7] = 2.0
+    rays = C(rays_np)
+    dev = {k: C(v) for k, v in st.items()}
+    zs = torch.linspace(0, 1, Nc, device=DEV)
+    z = (rays[:, 6:7] * (1 - zs) + rays[:, 7:8] * zs).contiguous()
+    trn = ops.render_rays(ops.pack_mlp_weights_h2(dev), None, rays, Nc, 0, train=True, precision="f32h2", z_coarse=z)
+    P = R * Nc
+    acts, raw = trn["acts_coarse"], trn["raw_coarse"].view(P, 65)
+    rows = acts[:4 * 10 * P * 256].view(torch.float32).view(10, P, 256)
+    word = acts[4 * 10 * P * 256 + 32 * 10 * P:][:4].view(torch.float32)
+    x = ops.embed_points(rays, z, ops.posenc(rays[:, 3:6].contiguous(), 4))
+    # the range word: the largest |operand| of the pass -- saved activations and embedded inputs
+    top = max(float(rows[:9].abs().max()), float(rows[9, :, :128].abs().max()), float(x.abs().max()))
+    assert float(word) == pytest.approx(top, rel=1e-5) and 0.5 < top < 100.0, (float(word), top)
+    assert float(rows[2, :, :64].abs().max()) < 2.0 ** -9 and float(rows[2, :, 64:].abs().max()) > 2.0 ** -4          # the small columns ARE small
+    g = torch.Generator().manual_seed(3)
+    d_out = torch.randn(P, 65, generator=g).to(DEV)
+    pack_t = ops.pack_mlp_weights_t_h2(dev)
+    g2 = ops.mlp_backward(pack_t, x, raw, d_out, acts, wgrad_bf16="f16x2", dgrad_h2=True)
+    g3 = ops.mlp_backward(pack_t, x, raw, d_out, acts, wgrad_bf16="bf16x3", dgrad_h2=True)
+    with torch.enable_grad():
+        w = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in st.items()}
+        (O.mlp_forward(w, x.cpu().double()) * d_out.cpu().double()).sum().backward()
+    worst = {}
+    for name, cols in (("xyz_encoding_4.0.weight", slice(0, 64)), ("xyz_encoding_1.0.weight", slice(0, 3)), ("xyz_encoding_5.0.weight", slice(0, 3))):
+        k = ops.MLP_TENSOR_NAMES.index(name)
+        ref = w[name].grad
+        colmax = ref.abs().amax(0).clamp_min(1e-300)
+        e2 = ((g2[k].cpu().double() - ref).abs().amax(0) / colmax)[cols]
+        e3 = ((g3[k].cpu().double() - ref).abs().amax(0) / colmax)[cols]
+        worst[name] = (float(e2.max()), float(e3.max()))
+        assert not torch.equal(g2[k], g3[k]), name + ": the f16x2 kernel did not run"
+        # column by column as good as bf16x3 (both sit at the fp32 level of the shared data gradient's deltas: a few 1e-7 of the column's largest entry)
+        assert bool((e2 <= torch.maximum(4.0 * e3, torch.full_like(e3, 2e-6))).all()), (name, worst[name])
+    print("per-column max error / column max, small-activation columns: %s" % worst)
