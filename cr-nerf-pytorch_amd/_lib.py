@@ -31,6 +31,7 @@ EXPORTS = [
     "crnerf_packed_mlp_x3_bytes", "crnerf_pack_mlp_weights_x3", "crnerf_mlp_forward_f32x3", "crnerf_render_rays_f32x3", "crnerf_render_rays_train_f32x3", "crnerf_packed_mlp_t_x3_bytes", "crnerf_pack_mlp_weights_t_x3", "crnerf_mlp_backward_x3_f32", "crnerf_packed_mlp_bf16_bytes", "crnerf_pack_mlp_weights_bf16", "crnerf_mlp_forward_bf16", "crnerf_render_rays_bf16", "crnerf_render_rays_bf16_fine",
     "crnerf_decoder_content_backward_workspace_bytes", "crnerf_decoder_content_backward_f32",
     "crnerf_encoder_train_saved_bytes", "crnerf_encoder_train_scratch_bytes", "crnerf_encoder_forward_train_f32", "crnerf_encoder_backward_f32",
+    "crnerf_encoder_train_band_saved_bytes", "crnerf_encoder_train_band_scratch_bytes", "crnerf_encoder_forward_train_band_f32", "crnerf_encoder_backward_band_f32",
     "crnerf_loss_workspace_bytes", "crnerf_loss_f32", "crnerf_loss_backward_f32", "crnerf_grid_sample_batch_f32", "crnerf_adam_max_tensors", "crnerf_adam_step_f32",
     "crnerf_conv2d_f32", "crnerf_conv2d_backward_f32", "crnerf_bn_prelu_f32", "crnerf_bn_prelu_train_f32", "crnerf_bn_prelu_backward_f32", "crnerf_avgpool3s2_f32",
     "crnerf_fglo_f32", "crnerf_fglo_backward_f32", "crnerf_bilinear_gather_f32", "crnerf_bilinear_gather_backward_f32",
@@ -196,6 +197,10 @@ def load():
             "crnerf_encoder_train_scratch_bytes": (ctypes.c_size_t, [i32, i32]),
             "crnerf_encoder_forward_train_f32": (ctypes.c_int, [vp, i32, i32, pp, vp, vp, vp]),
             "crnerf_encoder_backward_f32": (ctypes.c_int, [i32, i32, pp, vp, vp, vp, vp, pp, vp, vp]),
+            "crnerf_encoder_train_band_saved_bytes": (ctypes.c_size_t, [i32, i32, i32]),
+            "crnerf_encoder_train_band_scratch_bytes": (ctypes.c_size_t, [i32, i32, i32]),
+            "crnerf_encoder_forward_train_band_f32": (ctypes.c_int, [vp, i32, i32, i32, i32, i32, i32, pp, vp, vp, vp]),
+            "crnerf_encoder_backward_band_f32": (ctypes.c_int, [i32, i32, i32, i32, i32, i32, pp, vp, vp, vp, vp, pp, vp, vp]),
             "crnerf_loss_workspace_bytes": (ctypes.c_size_t, []),
             "crnerf_loss_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, vp, vp]),
             "crnerf_loss_backward_f32": (ctypes.c_int, [ctypes.POINTER(LossArgs), vp, ctypes.POINTER(LossGrads), vp]),

@@ -589,6 +589,47 @@ class EncoderFn(torch.autograd.Function):
         return (d_img.view(ctx.image_shape) if d_img is not None else None,) + _param_grads(ctx, w, grads)
 
 
+class BandEncoderFn(torch.autograd.Function):
+    """encoder_sameoutputsize.forward on a re-rendered image in ray-parallel training (round 6): every rank of `group` holds the whole
+    image (the decoder is replicated) but runs the seven layers on ITS band of rows only (+ a 12-row halo where the band is cut inside the image:
+    crnerf_encoder_forward_train_band_f32) and produces its rows of the 32 x 32 style grid; the grid is all-gathered (32 KB per rank).  Backward:
+    every rank holds dL/d(grid) (the consumers are replicated), takes its rows, runs the band backward, and the bands' image gradients -- they
+    overlap in the halos -- are summed by one all-reduce of the image-sized buffer (12 B per pixel).  The weight gradients are this band's PART of
+    the whole image's; they leave multiplied by the group size (exact: a power of two), because the encoders' other pass (the photo, replicated on
+    every rank) yields whole gradients and sync_ray_parallel_gradients AVERAGES replicated modules: average(whole + ws * part_r) = whole + sum of
+    the parts."""
+
+    @staticmethod
+    def forward(ctx, image, plan, group, *w):
+        import torch.distributed as dist
+        from .parallel import _timed
+        H, row0, rows, o0, o1, ws = plan
+        sub = image[0, :, row0:row0 + rows, :].contiguous()
+        own, saved, hw = ops.encoder_forward_train_band(sub, H, row0, o0, o1, w)
+        full = torch.empty(1024, 64, dtype=torch.float32, device=own.device)
+        _timed("allgather_style_grid_rows", lambda: dist.all_gather_into_tensor(full, own, group=group), own.device)
+        ctx.save_for_backward(own, saved, *w)
+        ctx.hw, ctx.plan, ctx.group, ctx.image_shape = hw, plan, group, image.shape
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(t) for t in w] if _DEFER_ON[0] else None)
+        return full
+
+    @staticmethod
+    def backward(ctx, d_out):
+        import torch.distributed as dist
+        from .parallel import _timed
+        own, saved, *w = ctx.saved_tensors
+        H, row0, rows, o0, o1, ws = ctx.plan
+        want = ctx.needs_input_grad[0]
+        grads, d_sub = ops.encoder_backward_band(w, saved, ctx.hw, H, row0, o0, o1, own, d_out[o0 * 32:o1 * 32].contiguous(), want_d_image=want)
+        d_img = None
+        if want:
+            d_img = torch.zeros(ctx.image_shape, dtype=torch.float32, device=own.device)
+            d_img[0, :, row0:row0 + rows, :] = d_sub
+            _timed("allreduce_image_gradient_12B_per_pixel", lambda: dist.all_reduce(d_img, group=ctx.group), own.device)
+        grads = [g * float(ws) for g in grads]
+        return (d_img, None, None) + _param_grads(ctx, w, grads)
+
+
 class ContentDecoderFn(torch.autograd.Function):
     """style_net.forward(content, None, type='content'): fwd crnerf_crossray_decode_f32 (style == NULL),
     bwd crnerf_decoder_content_backward_f32."""

@@ -624,6 +624,26 @@ int crnerf_encoder_forward_train_f32(const float* image, int H, int W, const flo
   return launch_encoder_forward_train(image, H, W, weights, saved, out, (hipStream_t)stream);
 }
 
+size_t crnerf_encoder_train_band_saved_bytes(int H, int W, int n_out_rows) { return encoder_train_saved_bytes(H, W, n_out_rows * 32); }
+size_t crnerf_encoder_train_band_scratch_bytes(int H, int W, int n_out_rows) { return encoder_train_scratch_bytes(H, W, n_out_rows * 32); }
+
+int crnerf_encoder_forward_train_band_f32(const float* image_rows, int H, int W, int H_image, int row0, int o0, int o1, const float* const* weights, void* saved,
+                                          float* out, void* stream) {
+  REQUIRE(image_rows, "image_rows"); REQUIRE(weights, "weights"); REQUIRE(saved, "saved"); REQUIRE(out, "out");
+  for (int i = 0; i < CRNERF_ENCODER_TENSORS; ++i)
+    if (!weights[i]) return set_error(CRNERF_ERR_NULL, "encoder_forward_train_band: a weight pointer is NULL");
+  return launch_encoder_forward_train_band(image_rows, H, W, H_image, row0, o0, o1, weights, saved, out, (hipStream_t)stream);
+}
+
+int crnerf_encoder_backward_band_f32(int H, int W, int H_image, int row0, int o0, int o1, const float* const* weights, const void* saved, const float* out,
+                                     const float* d_out, void* scratch, float* const* grads, float* d_image_rows, void* stream) {
+  REQUIRE(weights, "weights"); REQUIRE(saved, "saved"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");
+  if (H < 8 || W < 8) return set_error(CRNERF_ERR_SHAPE, "encoder_backward_band: band must be at least 8x8");
+  for (int i = 0; i < CRNERF_ENCODER_TENSORS; ++i)
+    if (!weights[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "encoder_backward_band: a weight or gradient pointer is NULL");
+  return launch_encoder_backward_band(H, W, H_image, row0, o0, o1, weights, saved, out, d_out, scratch, grads, d_image_rows, (hipStream_t)stream);
+}
+
 int crnerf_encoder_backward_f32(int H, int W, const float* const* weights, const void* saved, const float* out, const float* d_out, void* scratch,
                                 float* const* grads, float* d_image, void* stream) {
   REQUIRE(weights, "weights"); REQUIRE(saved, "saved"); REQUIRE(out, "out"); REQUIRE(d_out, "d_out"); REQUIRE(scratch, "scratch"); REQUIRE(grads, "grads");

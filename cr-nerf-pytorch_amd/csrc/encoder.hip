@@ -251,14 +251,16 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict_
 }
 
 // AdaptiveAvgPool2d(S): window [floor(o*in/S), ceil((o+1)*in/S))
-__global__ void adaptive_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int S) {
+// Row band (round 6, the encoder over a band of an image's rows in ray-parallel training): `in` holds rows [yoff, yoff + H) of a map of Hg rows and
+// only the output rows [o0, o1) are produced (out[(oy - o0) * S + ox]); the windows are those of the WHOLE map.  Whole map: Hg = H, yoff = 0, [0, S).
+__global__ void adaptive_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int S, int Hg, int yoff, int o0, int o1) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= S * S * C) return;
-  const int c = idx % C, px = idx / C, oy = px / S, ox = px % S;
-  const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S, x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+  if (idx >= (o1 - o0) * S * C) return;
+  const int c = idx % C, px = idx / C, oy = o0 + px / S, ox = px % S;
+  const int y0 = (oy * Hg) / S, y1 = ((oy + 1) * Hg + S - 1) / S, x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
   float s = 0.0f;
   for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) s += in[((long)y * W + x) * C + c];
+    for (int x = x0; x < x1; ++x) s += in[((long)(y - yoff) * W + x) * C + c];
   out[idx] = s / (float)((y1 - y0) * (x1 - x0));
 }
 
@@ -296,8 +298,8 @@ void enc_chw_to_hwc(const float* in, float* out, int C, int HW, hipStream_t st) 
 void enc_maxpool2(const float* in, float* out, int H, int W, int C, hipStream_t st) {
   hipLaunchKernelGGL(maxpool2_kernel, dim3(((H / 2) * (W / 2) * C + 255) / 256), dim3(256), 0, st, in, out, H, W, C);
 }
-void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st) {
-  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((S * S * C + 255) / 256), dim3(256), 0, st, in, out, H, W, C, S);
+void enc_adaptive_avgpool(const float* in, float* out, int H, int W, int C, int S, hipStream_t st, int Hg, int yoff, int o0, int o1) {
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(((o1 - o0) * S * C + 255) / 256), dim3(256), 0, st, in, out, H, W, C, S, Hg, yoff, o0, o1);
 }
 
 static const int ENC_CIN[7] = {3, 3, 64, 64, 128, 128, 128}, ENC_COUT[7] = {3, 64, 64, 128, 128, 128, 64}, ENC_TAPS[7] = {1, 9, 9, 9, 9, 9, 1};
@@ -341,7 +343,7 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
   enc_conv_gemm(9, a, xc, w[8], w[9], b, H2, W2, 128, 128, st);         // conv5 + relu5
   const int H4 = H2 / 2, W4 = W2 / 2;
   enc_conv_gemm_pooled(b, xc, w[10], w[11], a, H2, W2, 128, 128, st);   // max-pool + conv6 + relu6
-  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((32 * 32 * 128 + 255) / 256), dim3(256), 0, st, a, b, H4, W4, 128, 32);
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((32 * 32 * 128 + 255) / 256), dim3(256), 0, st, a, b, H4, W4, 128, 32, H4, 0, 0, 32);
   enc_conv_gemm(1, b, nullptr, w[12], w[13], out, 32, 32, 128, 64, st);   // conv7 + relu7
   return check_launch("encoder_forward");
 }

@@ -155,9 +155,13 @@ int launch_rng_fill(float* out, long R, int n, unsigned long long seed, int stre
 size_t content_backward_workspace_floats(long HW);
 int launch_content_backward(const float* content, long HW, const float* W, const float* rgb, long rgb_stride, const float* d_rgb, long d_stride,
                             float* workspace, float* d_content, float* dW, float* db, hipStream_t stream);
-size_t encoder_train_saved_bytes(int H, int W);
-size_t encoder_train_scratch_bytes(int H, int W);
+size_t encoder_train_saved_bytes(int H, int W, int n_out = 1024);
+size_t encoder_train_scratch_bytes(int H, int W, int n_out = 1024);
 int launch_encoder_forward_train(const float* img, int H, int W, const float* const* w, void* saved, float* out, hipStream_t st);
+// the same over a band of rows of an image of Hg rows (encoder_train.hip EncBand): rows [row0, row0 + H) in, output rows [o0, o1) of the 32 x 32 map out
+int launch_encoder_forward_train_band(const float* img, int H, int W, int Hg, int row0, int o0, int o1, const float* const* w, void* saved, float* out, hipStream_t st);
+int launch_encoder_backward_band(int H, int W, int Hg, int row0, int o0, int o1, const float* const* w, const void* saved, const float* out, const float* d_out,
+                                 void* scratch, float* const* grads, float* d_img, hipStream_t st);
 int launch_encoder_backward(int H, int W, const float* const* w, const void* saved, const float* out, const float* d_out, void* scratch,
                             float* const* grads, float* d_img, hipStream_t st);
 

@@ -803,6 +803,35 @@ def encoder_backward(weights, saved, hw, out, d_out, want_d_image=True):
     return grads, d_img
 
 
+def encoder_forward_train_band(image_rows, h_image, row0, o0, o1, weights):
+    """crnerf_encoder_forward_train_band_f32: the training forward of the appearance encoder over rows [row0, row0 + H) of an image of `h_image` rows
+    (image_rows [3,H,W] contiguous) -> (rows [o0, o1) of the 32 x 32 grid as [(o1 - o0) * 32, 64], saved, (H, W))."""
+    lib = _lib.load()
+    img = _f32c(image_rows, "image_rows")
+    _, H, W = img.shape
+    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    saved = torch.empty(lib.crnerf_encoder_train_band_saved_bytes(H, W, o1 - o0), dtype=torch.uint8, device=img.device)
+    out = torch.empty((o1 - o0) * 32, 64, dtype=torch.float32, device=img.device)
+    _lib.check(lib.crnerf_encoder_forward_train_band_f32(_lib.dev_ptr(img), H, W, int(h_image), int(row0), int(o0), int(o1), _lib.ptr_array(ws, "encoder weight"),
+                                                         ctypes.c_void_p(saved.data_ptr()), _lib.dev_ptr(out), _lib.stream_ptr()), "crnerf_encoder_forward_train_band_f32")
+    return out, saved, (H, W)
+
+
+def encoder_backward_band(weights, saved, hw, h_image, row0, o0, o1, out, d_out, want_d_image=True):
+    """crnerf_encoder_backward_band_f32 -> (this band's part of the 14 weight gradients, d_image_rows [3,H,W] or None)."""
+    lib = _lib.load()
+    H, W = hw
+    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    grads = [torch.empty_like(t) for t in ws]
+    d_img = torch.empty(3, H, W, dtype=torch.float32, device=out.device) if want_d_image else None
+    scratch = torch.empty(lib.crnerf_encoder_train_band_scratch_bytes(H, W, o1 - o0), dtype=torch.uint8, device=out.device)
+    _lib.check(lib.crnerf_encoder_backward_band_f32(H, W, int(h_image), int(row0), int(o0), int(o1), _lib.ptr_array(ws, "encoder weight"),
+                                                    ctypes.c_void_p(saved.data_ptr()), _lib.dev_ptr(out), _lib.dev_ptr(_f32c(d_out, "d_out")),
+                                                    ctypes.c_void_p(scratch.data_ptr()), _lib.ptr_array(grads, "encoder grad"), _lib.dev_ptr(d_img), _lib.stream_ptr()),
+               "crnerf_encoder_backward_band_f32")
+    return grads, d_img
+
+
 def crossray_decode_backward(content_pm, style_pm, weights, d_rgb):
     """Backward of crossray_decode: returns (d_content[HW,64], d_style[HWs,64], [22 weight gradients])."""
     lib = _lib.load()

@@ -313,6 +313,35 @@ def gather_rays(x, n_total, group=None):
     return GatherRays.apply(x, n_total, group)
 
 
+ENCODER_BAND_HALO = 12     # rows: the seven layers reach 10 rows beyond a pixel (3x3, 3x3, pool, 3x3, 3x3, pool, 3x3); a multiple of 4 keeps the pools aligned
+
+
+def encoder_band_plan(H, W, world_size, rank):
+    """(H, row0, rows, o0, o1, world_size) for `rank`'s band of an H x W image, or None when the image does not split evenly: the ranks own H /
+    world_size rows each (a multiple of 4: two 2 x 2 max-pools) and 32 / world_size rows of the 32 x 32 style grid, whose pooling windows then lie
+    inside the owned rows; the band adds ENCODER_BAND_HALO rows on every side that is cut inside the image."""
+    if world_size < 2 or 32 % world_size or H % world_size or (H // world_size) % 4 or H // world_size < 8 or W < 8:
+        return None
+    per = H // world_size
+    r0, r1 = rank * per, (rank + 1) * per
+    row0, end = max(0, r0 - ENCODER_BAND_HALO), min(H, r1 + ENCODER_BAND_HALO)
+    return (H, row0, end - row0, rank * (32 // world_size), (rank + 1) * (32 // world_size), world_size)
+
+
+def encode_banded(enc, image, group=None):
+    """enc(image) for a replicated [1,3,H,W] image in grad mode, the work split into row bands over the ranks of `group` (autograd.BandEncoderFn);
+    None when the image does not split (the caller then runs the replicated pass).  Every rank must call it for the same image."""
+    if not (torch.is_grad_enabled() and image.dim() == 4 and image.shape[0] == 1 and image.shape[1] == 3):
+        return None
+    plan = encoder_band_plan(int(image.shape[2]), int(image.shape[3]), dist.get_world_size(group), dist.get_rank(group))
+    if plan is None:
+        return None
+    from .autograd import BandEncoderFn
+    convs = (enc.conv1, enc.conv2, enc.conv3, enc.conv4, enc.conv5, enc.conv6, enc.conv7)
+    grid = BandEncoderFn.apply(image.to(torch.float32), plan, group, *[t for c in convs for t in (c.weight, c.bias)])
+    return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)
+
+
 def sync_ray_parallel_gradients(sharded_modules, replicated_modules, group=None):
     """After loss.backward() of a ray-parallel step: parameters of the sharded part (the MLPs) hold partial sums over this
     rank's rays -> SUM over ranks; parameters of the replicated part (decoder, encoders, mask network) hold the full

@@ -148,6 +148,8 @@ class TrainingSystem:
         # switch it off); assign True / False to `fused_grad_accumulation` to override.
         self._ray_parallel_requested = ray_parallel_group is not False
         self._fused_grad_override = None
+        # ray-parallel mode: the encoder passes over the re-rendered images run as row bands, one per rank (round 6); False = replicated, as up to round 5
+        self.shard_encoders = True
 
     @property
     def fused_grad_accumulation(self):
@@ -186,6 +188,17 @@ class TrainingSystem:
         from .parallel import sync_ray_parallel_gradients
         sharded = [m for k, m in self.models.items() if k in ("coarse", "fine")]
         sync_ray_parallel_gradients(sharded, [m for m in self.models_to_train if m not in sharded], self.ray_group)
+
+    def _encode(self, enc, image):
+        """An encoder pass over a re-rendered image (:219, :223-224).  Ray-parallel mode: the ranks split the image into row bands
+        (parallel.encode_banded -- every rank holds the whole image, the decoder being replicated); anywhere else, or when the image does not
+        split evenly over the ranks, the whole pass."""
+        if self.ray_group is not False and self.shard_encoders and self.training:
+            from .parallel import encode_banded
+            out = encode_banded(enc, image, self.ray_group)
+            if out is not None:
+                return out
+        return enc(image)
 
     def decode(self, results, type, **kwargs):                                              # :127-149
         feature = results['feature_' + type] if type != 'content' else results['feature_fine']
@@ -259,12 +272,12 @@ class TrainingSystem:
         if hp.encode_random:
             results['a_embedded_random'] = kwargs['a_embedded_random']
             results = self.decode(results, "fine_random", **kwargs)
-            results['a_embedded_random_rec'] = self.enc_a(results['rgb_fine_random'])       # :219
+            results['a_embedded_random_rec'] = self._encode(self.enc_a, results['rgb_fine_random'])       # :219
             results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
             self.embedding_a_list[image_id] = kwargs['a_embedded_from_img'].clone().detach()
         if getattr(hp, "encode_c", False):                                                  # :222-224
-            results['content_with_a_embed'] = self.enc_cont(results['rgb_fine_img'])
-            results['content_wo_a_embed'] = self.enc_cont(results['rgb_content_img'])
+            results['content_with_a_embed'] = self._encode(self.enc_cont, results['rgb_fine_img'])
+            results['content_wo_a_embed'] = self._encode(self.enc_cont, results['rgb_content_img'])
         return results
 
     def training_step(self, batch):                                                         # :268-290

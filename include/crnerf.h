@@ -420,6 +420,20 @@ size_t crnerf_encoder_train_scratch_bytes(int H, int W);
 int crnerf_encoder_forward_train_f32(const float* image, int H, int W, const float* const* weights, void* saved, float* out, void* stream);
 int crnerf_encoder_backward_f32(int H, int W, const float* const* weights, const void* saved, const float* out, const float* d_out,
                                 void* scratch, float* const* grads, float* d_image, void* stream);
+/* The same twins over a BAND of rows of an image (round 6: in ray-parallel training the encoder passes over the re-rendered H_image x W images are
+ * split into row bands, one per rank -- DESIGN 4).  image_rows[3,H,W] = rows [row0, row0 + H) of the image (contiguous; row0 a multiple of 4); the
+ * seven layers run on the band as on an image of H rows, so the band must bring a halo of >= 12 rows beyond the rows whose outputs are wanted
+ * wherever it is cut inside the image (10 rows = the layers' receptive reach; what the reflection padding gets wrong at a cut edge then never
+ * reaches them).  Only the final AdaptiveAvgPool2d(32) knows the whole image: out[(o1 - o0) * 32, 64] = rows [o0, o1) of the 32 x 32 style grid,
+ * with the whole image's pooling windows (which must lie inside the band).  Backward: d_out[(o1 - o0) * 32, 64] -> grads[14] (this band's part
+ * of the weight gradients: the bands' results ADD UP to the whole image's) and d_image_rows[3,H,W] (optional): what the band's output rows
+ * contribute to the gradient of the image rows it read -- halo rows included, the caller sums overlapping bands.  n_out_rows = o1 - o0. */
+size_t crnerf_encoder_train_band_saved_bytes(int H, int W, int n_out_rows);
+size_t crnerf_encoder_train_band_scratch_bytes(int H, int W, int n_out_rows);
+int crnerf_encoder_forward_train_band_f32(const float* image_rows, int H, int W, int H_image, int row0, int o0, int o1, const float* const* weights, void* saved,
+                                          float* out, void* stream);
+int crnerf_encoder_backward_band_f32(int H, int W, int H_image, int row0, int o0, int o1, const float* const* weights, const void* saved, const float* out,
+                                     const float* d_out, void* scratch, float* const* grads, float* d_image_rows, void* stream);
 
 /* ---- training-side neighbours of the path ------------------------------------------------------
  * CRNeRFLoss.forward, losses.py:49-78 (mask_regularize :80-91, _l2_regularize :93-96).  The seven terms, in the

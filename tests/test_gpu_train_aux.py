@@ -191,6 +191,48 @@ def test_encoder_backward_vs_autograd_oracle(H, W):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("H,W,ws", [(64, 40, 2), (64, 64, 4), (256, 32, 8), (128, 24, 4), (96, 16, 8)])
+def test_encoder_row_bands_add_up_to_the_whole_image(H, W, ws):
+    """crnerf_encoder_{forward_train,backward}_band_f32 (round 6: the encoder passes of ray-parallel training split into row bands, one per rank):
+    with parallel.encoder_band_plan's bands -- H / ws owned rows + a 12-row halo wherever the band is cut inside the image -- the bands' output
+    rows ARE the whole image's output rows (bit for bit: what the reflection padding gets wrong at a cut edge never reaches an owned row), and
+    the bands' weight gradients and image gradients add up to the whole image's (fp32 summation order aside)."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import ops
+    from crnerf_amd.parallel import encoder_band_plan
+    st = synth.encoder_state(57, 2.0)
+    names = ["conv%d.%s" % (l, t) for l in range(1, 8) for t in ("weight", "bias")]
+    w = [torch.from_numpy(st[n]).to(DEV) for n in names]
+    g = torch.Generator().manual_seed(H + W + ws)
+    img = torch.rand(3, H, W, generator=g).to(DEV)
+    d_out = torch.randn(1024, 64, generator=g).to(DEV)
+    out, saved, hw = ops.encoder_forward_train(img, w)
+    grads, d_img = ops.encoder_backward(w, saved, hw, out, d_out)
+    sum_g = [torch.zeros_like(t) for t in grads]
+    sum_d = torch.zeros_like(d_img)
+    rows_done = 0
+    for rank in range(ws):
+        plan = encoder_band_plan(H, W, ws, rank)
+        assert plan is not None
+        _, row0, rows, o0, o1, _ = plan
+        assert rows < H or ws * 12 >= H                      # a real band wherever the image is large enough
+        rows_done += rows
+        sub = img[:, row0:row0 + rows].contiguous()
+        own, sv, shw = ops.encoder_forward_train_band(sub, H, row0, o0, o1, w)
+        assert torch.equal(own, out[o0 * 32:o1 * 32]), (rank, float((own - out[o0 * 32:o1 * 32]).abs().max()))
+        gb, db = ops.encoder_backward_band(w, sv, shw, H, row0, o0, o1, own, d_out[o0 * 32:o1 * 32].contiguous())
+        for a, b in zip(sum_g, gb):
+            a += b
+        sum_d[:, row0:row0 + rows] += db
+    if H >= 8 * 12:
+        assert rows_done < ws * H                            # (the bands are smaller than ws copies of the image)
+    for name, a, b in zip(names, sum_g, grads):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((sum_d - d_img).abs().max()) <= 2e-5 * float(d_img.abs().max()) + 1e-8
+    assert encoder_band_plan(H + 2, W, ws, 0) is None and encoder_band_plan(H, W, 3, 0) is None      # no even split: the caller runs the whole pass
+
+
+@torch.no_grad()
 def test_video_frames_shard_across_ranks_without_exchange():
     """appearance_modification_video.py:224-262 through crnerf_amd.video: the frame list is cut rank-wise; the union of two
     'ranks' equals the single-rank run frame for frame (frames are independent: no collective)."""

@@ -55,7 +55,8 @@ def test_train_forward_equals_inference_and_standalone_twins(R, Nc, Ni):
         fa, fs = a_f[:4 * n_act].view(torch.float32).view(10, R * N, 256), a_s[:4 * n_act].view(torch.float32).view(10, R * N, 256)
         assert float((fa[:9] - fs[:9]).abs().max()) <= 2e-5 * float(fs[:9].abs().max()) and float((fa[9, :, :128] - fs[9, :, :128]).abs().max()) <= 2e-5
         # relu bits are consistent with the saved activations of the same buffer
-        bits = a_f[4 * n_act:].view(torch.int64).view(10, R * N, 4)
+        bits = a_f[4 * n_act:].view(torch.int64)[:10 * R * N * 4].view(10, R * N, 4)      # (behind the bits: the 256-byte line of the range word, kernels.h)
+        assert int(a_f[4 * n_act + 320 * R * N:][:4].view(torch.int32)) == 0                    # the fp32 twin tracks no operand range: the word is zeroed
         g = 2
         k = torch.arange(64, device=DEV)
         feat = 16 * (k // 4) + 4 * g + (k % 4)
