@@ -653,6 +653,38 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
         return loss.detach()
 
     dt, last = timed_steps(a, step, use_dist, dist, dev)
+    # One more step, instrumented: where the ray-SHARDED part (the two MLPs' render, forward and backward: 1 / N of it per rank) ends and the rest
+    # begins.  Events: step start | features ready (render + all-gather done) | forward done | gradient arrives back at the features (everything
+    # downstream of the render has been differentiated) | backward done | gradients synchronised + Adam done.
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    fired = []
+
+    def probe(results):
+        ev[1].record()
+        for k in ("feature_coarse", "feature_fine"):
+            if k in results and results[k].requires_grad:
+                results[k].register_hook(lambda g, k=k: (fired.append(k), ev[3].record())[0] and None)     # the last one to fire leaves the stamp
+    sysm.after_render = probe
+    batch = batcher.__getitem__(counter[0], 0)
+    opt.zero_grad(set_to_none=True)
+    ev[0].record()
+    loss, _, _ = sysm.training_step(batch)
+    ev[2].record()
+    loss.backward()
+    ev[4].record()
+    if use_dist:
+        sysm.sync_gradients()
+    opt.step()
+    ev[5].record()
+    torch.cuda.synchronize()
+    sysm.after_render = None
+    t = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    sections = {"render_forward_ms": t[0], "rest_forward_ms": t[1], "rest_backward_ms": t[2], "render_backward_ms": t[3], "sync_and_adam_ms": t[4],
+                "sharded_ms": t[0] + t[3], "not_sharded_ms": t[1] + t[2] + t[4],
+                "note": "one instrumented step after the timed ones, HIP events on the launch stream.  sharded = the renderer's forward and backward over this "
+                        "rank's rays (1 / N of the batch).  not_sharded = decodes, mask network, loss, optimiser and -- replicated at N = 1, row bands over "
+                        "the ranks at N > 1 (parallel.encode_banded) -- the three encoder passes over the re-rendered images: the part that does not "
+                        "shrink as 1 / N (DESIGN 4)"}
     pts = R * (nc + nc + ni)
     achieved = 3 * pts * FLOP_PER_POINT / dt * a.steps / 1e12 / world      # per GPU: algorithmic fp32 FLOPs of forward + data gradient + weight gradient
     # auto: what the matrix cores are ISSUED -- forward 3.02 x, data gradient 3 x, weight gradient 3 x (two fp16 pieces per operand, three MFMAs per
@@ -676,7 +708,7 @@ def strong_configs3(a, dev, world, rank, use_dist, dist):
                                  "time).  f32: 3 x the forward's algorithmic FLOPs on the fp32 MFMA.  auto: the ISSUED fp16 MFMA work (9.02 x the "
                                  "forward's algorithmic FLOPs) against the nominal 2.5 PFLOP/s -- the three big kernels of that step are bound by their activation / "
                                  "delta rows in HBM, not by the matrix cores (DESIGN 3.5); fp32_work_tflops = the algorithmic fp32 work"},
-            "loss": float(last), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+            "loss": float(last), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "sections": sections}
     if use_dist and world > 1:
         chk = torch.tensor([float(last), float(sum(p.detach().double().sum() for p in sysm.parameters()))], dtype=torch.float64, device=dev)
         allc = [torch.zeros_like(chk) for _ in range(world)]

@@ -150,6 +150,7 @@ class TrainingSystem:
         self._fused_grad_override = None
         # ray-parallel mode: the encoder passes over the re-rendered images run as row bands, one per rank (round 6); False = replicated, as up to round 5
         self.shard_encoders = True
+        self.after_render = None                # callable(results) between the render (+ feature gather) and the decodes, or None
 
     @property
     def fused_grad_accumulation(self):
@@ -260,6 +261,8 @@ class TrainingSystem:
                     results[k] = gather_rays(results[k], B, self.ray_group)
             if "feature_fine_random" in results:
                 results["feature_fine_random"] = results["feature_fine"]
+        if self.after_render is not None:      # measurement hook (bench.py --workload configs3): the boundary between the ray-sharded part and the rest
+            self.after_render(results)
         results = self.decode(results, "coarse", **kwargs)
         if hp.N_importance > 0:
             results = self.decode(results, "fine", **kwargs)
