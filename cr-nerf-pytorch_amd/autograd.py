@@ -518,10 +518,21 @@ def _defer(params, grads):
         torch.autograd.Variable._execution_engine.queue_callback(lambda task=task: _flush_deferred(task))
     for p, g in zip(params, grads):
         pend.setdefault(id(p), (p, []))[1].append(g)
+    if grads and grads[0].is_cuda:
+        # the node may have run on a side stream (pipeline.TrainingSystem's branch streams: a node's backward runs on its forward's stream); the
+        # end-of-pass sum runs on the stream backward() was called on and must wait for these gradients -- they never pass an AccumulateGrad
+        # node, so the engine's own end-of-pass stream synchronisation does not know them
+        ev = torch.cuda.Event()
+        ev.record()
+        pend.setdefault("__events__", []).append(ev)
 
 
 def _flush_deferred(task):
     pend = _DEFERRED.pop(task, None)
+    if not pend:
+        return
+    for ev in pend.pop("__events__", ()):
+        torch.cuda.current_stream().wait_event(ev)
     if not pend:
         return
     with torch.no_grad():

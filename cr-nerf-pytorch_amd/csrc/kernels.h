@@ -70,8 +70,7 @@ int launch_encoder_forward(const float* img, int H, int W, const float* const* w
 size_t wgrad_workspace_floats(long P, int M, int N, int bf16 = 0);   // bf16: the mode wgrad() will be called with (3 = f16x2: narrow jobs run on half chunks)
 // bf16 != 0: full 256 x 256 tiles multiply bf16-rounded operands on the bf16 MFMA (fp32 accumulate); other shapes stay fp32
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr, const uint32_t* amax = nullptr,
-          const float* sig = nullptr, float* sig_dst = nullptr, float* sig_db = nullptr);   // sig: a one-column delta riding in a full f16x2 job (static_sigma beside xyz_encoding_final)
+          hipStream_t st, int bf16 = 0, const uint32_t* dmax = nullptr, const uint32_t* amax = nullptr);
 // several such products in ONE launch + ONE reduction (small batches: a launch per job is mostly ramp-up and drain); at most 16 jobs
 // bf16: 0 fp32 operands, 1 bf16-rounded, 2 "bf16x3", 3 "f16x2" (full tiles; dmax = the bits of max |D| over the tensor, see wgrad_h2_kernel)
 struct WgradSpec { const float* D; int ldd, M; const float* A; int lda, N; float* dst; int ldc; float* db; float weight; int bf16; long P; const uint32_t* dmax = nullptr;

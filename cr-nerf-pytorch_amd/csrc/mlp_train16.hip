@@ -205,8 +205,6 @@ struct WgradJob {
   int bf16;                            // != 0: the full 256 x 256 tiles multiply bf16-rounded operands (fp32 accumulate), see wgrad_kernel
   const uint32_t* dmax;                // wgrad_h2_kernel: the bits of max |D| over the whole tensor (written by the h2 data gradient), or null
   const uint32_t* amax;                // wgrad_h2_kernel: the saved state's range word (bits of the h2 forward's largest |operand|, kernels.h), or null
-  const float* sig;                    // wgrad_h2_sig_kernel: a second, one-column delta d_sig[P] riding in this job (static_sigma reads the same activation
-  float* sig_partial;                  // rows as xyz_encoding_final): its partial sums [nchunk][N], then the bias sums [nchunk] (single-job launches: nchunk = gridDim.x)
 };
 
 __device__ __forceinline__ uint32_t pk_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32: a -> low half, b -> high half
@@ -595,10 +593,7 @@ __device__ __forceinline__ void max_slot(float (&m)[4], const float __attribute_
 // MODE 1: the "bf16x3" weight gradients (CRNERF_BWD_WGRAD_BF16X3); MODE 2: the "f16x2" form of the full tiles with bf16x3 behind it -- see the
 // full-tile branch below; MODE 4: MODE 2 for jobs without a full tile, compiled without that branch (wgrad_h2_narrow_kernel: half the registers,
 // two workgroups per CU)
-// SIG (MODE 2, one 256 x 256 block): the job also forms static_sigma's weight gradient dWsig[n] = sum_p d_sig[p] a[p][n] and its bias gradient from
-// the activation rows it streams anyway (round 6: the sigma head reads h8 like xyz_encoding_final does -- as its own job it read the 1 KB per
-// point a second time, 4 ms of a 65,536-ray step): 32 fp32 FMAs + 8 adds per k-step and lane in the MFMAs' shadow, exact fp32 products.
-template <int MODE = 0, bool SIG = false>
+template <int MODE = 0>
 __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, const int by, const int bz) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the wave's tile origin lives in SGPRs
   const int i = lane & 31, kk = lane >> 5;
@@ -691,9 +686,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
       const bool do_bias3 = j.bias_partial && bz == 0 && bias_wave;
       f32x4 bsum3 = {0.0f, 0.0f, 0.0f, 0.0f};
       bool done_h = false;
-      f32x4 sacc = {0.0f, 0.0f, 0.0f, 0.0f};     // SIG: sum_p d_sig[p] a[p][n0 + 4i + t] over this lane's points
-      float sbias = 0.0f;                         //      sum_p d_sig[p]
-      bool sig_done = false;
       if constexpr (MODE == 2) {
         if (j.dmax && ((p1 - p0) & 31) == 0 && p1 > p0) {
           // ---- "f16x2" (the default behind the h2 data gradient, launch_mlp_backward): the same stream with every operand split into TWO fp16 pieces,
@@ -728,37 +720,10 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
           split_all_h<0>(araw, Ah[0][0], one); split_all_h<1>(araw, Ah[0][1], one); split_all_h<2>(araw, Ah[0][2], one); split_all_h<3>(araw, Ah[0][3], one);
           split_all_h<0>(draw[0], Dh[0], sd);
           max_slot(amx, araw[0], araw[1]); max_slot(amx, araw[2], araw[3]); max_slot(amx, araw[4], araw[5]); max_slot(amx, araw[6], araw[7]);
-          // SIG: d_sig of this lane's eight points of a k-step = 32 contiguous bytes (chunks start on multiples of 32 points)
-          // (a uniform base in SGPRs + one per-lane byte offset, like the rows: the stream has no registers to spare for a per-lane pointer)
-          const char* sgs = SIG ? (const char*)(j.sig + p0) : nullptr;
-          const uint32_t sgo = 32u * (uint32_t)kk;
-          f32x4 sg0 = {0.0f, 0.0f, 0.0f, 0.0f}, sg1 = {0.0f, 0.0f, 0.0f, 0.0f};
-          if constexpr (SIG) {
-            sg0 = *(const f32x4*)(sgs + sgo); sg1 = *(const f32x4*)(sgs + sgo + 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sacc += (e < 4 ? sg0[e & 3] : sg1[e & 3]) * araw[e];     // k-step 0's rows (the loop handles the rows it requests)
-            sbias += ((sg0[0] + sg0[1]) + (sg0[2] + sg0[3])) + ((sg1[0] + sg1[1]) + (sg1[2] + sg1[3]));
-          }
           auto fragh = [](const uint32_t (&w)[4]) { return __builtin_bit_cast(xh16x8_t, make_uint4(w[0], w[1], w[2], w[3])); };
           // One phase = the 12 MFMAs of delta column A against the four activation columns of buffer C (every accumulator: d2 a1, d1 a2, d1 a1, the
           // four accumulators taking turns); behind MFMA g rides micro-stage g of split X (g < 4), g - 4 of split Y (g < 8), or one slot of the tail
           // (two bias rows, two range slots), and a scheduling fence.
-          float keep = 1.0f;                                               // SIG: 0 in the last k-step, whose "next" rows are its own again
-          // SIG: slot k = 0..35 of phases 1-3 (the next k-step's activation rows have landed by then): 0, 1 the keep factor, 2..33 one FMA each
-          // (row e = (k - 2) / 4, column t = (k - 2) % 4), 34, 35 the bias sums -- one more VALU instruction (four in the four slots at the ends)
-          // behind an MFMA that had four
-          auto sig_slot = [&](auto K_) {
-            if constexpr (SIG) {
-              constexpr int k = decltype(K_)::value;
-              if constexpr (k == 0) sg0 *= keep;
-              else if constexpr (k == 1) sg1 *= keep;
-              else if constexpr (k < 34) {
-                constexpr int e = (k - 2) / 4, t = (k - 2) % 4;
-                sacc[t] = fmaf(e < 4 ? sg0[e & 3] : sg1[e & 3], araw[e][t], sacc[t]);
-              } else if constexpr (k == 34) sbias += (sg0[0] + sg0[1]) + (sg0[2] + sg0[3]);
-              else sbias += (sg1[0] + sg1[1]) + (sg1[2] + sg1[3]);
-            }
-          };
           auto phase = [&](auto A_, auto DS_, auto C_, auto&& x_stage, auto&& y_stage, auto&& tail) {
             constexpr int a = decltype(A_)::value, ds = decltype(DS_)::value, c = decltype(C_)::value;
             static_for<12>([&](auto G) {
@@ -768,7 +733,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
               if constexpr (g < 4) x_stage(G);
               else if constexpr (g < 8) y_stage(std::integral_constant<int, g - 4>{});
               else tail(std::integral_constant<int, g - 8>{});
-              if constexpr (a >= 1) sig_slot(std::integral_constant<int, 12 * (a - 1) + g>{});
               __builtin_amdgcn_sched_barrier(0);
             });
           };
@@ -782,11 +746,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
             ab += adv * sa_b;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { draw[n][e] = *(const f32x4*)(db + vd[e]); araw[e] = *(const f32x4*)(ab + va[e]); }
-            if constexpr (SIG) {
-              sgs += adv * 64;
-              keep = (float)adv;
-              sg0 = *(const f32x4*)(sgs + sgo); sg1 = *(const f32x4*)(sgs + sgo + 16);
-            }
             __builtin_amdgcn_sched_barrier(0);
             // the same rotation as the bf16x3 k-step: delta pieces through three sets, the next k-step's activation rows first touched in phase 1
             phase(I0{}, I0{}, IC{}, [&](auto K) { split_stage_h<decltype(K)::value, 1>(draw[c], Dh[1], sd); },
@@ -806,7 +765,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
           }
-          sig_done = true;     // (fp32 FMAs on the rows themselves: they stand whatever the fp16 range verdict below says)
           const float am = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3])) * one, dm = fmaxf(fmaxf(dmx[0], dmx[1]), fmaxf(dmx[2], dmx[3])) * sd;
           const bool in_range = am < 65504.0f && dm < 65504.0f;          // (an Inf or a NaN among the operands fails it too)
           if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
@@ -934,22 +892,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
         take16(pb + 16);
       }
       }
-      }
-      if constexpr (SIG) {
-        if (m0 == by * 256) {                       // the waves of the block's first row half: each column once
-          if (!sig_done) {                          // the f16x2 stream did not run (a ragged last chunk, no range word): the same sums the plain way
-            for (long pt = p0 + kk; pt < p1; pt += 2) {
-              const float sv = j.sig[pt];
-              sacc += sv * *(const f32x4*)(abase + pt * j.lda);
-              sbias += sv;
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < 4; ++t) sacc[t] += __shfl_xor(sacc[t], 32);
-          float sb = sbias + __shfl_xor(sbias, 32);
-          if (kk == 0) *(f32x4*)(j.sig_partial + (long)bx * j.N + n0 + 4 * i) = sacc;
-          if (lane == 0 && n0 == bz * 256) j.sig_partial[(long)gridDim.x * j.N + bx] = sb;
-        }
       }
       if (do_bias3) {
 #pragma unroll
@@ -1103,7 +1045,6 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& j, const int bx, cons
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob j) { wgrad_body<0>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(WgradJob j) { wgrad_body<1>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 __global__ __launch_bounds__(256, 1) void wgrad_h2_kernel(WgradJob j) { wgrad_body<2>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
-__global__ __launch_bounds__(256, 1) void wgrad_h2_sig_kernel(WgradJob j) { wgrad_body<2, true>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
 // The smallest jobs (128 x 27, 64 x 128: one or two accumulator tiles per wave) compiled for 256 registers: two workgroups share a CU, each on half a
 // chunk -- twice the row bytes in flight per CU, which is what bounds these jobs (wgrad()).
 __global__ __launch_bounds__(256, 2) void wgrad_h2_narrow_kernel(WgradJob j) { wgrad_body<4>(j, blockIdx.x, blockIdx.y, blockIdx.z); }
@@ -1198,24 +1139,16 @@ size_t wgrad_workspace_floats(long P, int M, int N, int bf16) {
 }
 
 int wgrad(const float* D, int ldd, int M, const float* A, int lda, int N, float* dst, int ldc, float* db, long P, float* ws,
-          hipStream_t st, int bf16, const uint32_t* dmax, const uint32_t* amax, const float* sig, float* sig_dst, float* sig_db) {
+          hipStream_t st, int bf16, const uint32_t* dmax, const uint32_t* amax) {
   // at most two accumulator tiles per wave (dir_encoding's direction block, static_rgb): wgrad_h2_narrow_kernel, two workgroups per CU on half chunks
   // (measured per 2^19 points: 139 -> 93 and 142 -> 119 us; the 93-column embedding blocks gain nothing from it, dir_encoding's 4 x 2 tiles spill in 256 registers)
   const bool narrow = bf16 == 3 && M <= 128 && N <= 128;
   const int chunk = wgrad_job_chunk(P, M, N, bf16);     // (narrow: 2 x nchunk x (M N + M) stays inside the workspace of a full block; wgrad_workspace_floats(.., 3) sizes it)
   const int nchunk = (int)((P + chunk - 1) / chunk);
   float* bws = ws + (size_t)nchunk * M * N;
-  // sig (f16x2, one full 256 x 256 block): static_sigma's gradients ride in this job (wgrad_h2_sig_kernel); their partial sums sit behind the job's own
-  const bool with_sig = sig && bf16 == 3 && !narrow && M == 256 && N == 256 && (ldd & 3) == 0 && (lda & 3) == 0;
-  float* sws = bws + (size_t)nchunk * M;
-  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr, bf16 == 3 ? amax : nullptr,
-             with_sig ? sig : nullptr, with_sig ? sws : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
-  if (sig && !with_sig) return set_error(-3, "wgrad: the sigma-head fold needs the f16x2 mode on one full 256 x 256 block");
+  WgradJob j{D, ldd, M, A, lda, N, ws, db ? bws : nullptr, P, chunk, bf16 >= 2 ? 0 : bf16, bf16 == 3 ? dmax : nullptr, bf16 == 3 ? amax : nullptr};   // bf16x3 / f16x2: their own kernels (wgrad_body<1>, <2>)
   if (narrow) hipLaunchKernelGGL(wgrad_h2_narrow_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
-  else if (with_sig) {
-    hipLaunchKernelGGL(wgrad_h2_sig_kernel, dim3(nchunk, 1, 1), dim3(256), 0, st, j);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N + 1 + 255) / 256), dim3(256), 0, st, sws, nchunk, 1, N, sig_dst, N, sws + (size_t)nchunk * N, sig_db);
-  } else if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
+  else if (bf16 == 3) hipLaunchKernelGGL(wgrad_h2_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else if (bf16 == 2) hipLaunchKernelGGL(wgrad_x3_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   else hipLaunchKernelGGL(wgrad_kernel, dim3(nchunk, (M + 255) / 256, (N + 255) / 256), dim3(256), 0, st, j);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + (db ? M : 0) + 255) / 256), dim3(256), 0, st, ws, nchunk, M, N, dst, ldc, bws, db);
@@ -1230,7 +1163,7 @@ size_t mlp_train_acts_bytes(long P) { return acts_rows_bytes(P) + ACTS_RANGE_BYT
 size_t mlp_train_scratch_bytes(long P) {
   const int chunk = wg_chunk(P);
   const size_t nchunk = (size_t)((P + chunk - 1) / chunk);
-  size_t wsf = nchunk * (size_t)(256 * 256 + 256 + 256 + 1);       // per-layer launches (CRNERF_WGRAD_BATCH=0): a block's partial sums, its bias sums, the sigma head's
+  size_t wsf = nchunk * (size_t)(256 * 256 + 256);                 // per-layer launches (CRNERF_WGRAD_BATCH=0)
   if (wgrad_batch_workspace_floats() > wsf) wsf = wgrad_batch_workspace_floats();   // the batched launch keeps every job's partial sums
   return (size_t)ACT_SLOTS * P * ACT_W * 4 + (size_t)P * FEAT_DIM * 4 + (size_t)P * 4 + WG_RANGE_WORDS * 4 + wsf * 4;   // deltas | d_rgb | d_sig | range words | partial sums
 }
@@ -1303,7 +1236,7 @@ int wgrad_batch(const WgradSpec* specs, int n, float* ws, size_t ws_floats, hipS
     x3 = x3 || sp.bf16 == 2;
     h2 = h2 || sp.bf16 == 3;
     b.job[q] = WgradJob{sp.D, sp.ldd, sp.M, sp.A, sp.lda, sp.N, w, sp.db ? bws : nullptr, sp.P, (int)chunk[order[q]], sp.bf16 >= 2 ? 0 : sp.bf16,
-                        sp.bf16 == 3 ? sp.dmax : nullptr, sp.bf16 == 3 ? sp.amax : nullptr, nullptr, nullptr};
+                        sp.bf16 == 3 ? sp.dmax : nullptr, sp.bf16 == 3 ? sp.amax : nullptr};
     b.first[q] = blocks;
     b.nchunk[q] = nc;
     b.my[q] = (sp.M + 255) / 256;
@@ -1372,13 +1305,8 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
       wgrad(D(l), ACT_W, 256, A(l - 1), ACT_W, 256, grads[2 * l], 256, grads[2 * l + 1], P, ws, stream, wb, R(l), amax);
     }
   }
-  static const bool sig_fold = [] { const char* e = getenv("CRNERF_WGRAD_SIG_FOLD"); return e ? atoi(e) != 0 : true; }();
-  if (wb == 3 && sig_fold) {   // xyz_encoding_final with static_sigma riding in it: both read h8, one pass over its rows (wgrad_h2_sig_kernel)
-    if (int rc = wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8), amax, d_sig, grads[18], grads[19])) return rc;
-  } else {
-    wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8), amax);      // xyz_encoding_final
-    wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
-  }
+  wgrad(D(8), ACT_W, 256, A(7), ACT_W, 256, grads[16], 256, grads[17], P, ws, stream, wb, R(8), amax);      // xyz_encoding_final
+  wgrad(d_sig, 1, 1, A(7), ACT_W, 256, grads[18], 256, grads[19], P, ws, stream);                 // static_sigma
   wgrad(D(9), ACT_W, 128, A(8), ACT_W, 256, grads[20], 256 + DIR_DIM, grads[21], P, ws, stream, wb, R(9), amax);  // dir_encoding: cat([final, dir])
   wgrad(D(9), ACT_W, 128, x + XYZ_DIM, IN_DIM, DIR_DIM, grads[20] + 256, 256 + DIR_DIM, nullptr, P, ws, stream, wb, R(9), amax);
   wgrad(d_rgb, FEAT_DIM, FEAT_DIM, A(9), ACT_W, 128, grads[22], 128, grads[23], P, ws, stream, wb, R(ACT_SLOTS), amax);   // static_rgb

@@ -672,7 +672,8 @@ _ws_cache = {}
 
 
 def crossray_workspace(device):
-    key = (device.type, device.index)
+    # one per device AND stream: pipeline.TrainingSystem runs independent decodes side by side on their own streams (round 6)
+    key = (device.type, device.index, int(_lib.stream_ptr().value or 0))
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(_lib.load().crnerf_crossray_workspace_bytes(), dtype=torch.uint8, device=device)

@@ -116,6 +116,30 @@ def render_frame(models, embeddings, enc_a, style_img, H, W, K, c2w, hparams_, n
     return decode_image(models, res, H, W, a_emb).reshape(int(H), int(W), 3).clamp(0, 1)
 
 
+class _Branches:
+    """Independent chains of a step on their own streams: run(k, fn) enqueues fn on stream k (which first waits for everything the calling stream
+    has enqueued so far -- the first time it is used in this step; later calls on the same stream just follow), join() makes the calling stream
+    wait for all of them.  streams = None: everything runs inline on the calling stream."""
+
+    def __init__(self, streams):
+        self.streams, self.used = streams, set()
+        self.main = torch.cuda.current_stream() if streams is not None else None
+
+    def run(self, k, fn):
+        if self.streams is None:
+            return fn()
+        st = self.streams[k]
+        if k not in self.used:
+            st.wait_stream(self.main)
+            self.used.add(k)
+        with torch.cuda.stream(st):
+            return fn()
+
+    def join(self):
+        for k in self.used:
+            self.main.wait_stream(self.streams[k])
+
+
 class TrainingSystem:
     """The training-side orchestration of the reference's NeRFSystem without Lightning: same dict keys, same order of
     operations, autograd through the HIP twins (models/rendering.py grad path, autograd.py) and the fused loss."""
@@ -151,6 +175,10 @@ class TrainingSystem:
         # ray-parallel mode: the encoder passes over the re-rendered images run as row bands, one per rank (round 6); False = replicated, as up to round 5
         self.shard_encoders = True
         self.after_render = None                # callable(results) between the render (+ feature gather) and the decodes, or None
+        import os
+        # the decode / encoder chains of a step side by side on four streams (forward's comment); False / CRNERF_BRANCH_STREAMS=0: one stream
+        self.branch_streams = os.environ.get("CRNERF_BRANCH_STREAMS", "1") != "0"
+        self._streams = {}
 
     @property
     def fused_grad_accumulation(self):
@@ -189,6 +217,12 @@ class TrainingSystem:
         from .parallel import sync_ray_parallel_gradients
         sharded = [m for k, m in self.models.items() if k in ("coarse", "fine")]
         sync_ray_parallel_gradients(sharded, [m for m in self.models_to_train if m not in sharded], self.ray_group)
+
+    def _branch_streams(self, device):
+        key = torch.device(device).index
+        if key not in self._streams:
+            self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
+        return self._streams[key]
 
     def _encode(self, enc, image):
         """An encoder pass over a re-rendered image (:219, :223-224).  Ray-parallel mode: the ranks split the image into row bands
@@ -263,24 +297,33 @@ class TrainingSystem:
                 results["feature_fine_random"] = results["feature_fine"]
         if self.after_render is not None:      # measurement hook (bench.py --workload configs3): the boundary between the ray-sharded part and the rest
             self.after_render(results)
-        results = self.decode(results, "coarse", **kwargs)
+        # The four decodes (:205-218) and the three encoder passes over the re-rendered images (:219, :223-224) are four independent chains of small
+        # kernels -- coarse | fine -> enc_cont | content -> enc_cont | fine_random -> enc_a -- each a few dozen launches that use a few CUs for a
+        # few microseconds.  Round 6: one HIP stream per chain (self.branch_streams), so the chains run side by side instead of one after the
+        # other, forward and -- a node's backward runs on its forward's stream -- backward.  Same kernels, same arithmetic, same results.
+        br = _Branches(self._branch_streams(rays.device) if (self.branch_streams and self.training and torch.is_grad_enabled() and self.ray_group is False) else None)
+        br.run(0, lambda: self.decode(results, "coarse", **kwargs))
         if hp.N_importance > 0:
-            results = self.decode(results, "fine", **kwargs)
+            br.run(1, lambda: self.decode(results, "fine", **kwargs))
         if getattr(hp, "encode_c", False):
-            results = self.decode(results, "content", **kwargs)                             # :207-208
+            br.run(2, lambda: self.decode(results, "content", **kwargs))                     # :207-208
         if self.implicit_mask is not None:
             results['out_mask'] = kwargs['mask_embedded_from_img']                          # :210-211
         results['a_embedded'] = kwargs['a_embedded_from_img']
         results['whole_img'] = whole_img
         if hp.encode_random:
             results['a_embedded_random'] = kwargs['a_embedded_random']
-            results = self.decode(results, "fine_random", **kwargs)
-            results['a_embedded_random_rec'] = self._encode(self.enc_a, results['rgb_fine_random'])       # :219
-            results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
+
+            def random_chain():
+                self.decode(results, "fine_random", **kwargs)
+                results['a_embedded_random_rec'] = self._encode(self.enc_a, results['rgb_fine_random'])       # :219
+                results['rgb_fine_random'] = results['rgb_fine_random'].reshape(3, int(H) * int(W)).t()
+            br.run(3, random_chain)
             self.embedding_a_list[image_id] = kwargs['a_embedded_from_img'].clone().detach()
         if getattr(hp, "encode_c", False):                                                  # :222-224
-            results['content_with_a_embed'] = self._encode(self.enc_cont, results['rgb_fine_img'])
-            results['content_wo_a_embed'] = self._encode(self.enc_cont, results['rgb_content_img'])
+            br.run(1, lambda: results.__setitem__('content_with_a_embed', self._encode(self.enc_cont, results['rgb_fine_img'])))
+            br.run(2, lambda: results.__setitem__('content_wo_a_embed', self._encode(self.enc_cont, results['rgb_content_img'])))
+        br.join()
         return results
 
     def training_step(self, batch):                                                         # :268-290
