@@ -417,7 +417,7 @@ def get_training_bf16_fused():
 
 
 def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coarse, u, noise_c, noise_f, noise_std, rng=None):
-    """Grad-mode render of `rays` in ray chunks of ~2^20 fine sample points (rays are independent; the chunk bounds the
+    """Grad-mode render of `rays` in ray chunks of <= 2^21 fine sample points (rays are independent; the chunk bounds the
     backward's scratch -- 10 KB of layer deltas per point -- and, in recompute mode, the live activations)."""
     from .models.rendering import _linspace_tables
     R = rays.shape[0]
@@ -429,7 +429,13 @@ def fused_render_with_grad(coarse, fine, rays, Nc, Ni, use_disp, view_dir, z_coa
         z_coarse = z_coarse.expand(R, Nc).contiguous()
     names = ops.MLP_TENSOR_NAMES
     params = list(ops.mlp_params(coarse)) + (list(ops.mlp_params(fine)) if Ni > 0 else [])
-    step = max(4, ((1 << 20) // (Nc + Ni)) // 4 * 4)
+    import os
+    # ray chunks of <= 2^21 fine-pass points (round 6; 2^20 before): half as many launches, partial-sum slabs and kernel tails -- the 65,536-ray
+    # step 191.8 -> 186.9 / 188.3 ms, 16,384 rays 50.8 -> 49.5 ms, +11 GB of backward scratch (2.8 M points: no better; the kernels address rows
+    # with 32-bit offsets, < 3.9 M points per call).  Recompute mode keeps 2^20: there the chunk IS the step's activation memory.
+    max_pts = int(os.environ.get("CRNERF_TRAIN_CHUNK_POINTS", str(1 << (20 if get_training_recompute() else 21))))
+    n_chunks = max(1, -(-R * (Nc + Ni) // max_pts))                 # equal chunks of at most max_pts fine-pass points
+    step = max(4, -(-(-(-R // n_chunks)) // 4) * 4)
     parts = []
     # packs of this call's weights, made once and shared by the chunks' nodes (forward packs, and the transposed ones their backward makes); the
     # dict dies with the graph.  The weights cannot change between this forward and its backward without autograd objecting to the saved

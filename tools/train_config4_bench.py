@@ -85,6 +85,7 @@ if os.environ.get("CRNERF_TRAIN_BENCH_PROFILE"):      # host-side profile of the
 t0 = time.perf_counter()
 for i in range(n):
     l = step(n_warm + i)
+t_host = (time.perf_counter() - t0) / n          # the host's time to ENQUEUE a step (the last step's kernels are still running)
 if prof is not None:
     prof.disable()
 torch.cuda.synchronize()
@@ -108,5 +109,5 @@ if prof is not None:
     buf = io.StringIO()
     pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
     print(buf.getvalue())
-print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.1f ms -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
-      % (R, side, side, NC, NI, dt * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
+print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.2f ms (host enqueue %.2f ms) -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
+      % (R, side, side, NC, NI, dt * 1e3, t_host * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
