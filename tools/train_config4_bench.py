@@ -65,7 +65,11 @@ def step(i):
     batch = batcher.__getitem__(i, 0)
     opt.zero_grad(set_to_none=True)
     loss, loss_d, _ = sysm.training_step(batch)
-    loss.backward()
+    if os.environ.get("CRNERF_BWD_SINGLE_THREAD") == "1":       # experiment: the autograd engine on the calling thread (no hand-over to its device thread)
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
+    else:
+        loss.backward()
     if world > 1:
         sysm.sync_gradients()
     opt.step()
