@@ -89,12 +89,14 @@ def _grads(models, fn):
 
 @pytest.mark.parametrize("mode", ["f32", "auto"])
 @pytest.mark.parametrize("R", [64, 8200])     # 8200 rays x 128 samples: two ray chunks of the fused path
-def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R, mode):
+def test_fused_grad_path_matches_unfused_twins_and_recompute_mode(R, mode, monkeypatch):
     """mode "f32": the fused training renderer against the un-fused fp32 twins -- the same arithmetic, 3e-4 of each gradient's largest entry.
     mode "auto" (the default forward / data-gradient mode since round 4: the h2 core with its f32x3 safety net): fp32-accurate, not the same
     products, and these gain-2 nets turn a 1e-7 difference of a coarse weight into another fine depth -- 3e-2 (measured 1.0e-2 at 64 rays, 4e-3 at
-    8,200); recompute stays bit-identical."""
+    8,200); recompute stays bit-identical -- over the same ray chunks (round 6: the default chunk is 2^21 points, recompute mode keeps 2^20; the
+    chunking decides the summation order of the weight gradients, so both legs are pinned to 2^20 here: 8,200 rays are two chunks)."""
     from crnerf_amd.models import rendering
+    monkeypatch.setenv("CRNERF_TRAIN_CHUNK_POINTS", str(1 << 20))
     AG.set_training_forward_precision(mode)
     try:
         _fused_vs_unfused(R, 3e-4 if mode == "f32" else 3e-2, rendering)
