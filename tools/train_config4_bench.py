@@ -112,6 +112,7 @@ if prof is not None:
     import io, pstats
     buf = io.StringIO()
     pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+    pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(70)
     print(buf.getvalue())
 print("config-4 training step, %d rays (%dx%d grid) x (%d+%d): %.2f ms (host enqueue %.2f ms) -> %.1f k rays/s; fwd+bwd MLP work %.1f TFLOP/s; loss %.4f; peak mem %.1f GB"
       % (R, side, side, NC, NI, dt * 1e3, t_host * 1e3, R / dt / 1e3, 3 * pts * 1.233152e6 / dt / 1e12, float(l), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
