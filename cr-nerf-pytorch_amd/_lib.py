@@ -25,6 +25,7 @@ EXPORTS = [
     "crnerf_ray_directions_f32", "crnerf_rays_from_directions_f32", "crnerf_generate_rays_f32",
     "crnerf_encoder_workspace_bytes", "crnerf_encoder_forward_f32",
     "crnerf_crossray_backward_workspace_bytes", "crnerf_crossray_decode_backward_f32", "crnerf_crossray_decode_sharded_f32",
+    "crnerf_crossray_decode_backward_sharded_f32",
     "crnerf_packed_mlp_h2_bytes", "crnerf_pack_mlp_weights_h2", "crnerf_mlp_forward_f32h2", "crnerf_render_rays_f32h2",
     "crnerf_render_rays_f32x3_repair", "crnerf_mlp_forward_f32x3_repair",
     "crnerf_render_rays_train_f32h2", "crnerf_render_rays_train_f32x3_repair", "crnerf_packed_mlp_t_h2_bytes", "crnerf_pack_mlp_weights_t_h2", "crnerf_mlp_backward_h2_f32", "crnerf_pack_mlp_weights_h2_async", "crnerf_pack_h2_status",
@@ -190,6 +191,7 @@ def load():
             "crnerf_crossray_backward_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
             "crnerf_crossray_decode_backward_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, i64, vp, vp, vp, pp, vp]),
             "crnerf_crossray_decode_sharded_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, i32, vp, f64, vp, vp, i64, vp]),
+            "crnerf_crossray_decode_backward_sharded_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, i64, vp, vp, vp, pp, i32, vp, f64, vp, vp]),
             "crnerf_crossray_decode_f32": (ctypes.c_int, [vp, i64, vp, i64, pp, vp, vp, i64, vp]),
             "crnerf_decoder_content_backward_workspace_bytes": (ctypes.c_size_t, [i64]),
             "crnerf_decoder_content_backward_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp]),

@@ -606,6 +606,79 @@ class EncoderFn(torch.autograd.Function):
         return (d_img.view(ctx.image_shape) if d_img is not None else None,) + _param_grads(ctx, w, grads)
 
 
+class DecodeShardedFn(torch.autograd.Function):
+    """style_net.forward in ray-parallel training with the content grid SHARDED (round 6): every rank decodes its own block of pixels
+    -- the forward is parallel.decode_sharded's three phases around two all-reduces (64 channel sums, 1,024 Gram sums) -- and the RGB planes are
+    all-gathered (12 B per pixel), because what consumes the image (the loss, the encoder passes) is replicated.  Backward: every rank holds
+    dL/d(image), takes its pixels' columns and runs crnerf_crossray_decode_backward_sharded_f32's three phases around two all-reduces (the
+    gradient of the folded affine: 320 floats; the column sums of the centred chain's input gradient: 64 floats).  d_content stays local (it feeds
+    this rank's renderer: no feature all-gather any more), d_style and every gradient except the content chain's three convolutions come out
+    whole on every rank; those six tensors are this rank's part and leave multiplied by the group size, so that the AVERAGE that
+    sync_ray_parallel_gradients takes over replicated modules is the sum of the parts (cf. BandEncoderFn)."""
+
+    @staticmethod
+    def forward(ctx, xp, sp, group, n_total, *w):
+        import torch.distributed as dist
+        from .parallel import _timed
+        ws = dist.get_world_size(group)
+        dev = xp.device
+        xchg = torch.zeros(64 + 1024, dtype=torch.float32, device=dev)
+        count = float(n_total)
+        ops.crossray_decode_sharded(xp, sp, w, 0, xchg, count)
+        _timed("allreduce_channel_sums_64f", lambda: dist.all_reduce(xchg[:64], group=group), dev)
+        ops.crossray_decode_sharded(xp, sp, w, 1, xchg, count)
+        _timed("allreduce_gram_1024f", lambda: dist.all_reduce(xchg[64:], group=group), dev)
+        rgb_local = ops.crossray_decode_sharded(xp, sp, w, 2, xchg, count)
+        full = torch.empty(ws * 3, xp.shape[0], dtype=torch.float32, device=dev)
+        _timed("allgather_rgb_12B_per_pixel", lambda: dist.all_gather_into_tensor(full, rgb_local.contiguous(), group=group), dev)
+        ctx.save_for_backward(xp, sp, xchg, *w)
+        ctx.group, ctx.count, ctx.rank, ctx.ws = group, count, dist.get_rank(group), ws
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(t) for t in w] if _DEFER_ON[0] else None)
+        return full.view(ws, 3, xp.shape[0]).permute(1, 0, 2).reshape(3, ws * xp.shape[0])
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        import torch.distributed as dist
+        from .parallel import _timed
+        xp, sp, xchg, *w = ctx.saved_tensors
+        n = xp.shape[0]
+        d_local = d_rgb[:, ctx.rank * n:(ctx.rank + 1) * n].contiguous()
+        xb = torch.zeros(384, dtype=torch.float32, device=xp.device)
+        st = ops.crossray_decode_backward_sharded(xp, sp, w, d_local, 0, xchg, ctx.count, xb)
+        _timed("allreduce_affine_gradient_320f", lambda: dist.all_reduce(xb[:320], group=ctx.group), xp.device)
+        ops.crossray_decode_backward_sharded(xp, sp, w, d_local, 1, xchg, ctx.count, xb, st)
+        _timed("allreduce_column_sums_64f", lambda: dist.all_reduce(xb[320:], group=ctx.group), xp.device)
+        _, dx, ds, grads = ops.crossray_decode_backward_sharded(xp, sp, w, d_local, 2, xchg, ctx.count, xb, st)
+        grads = [g * float(ctx.ws) if 8 <= i <= 13 else g for i, g in enumerate(grads)]
+        return (dx, ds, None, None) + _param_grads(ctx, w, grads)
+
+
+class ContentDecodeShardedFn(torch.autograd.Function):
+    """style_net.forward(content, None, type="content") on a ray-sharded grid: per pixel, no statistics -- decode the local pixels, all-gather RGB;
+    backward on the local pixels, the two parameter gradients (sums over pixels) leave multiplied by the group size (see DecodeShardedFn)."""
+
+    @staticmethod
+    def forward(ctx, xp, rgb_w, rgb_b, group, all_weights):
+        import torch.distributed as dist
+        from .parallel import _timed
+        ws = dist.get_world_size(group)
+        out = ops.crossray_decode(xp, None, all_weights)          # planar [3, n_local]
+        full = torch.empty(ws * 3, xp.shape[0], dtype=torch.float32, device=xp.device)
+        _timed("allgather_rgb_12B_per_pixel", lambda: dist.all_gather_into_tensor(full, out.contiguous(), group=group), xp.device)
+        ctx.save_for_backward(xp, rgb_w, out)
+        ctx.w_shape, ctx.rank, ctx.ws = rgb_w.shape, dist.get_rank(group), ws
+        ctx.defer, ctx.leaves = _DEFER_ON[0], ([_leaf_of(rgb_w), _leaf_of(rgb_b)] if _DEFER_ON[0] else None)
+        return full.view(ws, 3, xp.shape[0]).permute(1, 0, 2).reshape(3, ws * xp.shape[0])
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        xp, rgb_w, out = ctx.saved_tensors
+        n = xp.shape[0]
+        dx, dw, db = ops.decoder_content_backward(xp, rgb_w, out, d_rgb[:, ctx.rank * n:(ctx.rank + 1) * n].contiguous())
+        gw, gb = _param_grads(ctx, (rgb_w, db), (dw.view(ctx.w_shape) * float(ctx.ws), db * float(ctx.ws)))
+        return dx, gw, gb, None, None
+
+
 class BandEncoderFn(torch.autograd.Function):
     """encoder_sameoutputsize.forward on a re-rendered image in ray-parallel training (round 6): every rank of `group` holds the whole
     image (the decoder is replicated) but runs the seven layers on ITS band of rows only (+ a 12-row halo where the band is cut inside the image:

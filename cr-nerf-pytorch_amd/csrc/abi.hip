@@ -594,6 +594,25 @@ int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const 
   return launch_crossray_decode_backward(d, d_rgb, (long)d_plane_stride, (float*)workspace, d_content, d_style, grads, (hipStream_t)stream);
 }
 
+int crnerf_crossray_decode_backward_sharded_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* w, const float* d_rgb,
+                                                int64_t d_plane_stride, void* workspace, float* d_content, float* d_style, float* const* grads, int phase,
+                                                const float* fwd_xchg, double count_global, float* xb, void* stream) {
+  REQUIRE(content, "content"); REQUIRE(style, "style"); REQUIRE(w, "weights"); REQUIRE(d_rgb, "d_rgb"); REQUIRE(workspace, "workspace");
+  REQUIRE(d_content, "d_content"); REQUIRE(d_style, "d_style"); REQUIRE(grads, "grads"); REQUIRE(fwd_xchg, "fwd_xchg"); REQUIRE(xb, "xb");
+  if (HW <= 0 || HWs <= 0) return set_error(CRNERF_ERR_SHAPE, "crossray_decode_backward_sharded: empty grid (every rank must hold pixels)");
+  if (phase < 0 || phase > 2) return set_error(CRNERF_ERR_CONFIG, "crossray_decode_backward_sharded: phase must be 0, 1 or 2");
+  for (int i = 0; i < CRNERF_DECODER_TENSORS; ++i)
+    if (!w[i] || !grads[i]) return set_error(CRNERF_ERR_NULL, "crossray_decode_backward_sharded: a weight or gradient pointer is NULL");
+  DecodeArgs d;
+  d.content = content; d.HW = (long)HW; d.style = style; d.HWs = (long)HWs;
+  d.snet = CnnTensors{w[0], w[1], w[2], w[3], w[4], w[5]}; d.snet_fc_w = w[6]; d.snet_fc_b = w[7];
+  d.cnet = CnnTensors{w[8], w[9], w[10], w[11], w[12], w[13]}; d.cnet_fc_w = w[14]; d.cnet_fc_b = w[15];
+  d.lin = FoldTensors{w[16], w[17], w[18], w[19], w[20], w[21]};
+  d.workspace = nullptr; d.rgb = nullptr; d.plane_stride = 0;
+  return launch_crossray_decode_backward_sharded(d, d_rgb, (long)d_plane_stride, (float*)workspace, d_content, d_style, grads, phase, fwd_xchg, count_global, xb,
+                                                 (hipStream_t)stream);
+}
+
 int crnerf_crossray_apply_f32(const float* x, int64_t HW, const float* affine, float* rgb, int64_t plane_stride, void* stream) {
   if (HW == 0) return 0;
   REQUIRE(x, "x"); REQUIRE(affine, "affine"); REQUIRE(rgb, "rgb");

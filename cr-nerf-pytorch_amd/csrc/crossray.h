@@ -41,5 +41,9 @@ int launch_crossray_decode_sharded(const DecodeArgs& d, int phase, float* xchg, 
 size_t crossray_backward_workspace_floats(long HW, long HWs);
 int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
                                     float* d_style, float* const* grads, hipStream_t stream);
+// the same in three phases around two all-reduces, for a ray-sharded content grid (crossray.hip); phase -1 = the one-GPU call above
+int launch_crossray_decode_backward_sharded(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
+                                            float* d_style, float* const* grads, int phase, const float* fwd_xchg, double count_global, float* xb,
+                                            hipStream_t stream);
 
 }  // namespace crnerf

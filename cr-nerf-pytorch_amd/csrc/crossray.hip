@@ -1177,12 +1177,13 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_chain_mfma_kernel(ChainJob j0,
 }
 
 // dst[px][c] (+)= dxc[px][c] + (dmean[c] - colsum[c]) / P
+// count: the pixels the mean was taken over (P, or the GLOBAL pixel count of a ray-sharded grid: colsum is then the global column sum)
 __global__ void dec_bwd_finish_kernel(float* __restrict__ dst, const float* __restrict__ dxc, const float* __restrict__ dmean,
-                                      const float* __restrict__ colsum, long P, int accumulate) {
+                                      const float* __restrict__ colsum, long P, int accumulate, float count) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * 64) return;
   const int c = (int)(idx & 63);
-  const float v = dxc[idx] + (dmean[c] - colsum[c]) / (float)P;
+  const float v = dxc[idx] + (dmean[c] - colsum[c]) / count;
   dst[idx] = accumulate ? dst[idx] + v : v;
 }
 
@@ -1202,7 +1203,7 @@ size_t crossray_backward_workspace_floats(long HW, long HWs) {
   size_t n = CROSSRAY_WORKSPACE_BYTES / 4;                       // forward decode workspace (stats live here)
   n += (size_t)3 * HW + 4 * (size_t)HW;                          // scratch rgb, d_pre[HW,4]
   n += (size_t)P * (64 + 128 + 64 + 128 + 64 + 32 + 64);         // xc, h1, h2, d1, d2, d3, dxc
-  n += 4096 + 2 * 2048 + 1024;                                   // dA/dv, dm, S/dg buffers, mean terms, column sums
+  n += 4096 + 2 * 2048 + 1024 + 1152;                            // dA/dv, dm, S/dg buffers, mean terms, column sums, the sharded backward's copy of the forward's sums
   WgradSpec sp[6];
   dec_conv_wgrad_specs(HW, HWs, sp);
   size_t wg = wgrad_batch_ws_floats(sp, 6);
@@ -1213,7 +1214,26 @@ size_t crossray_backward_workspace_floats(long HW, long HWs) {
 
 int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
                                     float* d_style, float* const* grads, hipStream_t stream) {
+  return launch_crossray_decode_backward_sharded(d, d_rgb, d_plane_stride, workspace, d_content, d_style, grads, -1, nullptr, (double)d.HW, nullptr, stream);
+}
+
+// Ray-sharded backward (round 6; the training twin of launch_crossray_decode_sharded): the content grid is this rank's block of pixels, the style
+// grid is replicated.  What crosses pixels in the backward are the same two kinds of sums as in the forward -- the gradient of the folded affine
+// (dA [3,64], dv [3]: sums over pixels of d_pre (x) x) and the column sums of the centred chain's input gradient -- so the pass is cut at them:
+//   phase 0: the forward's statistics from the GLOBAL sums `fwd_xchg` (channel sums | Gram sums, as the forward's all-reduces left them), d_pre,
+//            the direct path of x, dA | dv of the LOCAL pixels -> xb[0:256] | xb[256:320]                       | all-reduce xb[0:320]
+//   phase 1: everything that is replicated arithmetic on global quantities (small matrices, both fc layers), the conv chains (local content
+//            pixels, the style grid), the six conv weight gradients, the column sums of dxc: content -> xb[320:384]  | all-reduce xb[320:384]
+//   phase 2: the centring terms with the global count and the global column sums.
+// grads: the content chain's six conv gradients (grads[8..13]) are this rank's PART (sums over its pixels); every other gradient and d_style are
+// computed from all-reduced quantities or from the replicated style grid and are the WHOLE gradient on every rank.  phase -1: one GPU, one call.
+int launch_crossray_decode_backward_sharded(const DecodeArgs& d, const float* d_rgb, long d_plane_stride, float* workspace, float* d_content,
+                                            float* d_style, float* const* grads, int phase, const float* fwd_xchg, double count_global, float* xb,
+                                            hipStream_t stream) {
   if (d.HW <= 0 || d.HWs <= 0 || !d.style) return set_error(-2, "crossray_decode_backward: needs a content and a style grid");
+  if (phase >= 0 && (!fwd_xchg || !xb || !(count_global > 0))) return set_error(-2, "crossray_decode_backward_sharded: needs the forward's global sums, the exchange buffer and the global pixel count");
+  const bool all = phase < 0;
+  const float inv_count = (float)(1.0 / count_global);
   const long HW = d.HW, HWs = d.HWs;
   float* p = workspace;
   float* fwd_ws = p; p += CROSSRAY_WORKSPACE_BYTES / 4;
@@ -1228,6 +1248,8 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   float* d3[2] = {take(HW * 32), take(HWs * 32)};
   float* dxc[2] = {take(HW * 64), take(HWs * 64)};
   float* dA = take(256); float* dv = take(64);
+  float* fx = take(64 + 1024 + 64);                  // sharded: a scratch copy of the forward's exchange block (phases 0 / 1 of the forward rewrite theirs)
+  if (!all) { dA = xb; dv = xb + 256; }              // the all-reduced buffers ARE the operands of phase 1
   float* dm_s = take(1024); float* dm_c = take(1024);
   float* S_s = take(2048); float* S_c = take(2048);
   float* dmean_c = take(64); float* dmean_s = take(64); float* cs_c = take(64); float* cs_s = take(64);
@@ -1236,22 +1258,41 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   // 0. forward again: stats + affine into fwd_ws
   DecodeArgs f = d;
   f.workspace = fwd_ws; f.rgb = rgb; f.plane_stride = HW;
-  if (int rc = launch_crossray_decode(f, stream)) return rc;
   float* st = fwd_ws + WS_STATS;
-  // 1. d_pre, direct dx; 2. dA, dv
-  hipLaunchKernelGGL(dec_bwd_pre_kernel, dim3((unsigned)((HW * 4 + 255) / 256)), dim3(256), 0, stream, d.content, HW, st + ST_AFFINE, d_rgb,
-                     d_plane_stride, d_pre, d_content);
-  wgrad(d_pre, 4, 3, d.content, 64, 64, dA, 64, dv, HW, wws, stream);
+  if (all || phase == 0) {
+    if (all) {
+      if (int rc = launch_crossray_decode(f, stream)) return rc;
+    } else {
+      // the sharded forward's three phases with the GLOBAL sums in place of what its all-reduces delivered: phase 0 / 1 write this rank's local
+      // sums into the block they are given (a scratch copy), phase 1 / 2 read the global channel sums / Gram from where they are handed over
+      if (int rc = launch_crossray_decode_sharded(f, 0, fx + 1088, count_global, stream)) return rc;          // (style partial sums into the workspace)
+      if (hipMemcpyAsync(fx, fwd_xchg, 64 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return set_error(-10, "hipMemcpyAsync failed");
+      if (int rc = launch_crossray_decode_sharded(f, 1, fx, count_global, stream)) return rc;                 // content mean (global), style Gram; fx[64:] = local Gram (unused)
+      if (hipMemcpyAsync(fx + 64, fwd_xchg + 64, 1024 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return set_error(-10, "hipMemcpyAsync failed");
+      if (hipMemcpyAsync(st + ST_CGRAM, fwd_xchg + 64, 1024 * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return set_error(-10, "hipMemcpyAsync failed");
+      if (int rc = launch_crossray_decode_sharded(f, 2, fx, count_global, stream)) return rc;                 // both fc layers, fold -> the affine
+    }
+    // 1. d_pre, direct dx; 2. dA, dv
+    hipLaunchKernelGGL(dec_bwd_pre_kernel, dim3((unsigned)((HW * 4 + 255) / 256)), dim3(256), 0, stream, d.content, HW, st + ST_AFFINE, d_rgb,
+                       d_plane_stride, d_pre, d_content);
+    wgrad(d_pre, 4, 3, d.content, 64, 64, dA, 64, dv, HW, wws, stream);
+    if (!all) return check_launch("crossray_decode_backward phase 0");
+  }
+  if (phase == 2) {
+    hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HW * 64 + 255) / 256)), dim3(256), 0, stream, d_content, dxc[0], dmean_c, xb + 320, HW, 1, (float)count_global);
+    hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HWs * 64 + 255) / 256)), dim3(256), 0, stream, d_style, dxc[1], dmean_s, cs_s, HWs, 0, (float)HWs);
+    return check_launch("crossray_decode_backward phase 2");
+  }
   // 3. small matrices
   SmallBwd sb{dA, dv, st + ST_CMEAN, st + ST_SMEAN, st + ST_SMAT, st + ST_CMAT, d.lin,
               grads[16], grads[17], grads[18], grads[19], grads[20], grads[21], dm_s, dm_c, dmean_c, dmean_s};
   hipLaunchKernelGGL(dec_bwd_small_kernel, dim3(1), dim3(256), 0, stream, sb);
   // 4. fc layers: snet = grads[6], [7]; cnet = grads[14], [15]
   FcBwd fs{dm_s, st + ST_SGRAM, (float)(1.0 / (double)HWs), d.snet_fc_w, grads[6], grads[7], S_s};
-  FcBwd fc{dm_c, st + ST_CGRAM, (float)(1.0 / (double)HW), d.cnet_fc_w, grads[14], grads[15], S_c};
+  FcBwd fc{dm_c, st + ST_CGRAM, inv_count, d.cnet_fc_w, grads[14], grads[15], S_c};
   hipLaunchKernelGGL(dec_bwd_fc_kernel, dim3(256, 2), dim3(256), 0, stream, fs, fc);
   // S = (dG + dG^T) / count with dG = dg.view(32,32): G = G_sum / count, G_sum = sum_px h3 h3^T
-  hipLaunchKernelGGL(dec_bwd_sym_kernel, dim3(2), dim3(256), 0, stream, S_s, (float)(1.0 / (double)HWs), S_c, (float)(1.0 / (double)HW));
+  hipLaunchKernelGGL(dec_bwd_sym_kernel, dim3(2), dim3(256), 0, stream, S_s, (float)(1.0 / (double)HWs), S_c, inv_count);
   // 5. conv chains
   const int nb_c = (int)((HW + 63) / 64 < 1024 ? (HW + 63) / 64 : 1024), nb_s = (int)((HWs + 63) / 64 < 1024 ? (HWs + 63) / 64 : 1024);
   ChainJob jc{d.content, HW, st + ST_CMEAN, d.cnet, S_c, xc[0], h1[0], h2[0], d1[0], d2[0], d3[0], dxc[0], nb_c};
@@ -1286,10 +1327,11 @@ int launch_crossray_decode_backward(const DecodeArgs& d, const float* d_rgb, lon
   // 7. centering terms
   SumJob s0{dxc[0], HW, sum_ws, chansum_blocks(HW)}, s1{dxc[1], HWs, sum_ws + 64 * CROSSRAY_SUM_BLOCKS, chansum_blocks(HWs)};
   hipLaunchKernelGGL(chansum_partial_kernel, dim3(s0.nblk + s1.nblk), dim3(SUM_THREADS), 0, stream, s0, s1);
-  RedJob r0{s0.partial, s0.nblk, cs_c}, r1{s1.partial, s1.nblk, cs_s};
+  RedJob r0{s0.partial, s0.nblk, all ? cs_c : xb + 320}, r1{s1.partial, s1.nblk, cs_s};
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1, 2), dim3(RED_THREADS), 0, stream, r0, r1, 64);
-  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HW * 64 + 255) / 256)), dim3(256), 0, stream, d_content, dxc[0], dmean_c, cs_c, HW, 1);
-  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HWs * 64 + 255) / 256)), dim3(256), 0, stream, d_style, dxc[1], dmean_s, cs_s, HWs, 0);
+  if (!all) return check_launch("crossray_decode_backward phase 1");       // (the content column sums wait for their all-reduce)
+  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HW * 64 + 255) / 256)), dim3(256), 0, stream, d_content, dxc[0], dmean_c, cs_c, HW, 1, (float)HW);
+  hipLaunchKernelGGL(dec_bwd_finish_kernel, dim3((unsigned)((HWs * 64 + 255) / 256)), dim3(256), 0, stream, d_style, dxc[1], dmean_s, cs_s, HWs, 0, (float)HWs);
   return check_launch("crossray_decode_backward");
 }
 

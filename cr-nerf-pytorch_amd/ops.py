@@ -868,6 +868,26 @@ def crossray_decode_sharded(content_pm, style_pm, weights, phase, xchg, count_gl
     return rgb
 
 
+def crossray_decode_backward_sharded(content_pm, style_pm, weights, d_rgb_local, phase, fwd_xchg, count_global, xb, state=None):
+    """One phase (0, 1, 2) of the ray-sharded decoder backward (crnerf_crossray_decode_backward_sharded_f32).  state: None for phase 0 -- the call
+    allocates (workspace, d_content, d_style, grads) and returns it; pass it back for phases 1 and 2.  The caller all-reduces xb[0:320] after
+    phase 0 and xb[320:384] after phase 1.  After phase 2: d_content [HW_local,64], d_style [HWs,64], grads (22; [8..13] are this rank's part)."""
+    lib = _lib.load()
+    x, s, d_rgb = _f32c(content_pm, "content"), _f32c(style_pm, "style"), _f32c(d_rgb_local, "d_rgb")
+    HW, HWs = x.shape[0], s.shape[0]
+    ws_t = [_f32c(t.detach(), "decoder weight") for t in weights]
+    if state is None:
+        state = (torch.empty(lib.crnerf_crossray_backward_workspace_bytes(HW, HWs), dtype=torch.uint8, device=x.device), torch.empty_like(x),
+                 torch.empty_like(s), [torch.empty_like(t) for t in ws_t])
+    work, dx, ds, grads = state
+    _lib.check(lib.crnerf_crossray_decode_backward_sharded_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(s), HWs, _lib.ptr_array(ws_t, "decoder weight"),
+                                                               _lib.dev_ptr(d_rgb), d_rgb.stride(0), ctypes.c_void_p(work.data_ptr()), _lib.dev_ptr(dx),
+                                                               _lib.dev_ptr(ds), _lib.ptr_array(grads, "decoder grad"), int(phase), _lib.dev_ptr(fwd_xchg),
+                                                               float(count_global), _lib.dev_ptr(xb), _lib.stream_ptr()),
+               "crnerf_crossray_decode_backward_sharded_f32")
+    return state
+
+
 # ---------------------------------------------------------------- training-side neighbours (SURVEY 8f N4)
 LOSS_KEYS = ("kl_a", "rec_a_random", "c_l", "content_constraint", "r_ms", "r_md", "f_l")
 

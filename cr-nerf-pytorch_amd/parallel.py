@@ -342,6 +342,19 @@ def encode_banded(enc, image, group=None):
     return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)
 
 
+def decode_sharded_train(net, feature_local, style_feature, n_total, group=None, content_only=False):
+    """style_net.forward for training on a ray-sharded feature grid (autograd.DecodeShardedFn / ContentDecodeShardedFn): feature_local [n_local,64]
+    (this rank's block, every rank the same n_local), style_feature [1,64,h,w] replicated (ignored with content_only) -> RGB planar [3, n_total]
+    on every rank, differentiable; the feature gradient stays local."""
+    from .autograd import ContentDecodeShardedFn, DecodeShardedFn
+    xp = feature_local.contiguous()
+    if content_only:
+        w, b = net.decoder.rgb_tensors()
+        return ContentDecodeShardedFn.apply(xp, w, b, group, net.decoder_tensors())
+    sp = style_feature.permute(0, 2, 3, 1).reshape(-1, style_feature.shape[1]).contiguous()
+    return DecodeShardedFn.apply(xp, sp, group, int(n_total), *net.decoder_tensors())
+
+
 def sync_ray_parallel_gradients(sharded_modules, replicated_modules, group=None):
     """After loss.backward() of a ray-parallel step: parameters of the sharded part (the MLPs) hold partial sums over this
     rank's rays -> SUM over ranks; parameters of the replicated part (decoder, encoders, mask network) hold the full

@@ -174,6 +174,7 @@ class TrainingSystem:
         self._fused_grad_override = None
         # ray-parallel mode: the encoder passes over the re-rendered images run as row bands, one per rank (round 6); False = replicated, as up to round 5
         self.shard_encoders = True
+        self.shard_decodes = True               # ... and the four decodes over each rank's own pixels (DecodeShardedFn); False: features gathered, decodes replicated
         self.after_render = None                # callable(results) between the render (+ feature gather) and the decodes, or None
         import os
         # the decode / encoder chains of a step side by side on four streams (forward's comment); False / CRNERF_BRANCH_STREAMS=0: one stream
@@ -238,13 +239,22 @@ class TrainingSystem:
     def decode(self, results, type, **kwargs):                                              # :127-149
         feature = results['feature_' + type] if type != 'content' else results['feature_fine']
         H, W = int(kwargs['H']), int(kwargs['W'])
-        grid = feature.t().reshape(1, feature.shape[-1], H, W)                              # 'n1 n3 -> n3 n1' then ' n3 (h w) -> 1 n3 h w'
+        grid = None if getattr(self, "_sharded_decode", None) else feature.t().reshape(1, feature.shape[-1], H, W)   # 'n1 n3 -> n3 n1' then ' n3 (h w) -> 1 n3 h w'
+        sharded = getattr(self, "_sharded_decode", None)      # ray-parallel training: (group, rays of the whole batch) -- `feature` is this rank's block
         if type == "content":                                                               # decoder only, no appearance transfer (:145-148)
-            results['rgb_content_img'] = self.models['decoder'](grid, None, type="content")
+            if sharded:
+                from .parallel import decode_sharded_train
+                results['rgb_content_img'] = decode_sharded_train(self.models['decoder'], feature, None, sharded[1], sharded[0], content_only=True).view(1, 3, H, W)
+            else:
+                results['rgb_content_img'] = self.models['decoder'](grid, None, type="content")
             results['rgb_content'] = None
             return results
         style = kwargs['a_embedded_random'] if type == "fine_random" else kwargs['a_embedded_from_img']
-        rgbs_pred = self.models['decoder'](grid, style)
+        if sharded:
+            from .parallel import decode_sharded_train
+            rgbs_pred = decode_sharded_train(self.models['decoder'], feature, style, sharded[1], sharded[0]).view(1, 3, H, W)
+        else:
+            rgbs_pred = self.models['decoder'](grid, style)
         if type == "fine":
             results['rgb_fine_img'] = rgbs_pred
         if type != "fine_random":                                                           # fine_random is rearranged later (:221)
@@ -289,12 +299,20 @@ class TrainingSystem:
                 results[k] += [v]
         for k, v in results.items():
             results[k] = v[0] if len(v) == 1 else torch.cat(v, 0)    # (one chunk is the rule here: cat of a single tensor would copy it)
-        if self.ray_group is not False:      # the decoder is cross-ray: every rank gets the whole feature grid (weights_* / depth_* stay local)
-            for k in ("feature_coarse", "feature_fine"):
-                if k in results:
-                    results[k] = gather_rays(results[k], B, self.ray_group)
-            if "feature_fine_random" in results:
-                results["feature_fine_random"] = results["feature_fine"]
+        self._sharded_decode = None
+        if self.ray_group is not False:
+            import torch.distributed as dist
+            ws = dist.get_world_size(self.ray_group)
+            if self.shard_decodes and self.training and torch.is_grad_enabled() and B % ws == 0 and B // ws > 0:
+                # round 6: the decodes stay sharded -- every rank decodes its own pixels around the two all-reduces of the decoder's statistics and
+                # RGB is all-gathered (parallel.decode_sharded_train); the feature rows are NOT gathered, their gradient never leaves the rank
+                self._sharded_decode = (self.ray_group, B)
+            else:      # the decoder is cross-ray: every rank gets the whole feature grid (weights_* / depth_* stay local)
+                for k in ("feature_coarse", "feature_fine"):
+                    if k in results:
+                        results[k] = gather_rays(results[k], B, self.ray_group)
+                if "feature_fine_random" in results:
+                    results["feature_fine_random"] = results["feature_fine"]
         if self.after_render is not None:      # measurement hook (bench.py --workload configs3): the boundary between the ray-sharded part and the rest
             self.after_render(results)
         # The four decodes (:205-218) and the three encoder passes over the re-rendered images (:219, :223-224) are four independent chains of small

@@ -400,6 +400,16 @@ size_t crnerf_crossray_backward_workspace_bytes(int64_t HW, int64_t HWs);
 int crnerf_crossray_decode_backward_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
                                         const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_style,
                                         float* const* grads, void* stream);
+/* The same backward for a content grid that is ray-sharded over the ranks of a group (round 6; the training twin of
+ * crnerf_crossray_decode_sharded_f32): three phases around two all-reduces, driven by the caller (parallel.DecodeShardedFn).
+ *   fwd_xchg[64 + 1024] : the forward's GLOBAL channel sums and Gram sums (what its two all-reduces delivered); count_global = the global pixel count
+ *   xb[384]             : exchange buffer.  phase 0 leaves this rank's dA [3,64] (ld 64) | dv [3] in xb[0:256] | xb[256:320] -> all-reduce xb[0:320];
+ *                         phase 1 leaves the column sums of the centred chain's input gradient in xb[320:384] -> all-reduce; phase 2 finishes.
+ * The workspace (crnerf_crossray_backward_workspace_bytes(HW, HWs), HW = this rank's pixels) carries the state between the phases.  grads[8..13] (the
+ * content chain's three convolutions) come out as this rank's PART -- sums over its pixels; every other gradient and d_style are whole on every rank. */
+int crnerf_crossray_decode_backward_sharded_f32(const float* content, int64_t HW, const float* style, int64_t HWs, const float* const* weights,
+                                                const float* d_rgb, int64_t d_plane_stride, void* workspace, float* d_content, float* d_style,
+                                                float* const* grads, int phase, const float* fwd_xchg, double count_global, float* xb, void* stream);
 /* Backward of the decoder-only call style_net.forward(content, None, type="content") (linearStyleTransfer.py:285-287;
  * forward = crnerf_crossray_decode_f32 with style == NULL): rgb = sigmoid(W x + b) with W = decoder.feat_2_rgb_list.0.weight
  * [3,64].  rgb / d_rgb planar with their strides -> d_content[HW,64], d_w[3,64], d_b[3]. */

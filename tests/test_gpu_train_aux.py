@@ -233,6 +233,70 @@ def test_encoder_row_bands_add_up_to_the_whole_image(H, W, ws):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("hw,ws", [(32 * 32, 2), (96 * 64, 4), (40 * 24, 8)])
+def test_sharded_decoder_backward_adds_up_to_the_whole_grid(hw, ws):
+    """crnerf_crossray_decode_backward_sharded_f32 (round 6: the decodes of ray-parallel training over each rank's own pixels): `ws` ranks emulated
+    one after the other on this GPU -- the all-reduces are sums of the exchange buffers -- against the one-call backward over the whole grid:
+    d_content blocks concatenate to the whole grid's, d_style and the replicated gradients agree on every rank, the content chain's six conv
+    gradients (the ranks' parts) add up."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import ops
+    from crnerf_amd.models.linearStyleTransfer import style_net
+
+    class A:
+        nerf_out_dim, img_wh = 64, [32, 32]
+    net = style_net(A()).to(DEV)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3, 1.0, 40.0).items()})
+    w = [t.detach() for t in net.decoder_tensors()]
+    g = torch.Generator().manual_seed(hw + ws)
+    x = torch.rand(hw, 64, generator=g).to(DEV)
+    sp = torch.rand(1024, 64, generator=g).to(DEV)
+    d_rgb = torch.randn(3, hw, generator=g).to(DEV)
+    dx_ref, ds_ref, g_ref = ops.crossray_decode_backward(x, sp, w, d_rgb)
+    rgb_ref = ops.crossray_decode(x, sp, w)
+    n = hw // ws
+    blocks = [x[r * n:(r + 1) * n].contiguous() for r in range(ws)]
+    # forward, three phases, the two all-reduces as sums
+    xch = [torch.zeros(64 + 1024, device=DEV) for _ in range(ws)]
+    for r in range(ws):
+        ops.crossray_decode_sharded(blocks[r], sp, w, 0, xch[r], float(hw))
+    tot = sum(c[:64] for c in xch)
+    for c in xch:
+        c[:64] = tot
+    for r in range(ws):
+        ops.crossray_decode_sharded(blocks[r], sp, w, 1, xch[r], float(hw))
+    tot = sum(c[64:] for c in xch)
+    for c in xch:
+        c[64:] = tot
+    rgb = torch.cat([ops.crossray_decode_sharded(blocks[r], sp, w, 2, xch[r], float(hw)) for r in range(ws)], 1)
+    torch.testing.assert_close(rgb, rgb_ref, atol=2e-6, rtol=1e-5)
+    # backward, three phases
+    xb = [torch.zeros(384, device=DEV) for _ in range(ws)]
+    d_loc = [d_rgb[:, r * n:(r + 1) * n].contiguous() for r in range(ws)]
+    st = [ops.crossray_decode_backward_sharded(blocks[r], sp, w, d_loc[r], 0, xch[r], float(hw), xb[r]) for r in range(ws)]
+    tot = sum(b[:320] for b in xb)
+    for b in xb:
+        b[:320] = tot
+    for r in range(ws):
+        ops.crossray_decode_backward_sharded(blocks[r], sp, w, d_loc[r], 1, xch[r], float(hw), xb[r], st[r])
+    tot = sum(b[320:] for b in xb)
+    for b in xb:
+        b[320:] = tot
+    outs = [ops.crossray_decode_backward_sharded(blocks[r], sp, w, d_loc[r], 2, xch[r], float(hw), xb[r], st[r]) for r in range(ws)]
+
+    def close(a, b, name):
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-8, (name, float((a - b).abs().max()), float(b.abs().max()))
+    close(torch.cat([o[1] for o in outs]), dx_ref, "d_content")
+    for r, o in enumerate(outs):
+        close(o[2], ds_ref, "d_style rank %d" % r)
+        for i, (a, b) in enumerate(zip(o[3], g_ref)):
+            if not 8 <= i <= 13:
+                close(a, b, "grad %d rank %d" % (i, r))
+    for i in range(8, 14):
+        close(sum(o[3][i] for o in outs), g_ref[i], "content-chain grad %d (sum of the parts)" % i)
+
+
+@torch.no_grad()
 def test_video_frames_shard_across_ranks_without_exchange():
     """appearance_modification_video.py:224-262 through crnerf_amd.video: the frame list is cut rank-wise; the union of two
     'ranks' equals the single-rank run frame for frame (frames are independent: no collective)."""
