@@ -288,11 +288,25 @@ def dev_ptr(t, name="tensor", dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_PTR_ARRAYS = {}      # tuple of device addresses -> the ctypes array that holds them
+
+
 def ptr_array(tensors, name):
+    """HOST array of the tensors' device pointers (every `const float* const*` of the ABI).  A training step builds ~40 of them, mostly for the
+    same parameter lists (their addresses are stable: optim.FlatAdam keeps p.data a view of one flat buffer) and for gradient lists the caching
+    allocator hands back at the same addresses step after step: the arrays are kept by address tuple (round 6: 13 us -> 3 us per call; the
+    1,024-ray step is host-bound).  The tensors are validated when an array is built; a hit means the same addresses passed that before."""
+    key = tuple([t.data_ptr() for t in tensors])
+    arr = _PTR_ARRAYS.get(key)
+    if arr is not None:
+        return arr
     arr = (ctypes.c_void_p * len(tensors))()
     dev = _current_device()
     for i, t in enumerate(tensors):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.device.index != dev:
             raise _bad_tensor(t, "%s[%d]" % (name, i), torch.float32)
         arr[i] = t.data_ptr()
+    if len(_PTR_ARRAYS) >= 4096:
+        _PTR_ARRAYS.clear()
+    _PTR_ARRAYS[key] = arr
     return arr

@@ -486,6 +486,7 @@ class CompositeFn(torch.autograd.Function):
 # forward runs: pipeline.TrainingSystem switches it on around its forward unless torch DDP may be listening) the backward of these nodes hands the
 # engine None for the parameters, keeps the gradients, and ONE callback at the end of the backward pass sums them with multi-tensor adds and
 # writes / accumulates .grad.  Not for torch.autograd.grad() callers, parameter hooks or DDP's reducer: those need AccumulateGrad to run.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda dev: torch.cuda.current_stream(dev).cuda_stream)
 _DEFER_ON = [False]
 _DEFERRED = {}       # graph-task id -> {id(param): (param, [gradients])}: one entry per backward pass that has deferred something and not finished yet
 
@@ -527,18 +528,24 @@ def _defer(params, grads):
     if grads and grads[0].is_cuda:
         # the node may have run on a side stream (pipeline.TrainingSystem's branch streams: a node's backward runs on its forward's stream); the
         # end-of-pass sum runs on the stream backward() was called on and must wait for these gradients -- they never pass an AccumulateGrad
-        # node, so the engine's own end-of-pass stream synchronisation does not know them
-        ev = torch.cuda.Event()
-        ev.record()
-        pend.setdefault("__events__", []).append(ev)
+        # node, so the engine's own end-of-pass stream synchronisation does not know them.  One Stream object per distinct raw stream and pass
+        # (the raw handle is a cheap lookup; torch.cuda.current_stream() is not): the flush waits for everything enqueued on it so far
+        raw = _raw_stream(grads[0].device.index)
+        streams = pend.setdefault("__streams__", {})
+        if raw not in streams:
+            streams[raw] = torch.cuda.current_stream(grads[0].device)
 
 
 def _flush_deferred(task):
     pend = _DEFERRED.pop(task, None)
     if not pend:
         return
-    for ev in pend.pop("__events__", ()):
-        torch.cuda.current_stream().wait_event(ev)
+    side = pend.pop("__streams__", {})
+    if side:
+        cur = torch.cuda.current_stream()
+        for st in side.values():
+            if st != cur:
+                cur.wait_stream(st)
     if not pend:
         return
     with torch.no_grad():
@@ -565,10 +572,10 @@ def _leaf_of(t):
 
 def _param_grads(ctx, params, grads):
     """What a multi-use node returns for its parameters: the gradients, or -- deferred -- None for every tensor whose leaf is known (ctx.leaves)."""
-    grads = [g.view_as(t) for g, t in zip(grads, params)]
+    grads = [g if g.shape == t.shape else g.view_as(t) for g, t in zip(grads, params)]
     if not getattr(ctx, "defer", False):
         return tuple(grads)
-    keep = [(leaf, g.view(leaf.shape)) for leaf, g in zip(ctx.leaves, grads) if leaf is not None]
+    keep = [(leaf, g if g.shape == leaf.shape else g.view(leaf.shape)) for leaf, g in zip(ctx.leaves, grads) if leaf is not None]
     _defer([k[0] for k in keep], [k[1] for k in keep])
     return tuple(None if leaf is not None else g for leaf, g in zip(ctx.leaves, grads))
 

@@ -15,6 +15,12 @@ MLP_TENSOR_SHAPES = (
     + [(256, 256), (256,), (1, 256), (1,), (128, 283), (128,), (64, 128), (64,)])
 
 
+def _wlist(weights, name):
+    """The parameter tensors of a call as they are (fp32, contiguous: checked; no detach -- they are only asked for their address and their shape,
+    and a training step passes ~450 of them)."""
+    return [t if (t.dtype == torch.float32 and t.is_contiguous()) else _f32c(t.detach(), name) for t in weights]
+
+
 def _slots_valid(slots):
     for d, name, q in slots:
         if d.get(name) is not q:
@@ -741,7 +747,7 @@ def crossray_decode(content_pm, style_pm, weights, out=None):
     HW = x.shape[0]
     if out is None:
         out = torch.empty(3, HW, dtype=torch.float32, device=x.device)
-    arr = _lib.ptr_array([_f32c(t.detach(), "decoder weight") for t in weights], "decoder weight")
+    arr = _lib.ptr_array(_wlist(weights, "decoder weight"), "decoder weight")
     _lib.check(lib.crnerf_crossray_decode_f32(_lib.dev_ptr(x), HW, _lib.dev_ptr(s), s.shape[0] if s is not None else 0, arr,
                                               ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), out.stride(0), _lib.stream_ptr()),
                "crnerf_crossray_decode_f32")
@@ -755,7 +761,7 @@ def encoder_forward(image, weights):
     H, W = img.shape[-2], img.shape[-1]
     ws = torch.empty(lib.crnerf_encoder_workspace_bytes(H, W), dtype=torch.uint8, device=img.device)
     out = torch.empty(1024, 64, dtype=torch.float32, device=img.device)
-    arr = _lib.ptr_array([_f32c(t.detach(), "encoder weight") for t in weights], "encoder weight")
+    arr = _lib.ptr_array(_wlist(weights, "encoder weight"), "encoder weight")
     _lib.check(lib.crnerf_encoder_forward_f32(_lib.dev_ptr(img), H, W, arr, ctypes.c_void_p(ws.data_ptr()), _lib.dev_ptr(out), _lib.stream_ptr()),
                "crnerf_encoder_forward_f32")
     return out
@@ -782,7 +788,7 @@ def encoder_forward_train(image, weights):
     if img.dim() == 4:
         img = img[0]
     _, H, W = img.shape
-    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    ws = _wlist(weights, "encoder weight")
     saved = torch.empty(lib.crnerf_encoder_train_saved_bytes(H, W), dtype=torch.uint8, device=img.device)
     out = torch.empty(1024, 64, dtype=torch.float32, device=img.device)
     _lib.check(lib.crnerf_encoder_forward_train_f32(_lib.dev_ptr(img), H, W, _lib.ptr_array(ws, "encoder weight"), ctypes.c_void_p(saved.data_ptr()),
@@ -793,7 +799,7 @@ def encoder_forward_train(image, weights):
 def encoder_backward(weights, saved, hw, out, d_out, want_d_image=True):
     lib = _lib.load()
     H, W = hw
-    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    ws = _wlist(weights, "encoder weight")
     grads = [torch.empty_like(t) for t in ws]
     d_img = torch.empty(3, H, W, dtype=torch.float32, device=out.device) if want_d_image else None
     scratch = torch.empty(lib.crnerf_encoder_train_scratch_bytes(H, W), dtype=torch.uint8, device=out.device)
@@ -810,7 +816,7 @@ def encoder_forward_train_band(image_rows, h_image, row0, o0, o1, weights):
     lib = _lib.load()
     img = _f32c(image_rows, "image_rows")
     _, H, W = img.shape
-    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    ws = _wlist(weights, "encoder weight")
     saved = torch.empty(lib.crnerf_encoder_train_band_saved_bytes(H, W, o1 - o0), dtype=torch.uint8, device=img.device)
     out = torch.empty((o1 - o0) * 32, 64, dtype=torch.float32, device=img.device)
     _lib.check(lib.crnerf_encoder_forward_train_band_f32(_lib.dev_ptr(img), H, W, int(h_image), int(row0), int(o0), int(o1), _lib.ptr_array(ws, "encoder weight"),
@@ -822,7 +828,7 @@ def encoder_backward_band(weights, saved, hw, h_image, row0, o0, o1, out, d_out,
     """crnerf_encoder_backward_band_f32 -> (this band's part of the 14 weight gradients, d_image_rows [3,H,W] or None)."""
     lib = _lib.load()
     H, W = hw
-    ws = [_f32c(t.detach(), "encoder weight") for t in weights]
+    ws = _wlist(weights, "encoder weight")
     grads = [torch.empty_like(t) for t in ws]
     d_img = torch.empty(3, H, W, dtype=torch.float32, device=out.device) if want_d_image else None
     scratch = torch.empty(lib.crnerf_encoder_train_band_scratch_bytes(H, W, o1 - o0), dtype=torch.uint8, device=out.device)
@@ -838,7 +844,7 @@ def crossray_decode_backward(content_pm, style_pm, weights, d_rgb):
     lib = _lib.load()
     x, s, d_rgb = _f32c(content_pm, "content"), _f32c(style_pm, "style"), _f32c(d_rgb, "d_rgb")
     HW, HWs = x.shape[0], s.shape[0]
-    ws_t = [_f32c(t.detach(), "decoder weight") for t in weights]
+    ws_t = _wlist(weights, "decoder weight")
     grads = [torch.empty_like(t) for t in ws_t]
     dx, ds = torch.empty_like(x), torch.empty_like(s)
     work = torch.empty(lib.crnerf_crossray_backward_workspace_bytes(HW, HWs), dtype=torch.uint8, device=x.device)
@@ -857,7 +863,7 @@ def crossray_decode_sharded(content_pm, style_pm, weights, phase, xchg, count_gl
     n = content_pm.shape[0]
     x = _f32c(content_pm, "content") if n else None
     ws = crossray_workspace(s.device)
-    arr = _lib.ptr_array([_f32c(t.detach(), "decoder weight") for t in weights], "decoder weight")
+    arr = _lib.ptr_array(_wlist(weights, "decoder weight"), "decoder weight")
     if phase == 2 and rgb is None:
         rgb = torch.empty(3, n, dtype=torch.float32, device=s.device)
     _lib.check(lib.crnerf_crossray_decode_sharded_f32(_lib.dev_ptr(x), n, _lib.dev_ptr(s), s.shape[0], arr, int(phase), _lib.dev_ptr(xchg),
@@ -875,7 +881,7 @@ def crossray_decode_backward_sharded(content_pm, style_pm, weights, d_rgb_local,
     lib = _lib.load()
     x, s, d_rgb = _f32c(content_pm, "content"), _f32c(style_pm, "style"), _f32c(d_rgb_local, "d_rgb")
     HW, HWs = x.shape[0], s.shape[0]
-    ws_t = [_f32c(t.detach(), "decoder weight") for t in weights]
+    ws_t = _wlist(weights, "decoder weight")
     if state is None:
         state = (torch.empty(lib.crnerf_crossray_backward_workspace_bytes(HW, HWs), dtype=torch.uint8, device=x.device), torch.empty_like(x),
                  torch.empty_like(s), [torch.empty_like(t) for t in ws_t])
