@@ -350,3 +350,30 @@ def test_peer_exchange_refuses_to_start_without_peer_access(can_access):
     else:
         for r in (0, 1):
             assert "hipDeviceCanAccessPeer" in res[r] and "rank 0 (GPU 0000:01:00) has no peer access to rank 1" in res[r] and "RCCL" in res[r], res[r]
+
+
+def test_encoder_band_plan_partitions_the_image_and_the_style_grid():
+    """parallel.encoder_band_plan (round 6: the encoder passes of ray-parallel training as per-rank row bands): the owned rows partition the image,
+    the owned rows of the 32 x 32 style grid partition it, every band starts on a multiple of 4 (two 2 x 2 max-pools), brings the 12-row halo
+    wherever it is cut inside the image and none at the image's own edges, and the pooling windows of the owned outputs lie inside the owned
+    rows; images that do not split evenly have no plan (the caller runs the replicated pass)."""
+    from crnerf_amd.parallel import ENCODER_BAND_HALO, encoder_band_plan
+    for H, W, ws in ((256, 256, 8), (256, 256, 4), (128, 96, 2), (64, 64, 2), (96, 16, 8), (32, 32, 4)):
+        owned, out_rows = [], []
+        for rank in range(ws):
+            plan = encoder_band_plan(H, W, ws, rank)
+            assert plan is not None, (H, W, ws, rank)
+            Hg, row0, rows, o0, o1, n = plan
+            per = H // ws
+            r0, r1 = rank * per, (rank + 1) * per
+            assert Hg == H and n == ws and row0 % 4 == 0 and rows % 4 == 0 and rows >= 8
+            assert row0 == max(0, r0 - ENCODER_BAND_HALO) and row0 + rows == min(H, r1 + ENCODER_BAND_HALO)
+            assert row0 <= r0 and r1 <= row0 + rows
+            h4 = (H // 2) // 2
+            y0, y1 = (o0 * h4) // 32, (o1 * h4 + 31) // 32              # quarter-resolution rows the owned outputs pool over
+            assert r0 // 4 <= y0 and y1 <= -(-r1 // 4), (plan, y0, y1)
+            owned += list(range(r0, r1))
+            out_rows += list(range(o0, o1))
+        assert owned == list(range(H)) and out_rows == list(range(32))
+    for H, W, ws in ((250, 256, 8), (256, 256, 3), (24, 64, 8), (256, 4, 2), (256, 256, 1), (256, 256, 64)):
+        assert encoder_band_plan(H, W, ws, 0) is None, (H, W, ws)
