@@ -222,7 +222,7 @@ class TrainingSystem:
     def _branch_streams(self, device):
         key = torch.device(device).index
         if key not in self._streams:
-            self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
+            self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(6)]
         return self._streams[key]
 
     def _encode(self, enc, image):
@@ -270,7 +270,12 @@ class TrainingSystem:
         results = defaultdict(list)
         kwargs = {'args': hp}
         whole_img = (whole_img + 1) / 2                                                     # [-1,1] -> [0,1]  :156
-        kwargs['a_embedded_from_img'] = self.enc_a(whole_img)
+        # The photo's two consumers -- the appearance encoder and the mask network -- need nothing from the renderer and the renderer nothing
+        # from them: with branch streams they run beside it, forward and (a node's backward runs on its forward's stream) backward, where the
+        # mask network's ~90 small launches slot in between the workgroups of the MLP's big kernels.  Joined before the decodes / the loss.
+        use_br = self.branch_streams and self.training and torch.is_grad_enabled() and self.ray_group is False
+        pre = _Branches(self._branch_streams(rays.device)[4:6] if use_br else None)
+        kwargs['a_embedded_from_img'] = pre.run(0, lambda: self.enc_a(whole_img))
         if hp.encode_random:
             seen = [k for k, v in enumerate(self.embedding_a_list) if v is not None]
             kwargs['a_embedded_random'] = kwargs['a_embedded_from_img'] if len(seen) == 0 else self.embedding_a_list[self._draw(seen)]
@@ -278,9 +283,12 @@ class TrainingSystem:
             from .models.lightweight_seg import mask_at_pixels
             if hw_whole is None or (rgb_idx is None and not val_mode):
                 raise ValueError("crnerf_amd: use_mask needs the batch's rgb_idx and the full-resolution image size (hw_whole)")
-            pred_mask = self.implicit_mask(whole_img)
-            # interpolate(pred_mask, hw_whole) -> '(h w) n' -> [rgb_idx], evaluated only at the batch's pixels (all of them in val_mode)
-            kwargs['mask_embedded_from_img'] = mask_at_pixels(pred_mask, hw_whole, None if val_mode else rgb_idx.reshape(-1))
+
+            def mask_chain():
+                pred_mask = self.implicit_mask(whole_img)
+                # interpolate(pred_mask, hw_whole) -> '(h w) n' -> [rgb_idx], evaluated only at the batch's pixels (all of them in val_mode)
+                return mask_at_pixels(pred_mask, hw_whole, None if val_mode else rgb_idx.reshape(-1))
+            kwargs['mask_embedded_from_img'] = pre.run(1, mask_chain)
         kwargs["H"], kwargs["W"] = H, W
         B = rays.shape[0]
         image_id = int(ts[0]) if image_id is None else int(image_id)   # (int(ts[0]) waits for the device; the batcher knows it on the host)
@@ -313,13 +321,14 @@ class TrainingSystem:
                         results[k] = gather_rays(results[k], B, self.ray_group)
                 if "feature_fine_random" in results:
                     results["feature_fine_random"] = results["feature_fine"]
+        pre.join()                             # the appearance embedding (the decodes read it) and the mask (the loss does)
         if self.after_render is not None:      # measurement hook (bench.py --workload configs3): the boundary between the ray-sharded part and the rest
             self.after_render(results)
         # The four decodes (:205-218) and the three encoder passes over the re-rendered images (:219, :223-224) are four independent chains of small
         # kernels -- coarse | fine -> enc_cont | content -> enc_cont | fine_random -> enc_a -- each a few dozen launches that use a few CUs for a
         # few microseconds.  Round 6: one HIP stream per chain (self.branch_streams), so the chains run side by side instead of one after the
         # other, forward and -- a node's backward runs on its forward's stream -- backward.  Same kernels, same arithmetic, same results.
-        br = _Branches(self._branch_streams(rays.device) if (self.branch_streams and self.training and torch.is_grad_enabled() and self.ray_group is False) else None)
+        br = _Branches(self._branch_streams(rays.device)[:4] if use_br else None)
         br.run(0, lambda: self.decode(results, "coarse", **kwargs))
         if hp.N_importance > 0:
             br.run(1, lambda: self.decode(results, "fine", **kwargs))
