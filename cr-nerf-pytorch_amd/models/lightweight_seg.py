@@ -173,7 +173,11 @@ class Context_Guided_Network(nn.Module):
 
     # ---- the training step's fast path: the whole network as one autograd node (csrc/cgnet_chain.hip) ----
     def _chain_modules(self):
-        """(parameter list, BatchNorm list) in the order csrc/cgnet_chain.hip documents -- the module tree's own order."""
+        """(parameter list, BatchNorm list) in the order csrc/cgnet_chain.hip documents -- the module tree's own order; kept per module."""
+        from .. import ops as _ops
+        return _ops.cached_list(self, "chain_modules", self._build_chain_modules)
+
+    def _build_chain_modules(self):
         def cbp(m):
             return [m.conv.weight, m.bn.weight, m.bn.bias, m.act.weight], [m.bn]
 

@@ -98,12 +98,13 @@ class encoder_sameoutputsize(nn.Module):
     def forward(self, x):
         if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3:
             raise ValueError("encoder_sameoutputsize expects [1,3,H,W], got %s" % (tuple(x.shape),))
-        convs = (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7)
+        weights = ops.cached_list(self, "conv_tensors", lambda: [t for c in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6,
+                                                                             self.conv7) for t in (c.weight, c.bias)])
         if torch.is_grad_enabled() and (x.requires_grad or ops.any_requires_grad(self)):
             from ..autograd import EncoderFn   # training: HIP forward-with-save + HIP backward (csrc/encoder_train.hip)
-            grid = EncoderFn.apply(x.to(torch.float32).contiguous(), *[t for c in convs for t in (c.weight, c.bias)])
+            grid = EncoderFn.apply(x.to(torch.float32).contiguous(), *weights)
             return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)
-        grid = ops.encoder_forward(x, [t for c in convs for t in (c.weight, c.bias)])       # [1024,64] pixel-major
+        grid = ops.encoder_forward(x, weights)       # [1024,64] pixel-major
         return grid.view(1, 32, 32, 64).permute(0, 3, 1, 2)                                   # NCHW view, zero-copy for style_net
 
 
@@ -145,7 +146,14 @@ class style_net(nn.Module):
         return ops.crossray_decode(xp, sp, self.decoder_tensors()).view(1, 3, H, W)
 
     def decoder_tensors(self):
-        """The 22 parameter tensors in state_dict order (crnerf_crossray_decode_f32's `weights`)."""
-        mn = self.multi_net
-        return (mn.snet.conv_tensors() + [mn.snet.fc.weight, mn.snet.fc.bias] + mn.cnet.conv_tensors() + [mn.cnet.fc.weight, mn.cnet.fc.bias]
-                + mn.lin_tensors() + list(self.decoder.rgb_tensors()))
+        """The 22 parameter tensors in state_dict order (crnerf_crossray_decode_f32's `weights`): the 1 x 1 convolutions' [cout, cin, 1, 1] weights as
+        [cout, cin] views.  The Parameter objects are looked up once per module (ops.cached_list: a step asks four times, through ~140 attribute
+        lookups each); the views are made per call -- every use of the decoder keeps its own view node, so gradients accumulate use by use in
+        the same order with and without deferred accumulation (tests/test_gpu_train_aux.py: bit-equal)."""
+        def build():
+            mn = self.multi_net
+            convs = lambda net: [t for i in (0, 2, 4) for t in (net.convs[i].weight, net.convs[i].bias)]  # noqa: E731
+            rgb = self.decoder.feat_2_rgb_list[0]
+            return (convs(mn.snet) + [mn.snet.fc.weight, mn.snet.fc.bias] + convs(mn.cnet) + [mn.cnet.fc.weight, mn.cnet.fc.bias]
+                    + [mn.compress.weight, mn.compress.bias, mn.unzip.weight, mn.unzip.bias, rgb.weight, rgb.bias])
+        return [p.reshape(p.shape[0], p.shape[1]) if p.dim() == 4 else p for p in ops.cached_list(self, "decoder_params", build)]

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI: allocate outputs with torch, enqueue the HIP kernels on the
 current stream.  Every function here runs on the GPU or raises."""
 import ctypes
+import os
 
 import torch
 
@@ -40,6 +41,26 @@ def cached_params(module):
         slots = tuple((m._parameters, name, q) for m in module.modules() for name, q in m._parameters.items() if q is not None)
         c = (slots, tuple(s[2] for s in slots))
         module.__dict__["_crnerf_pcache"] = c
+    return c[1]
+
+
+_LIST_CACHE = os.environ.get("CRNERF_LIST_CACHE", "1") != "0"      # 0: measurement switch (A/B of the host time)
+
+
+def cached_list(module, key, build):
+    """A list of a module's Parameter objects (or sub-modules) in kernel order, looked up once per module and generation of the parameter slots
+    (cached_params' identity check: a swapped Parameter rebuilds it).  The training step asked for these lists ~20 times per step through 570
+    attribute lookups (round 6: the 1,024-ray step is host-bound).  Parameters and modules only -- a cached VIEW would be one autograd node
+    shared by every use in a step, and the uses' gradients would then be summed in the engine's order instead of use by use."""
+    if not _LIST_CACHE:
+        return build()
+    cached_params(module)
+    tag = module.__dict__["_crnerf_pcache"]
+    store = module.__dict__.setdefault("_crnerf_lists", {})
+    c = store.get(key)
+    if c is None or c[0] is not tag:
+        c = (tag, build())
+        store[key] = c
     return c[1]
 
 
@@ -165,7 +186,7 @@ def _mlp_tensor_list(state):
         t = state[name]
         if tuple(t.shape) != shape:
             raise ValueError("crnerf_amd: %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
-        tensors.append(_f32c(t.detach(), name))
+        tensors.append(t if (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda) else _f32c(t.detach(), name))
     return tensors
 
 

@@ -449,3 +449,25 @@ def test_deferred_gradients_leave_frozen_parameters_alone():
     assert frozen.grad is None and torch.equal(x.grad, torch.ones(3))
     live = torch.nn.Parameter(torch.ones(3, 1, 1, 1))
     assert AG._leaf_of(live) is live and AG._leaf_of(live.view(3, 1)) is live
+
+
+def test_cached_lists_follow_replaced_parameters_and_hold_no_views():
+    """ops.cached_list (round 6): the decoder's / encoder's kernel-order lists are looked up once per module; a swapped Parameter rebuilds them,
+    and the decoder's reshaped [cout, cin] views are made per call (one view node per use: the gradient accumulation order of a step stays
+    use by use)."""
+    import _procedural_scene as S
+    from crnerf_amd.models.linearStyleTransfer import encoder_sameoutputsize, style_net
+    net = style_net(args=S.hparams(), residual_blocks=1)
+    a, b = net.decoder_tensors(), net.decoder_tensors()
+    assert len(a) == 22 and [tuple(t.shape) for t in a[:8]] == [(128, 64), (128,), (64, 128), (64,), (32, 64), (32,), (1024, 1024), (1024,)]
+    for x, y in zip(a, b):
+        assert x.data_ptr() == y.data_ptr() and ((x is y) == isinstance(x, torch.nn.Parameter))
+    named = dict(net.named_parameters())
+    assert a[6] is named["multi_net.snet.fc.weight"] and a[21] is named["decoder.feat_2_rgb_list.0.bias"]
+    net.multi_net.snet.fc.weight = torch.nn.Parameter(torch.zeros(1024, 1024))
+    assert net.decoder_tensors()[6] is net.multi_net.snet.fc.weight
+    enc = encoder_sameoutputsize(out_channel=64)
+    lst = ops.cached_list(enc, "probe", lambda: [enc.conv1.weight])
+    assert ops.cached_list(enc, "probe", lambda: [enc.conv1.weight]) is lst
+    enc.load_state_dict({k: v.clone() for k, v in enc.state_dict().items()}, assign=True)
+    assert ops.cached_list(enc, "probe", lambda: [enc.conv1.weight])[0] is enc.conv1.weight
