@@ -61,7 +61,36 @@ opt = (torch.optim.Adam(sysm.parameters(), lr=5e-4, fused=True) if os.environ.ge
        else optim.FlatAdam(sysm.parameters(), lr=5e-4, eps=1e-8))
 
 
+# Upper bound of what batching same-shape auxiliary passes could give (VERDICT r5 missing #4), measured without building it: CRNERF_PROBE_DROP
+# names passes that are NOT run at all -- their consumer gets another pass's result, so the numbers mean nothing and only the step time is read.
+# A batched pass still does the dropped pass's device work and part of its host work; dropping it removes both.
+#   enc2: enc_cont(rgb_content_img) reuses enc_cont(rgb_fine_img)      enc3: both reuse enc_a(rgb_fine_random)
+#   dec2: the content decode reuses the fine decode                      dec3: fine_random reuses it as well
+_drop = set(filter(None, os.environ.get("CRNERF_PROBE_DROP", "").split(",")))
+if _drop:
+    _enc, _dec, _seen = sysm._encode, sysm.decode, {}
+
+    def _encode_probe(enc, image):
+        key = "any" if "enc3" in _drop else (id(enc) if "enc2" in _drop and enc is sysm.enc_cont else None)
+        if key is None:
+            return _enc(enc, image)
+        if key not in _seen:
+            _seen[key] = _enc(enc, image)
+        return _seen[key]
+
+    def _decode_probe(results, type, **kw):
+        if (type == "content" and _drop & {"dec2", "dec3"}) or (type == "fine_random" and "dec3" in _drop):
+            results["rgb_content_img" if type == "content" else "rgb_fine_random"] = results["rgb_fine_img"]
+            if type == "content":
+                results["rgb_content"] = None
+            return results
+        return _dec(results, type, **kw)
+    sysm._encode, sysm.decode = _encode_probe, _decode_probe
+
+
 def step(i):
+    if _drop:
+        _seen.clear()
     batch = batcher.__getitem__(i, 0)
     opt.zero_grad(set_to_none=True)
     loss, loss_d, _ = sysm.training_step(batch)
