@@ -441,6 +441,53 @@ def test_fused_grad_accumulation_equals_accumulategrad_bit_for_bit():
             torch.testing.assert_close(a, b, rtol=1e-2, atol=1e-3 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("side", [16, 64])
+def test_branch_streams_leave_the_step_bit_identical(side):
+    """pipeline.TrainingSystem.branch_streams (round 6): the decode / encoder chains, the photo's encoder and the mask network run on six HIP streams
+    beside each other, forward and backward.  Same kernels, same arithmetic: loss and every gradient equal the one-stream step's bit for bit (the mask
+    network's atomically summed weight gradients apart), and stay so over repeated steps -- a missing event wait would show as a difference here."""
+    import crnerf_amd.synth as synth
+    from crnerf_amd import pipeline
+
+    class HPT(HP):
+        nerf_out_dim, pertubeCord, N_emb_xyz, N_emb_dir, use_disp, encode_a, encode_random, N_a = 64, False, 15, 4, False, True, True, 48
+        img_wh, N_samples, N_importance, perturb, noise_std, chunk, N_vocab = [side, side], 32, 32, 0.0, 0.0, 128, 8
+        encode_c, use_mask = True, True
+    R = side * side
+    batch = {"rays": torch.from_numpy(synth.rays(R, H=side, W=side)).to(DEV), "ts": torch.full((R,), 3, dtype=torch.int64, device=DEV),
+             "rgbs": torch.rand(R, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(1)), "whole_img": torch.rand(1, 3, 64, 80, device=DEV) * 2 - 1,
+             "rgb_idx": torch.arange(R, device=DEV) * 7, "img_wh": torch.tensor([640, 512])}
+    torch.manual_seed(0)
+    sys_ = pipeline.TrainingSystem(HPT(), device=DEV)
+    assert sys_.branch_streams is True
+    sys_.enc_cont.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(5, 2.0).items()})
+    sys_.models["decoder"].load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state(3).items()})
+    sys_.enc_a.load_state_dict({k: torch.from_numpy(v) for k, v in synth.encoder_state(4, 2.0).items()})
+    n_exact = len(list(sys_.parameters())) - len(list(sys_.implicit_mask.parameters()))
+
+    def step(streams):
+        sys_.branch_streams = streams
+        sys_.global_step = 0                                  # the state a step leaves behind: the annealing step and the seen appearances (:98, :212-214)
+        sys_.embedding_a_list = [None] * len(sys_.embedding_a_list)
+        torch.manual_seed(7)
+        for p in sys_.parameters():
+            p.grad = None
+        loss, _, res = sys_.training_step(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.clone() for p in sys_.parameters()], res["rgb_fine"].detach().clone()
+
+    ref = step(False)
+    for rep in range(4):
+        got = step(True)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), rep
+        for i, (a, b) in enumerate(zip(got[1], ref[1])):
+            if i < n_exact:
+                assert torch.equal(a, b), (rep, i)
+            else:
+                torch.testing.assert_close(a, b, rtol=1e-2, atol=1e-3 * float(b.abs().max()))
+
+
 def test_loss_reads_encoder_views_in_memory_order():
     """The encoders hand the loss NCHW *views* of pixel-major memory.  The embedding / content terms are order-free reductions, so the kernel
     reads such views in memory order (no transposing copy) and writes their gradients with the same strides: values equal to the contiguous
