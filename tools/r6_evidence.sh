@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the round-6 evidence in one call -> gpurun_out/r6e/ (copied into profiles/r5/ afterwards).
+# GPU box: the round-6 evidence in one call -> gpurun_out/r6e/ (copied into profiles/r6/ afterwards).
 # usage: bash tools/r6_evidence.sh
 set -u
 O=$GRAFT_REPO_ROOT/gpurun_out/r6e
