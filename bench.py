@@ -721,6 +721,11 @@ def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2])
     a = parse()
+    # stdout carries the ONE JSON line and nothing else: libraries that print to fd 1 (RCCL's version banner at communicator creation in this image)
+    # go to stderr for the life of the process; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -765,7 +770,8 @@ def main():
                                 "expected on xGMI (DESIGN section 4): ~10-25 us per tiny all-reduce, all-gather ~ 12 B/pixel / link rate + ~20 us")
                 line["collectives"] = coll
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            json_out.write(json.dumps(line) + "\n")
+            json_out.flush()
         if exchange is not None:
             exchange.check()
             exchange.close()

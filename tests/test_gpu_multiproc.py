@@ -69,6 +69,23 @@ def _json_line(out):
     return json.loads(lines[0])
 
 
+def test_bench_one_rank_over_rccl_leaves_exactly_the_json_line_on_stdout():
+    """The driver's launcher with ONE rank and the production backend (nccl = RCCL; two ranks cannot share this box's one GPU): the process group,
+    the collectives of the step and their timers run over RCCL, and stdout holds exactly one line -- the JSON -- although RCCL prints its version
+    banner to fd 1 at communicator creation (bench.py sends everything but the line to stderr)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CRNERF_BENCH_TEST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["collectives"]["backend"].startswith("nccl") and j["collectives"]["world_size"] == 1
+    assert j["collectives"]["per_call_ms"], j["collectives"]
+
+
 def test_bench_strong_scaling_one_frame_split_over_two_ranks():
     """--scaling strong --workload configs2: ONE frame's rays split over the ranks; the gathered image is the single-process image."""
     args = ["bench.py", "--scaling", "strong", "--workload", "configs2", "--frame", "120x160", "--steps", "2", "--warmup", "1"]
