@@ -976,11 +976,28 @@ def main():
                 # configs[3]'s training step at the reference's own batch (command/train.sh:24: 1,024 rays) and at 16,384 rays: the whole
                 # train.sh configuration (batcher, encoders, mask network, grad-mode render, decodes, loss, backward, Adam), training defaults
                 import argparse
+                import gc
+                gc.collect()
+                gc.freeze()     # what the legs above left on the heap (oracle tensors, fixtures) is not this step's garbage: without this every
+                                # generation-2 collection during the host-bound 1,024-ray steps walks it (6.3-7.0 ms per step against 5.3-5.8 in a process that only trains)
                 for tr, st in ((1024, 30), (16384, 6)):
                     ta = argparse.Namespace(**dict(vars(a), train_rays=tr, steps=st, warmup=5, train_precision="auto"))
                     tl = strong_configs3(ta, dev, 1, 0, False, None)
                     line.setdefault("extra", {})["train_step_%d" % tr] = {"ms_per_step": tl["ms_per_step"], "rays_per_s": tl["value"], "dtype": tl["dtype"], "steps": st,
                                                            "fp32_work_tflops": tl["roofline"]["fp32_work_tflops"], "workload": tl["config"]["workload"]}
+                    if tr == 1024:
+                        # the same step with its two host threads (caller + autograd worker) inside one L3 domain (crnerf_amd.hostpin, opt-in):
+                        # this size is bound by those two handing the GIL over, and where they run decides 5.3 against 6 ms
+                        from crnerf_amd import hostpin
+                        pinned = hostpin.pin_step_threads(dev)
+                        try:
+                            tp = strong_configs3(ta, dev, 1, 0, False, None)
+                        finally:
+                            hostpin.unpin_host_threads(pinned)
+                        line["extra"]["train_step_1024"]["step_threads_in_one_l3_domain"] = {
+                            "ms_per_step": tp["ms_per_step"], "rays_per_s": tp["value"], "cpus": sorted(pinned["cpus"]) if pinned else None,
+                            "note": "crnerf_amd.hostpin.pin_step_threads(device) for this leg only (restored afterwards)"}
+                gc.unfreeze()
                 from crnerf_amd import autograd as _AG
                 _AG.set_training_forward_precision(None)
                 _AG.set_wgrad_precision(None)

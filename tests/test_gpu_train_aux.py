@@ -518,3 +518,33 @@ def test_loss_reads_encoder_views_in_memory_order():
     from crnerf_amd import ops
     assert ops._dense_flat(base["a_embedded"].permute(0, 3, 1, 2)).data_ptr() == base["a_embedded"].data_ptr()
     assert ops._dense_flat(base["a_embedded"][:, ::2]) is None and ops._dense_flat(base["a_embedded"].expand(2, 32, 32, 64)) is None
+
+
+def test_hostpin_finds_and_pins_the_autograd_worker():
+    """crnerf_amd.hostpin.pin_step_threads: the device's autograd worker is a thread of its own (not the caller); caller and worker end up in one
+    L3 domain, every other thread keeps its mask, and unpin restores both."""
+    import os
+    import threading
+    from crnerf_amd import hostpin
+    before = os.sched_getaffinity(0)
+    tid = hostpin.autograd_thread_id(DEV)
+    me = threading.get_native_id()
+    assert tid is not None and tid != me and str(tid) in os.listdir("/proc/self/task")
+    assert hostpin.autograd_thread_id(DEV) == tid                # the engine keeps one worker per device
+    others = {t: os.sched_getaffinity(t) for t in map(int, os.listdir("/proc/self/task")) if t not in (me, tid)}
+    saved = hostpin.pin_step_threads(DEV)
+    try:
+        if saved is not None:
+            dom = set(saved["cpus"])
+            assert os.sched_getaffinity(0) == dom and os.sched_getaffinity(tid) == dom and dom <= before
+            for t, m in others.items():
+                try:
+                    assert os.sched_getaffinity(t) == m
+                except OSError:
+                    pass
+            x = torch.ones(4, device=DEV, requires_grad=True)
+            (x * 2).sum().backward()
+            assert torch.equal(x.grad, torch.full((4,), 2.0, device=DEV))
+    finally:
+        hostpin.unpin_host_threads(saved)
+    assert os.sched_getaffinity(0) == before and os.sched_getaffinity(tid) == before

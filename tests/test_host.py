@@ -471,3 +471,46 @@ def test_cached_lists_follow_replaced_parameters_and_hold_no_views():
     assert ops.cached_list(enc, "probe", lambda: [enc.conv1.weight]) is lst
     enc.load_state_dict({k: v.clone() for k, v in enc.state_dict().items()}, assign=True)
     assert ops.cached_list(enc, "probe", lambda: [enc.conv1.weight])[0] is enc.conv1.weight
+
+
+def test_hostpin_confines_all_threads_to_one_cache_domain_and_restores():
+    """crnerf_amd.hostpin (round 6: the 1,024-ray training step is bound by two host threads handing the GIL over; with both inside one L3 domain it
+    sits on its device time).  pin_host_threads(): every thread the process has ends up inside one last-level-cache domain and inside the mask it
+    had; pin_step_threads(): the caller (and the device's autograd worker) only; unpin restores the masks; an explicit CPU set is honoured; a host
+    without cache topology in sysfs is left alone."""
+    import threading
+    from crnerf_amd import hostpin
+    before = os.sched_getaffinity(0)
+    stop = threading.Event()
+    th = threading.Thread(target=stop.wait)
+    th.start()
+    try:
+        saved = hostpin.pin_host_threads()
+        cpu = hostpin.current_cpu()
+        if saved is None:                                        # no cache topology here: nothing may have changed
+            assert os.sched_getaffinity(0) == before
+        else:
+            dom = set(saved["cpus"])
+            assert dom and dom <= before and dom <= hostpin.l3_domain(min(dom)) and (cpu is None or hostpin.current_cpu() in dom)
+            assert os.sched_getaffinity(0) == dom and os.sched_getaffinity(th.native_id) == dom
+            assert hostpin.allowed_before(saved) == before
+            hostpin.unpin_host_threads(saved)
+            assert os.sched_getaffinity(0) == before and os.sched_getaffinity(th.native_id) == before
+        # the recommended form: the caller and the autograd worker of the device only (on "cpu" the backward runs on the caller itself)
+        assert hostpin.autograd_thread_id("cpu") == threading.get_native_id()
+        saved = hostpin.pin_step_threads("cpu")
+        if saved is not None:
+            assert os.sched_getaffinity(0) == set(saved["cpus"]) and os.sched_getaffinity(th.native_id) == before
+            assert sorted(k for k in saved if k != "cpus") == [threading.get_native_id()]
+            hostpin.unpin_host_threads(saved)
+            assert os.sched_getaffinity(0) == before
+        one = {min(before)}
+        saved = hostpin.pin_host_threads(one)
+        assert os.sched_getaffinity(0) == one and saved["cpus"] == one
+        hostpin.unpin_host_threads(saved)
+        assert os.sched_getaffinity(0) == before
+        assert hostpin.l3_domain(min(before), sys_cpu="/nonexistent") is None and hostpin._parse_cpu_list("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    finally:
+        os.sched_setaffinity(0, before)
+        stop.set()
+        th.join()

@@ -106,8 +106,31 @@ def step(i):
 
 
 n_warm, n = (int(v) for v in os.environ.get("CRNERF_TRAIN_BENCH_STEPS", "2,3").split(","))
+if os.environ.get("CRNERF_PIN_HOST") == "1":          # crnerf_amd.hostpin: this thread and the autograd worker inside one L3 domain (A/B of the host-bound sizes); "ab": in-process free / all threads / the two
+    from crnerf_amd import hostpin
+    _pin = hostpin.pin_step_threads(dev)
+    print("host threads pinned to CPUs %s" % (sorted(_pin["cpus"]) if _pin else None), flush=True)
 for i in range(n_warm):
     step(i)
+if os.environ.get("CRNERF_PIN_HOST") == "ab":         # the same process and model, alternating: free / pinned / free / pinned ... (n steps each)
+    from crnerf_amd import hostpin
+    import threading
+    k = n_warm
+    for rep in range(3):
+        for pinned in (False, "all", "two"):
+            st = None if not pinned else hostpin.pin_host_threads(threads=None if pinned == "all" else [0, hostpin.autograd_thread_id(dev)])
+            for _ in range(5):
+                step(k); k += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step(k); k += 1
+            th = (time.perf_counter() - t0) / n
+            torch.cuda.synchronize()
+            print("in-process A/B, %-6s: %.2f ms per step (host enqueue %.2f ms)  threads %d  cpus %s"
+                  % (pinned or "free", (time.perf_counter() - t0) / n * 1e3, th * 1e3, len(os.listdir("/proc/self/task")),
+                     sorted(st["cpus"]) if st else "all"), flush=True)
+            hostpin.unpin_host_threads(st)
 torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
 prof = None
