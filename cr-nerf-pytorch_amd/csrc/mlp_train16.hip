@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <utility>
+#include <stdio.h>
 #include <stdlib.h>
 #include "kernels.h"
 #include "mlp_core16.h"
@@ -1277,7 +1278,16 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
   if (batched) {
     WgradSpec sp[WG_MAX_JOBS];
     int n = 0;
-    const float W_FULL = 1.0f, W_EMB = 0.52f, W_DIR = 0.66f, W_DIRE = 0.19f, W_RGB = 0.26f, W_SIG = 0.26f;   // measured per-point cost relative to a full block (profiles/r3/train_1024_before_ordered.txt)
+    // Per-point cost of the narrow jobs relative to a full 256 x 256 block: it sets every job's chunk length so that all workgroups of the launch
+    // carry about the same work.  The fp32 / bf16x3 blocks are bound by their matrix work (profiles/r3/train_1024_before_ordered.txt: the first
+    // row); the f16x2 blocks sit at the HBM read rate, where a narrow job costs what its rows cost, not what its tiles cost -- with the first row
+    // the narrow jobs' workgroups ran long after the full blocks had finished: wgrad_h2_batch_kernel 846 us per launch at 1,024 rays, 643 us with
+    // the second (profiles/r6/wgrad_batch_job_weights.txt; CRNERF_WGB_WEIGHTS="emb,dir,dire,rgb,sig" overrides both for measurements).
+    struct JobW { float emb, dir, dire, rgb, sig; };
+    static const JobW jw_matrix = {0.52f, 0.66f, 0.19f, 0.26f, 0.26f}, jw_rows = {1.1f, 1.1f, 0.7f, 0.7f, 0.8f};
+    static const JobW jw_env = [] { JobW w = {0, 0, 0, 0, 0}; if (const char* e = getenv("CRNERF_WGB_WEIGHTS")) sscanf(e, "%f,%f,%f,%f,%f", &w.emb, &w.dir, &w.dire, &w.rgb, &w.sig); return w; }();
+    const JobW& jw = jw_env.emb > 0 ? jw_env : (wb == 3 ? jw_rows : jw_matrix);
+    const float W_FULL = 1.0f, W_EMB = jw.emb, W_DIR = jw.dir, W_DIRE = jw.dire, W_RGB = jw.rgb, W_SIG = jw.sig;
     sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P, R(0), amax};                         // xyz_encoding_1
     for (int l = 1; l < 8; ++l) {
       if (l == 4) {                                                                                                                  // xyz_encoding_5: cat([xyz, h4]), nerf.py:168-169

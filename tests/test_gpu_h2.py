@@ -456,7 +456,8 @@ def test_train_auto_repairs_poisoned_rays_and_their_saved_rows():
 def test_train_auto_with_a_refused_pack_falls_back_on_the_device():
     """A weight >= 255 under set_training_forward_precision("auto"): the asynchronous h2 packs carry the range flag (crnerf_pack_h2_status says so),
     the h2 training twin marks every ray NaN, crnerf_render_rays_train_f32x3_repair renders them all, the h2 data gradient stands aside for the
-    f32x3 one -- all decided on the device.  Outputs and the refused model's gradients are then the f32x3 mode's, bit for bit."""
+    f32x3 one -- all decided on the device.  Outputs are then the f32x3 mode's bit for bit, the refused model's gradients to a few ulps (same products,
+    other chunk lengths in the batched weight-gradient sum)."""
     from crnerf_amd import autograd as AG
     from test_gpu_train_fused import _grads, _inputs, _modules
     models, emb, args = _modules(gain=2.45, sigma_bias=-1.0, band_limit=4)
@@ -486,9 +487,12 @@ def test_train_auto_with_a_refused_pack_falls_back_on_the_device():
         AG.set_training_forward_precision(None)
     for k in ("feature_coarse", "feature_fine", "weights_fine", "depth_fine"):
         assert not bool(torch.isnan(outs["auto"][k]).any()) and torch.equal(outs["auto"][k], outs["x3"][k]), k
-    for k in gx3:     # the fine model (refused pack): the f32x3 data gradient, bit for bit; the coarse model (accepted): the h2 one, fp32-level apart
+    # the fine model (refused pack): the f32x3 data gradient and the bf16x3 weight-gradient arithmetic -- the same products as the f32x3 mode's, summed
+    # in chunks of other lengths (the batched launch sizes its chunks for the f16x2 blocks' row-bound cost, round 6): equal to a few ulps of the
+    # sum; the coarse model (accepted): the h2 data gradient, fp32-level apart
+    for k in gx3:
         if k.startswith("fine"):
-            assert torch.equal(gau[k], gx3[k]), k
+            assert float((gau[k] - gx3[k]).norm() / (gx3[k].norm() + 1e-30)) <= 2e-6, k
         else:
             assert float((gau[k] - gx3[k]).norm() / (gx3[k].norm() + 1e-30)) <= 1e-4, k
 
