@@ -1285,7 +1285,12 @@ int launch_mlp_wgrads(const float* x, const float* acts, const float* deltas, co
     // the second (profiles/r6/wgrad_batch_job_weights.txt; CRNERF_WGB_WEIGHTS="emb,dir,dire,rgb,sig" overrides both for measurements).
     struct JobW { float emb, dir, dire, rgb, sig; };
     static const JobW jw_matrix = {0.52f, 0.66f, 0.19f, 0.26f, 0.26f}, jw_rows = {1.1f, 1.1f, 0.7f, 0.7f, 0.8f};
-    static const JobW jw_env = [] { JobW w = {0, 0, 0, 0, 0}; if (const char* e = getenv("CRNERF_WGB_WEIGHTS")) sscanf(e, "%f,%f,%f,%f,%f", &w.emb, &w.dir, &w.dire, &w.rgb, &w.sig); return w; }();
+    static const JobW jw_env = [] {
+      JobW w = {0, 0, 0, 0, 0};
+      const char* e = getenv("CRNERF_WGB_WEIGHTS");
+      const bool ok = e && sscanf(e, "%f,%f,%f,%f,%f", &w.emb, &w.dir, &w.dire, &w.rgb, &w.sig) == 5 && w.emb >= 0.05f && w.dir >= 0.05f && w.dire >= 0.05f && w.rgb >= 0.05f && w.sig >= 0.05f;
+      return ok ? w : JobW{0, 0, 0, 0, 0};       // anything else than five weights >= 0.05: ignored
+    }();
     const JobW& jw = jw_env.emb > 0 ? jw_env : (wb == 3 ? jw_rows : jw_matrix);
     const float W_FULL = 1.0f, W_EMB = jw.emb, W_DIR = jw.dir, W_DIRE = jw.dire, W_RGB = jw.rgb, W_SIG = jw.sig;
     sp[n++] = WgradSpec{D(0), ACT_W, 256, x, IN_DIM, XYZ_DIM, grads[0], XYZ_DIM, grads[1], W_EMB, wb, P, R(0), amax};                         // xyz_encoding_1
