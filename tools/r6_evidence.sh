@@ -25,8 +25,11 @@ for mode in "CRNERF_TRAIN_FWD=f32 CRNERF_WGRAD_F32=1" "" "CRNERF_TRAIN_CHUNK_POI
     env $mode CRNERF_TRAIN_BENCH_STEPS=3,10 python tools/train_config4_bench.py $r 2>&1 | tail -1 >> $O/train_config3_steps.txt
   done
 done
-for i in 1 2 3; do echo -n "[default, 40 steps] " >> $O/train_config3_steps.txt; CRNERF_TRAIN_BENCH_STEPS=5,40 python tools/train_config4_bench.py 1024 2>&1 | tail -1 >> $O/train_config3_steps.txt; done
-bash tools/train_step_trace.sh $O/train_config4_1024 grid_batch $GRAFT_REPO_ROOT/tools/train_config4_bench.py 1024 > $O/train_config4_1024.log 2>&1
+for i in 1 2 3; do for c in 0 1; do echo -n "[default, 60 steps, CRNERF_PIN_HOST=$c] " >> $O/train_config3_steps.txt; CRNERF_PIN_HOST=$c CRNERF_TRAIN_BENCH_STEPS=10,60 python tools/train_config4_bench.py 1024 2>&1 | grep "config-4" >> $O/train_config3_steps.txt; done; done
+for mode in "CRNERF_TRAIN_FWD=f32 CRNERF_WGRAD_F32=1" "CRNERF_TRAIN_BF16=1" "CRNERF_TRAIN_RECOMPUTE=1" "CRNERF_BRANCH_STREAMS=0"; do
+  echo -n "[$mode CRNERF_PIN_HOST=1] " >> $O/train_config3_steps.txt; env $mode CRNERF_PIN_HOST=1 CRNERF_TRAIN_BENCH_STEPS=10,40 python tools/train_config4_bench.py 1024 2>&1 | grep "config-4" >> $O/train_config3_steps.txt
+done
+CRNERF_PIN_HOST=1 bash tools/train_step_trace.sh $O/train_config4_1024 grid_batch $GRAFT_REPO_ROOT/tools/train_config4_bench.py 1024 > $O/train_config4_1024.log 2>&1
 bash tools/train_step_trace.sh $O/train_config4_65536 grid_batch $GRAFT_REPO_ROOT/tools/train_config4_bench.py 65536 > $O/train_config4_65536.log 2>&1
 bash tools/hbm_profile.sh mlp_train_bench.py r6e/hbm_train > /dev/null 2>&1
 bash tools/profile.sh r6e/prof_f32 > /dev/null 2>&1
